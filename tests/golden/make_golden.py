@@ -1,0 +1,310 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures under tests/golden/ by running the REFERENCE itself.
+
+Run in the build container only (it needs /root/reference, which never travels to the
+GPU box):
+
+    python tests/golden/make_golden.py            # all fixtures
+    python tests/golden/make_golden.py balance_n4 # a subset
+
+The reference (VMAS 1.5.2, pure PyTorch) is imported unmodified from /root/reference
+with the argument-storing `gym` stub of oracle/ref_shim on the path.  For every
+fixture we wrap the *instance* method ``world.step`` and record, for a sample of
+steps of a rollout driven by seeded random actions:
+
+  state0      [T, E, 6, B]  entity state entering World.step (pos.xy, vel.xy, rot, ang_vel)
+  ft_in       [T, A, 3, B]  agent state.force / state.torque entering World.step
+  masks       [T, S, W]     per substep: which static pairs passed World.collides
+                            (the batch-global broad phase, core.py:2797-2801)
+  state1      [T, E, 6, B]  entity state after World.step
+  sub         [T, S+1, E, 6, B]  (substeps > 1 only) state entering every substep, then
+                            the final state: lets every substep be teacher-forced
+  ft_out      [T, A, 3, B]  agent force/torque after the step (clamped values are
+                            written back, core.py:2021-2039)
+  jfr         [T, J, B]     per-env JointConstraint.fixed_rotation (joints.py:141-144)
+  egrav       [T, E, 2, B]  per-env entity gravity (only if some entity has one)
+  lidar       [T, L, R, B]  World.cast_rays for every Lidar sensor, measured on state0
+  spec        JSON of vectorizedmultiagentsimulator_amd.spec.WorldSpec
+
+Nothing numeric is computed by this repository's code here except the static
+``spec_from_world`` extraction; all recorded numbers come out of the reference.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+sys.path[:0] = [os.path.join(ROOT, "oracle", "ref_shim"), "/root/reference", ROOT]
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import vmas  # noqa: E402  (the reference)
+from vmas.simulator import core as rcore  # noqa: E402
+from vmas.simulator.joints import Joint  # noqa: E402
+
+from vectorizedmultiagentsimulator_amd.spec import spec_from_world  # noqa: E402
+
+
+def pack_state(world) -> np.ndarray:
+    rows = []
+    for e in world.entities:
+        s = e.state
+        rows.append(torch.cat([s.pos, s.vel, s.rot, s.ang_vel], dim=-1).T)  # [6, B]
+    return torch.stack(rows).detach().numpy().astype(np.float32).copy()
+
+
+def pack_ft(world) -> np.ndarray:
+    rows = []
+    for a in world.agents:
+        rows.append(torch.cat([a.state.force, a.state.torque], dim=-1).T)  # [3, B]
+    if not rows:
+        return np.zeros((0, 3, world.batch_dim), np.float32)
+    return torch.stack(rows).detach().numpy().astype(np.float32).copy()
+
+
+class StepRecorder:
+    """Wraps one reference World instance; see module docstring."""
+
+    def __init__(self, world, every: int = 1, start: int = 0):
+        self.world, self.every, self.start = world, every, start
+        self.spec = spec_from_world(world)
+        self.idx = {id(e): i for i, e in enumerate(world.entities)}
+        self.pair_index = {frozenset((p.a, p.b)): k for k, p in enumerate(self.spec.pairs)}
+        self.words = max((len(self.spec.pairs) + 31) // 32, 1)
+        self.rec = {k: [] for k in ("state0", "ft_in", "masks", "state1", "ft_out", "jfr", "egrav", "lidar", "sub")}
+        self.count = 0
+        self._in_step = False
+        self._cur_masks = None
+        self._orig_step = world.step
+        self._orig_collides = world.collides
+        self._orig_env_force = world._apply_vectorized_enviornment_force
+        world.step = self._step
+        world.collides = self._collides
+        world._apply_vectorized_enviornment_force = self._env_force
+
+    # -- hooks ------------------------------------------------------------
+    def _collides(self, a, b):
+        r = self._orig_collides(a, b)
+        if self._in_step and self._cur_masks is not None and r:
+            k = self.pair_index.get(frozenset((self.idx[id(a)], self.idx[id(b)])))
+            assert k is not None, f"pair ({a.name},{b.name}) collides but is not in the static pair list"
+            self._cur_masks[-1][k >> 5] |= np.uint32(1 << (k & 31))
+        return r
+
+    def _env_force(self):
+        if self._cur_masks is not None:
+            self._cur_masks.append(np.zeros(self.words, np.uint32))
+            self._cur_sub.append(pack_state(self.world))  # state entering this substep
+        return self._orig_env_force()
+
+    def _per_env_arrays(self):
+        w = self.world
+        B = w.batch_dim
+        jfr = np.zeros((len(self.spec.joints), B), np.float32)
+        k = 0
+        ents = list(w.entities)
+        for ia, ea in enumerate(ents):
+            for ib, eb in enumerate(ents):
+                if ib <= ia:
+                    continue
+                j = w._joints.get(frozenset({ea.name, eb.name}))
+                if j is None:
+                    continue
+                fr = j.fixed_rotation
+                if isinstance(fr, torch.Tensor):
+                    jfr[k] = fr.reshape(B).numpy()
+                else:
+                    jfr[k] = float(fr)
+                k += 1
+        eg = None
+        if any(e.per_env_gravity for e in self.spec.entities):
+            eg = np.zeros((len(ents), 2, B), np.float32)
+            for i, e in enumerate(ents):
+                if self.spec.entities[i].per_env_gravity:
+                    eg[i] = e.gravity.T.numpy()
+        return jfr, eg
+
+    def _lidar(self):
+        w = self.world
+        ents = list(w.entities)
+        L = self.spec.lidars
+        if not L:
+            return None
+        R = max(l.n_rays for l in L)
+        out = np.zeros((len(L), R, w.batch_dim), np.float32)
+        k = 0
+        for agent in w.agents:
+            for sensor in agent.sensors:
+                if not hasattr(sensor, "_angles"):
+                    continue
+                m = w.cast_rays(
+                    agent, sensor._angles + agent.state.rot, max_range=sensor._max_range,
+                    entity_filter=sensor.entity_filter,
+                )
+                assert ents.index(agent) == L[k].entity
+                out[k, : m.shape[1]] = m.T.numpy()
+                k += 1
+        return out
+
+    def _step(self):
+        take = self.count >= self.start and (self.count - self.start) % self.every == 0
+        self.count += 1
+        if not take:
+            return self._orig_step()
+        r = self.rec
+        r["state0"].append(pack_state(self.world))
+        r["ft_in"].append(pack_ft(self.world))
+        jfr, eg = self._per_env_arrays()
+        r["jfr"].append(jfr)
+        if eg is not None:
+            r["egrav"].append(eg)
+        lid = self._lidar()
+        if lid is not None:
+            r["lidar"].append(lid)
+        self._cur_masks = []
+        self._cur_sub = []
+        self._in_step = True
+        try:
+            out = self._orig_step()
+        finally:
+            self._in_step = False
+        assert len(self._cur_masks) == self.spec.substeps
+        r["masks"].append(np.stack(self._cur_masks))
+        self._cur_masks = None
+        r["state1"].append(pack_state(self.world))
+        r["ft_out"].append(pack_ft(self.world))
+        if self.spec.substeps > 1:
+            r["sub"].append(np.stack(self._cur_sub + [r["state1"][-1]]))
+        return out
+
+    def save(self, name: str):
+        arrays = {k: np.stack(v) for k, v in self.rec.items() if v}
+        arrays["spec"] = np.array(self.spec.to_json())
+        path = os.path.join(HERE, f"{name}.npz")
+        np.savez_compressed(path, **arrays)
+        T = arrays["state0"].shape[0]
+        on = int(sum(bin(int(w)).count("1") for w in arrays["masks"].reshape(-1)))
+        print(
+            f"{name}: T={T} E={self.spec.n_entities} A={self.spec.n_agents} P={len(self.spec.pairs)} "
+            f"J={len(self.spec.joints)} S={self.spec.substeps} L={len(self.spec.lidars)} "
+            f"mask-bits-on={on}/{T * self.spec.substeps * len(self.spec.pairs)} -> {os.path.getsize(path)} B"
+        )
+
+
+def rollout_env(name, scenario, B, steps, every, start=0, seed=0, toward=None, **kw):
+    """Seeded random actions; with ``toward=<entity name>`` the first two action
+    components are biased toward that entity so that contacts actually happen."""
+    torch.manual_seed(seed)
+    env = vmas.make_env(scenario, num_envs=B, device="cpu", seed=seed, continuous_actions=True, **kw)
+    rec = StepRecorder(env.world, every=every, start=start)
+    g = torch.Generator().manual_seed(1234)
+    ents = {e.name: e for e in env.world.entities}
+    for _ in range(steps):
+        acts = []
+        for a in env.agents:
+            u = a.action.u_range_tensor
+            r = torch.rand(B, a.action_size, generator=g) * 2 - 1
+            if toward is not None and a.name != toward:
+                d = ents[toward].state.pos - a.state.pos
+                d = d / d.norm(dim=-1, keepdim=True).clamp_min(1e-6)
+                r[:, :2] = 0.8 * d + 0.2 * r[:, :2]
+            acts.append(r * u)
+        env.step(acts)
+    rec.save(name)
+
+
+# ----------------------------------------------------------------------------
+# synthetic worlds built directly on the reference's classes: features that no
+# in-tree scenario exercises and a dense "contact soup".
+# ----------------------------------------------------------------------------
+def soup_world(B, seed, hollow=False, with_joints=True):
+    """All shape types, solid/hollow boxes, static/movable/rotatable mixes, joints,
+    clamps, frictions, entity gravity/drag - packed into a small area so that every
+    narrow-phase branch fires."""
+    w = rcore.World(
+        B, torch.device("cpu"), dt=0.1, substeps=3, drag=0.2, linear_friction=0.02, angular_friction=0.01,
+        x_semidim=1.0, y_semidim=0.8, collision_force=300, joint_force=120, contact_margin=2e-3,
+        gravity=(0.0, -0.03), torque_constraint_force=0.7,
+    )
+    L = rcore.Landmark
+    w.add_landmark(L("ghost", collide=False, shape=rcore.Sphere(0.07)))
+    w.add_landmark(L("ball", movable=True, rotatable=True, mass=2.0, shape=rcore.Sphere(0.06), max_speed=0.4))
+    w.add_landmark(L("stick", movable=True, rotatable=True, mass=1.5, shape=rcore.Line(0.5), drag=0.1))
+    w.add_landmark(L("stick2", movable=True, rotatable=True, mass=0.8, shape=rcore.Line(0.35), v_range=0.3))
+    w.add_landmark(L("wall", movable=False, rotatable=False, shape=rcore.Line(1.2)))
+    w.add_landmark(L("crate", movable=True, rotatable=True, mass=3.0, shape=rcore.Box(0.3, 0.2, hollow=hollow),
+                     linear_friction=0.05, gravity=(0.01, -0.02)))
+    w.add_landmark(L("crate2", movable=True, rotatable=False, mass=4.0, shape=rcore.Box(0.25, 0.25),
+                     angular_friction=0.03))
+    w.add_landmark(L("slab", movable=False, rotatable=True, mass=6.0, shape=rcore.Box(0.6, 0.1, hollow=True)))
+    A = rcore.Agent
+    w.add_agent(A("a0", shape=rcore.Sphere(0.05), max_f=0.8, max_t=0.05, u_range=1.0))
+    w.add_agent(A("a1", shape=rcore.Sphere(0.04), f_range=0.5, t_range=0.03, mass=0.7, max_speed=0.5))
+    w.add_agent(A("a2", shape=rcore.Box(0.16, 0.1), mass=1.2, angular_friction=0.02, drag=0.3))
+    w.add_agent(A("a3", shape=rcore.Line(0.3), mass=0.9, rotatable=True, movable=True, v_range=0.6))
+    w.add_agent(A("a4", shape=rcore.Sphere(0.05), movable=True, rotatable=False, collide=True,
+                  collision_filter=lambda e: e.name != "a0"))
+    if with_joints:
+        ents = {e.name: e for e in w.entities}
+        w.add_joint(Joint(ents["a0"], ents["ball"], anchor_a=(0.5, 0.5), anchor_b=(-1, 0), dist=0.0))
+        w.add_joint(Joint(ents["a1"], ents["crate"], anchor_a=(0, 0), anchor_b=(1, -1), dist=0.2,
+                          rotate_a=True, rotate_b=False, collidable=True, width=0.0, mass=0.5))
+        w.add_joint(Joint(ents["a3"], ents["stick2"], anchor_a=(1, 0), anchor_b=(-1, 0), dist=0.15,
+                          rotate_a=False, rotate_b=False, fixed_rotation_a=0.3, collidable=True, width=0.05,
+                          mass=0.4))
+    return w
+
+
+def rollout_soup(name, B, seed, rounds, steps_per_round, hollow, spread):
+    torch.manual_seed(seed)
+    w = soup_world(B, seed, hollow=hollow)
+    rec = StepRecorder(w, every=1)
+    g = torch.Generator().manual_seed(seed + 99)
+    for _ in range(rounds):
+        for e in w.entities:
+            if e.is_joint:
+                continue
+            e.set_pos((torch.rand(B, 2, generator=g) * 2 - 1) * spread, batch_index=None)
+            e.set_rot((torch.rand(B, 1, generator=g) * 2 - 1) * 3.1, batch_index=None)
+            e.set_vel((torch.rand(B, 2, generator=g) * 2 - 1) * 0.3, batch_index=None)
+            e.set_ang_vel((torch.rand(B, 1, generator=g) * 2 - 1) * 0.5, batch_index=None)
+        for _ in range(steps_per_round):
+            for a in w.agents:
+                a.state.force = (torch.rand(B, 2, generator=g) * 2 - 1) * 1.0
+                a.state.torque = (torch.rand(B, 1, generator=g) * 2 - 1) * 0.08
+            w.step()
+    rec.save(name)
+
+
+FIXTURES = {
+    # the five BASELINE.json configs (small batch versions) ------------------
+    "balance_n3": lambda: rollout_env("balance_n3", "balance", 4, 100, 5, n_agents=3),
+    "balance_n4": lambda: rollout_env("balance_n4", "balance", 8, 120, 6, n_agents=4),
+    "transport": lambda: rollout_env("transport", "transport", 8, 100, 5, toward="package 0"),
+    "transport_2pkg": lambda: rollout_env("transport_2pkg", "transport", 8, 100, 5, toward="package 1", n_packages=2),
+    "navigation_n8": lambda: rollout_env("navigation_n8", "navigation", 8, 60, 4, toward="agent_0", n_agents=8),
+    "football_5v5": lambda: rollout_env(
+        "football_5v5", "football", 8, 80, 5, n_blue_agents=5, n_red_agents=5, ai_red_agents=False
+    ),
+    # feature fixtures --------------------------------
+    "waterfall": lambda: rollout_env("waterfall", "waterfall", 8, 60, 3),
+    "pollock": lambda: rollout_env("pollock", "pollock", 8, 40, 4, lidar=True),
+    "reverse_transport": lambda: rollout_env("reverse_transport", "reverse_transport", 8, 80, 5),
+    "give_way": lambda: rollout_env("give_way", "give_way", 8, 60, 5),
+    "joint_passage": lambda: rollout_env("joint_passage", "joint_passage", 8, 60, 5),
+    "ball_trajectory": lambda: rollout_env("ball_trajectory", "ball_trajectory", 8, 40, 4),
+    "wind_flocking": lambda: rollout_env("wind_flocking", "wind_flocking", 8, 40, 4),
+    # synthetic: every clamp/friction/gravity knob + dense contacts ------------
+    "soup_solid": lambda: rollout_soup("soup_solid", 16, 7, rounds=6, steps_per_round=2, hollow=False, spread=0.45),
+    "soup_hollow": lambda: rollout_soup("soup_hollow", 16, 11, rounds=6, steps_per_round=2, hollow=True, spread=0.3),
+}
+
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(FIXTURES)
+    torch.set_num_threads(1)
+    for n in names:
+        FIXTURES[n]()

@@ -1,0 +1,56 @@
+"""Pins the CPU oracle (oracle/vmas_oracle.c) against the reference's own outputs.
+
+Each fixture holds (state0, forces, per-substep broad-phase masks) -> state1 tuples
+recorded from the unmodified reference (tests/golden/make_golden.py).  The oracle is
+run teacher-forced from state0 through all substeps of ONE World.step and must land
+on state1 within 1e-5 (north_star tolerance; see golden_util.tolerances).
+"""
+import numpy as np
+import pytest
+
+from golden_util import FIXTURES, compare_state, load, tolerances, ulp_sensitivity
+from oracle.oracle import Oracle
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_oracle_step_matches_reference(name):
+    g = load(name)
+    o = Oracle(g.spec)
+    worst = 0.0
+    for t in range(g.T):
+        st = np.ascontiguousarray(g.state0[t]).copy()
+        ft = np.ascontiguousarray(g.ft_in[t]).copy()
+        jfr = None if g.jfr is None else np.ascontiguousarray(g.jfr[t])
+        eg = None if g.egrav is None else np.ascontiguousarray(g.egrav[t])
+        for s in range(g.spec.substeps):
+            if g.sub is not None:  # teacher-force every substep
+                st = np.ascontiguousarray(g.sub[t, s]).copy()
+            kw = dict(pair_mask=np.ascontiguousarray(g.masks[t, s]), joint_fixed_rot=jfr, entity_gravity=eg,
+                      first_substep=s, n_substeps=1)
+            sens = ulp_sensitivity(lambda a, b: o.step(a, b, **kw), st, ft)
+            o.step(st, ft, **kw)
+            want = g.state1[t] if g.sub is None else g.sub[t, s + 1]
+            worst = max(worst, compare_state(st, want, f"{name}[t={t},s={s}] state", sens=sens,
+                                             **tolerances(g.spec)))
+        compare_state(ft, g.ft_out[t], f"{name}[t={t}] agent force/torque", atol=1e-6, rtol=1e-6)
+    print(f"{name}: max abs err {worst:.3e}")
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_oracle_pair_mask_matches_reference(name):
+    """The oracle's batch-global broad phase reproduces the reference's
+    World.collides decisions on the recorded entry state (substep 0)."""
+    g = load(name)
+    o = Oracle(g.spec)
+    for t in range(g.T):
+        m = o.pair_mask(np.ascontiguousarray(g.state0[t]))
+        assert np.array_equal(m[: g.masks.shape[-1]], g.masks[t, 0]), f"{name}[t={t}]"
+
+
+@pytest.mark.parametrize("name", [n for n in FIXTURES if load(n).lidar is not None])
+def test_oracle_lidar_matches_reference(name):
+    g = load(name)
+    o = Oracle(g.spec)
+    for t in range(g.T):
+        out = o.cast_rays(np.ascontiguousarray(g.state0[t]))
+        compare_state(out, g.lidar[t], f"{name}[t={t}] lidar", atol=1e-5, rtol=1e-5)

@@ -1,0 +1,189 @@
+"""ctypes mirror of ``include/vmas_hip.h`` and the loader of ``libvmas_hip.so``.
+
+The library is the product: there is NO fallback.  If it has not been built (see
+``__graft_entry__.build()`` / ``csrc/build.sh``) importing the loader raises
+``VmasHipLibraryMissing`` with the build command - loudly, never silently.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+ABI_VERSION = 1
+STATE_FIELDS = 6
+AGENT_FIELDS = 3
+
+SHAPE_SPHERE, SHAPE_BOX, SHAPE_LINE = 0, 1, 2
+
+F_MOVABLE = 1 << 0
+F_ROTATABLE = 1 << 1
+F_AGENT = 1 << 2
+F_HOLLOW = 1 << 3
+F_MAX_SPEED = 1 << 4
+F_V_RANGE = 1 << 5
+F_LIN_FRICTION = 1 << 6
+F_ANG_FRICTION = 1 << 7
+F_GRAVITY = 1 << 8
+F_MAX_F = 1 << 9
+F_F_RANGE = 1 << 10
+F_MAX_T = 1 << 11
+F_T_RANGE = 1 << 12
+
+PAIR_SS, PAIR_LS, PAIR_LL, PAIR_BS, PAIR_BL, PAIR_BB = range(6)
+
+
+class EntityDesc(C.Structure):
+    _fields_ = [
+        ("flags", C.c_uint32),
+        ("shape", C.c_int32),
+        ("agent_index", C.c_int32),
+        ("mass", C.c_float),
+        ("inertia", C.c_float),
+        ("length", C.c_float),
+        ("width", C.c_float),
+        ("radius", C.c_float),
+        ("bound_radius", C.c_float),
+        ("one_minus_drag", C.c_float),
+        ("max_speed", C.c_float),
+        ("v_range", C.c_float),
+        ("lin_friction", C.c_float),
+        ("ang_friction", C.c_float),
+        ("gravity", C.c_float * 2),
+        ("max_f", C.c_float),
+        ("f_range", C.c_float),
+        ("max_t", C.c_float),
+        ("t_range", C.c_float),
+    ]
+
+
+class PairDesc(C.Structure):
+    _fields_ = [("a", C.c_int32), ("b", C.c_int32), ("type", C.c_int32), ("bound_sum", C.c_float)]
+
+
+class JointDesc(C.Structure):
+    _fields_ = [
+        ("a", C.c_int32),
+        ("b", C.c_int32),
+        ("delta_a", C.c_float * 2),
+        ("delta_b", C.c_float * 2),
+        ("dist", C.c_float),
+        ("rotate", C.c_int32),
+        ("fixed_rotation", C.c_float),
+    ]
+
+
+class WorldDesc(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32),
+        ("n_entities", C.c_int32),
+        ("n_agents", C.c_int32),
+        ("n_pairs", C.c_int32),
+        ("n_joints", C.c_int32),
+        ("substeps", C.c_int32),
+        ("sub_dt", C.c_float),
+        ("gravity", C.c_float * 2),
+        ("has_gravity", C.c_int32),
+        ("x_semidim", C.c_float),
+        ("y_semidim", C.c_float),
+        ("collision_force", C.c_float),
+        ("joint_force", C.c_float),
+        ("contact_margin", C.c_float),
+        ("torque_constraint_force", C.c_float),
+        ("entities", C.POINTER(EntityDesc)),
+        ("pairs", C.POINTER(PairDesc)),
+        ("joints", C.POINTER(JointDesc)),
+    ]
+
+
+class StepArgs(C.Structure):
+    _fields_ = [
+        ("pair_mask", C.c_void_p),
+        ("joint_fixed_rot", C.c_void_p),
+        ("entity_gravity", C.c_void_p),
+        ("first_substep", C.c_int32),
+        ("n_substeps", C.c_int32),
+    ]
+
+
+class LidarDesc(C.Structure):
+    _fields_ = [
+        ("entity", C.c_int32),
+        ("n_rays", C.c_int32),
+        ("max_range", C.c_float),
+        ("n_targets", C.c_int32),
+        ("targets", C.POINTER(C.c_int32)),
+        ("angles", C.POINTER(C.c_float)),
+    ]
+
+
+class VmasHipLibraryMissing(ImportError):
+    pass
+
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "csrc", "libvmas_hip.so")
+
+#: every symbol include/vmas_hip.h declares (checked by tests/test_abi_symbols.py)
+EXPORTED_SYMBOLS = (
+    "vmas_world_create",
+    "vmas_world_destroy",
+    "vmas_world_step",
+    "vmas_world_pair_mask",
+    "vmas_world_set_lidars",
+    "vmas_world_cast_rays",
+    "vmas_world_set_lanes_per_env",
+    "vmas_world_get_lanes_per_env",
+    "vmas_world_step_bytes_per_env",
+    "vmas_last_error",
+    "vmas_abi_version",
+)
+
+_lib: Optional[C.CDLL] = None
+
+
+def load_library() -> C.CDLL:
+    """dlopen ``libvmas_hip.so`` and declare the prototypes.  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VmasHipLibraryMissing(
+            f"{LIB_PATH} not found: the HIP extension is not built. "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` (or "
+            "vectorizedmultiagentsimulator_amd/csrc/build.sh) - there is no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    lib.vmas_world_create.argtypes = [C.POINTER(WorldDesc), i32, i32, C.POINTER(vp)]
+    lib.vmas_world_create.restype = C.c_int
+    lib.vmas_world_destroy.argtypes = [vp]
+    lib.vmas_world_destroy.restype = None
+    lib.vmas_world_step.argtypes = [vp, vp, vp, i64, C.POINTER(StepArgs), vp]
+    lib.vmas_world_step.restype = C.c_int
+    lib.vmas_world_pair_mask.argtypes = [vp, vp, i64, vp, vp]
+    lib.vmas_world_pair_mask.restype = C.c_int
+    lib.vmas_world_set_lidars.argtypes = [vp, C.POINTER(LidarDesc), i32]
+    lib.vmas_world_set_lidars.restype = C.c_int
+    lib.vmas_world_cast_rays.argtypes = [vp, vp, i64, vp, vp]
+    lib.vmas_world_cast_rays.restype = C.c_int
+    lib.vmas_world_set_lanes_per_env.argtypes = [vp, i32]
+    lib.vmas_world_set_lanes_per_env.restype = C.c_int
+    lib.vmas_world_get_lanes_per_env.argtypes = [vp]
+    lib.vmas_world_get_lanes_per_env.restype = C.c_int
+    lib.vmas_world_step_bytes_per_env.argtypes = [vp]
+    lib.vmas_world_step_bytes_per_env.restype = i64
+    lib.vmas_last_error.argtypes = []
+    lib.vmas_last_error.restype = C.c_char_p
+    lib.vmas_abi_version.argtypes = []
+    lib.vmas_abi_version.restype = C.c_int
+    if lib.vmas_abi_version() != ABI_VERSION:
+        raise VmasHipLibraryMissing(
+            f"{LIB_PATH} has ABI version {lib.vmas_abi_version()}, expected {ABI_VERSION}: rebuild it"
+        )
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return (load_library().vmas_last_error() or b"").decode()
