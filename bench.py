@@ -1,0 +1,200 @@
+#!/usr/bin/env python
+"""bench.py - BASELINE.json's metric on the MI355X-native hot path.
+
+metric : env-steps/sec (batch x substeps) on `balance`, 32768 envs per GPU, n_agents=4
+step   : ONE World.step() (core.py:1972-2015) over the whole batch = one fused kernel
+         launch; state and the pre-generated agent forces are resident in HBM before
+         the timed region starts.
+timing : W warm-up steps, then exactly K steps between barrier+synchronize pairs; MAX
+         over ranks; rank 0 prints one JSON line.  Multi-GPU: the batch is sharded by
+         environment (weak scaling: 32768 envs per GPU), no data-path collective.
+roofline: achieved = algorithmic bytes per launch (384 B/env x envs) /
+         average launch duration from HIP events recorded on the launch stream around
+         the timed region.
+cpu_baseline: the C oracle (a scalar port of the reference algorithm, kind "port") on
+         the host cores, same workload, bounded to ~10 s; rank 0, N=1 only.
+
+Episodes are 100 steps long (actions ~ U(-1,1) * u_multiplier, reference law
+environment.py:536-548): every 100 steps the post-reset state is restored by a
+device-to-device copy inside the timed region (it costs one 6 MB copy per 100 launches).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+EPISODE = 100
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def build_world(num_envs, device, n_agents, lanes, seed):
+    from vectorizedmultiagentsimulator_amd.scenarios.balance import Scenario
+
+    torch.manual_seed(seed)
+    sc = Scenario()
+    w = sc.env_make_world(num_envs, device, n_agents=n_agents, lanes_per_env=lanes)
+    sc.env_reset_world_at(None)
+    return sc, w
+
+
+def make_forces(w, n_steps, seed, device):
+    """[n_steps, A, 3, ld] packed agent forces: u ~ U(-u_range, u_range) * u_multiplier."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    A = len(w.agents)
+    f = torch.zeros(n_steps, max(A, 1), 3, w._ld)
+    u = torch.rand(n_steps, A, 2, w.batch_dim, generator=g) * 2 - 1
+    for i, a in enumerate(w.agents):
+        f[:, i, 0:2, : w.batch_dim] = u[:, i] * float(a.u_range) * float(a.u_multiplier)
+    return f.to(device)
+
+
+def cpu_baseline(w, forces_cpu, state0_cpu, budget_s=10.0):
+    """Oracle (scalar C port of the reference algorithm) on the host cores."""
+    from oracle.oracle import Oracle
+
+    o = Oracle(w.spec)
+    threads = os.cpu_count() or 1
+    B = w.batch_dim
+    st = state0_cpu.copy()
+    o.step(st, forces_cpu[0].copy(), batch=B, threads=threads)  # warm-up (page-in, OpenMP pool)
+    st = state0_cpu.copy()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        if n % EPISODE == 0:
+            st[...] = state0_cpu
+        ft = forces_cpu[n % forces_cpu.shape[0]].copy()
+        o.step(st, ft, batch=B, threads=threads)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 2000:
+            break
+    return {
+        "value": B * n * w.substeps / el,
+        "unit": "env-steps/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{n} World.step() of balance n_agents=4 x {B} envs (same state/forces as the GPU run), "
+                  f"{el:.1f} s, C oracle with OpenMP over environments",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--num-envs", type=int, default=32768, help="environments PER GPU")
+    ap.add_argument("--n-agents", type=int, default=4)
+    ap.add_argument("--lanes", type=int, default=0, help="lanes per environment (0 = library default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world_size > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world_size,
+                                device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    sc, w = build_world(args.num_envs, device, args.n_agents, args.lanes, seed=rank)
+    be = w._get_backend()
+    state0 = w._state.clone()
+    forces = make_forces(w, EPISODE, 1234 + rank, device)
+    stream = torch.cuda.current_stream()
+
+    def run(n_steps, start=0):
+        done = 0
+        while done < n_steps:
+            k = (start + done) % EPISODE
+            if k == 0:
+                w._state.copy_(state0)
+            chunk = min(EPISODE - k, n_steps - done)
+            be.step_n(chunk, forces[k : k + chunk])
+            done += chunk
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(args.warmup)
+    fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    run(args.steps, start=args.warmup)
+    ev1.record(stream)
+    fence()
+    t1 = time.perf_counter()
+    wall = t1 - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # avg launch-to-launch duration on the stream
+
+    if dist is not None:
+        tt = torch.tensor([wall], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall = float(tt.item())
+
+    if rank == 0:
+        bytes_per_env = be.step_bytes_per_env()
+        ach = bytes_per_env * args.num_envs / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "env-steps/sec (batch x substeps) on 'balance'",
+            "value": world_size * args.num_envs * w.substeps * args.steps / wall,
+            "unit": "env-steps/s",
+            "n_gpus": world_size,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": wall / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"balance n_agents={args.n_agents}, {args.num_envs} envs/GPU, World.step() physics only, "
+                            f"random actions, {EPISODE}-step episodes",
+                "num_envs_per_gpu": args.num_envs,
+                "global_envs": world_size * args.num_envs,
+                "substeps": w.substeps,
+                "lanes_per_env": be.lanes_per_env,
+                "parallelism": f"env-sharded x{world_size}",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": ach,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel": "step_kernel",
+                "kernel_us": kernel_ms * 1e3,
+                "bytes_per_launch": bytes_per_env * args.num_envs,
+            },
+        }
+        if world_size == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w, forces.cpu().numpy(), state0.cpu().numpy())
+            out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

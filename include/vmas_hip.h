@@ -167,6 +167,13 @@ void vmas_world_destroy(VmasWorld* w);
 int vmas_world_step(VmasWorld* w, float* state, float* agent_ft, int64_t ld,
                     const VmasStepArgs* args /* may be NULL */, void* stream);
 
+/* `n_steps` consecutive World.step() calls enqueued from C with no host round trip in
+ * between (rollouts with pre-computed or scripted forces; also what bench.py times):
+ * step i reads - and, where clamps apply, rewrites - its agent forces at
+ * agent_ft + i * ft_step_stride floats (0 = the same buffer every step). */
+int vmas_world_step_n(VmasWorld* w, float* state, float* agent_ft, int64_t ld, int64_t ft_step_stride,
+                      int32_t n_steps, const VmasStepArgs* args /* may be NULL */, void* stream);
+
 /* Batch-global broad phase of World.collides (core.py:2797-2801): mask[p/32] bit
  * p%32 = any_env(|pos_a - pos_b| <= R_a + R_b).  `mask` is zeroed on the stream
  * first.  Only needed for exact small-batch parity; see DESIGN.md. */

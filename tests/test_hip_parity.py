@@ -1,0 +1,264 @@
+"""GPU parity tests: the HIP path (through the C ABI) against
+
+  (1) the committed reference fixtures (tests/golden/*.npz, produced by the reference), and
+  (2) the CPU oracle on the same seeded inputs, at small and at BASELINE.json sizes.
+
+Tolerance: north_star's 1e-5 (abs + rel), plus - only where the oracle MEASURES that a
+1-ulp change of inputs/libm results moves an output by more than that (light jointed
+bodies, see golden_util.ulp_sensitivity) - 8x that measured sensitivity.
+"""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import FIXTURES, compare_state, load, tolerances, ulp_sensitivity
+
+pytestmark = pytest.mark.gpu
+
+LANES = (1, 2, 4, 8, 16, 32, 64)
+
+
+def _hip(spec, B, lanes=0):
+    from vectorizedmultiagentsimulator_amd.backend import HipWorld
+
+    return HipWorld(spec, B, "cuda:0", lanes_per_env=lanes)
+
+
+def _up(hw, state, ft):
+    B = state.shape[-1]
+    hw.state.zero_()
+    hw.agent_ft.zero_()
+    hw.state[:, :, :B].copy_(torch.from_numpy(state))
+    if ft.shape[0]:
+        hw.agent_ft[: ft.shape[0], :, :B].copy_(torch.from_numpy(ft))
+
+
+def _down(hw, B, nA):
+    return hw.state[:, :, :B].cpu().numpy(), hw.agent_ft[:nA, :, :B].cpu().numpy()
+
+
+def _dev(hw, a, B):
+    """numpy [.., B] -> device [.., ld] (per-env optional inputs)"""
+    if a is None:
+        return None
+    t = torch.zeros(*a.shape[:-1], hw.ld, device=hw.state.device, dtype=torch.float32)
+    t[..., :B] = torch.from_numpy(np.ascontiguousarray(a))
+    return t
+
+
+def make_batch(g, B, seed):
+    """A large seeded batch around the fixture's recorded states (so contacts, joints and
+    clamps are active): sample (t, env) columns, jitter poses and forces."""
+    rng = np.random.default_rng(seed)
+    t = rng.integers(0, g.T, B)
+    e = rng.integers(0, g.B, B)
+    st = np.ascontiguousarray(g.state0[t, :, :, e].transpose(1, 2, 0)).astype(np.float32)  # [E,6,B]
+    ft = np.ascontiguousarray(g.ft_in[t, :, :, e].transpose(1, 2, 0)).astype(np.float32)
+    dyn = np.array([(s.flags & 3) != 0 for s in g.spec.entities])
+    noise = rng.normal(0, 1, st.shape).astype(np.float32)
+    scale = np.array([0.01, 0.01, 0.02, 0.02, 0.05, 0.05], np.float32)[None, :, None]
+    st = st + noise * scale * dyn[:, None, None]
+    ft = ft * (1 + 0.1 * rng.normal(0, 1, ft.shape).astype(np.float32))
+    jfr = None if g.jfr is None else np.ascontiguousarray(g.jfr[t, :, e].T).astype(np.float32)
+    eg = None if g.egrav is None else np.ascontiguousarray(g.egrav[t, :, :, e].transpose(1, 2, 0)).astype(np.float32)
+    return st, ft, jfr, eg
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_hip_step_matches_reference_golden(name):
+    """Teacher-forced, one substep at a time, with the reference's recorded broad-phase
+    decisions: HIP must land on the reference's own numbers."""
+    from oracle.oracle import Oracle
+
+    g = load(name)
+    o = Oracle(g.spec)
+    hw = _hip(g.spec, g.B)
+    worst = 0.0
+    for t in range(g.T):
+        ft = np.ascontiguousarray(g.ft_in[t]).copy()
+        st = np.ascontiguousarray(g.state0[t]).copy()
+        jfr_np = None if g.jfr is None else np.ascontiguousarray(g.jfr[t])
+        eg_np = None if g.egrav is None else np.ascontiguousarray(g.egrav[t])
+        jfr, eg = _dev(hw, jfr_np, g.B), _dev(hw, eg_np, g.B)
+        for s in range(g.spec.substeps):
+            if g.sub is not None:
+                st = np.ascontiguousarray(g.sub[t, s]).copy()
+            mask_np = np.ascontiguousarray(g.masks[t, s])
+            kw = dict(pair_mask=mask_np, joint_fixed_rot=jfr_np, entity_gravity=eg_np, first_substep=s, n_substeps=1)
+            sens = ulp_sensitivity(lambda a, b: o.step(a, b, **kw), st, ft)
+            _up(hw, st, ft)
+            mask = torch.from_numpy(mask_np.view(np.int32)).to(hw.state.device)
+            hw.step(pair_mask=mask, joint_fixed_rot=jfr, entity_gravity=eg, first_substep=s, n_substeps=1)
+            st, ft = _down(hw, g.B, g.spec.n_agents)
+            want = g.state1[t] if g.sub is None else g.sub[t, s + 1]
+            worst = max(worst, compare_state(st, want, f"{name}[t={t},s={s}] state", sens=sens, **tolerances(g.spec)))
+        compare_state(ft, g.ft_out[t], f"{name}[t={t}] agent force/torque", atol=1e-6, rtol=1e-6)
+    print(f"{name}: HIP vs reference max abs err {worst:.3e}")
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_hip_matches_oracle_every_lane_count(name):
+    """Full World.step (all substeps fused in one launch, no mask) on a 1000-env seeded
+    batch, for every lanes-per-env geometry, against the oracle."""
+    from oracle.oracle import Oracle
+
+    g = load(name)
+    o = Oracle(g.spec)
+    B = 1000  # deliberately not a multiple of 64: exercises the tail
+    st0, ft0, jfr_np, eg_np = make_batch(g, B, seed=3)
+    kw = dict(joint_fixed_rot=jfr_np, entity_gravity=eg_np)
+    sens = ulp_sensitivity(lambda a, b: o.step(a, b, **kw), st0, ft0)
+    want_s, want_f = st0.copy(), ft0.copy()
+    o.step(want_s, want_f, **kw)
+    for lanes in LANES:
+        try:
+            hw = _hip(g.spec, B, lanes)
+        except Exception as e:  # LDS tile too large for this geometry
+            assert "LDS" in str(e), e
+            continue
+        _up(hw, st0, ft0)
+        pad_before = hw.state[:, :, B:].clone()
+        hw.step(joint_fixed_rot=_dev(hw, jfr_np, B), entity_gravity=_dev(hw, eg_np, B))
+        st, ft = _down(hw, B, g.spec.n_agents)
+        compare_state(st, want_s, f"{name} lanes={lanes} state", sens=sens, **tolerances(g.spec))
+        compare_state(ft, want_f, f"{name} lanes={lanes} agent_ft", atol=1e-6, rtol=1e-6)
+        assert torch.equal(hw.state[:, :, B:], pad_before), "padding columns were written"
+        hw.close()
+
+
+@pytest.mark.parametrize("name", ["balance_n4", "waterfall", "pollock", "soup_solid"])
+def test_hip_is_deterministic(name):
+    g = load(name)
+    st0, ft0, jfr_np, eg_np = make_batch(g, 777, seed=5)
+    outs = []
+    for _ in range(2):
+        hw = _hip(g.spec, 777)
+        _up(hw, st0, ft0)
+        hw.step(joint_fixed_rot=_dev(hw, jfr_np, 777), entity_gravity=_dev(hw, eg_np, 777))
+        outs.append(hw.state.clone())
+    assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_hip_pair_mask_matches_oracle(name):
+    from oracle.oracle import Oracle
+
+    g = load(name)
+    if not g.spec.pairs:
+        pytest.skip("no collidable pairs")
+    o = Oracle(g.spec)
+    hw = _hip(g.spec, g.B)
+    for t in range(g.T):
+        st = np.ascontiguousarray(g.state0[t])
+        _up(hw, st, np.ascontiguousarray(g.ft_in[t]))
+        m = hw.pair_mask().cpu().numpy().view(np.uint32)
+        assert np.array_equal(m[: g.masks.shape[-1]], g.masks[t, 0]), f"{name}[t={t}] vs reference"
+        assert np.array_equal(m, o.pair_mask(st)), f"{name}[t={t}] vs oracle"
+
+
+@pytest.mark.parametrize("name", ["balance_n3", "navigation_n8", "football_5v5", "waterfall", "reverse_transport"])
+def test_hip_step_exact_free_running(name):
+    """step_exact (device broad phase + one substep per launch) over a whole step equals
+    the reference's state1 within the measured multi-substep conditioning."""
+    from oracle.oracle import Oracle
+
+    g = load(name)
+    o = Oracle(g.spec)
+    hw = _hip(g.spec, g.B)
+    for t in range(g.T):
+        st0 = np.ascontiguousarray(g.state0[t]).copy()
+        ft0 = np.ascontiguousarray(g.ft_in[t]).copy()
+        jfr_np = None if g.jfr is None else np.ascontiguousarray(g.jfr[t])
+        sens = ulp_sensitivity(lambda a, b: o.step_exact(a, b, joint_fixed_rot=jfr_np), st0, ft0)
+        _up(hw, st0, ft0)
+        hw.step_exact(joint_fixed_rot=_dev(hw, jfr_np, g.B))
+        st, _ = _down(hw, g.B, g.spec.n_agents)
+        compare_state(st, g.state1[t], f"{name}[t={t}] exact step", sens=sens, **tolerances(g.spec))
+
+
+@pytest.mark.parametrize("name", [n for n in FIXTURES if load(n).lidar is not None])
+def test_hip_lidar_matches_reference_and_oracle(name):
+    from oracle.oracle import Oracle
+
+    g = load(name)
+    o = Oracle(g.spec)
+    hw = _hip(g.spec, g.B)
+    L, R = g.lidar.shape[1], g.lidar.shape[2]
+    for t in range(g.T):
+        st = np.ascontiguousarray(g.state0[t])
+        _up(hw, st, np.ascontiguousarray(g.ft_in[t]))
+        out = hw.cast_rays()[:, :, : g.B].cpu().numpy()
+        compare_state(out[:L, :R], g.lidar[t], f"{name}[t={t}] lidar vs reference", atol=1e-5, rtol=1e-5)
+    # bigger seeded batch vs the oracle
+    B = 3000
+    st0, ft0, _, _ = make_batch(g, B, seed=9)
+    hw = _hip(g.spec, B)
+    _up(hw, st0, ft0)
+    out = hw.cast_rays()[:, :, :B].cpu().numpy()
+    want = o.cast_rays(st0)
+    # a ray grazing a shape flips hit/miss on a 1-ulp change; allow a handful of such rays
+    bad = np.abs(out - want) > 1e-5 + 1e-5 * np.abs(want)
+    assert bad.mean() < 2e-4, f"{name}: {bad.sum()} of {bad.size} rays differ"
+
+
+FULL_SIZE = [  # BASELINE.json configs (per-GPU shard sizes for the 8-GPU ones)
+    ("balance_n4", 32768),
+    ("transport", 16384),
+    ("transport_2pkg", 16384),
+    ("navigation_n8", 65536),
+    ("football_5v5", 16384),
+]
+
+
+@pytest.mark.parametrize("name,B", FULL_SIZE)
+def test_hip_full_size_vs_oracle(name, B):
+    """BASELINE.json batch sizes: one step against the oracle (all envs), then 20
+    free-running steps checking size-independent invariants: static entities untouched,
+    world bounds respected, speed limits respected, everything finite."""
+    from oracle.oracle import Oracle
+
+    g = load(name)
+    o = Oracle(g.spec)
+    st0, ft0, jfr_np, eg_np = make_batch(g, B, seed=11)
+    want_s, want_f = st0.copy(), ft0.copy()
+    o.step(want_s, want_f, joint_fixed_rot=jfr_np, entity_gravity=eg_np, threads=8)
+    hw = _hip(g.spec, B)
+    _up(hw, st0, ft0)
+    hw.step()
+    st, ft = _down(hw, B, g.spec.n_agents)
+    err = np.abs(st - want_s)
+    lim = 1e-5 + 1e-5 * np.abs(want_s)
+    frac = (err > lim).mean()
+    assert frac < 1e-5, f"{name}: {int((err > lim).sum())} of {err.size} values beyond 1e-5 (max {err.max():.2e})"
+    for _ in range(20):
+        hw.step()
+    st, _ = _down(hw, B, g.spec.n_agents)
+    assert np.isfinite(st).all()
+    for i, e in enumerate(g.spec.entities):
+        if not (e.flags & 1):
+            assert np.array_equal(st[i, 0:4], st0[i, 0:4]), f"static entity {e.name} moved"
+        if not (e.flags & 2):
+            assert np.array_equal(st[i, 4:6], st0[i, 4:6]), f"non-rotatable entity {e.name} rotated"
+        if e.flags & 1:
+            if g.spec.x_semidim is not None:
+                assert np.abs(st[i, 0]).max() <= np.float32(g.spec.x_semidim)
+            if g.spec.y_semidim is not None:
+                assert np.abs(st[i, 1]).max() <= np.float32(g.spec.y_semidim)
+            if e.flags & (1 << 4):
+                sp = np.hypot(st[i, 2].astype(np.float64), st[i, 3].astype(np.float64))
+                assert sp.max() <= e.max_speed * (1 + 1e-5)
+
+
+def test_hip_error_paths():
+    from vectorizedmultiagentsimulator_amd.backend import HipWorld, VmasHipError
+
+    g = load("balance_n3")
+    hw = HipWorld(g.spec, 4)
+    with pytest.raises(VmasHipError):
+        hw.set_lanes_per_env(3)
+    with pytest.raises(VmasHipError):
+        hw.step(first_substep=5)
+    with pytest.raises(VmasHipError):
+        hw.cast_rays()
+    with pytest.raises(VmasHipError):
+        HipWorld(g.spec, 0)

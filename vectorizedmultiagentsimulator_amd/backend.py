@@ -1,0 +1,190 @@
+"""``HipWorld`` - the packed, GPU-resident world state and the calls into libvmas_hip.so.
+
+PyTorch is plumbing only: it owns the device buffers and provides the stream.  All
+physics runs in the hand-written HIP kernels behind the C ABI (include/vmas_hip.h);
+there is no torch-op or CPU fallback anywhere in this module.
+
+Packed layout (see include/vmas_hip.h):
+    state[E, 6, ld]     f: pos.x pos.y vel.x vel.y rot ang_vel
+    agent_ft[A, 3, ld]  f: force.x force.y torque
+with the environment index fastest, ``ld`` a multiple of 64.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _abi as A
+from .spec import WorldSpec
+
+
+class VmasHipError(RuntimeError):
+    pass
+
+
+def _round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+class HipWorld:
+    """One world description instantiated for ``batch`` environments on one GPU."""
+
+    def __init__(self, spec: WorldSpec, batch: int, device="cuda:0", lanes_per_env: int = 0,
+                 state: Optional[torch.Tensor] = None, agent_ft: Optional[torch.Tensor] = None):
+        self.lib = A.load_library()  # raises VmasHipLibraryMissing - no fallback
+        self.spec = spec
+        self.batch = int(batch)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise VmasHipError(f"HipWorld needs a GPU device, got {self.device}")
+        if not torch.cuda.is_available():
+            raise VmasHipError("HipWorld: no GPU visible (torch.cuda.is_available() is False)")
+        self.device_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.ld = _round_up(self.batch, 64)
+        self.cdesc = spec.to_ctypes()
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device_index):
+            rc = self.lib.vmas_world_create(C.byref(self.cdesc.world), self.batch, self.device_index, C.byref(handle))
+        if rc != 0:
+            raise VmasHipError(A.last_error())
+        self._h = handle
+        dev = torch.device("cuda", self.device_index)
+        if state is None:
+            state = torch.zeros(spec.n_entities, A.STATE_FIELDS, self.ld, device=dev, dtype=torch.float32)
+        if agent_ft is None:
+            agent_ft = torch.zeros(max(spec.n_agents, 1), A.AGENT_FIELDS, self.ld, device=dev, dtype=torch.float32)
+        # caller-owned packed buffers (core.World) are adopted, not copied
+        assert state.shape == (spec.n_entities, A.STATE_FIELDS, self.ld) and state.is_contiguous()
+        assert agent_ft.shape == (max(spec.n_agents, 1), A.AGENT_FIELDS, self.ld) and agent_ft.is_contiguous()
+        assert state.dtype == torch.float32 and state.device == dev and agent_ft.device == dev
+        self.state, self.agent_ft = state, agent_ft
+        self._mask = torch.zeros(max((len(spec.pairs) + 31) // 32, 1), device=dev, dtype=torch.int32)
+        self._lidar_out: Optional[torch.Tensor] = None
+        if lanes_per_env:
+            self.set_lanes_per_env(lanes_per_env)
+        if spec.lidars:
+            rc = self.lib.vmas_world_set_lidars(self._h, self.cdesc.lidars, len(spec.lidars))
+            if rc != 0:
+                raise VmasHipError(A.last_error())
+            self._lidar_out = torch.zeros(len(spec.lidars), self.cdesc.max_rays, self.ld, device=dev, dtype=torch.float32)
+
+    # ------------------------------------------------------------------ lifecycle
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.vmas_world_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ knobs
+    def set_lanes_per_env(self, lanes: int):
+        if self.lib.vmas_world_set_lanes_per_env(self._h, int(lanes)) != 0:
+            raise VmasHipError(A.last_error())
+
+    @property
+    def lanes_per_env(self) -> int:
+        return self.lib.vmas_world_get_lanes_per_env(self._h)
+
+    def step_bytes_per_env(self) -> int:
+        return int(self.lib.vmas_world_step_bytes_per_env(self._h))
+
+    # ------------------------------------------------------------------ views
+    def pos(self, e: int) -> torch.Tensor:  # [B, 2] view
+        return self.state[e, 0:2, : self.batch].T
+
+    def vel(self, e: int) -> torch.Tensor:
+        return self.state[e, 2:4, : self.batch].T
+
+    def rot(self, e: int) -> torch.Tensor:  # [B, 1] view
+        return self.state[e, 4:5, : self.batch].T
+
+    def ang_vel(self, e: int) -> torch.Tensor:
+        return self.state[e, 5:6, : self.batch].T
+
+    def force(self, a: int) -> torch.Tensor:
+        return self.agent_ft[a, 0:2, : self.batch].T
+
+    def torque(self, a: int) -> torch.Tensor:
+        return self.agent_ft[a, 2:3, : self.batch].T
+
+    # ------------------------------------------------------------------ compute
+    def _stream(self, stream) -> C.c_void_p:
+        s = stream if stream is not None else torch.cuda.current_stream(self.device_index)
+        return C.c_void_p(s.cuda_stream)
+
+    @staticmethod
+    def _dptr(t: Optional[torch.Tensor]):
+        return None if t is None else C.c_void_p(t.data_ptr())
+
+    def step(
+        self,
+        pair_mask: Optional[torch.Tensor] = None,
+        joint_fixed_rot: Optional[torch.Tensor] = None,
+        entity_gravity: Optional[torch.Tensor] = None,
+        first_substep: int = 0,
+        n_substeps: int = 0,
+        stream=None,
+    ) -> None:
+        """World.step() for the whole batch, asynchronous on the (current) stream."""
+        args = A.StepArgs()
+        args.pair_mask = self._dptr(pair_mask)
+        if joint_fixed_rot is not None:
+            assert joint_fixed_rot.shape == (len(self.spec.joints), self.ld) and joint_fixed_rot.is_contiguous()
+        if entity_gravity is not None:
+            assert entity_gravity.shape == (self.spec.n_entities, 2, self.ld) and entity_gravity.is_contiguous()
+        args.joint_fixed_rot = self._dptr(joint_fixed_rot)
+        args.entity_gravity = self._dptr(entity_gravity)
+        args.first_substep, args.n_substeps = first_substep, n_substeps
+        rc = self.lib.vmas_world_step(
+            self._h, self._dptr(self.state), self._dptr(self.agent_ft), self.ld, C.byref(args), self._stream(stream)
+        )
+        if rc != 0:
+            raise VmasHipError(A.last_error())
+
+    def step_n(self, n_steps: int, forces: Optional[torch.Tensor] = None, stream=None) -> None:
+        """``n_steps`` World.step() launches enqueued from C.  ``forces`` [n_steps, A, 3, ld]
+        (packed like ``agent_ft``) supplies per-step agent forces; None re-uses ``agent_ft``."""
+        if forces is not None:
+            assert forces.shape == (n_steps,) + tuple(self.agent_ft.shape) and forces.is_contiguous()
+            assert forces.device == self.agent_ft.device and forces.dtype == torch.float32
+            ft, stride = forces, self.agent_ft.numel()
+        else:
+            ft, stride = self.agent_ft, 0
+        rc = self.lib.vmas_world_step_n(
+            self._h, self._dptr(self.state), self._dptr(ft), self.ld, stride, int(n_steps), None, self._stream(stream)
+        )
+        if rc != 0:
+            raise VmasHipError(A.last_error())
+
+    def pair_mask(self, stream=None) -> torch.Tensor:
+        """Batch-global broad phase of World.collides on the current state."""
+        rc = self.lib.vmas_world_pair_mask(
+            self._h, self._dptr(self.state), self.ld, self._dptr(self._mask), self._stream(stream)
+        )
+        if rc != 0:
+            raise VmasHipError(A.last_error())
+        return self._mask
+
+    def step_exact(self, joint_fixed_rot=None, entity_gravity=None, stream=None) -> None:
+        """World.step() with the reference's batch-global broad phase re-evaluated at
+        every substep (2 launches per substep; parity mode)."""
+        for s in range(self.spec.substeps):
+            m = self.pair_mask(stream)
+            self.step(m, joint_fixed_rot, entity_gravity, s, 1, stream)
+
+    def cast_rays(self, stream=None) -> torch.Tensor:
+        """World.cast_rays for every registered Lidar: [n_lidars, max_rays, ld]."""
+        if self._lidar_out is None:
+            raise VmasHipError("this world has no Lidar sensors")
+        rc = self.lib.vmas_world_cast_rays(
+            self._h, self._dptr(self.state), self.ld, self._dptr(self._lidar_out), self._stream(stream)
+        )
+        if rc != 0:
+            raise VmasHipError(A.last_error())
+        return self._lidar_out

@@ -1,0 +1,212 @@
+// vmas_device.h - device-side math of the VMAS physics step for gfx950 (CDNA4).
+//
+// Every function restates one reference routine (paths relative to
+// /root/reference/vmas/simulator/) with the reference's operation ORDER, in IEEE fp32
+// with FMA contraction off (build flag -ffp-contract=off).  The one fused operation is
+// the 2-vector norm: torch's CPU `linalg.vector_norm` over a size-2 dim is bitwise
+// sqrt(fma(y, y, x*x)), so that is what norm2() computes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vmas {
+
+#define VD __device__ __forceinline__
+
+constexpr float kLineMinDist = (float)(4.0 / 6e2);                         // utils.py:28
+constexpr float kHalfPi = (float)(3.14159265358979323846 / 2.0);           // torch.pi / 2 -> fp32
+constexpr float kInf = __builtin_huge_valf();
+
+struct v2 { float x, y; };
+VD v2 V(float x, float y) { v2 r; r.x = x; r.y = y; return r; }
+VD v2 operator+(v2 a, v2 b) { return V(a.x + b.x, a.y + b.y); }
+VD v2 operator-(v2 a, v2 b) { return V(a.x - b.x, a.y - b.y); }
+VD v2 operator-(v2 a) { return V(-a.x, -a.y); }
+VD float norm2(float x, float y) { return __fsqrt_rn(__fmaf_rn(y, y, x * x)); }
+VD float vnorm(v2 a) { return norm2(a.x, a.y); }
+VD float vdot(v2 a, v2 b) { return a.x * b.x + a.y * b.y; }               // (a*b).sum(-1)
+VD float vcross(v2 a, v2 b) { return a.x * b.y - a.y * b.x; }             // utils.py:193-197
+VD float sign_t(float x) { return x != x ? x : (float)((x > 0.f) - (x < 0.f)); }  // torch.sign
+VD float min_t(float a, float b) { return a != a ? a : (b != b ? b : (a < b ? a : b)); }  // NaN-propagating
+VD float max_t(float a, float b) { return a != a ? a : (b != b ? b : (a > b ? a : b)); }
+VD float clamp_t(float x, float r) { return x != x ? x : (x < -r ? -r : (x > r ? r : x)); }
+VD v2 rotate(v2 v, float c, float s) { return V(v.x * c - v.y * s, v.x * s + v.y * c); }  // utils.py:175-191
+
+// TorchUtils.clamp_with_norm utils.py:167-173
+VD v2 clamp_with_norm(v2 t, float max_norm) {
+  float n = vnorm(t);
+  v2 nt = V((t.x / n) * max_norm, (t.y / n) * max_norm);
+  return n > max_norm ? nt : t;
+}
+
+// torch.logaddexp(0, x): max(0, x) + log1p(exp(-|x|))
+VD float softplus0(float x) { return max_t(0.f, x) + log1pf(expf(-fabsf(0.f - x))); }
+
+// World._get_constraint_forces core.py:2805-2839 -> force on a (force on b is -f).
+// `c` = fp32(sign * force_multiplier), precomputed on the host like Python does.
+template <bool ATTRACTIVE>
+VD v2 constraint_force(v2 pa, v2 pb, float dist_min, float c, float k) {
+  v2 d = pa - pb;
+  float dist = vnorm(d);
+  float sign = ATTRACTIVE ? -1.f : 1.f;
+  float pen = softplus0((dist_min - dist) * sign / k) * k;
+  float den = dist > 0.f ? dist : 1e-8f;
+  v2 f = V(c * d.x / den * pen, c * d.y / den * pen);
+  bool zero = dist < 1e-6f;
+  zero = zero || (ATTRACTIVE ? (dist < dist_min) : (dist > dist_min));
+  return zero ? V(0.f, 0.f) : f;
+}
+
+// World._get_constraint_torques core.py:2841-2858 -> torque on b (torque on a is -t)
+VD float constraint_torque(float rot_a, float rot_b, float force_multiplier) {
+  float delta = rot_a - rot_b;
+  float ad = fabsf(delta);
+  float pen = expf(ad) - 1.f;
+  float t = force_multiplier * sign_t(delta) * pen;
+  return ad < 1e-9f ? 0.f : t;
+}
+
+// physics._get_closest_point_line physics.py:400-429; (c, s) = cos/sin(line_rot)
+template <bool LIMIT>
+VD v2 closest_point_line(v2 pos, float c, float s, float half_len, v2 p) {
+  v2 d = pos - p;
+  float dot = d.x * c + d.y * s;
+  float sg = sign_t(dot);
+  float m = fabsf(dot);
+  if (LIMIT) m = min_t(m, half_len);
+  float t = sg * m;
+  return V(pos.x - t * c, pos.y - t * s);
+}
+
+struct seg_t { v2 pos; float c, s, half; };  // centre, cos/sin(rot), half length
+
+// physics._get_all_lines_box physics.py:298-325; (c,s) = cos/sin(rot), (c2,s2) = cos/sin(rot + pi/2)
+VD void box_edges(v2 pos, float c, float s, float c2, float s2, float length, float width, seg_t e[4]) {
+  float hl = length / 2.f, hw = width / 2.f;
+  e[0].pos = V(pos.x + c * hl, pos.y + s * hl);
+  e[1].pos = V(pos.x - c * hl, pos.y - s * hl);
+  e[2].pos = V(pos.x + c2 * hw, pos.y + s2 * hw);
+  e[3].pos = V(pos.x - c2 * hw, pos.y - s2 * hw);
+  e[0].c = e[1].c = c2; e[0].s = e[1].s = s2; e[0].half = e[1].half = hw;
+  e[2].c = e[3].c = c;  e[2].s = e[3].s = s;  e[2].half = e[3].half = hl;
+}
+
+// physics._get_closest_point_box physics.py:263-295
+VD v2 closest_point_box(const seg_t e[4], v2 p) {
+  v2 best = V(kInf, kInf);
+  float dist = kInf;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v2 q = closest_point_line<true>(e[i].pos, e[i].c, e[i].s, e[i].half, p);
+    float d = vnorm(p - q);
+    bool cl = d < dist;
+    best = cl ? q : best;
+    dist = cl ? d : dist;
+  }
+  return best;
+}
+
+// physics._get_inner_point_box physics.py:13-23
+VD v2 inner_point_box(v2 outside, v2 surface, v2 box_pos, float& depth) {
+  v2 v = surface - outside;
+  v2 u = box_pos - surface;
+  float n = vnorm(v);
+  float xm = vdot(v, u) / n;
+  v2 x = V((v.x / n) * xm, (v.y / n) * xm);
+  bool z = n == 0.f;
+  x = z ? surface : x;
+  xm = z ? 0.f : xm;
+  depth = fabsf(xm);
+  return surface + x;
+}
+
+// physics._get_closest_points_line_line physics.py:144-219 (+132-141, 222-260)
+VD void closest_points_seg_seg(const seg_t& l1, const seg_t& l2, v2& p1, v2& p2) {
+  v2 xy1 = V(l1.half * l1.c, l1.half * l1.s);
+  v2 xy2 = V(l2.half * l2.c, l2.half * l2.s);
+  v2 a1 = l1.pos + xy1, a2 = l1.pos - xy1;
+  v2 b1 = l2.pos + xy2, b2 = l2.pos - xy2;
+  v2 r = a2 - a1, s = b2 - b1, qp = b1 - a1;
+  float cqpr = vcross(qp, r), cqps = vcross(qp, s), crs = vcross(r, s);
+  float u = cqpr / crs, t = cqps / crs;
+  bool hit = (crs != 0.f) && (0.f <= u) && (u <= 1.f) && (0.f <= t) && (t <= 1.f);
+  v2 pi = V(a1.x + t * r.x, a1.y + t * r.y);
+  v2 q1 = V(kInf, kInf), q2 = V(kInf, kInf);
+  float best = kInf;
+  {
+    v2 c2 = closest_point_line<true>(l2.pos, l2.c, l2.s, l2.half, a1);
+    float d = vnorm(a1 - c2);
+    bool cl = d < best; q1 = cl ? a1 : q1; q2 = cl ? c2 : q2; best = cl ? d : best;
+  }
+  {
+    v2 c2 = closest_point_line<true>(l2.pos, l2.c, l2.s, l2.half, a2);
+    float d = vnorm(a2 - c2);
+    bool cl = d < best; q1 = cl ? a2 : q1; q2 = cl ? c2 : q2; best = cl ? d : best;
+  }
+  {
+    v2 c1 = closest_point_line<true>(l1.pos, l1.c, l1.s, l1.half, b1);
+    float d = vnorm(c1 - b1);
+    bool cl = d < best; q1 = cl ? c1 : q1; q2 = cl ? b1 : q2; best = cl ? d : best;
+  }
+  {
+    v2 c1 = closest_point_line<true>(l1.pos, l1.c, l1.s, l1.half, b2);
+    float d = vnorm(c1 - b2);
+    bool cl = d < best; q1 = cl ? c1 : q1; q2 = cl ? b2 : q2; best = cl ? d : best;
+  }
+  p1 = hit ? pi : q1;
+  p2 = hit ? pi : q2;
+}
+
+// physics._get_closest_line_box physics.py:328-382 -> (on box, on line)
+VD void closest_seg_box(const seg_t be[4], const seg_t& line, v2& p_box, v2& p_line) {
+  v2 qb = V(kInf, kInf), ql = V(kInf, kInf);
+  float best = kInf;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v2 pb, pl;
+    closest_points_seg_seg(be[i], line, pb, pl);
+    float d = vnorm(pb - pl);
+    bool cl = d < best;
+    qb = cl ? pb : qb; ql = cl ? pl : ql; best = cl ? d : best;
+  }
+  p_box = qb; p_line = ql;
+}
+
+// physics._get_closest_box_box physics.py:26-129 -> (on A, on B)
+VD void closest_box_box(const seg_t ea[4], const seg_t eb[4], v2& pa, v2& pb) {
+  v2 qa = V(kInf, kInf), qb = V(kInf, kInf);
+  float best = kInf;
+  for (int i = 0; i < 4; ++i) {  // A's edges against box B -> (on B, on A's edge)
+    v2 on_b, on_a;
+    closest_seg_box(eb, ea[i], on_b, on_a);
+    float d = vnorm(on_a - on_b);
+    bool cl = d < best;
+    qa = cl ? on_a : qa; qb = cl ? on_b : qb; best = cl ? d : best;
+  }
+  for (int i = 0; i < 4; ++i) {  // B's edges against box A -> (on A, on B's edge)
+    v2 on_a, on_b;
+    closest_seg_box(ea, eb[i], on_a, on_b);
+    float d = vnorm(on_a - on_b);
+    bool cl = d < best;
+    qa = cl ? on_a : qa; qb = cl ? on_b : qb; best = cl ? d : best;
+  }
+  pa = qa; pb = qb;
+}
+
+// get_friction_force core.py:2055-2073
+VD v2 friction2(v2 vel, float coeff, float mass, float sub_dt) {
+  float speed = vnorm(vel);
+  float ffc = coeff * mass;
+  v2 f;
+  f.x = -(vel.x / speed) * min_t(ffc, (fabsf(vel.x) / sub_dt) * mass);
+  f.y = -(vel.y / speed) * min_t(ffc, (fabsf(vel.y) / sub_dt) * mass);
+  return speed == 0.f ? V(0.f, 0.f) : f;
+}
+VD float friction1(float vel, float coeff, float inertia, float sub_dt) {
+  float speed = fabsf(vel);
+  float ffc = coeff * inertia;
+  float f = -(vel / speed) * min_t(ffc, (fabsf(vel) / sub_dt) * inertia);
+  return speed == 0.f ? 0.f : f;
+}
+
+}  // namespace vmas
