@@ -422,12 +422,30 @@ static void step_env(const VmasWorldDesc* W, float* state, float* agent_ft, int6
     }
 
     /* ---- collisions core.py:2294-2786, type-major order ---- */
-    for (int p = 0; p < W->n_pairs; ++p) {
-      if (args && args->pair_mask && !((args->pair_mask[p >> 5] >> (p & 31)) & 1u)) continue;
-      v2 fa, fb;
-      float ta, tb;
-      pair_force(W, S, p, &fa, &ta, &fb, &tb);
-      upd(E, F, T, W->pairs[p].a, fa, ta, W->pairs[p].b, fb, tb);
+    {
+      /* jitter mode also permutes the ACCUMULATION order (the HIP path adds pair forces
+       * with LDS atomics from several lanes, so its order is not the reference's):
+       * p -> (p * stride + offset) mod n with gcd(stride, n) = 1. */
+      int n = W->n_pairs;
+      int64_t stride = 1, offset = 0;
+      if (g_jitter && n > 1) {
+        offset = (g_jitter >> 3) % n;
+        stride = 1 + (g_jitter >> 9) % (n - 1);
+        for (;;) {
+          int64_t a = stride, b = n;
+          while (b) { int64_t t = a % b; a = b; b = t; }
+          if (a == 1) break;
+          stride = stride % (n - 1) + 1;
+        }
+      }
+      for (int i = 0; i < n; ++i) {
+        int p = (int)(((int64_t)i * stride + offset) % n);
+        if (args && args->pair_mask && !((args->pair_mask[p >> 5] >> (p & 31)) & 1u)) continue;
+        v2 fa, fb;
+        float ta, tb;
+        pair_force(W, S, p, &fa, &ta, &fb, &tb);
+        upd(E, F, T, W->pairs[p].a, fa, ta, W->pairs[p].b, fb, tb);
+      }
     }
 
     /* ---- _integrate_state core.py:2862-2908 ---- */

@@ -136,7 +136,8 @@ def test_hip_is_deterministic(name):
         _up(hw, st0, ft0)
         hw.step(joint_fixed_rot=_dev(hw, jfr_np, 777), entity_gravity=_dev(hw, eg_np, 777))
         outs.append(hw.state.clone())
-    assert torch.equal(outs[0], outs[1])
+    # bitwise (NaNs of blown-up environments included)
+    assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
 
 
 @pytest.mark.parametrize("name", FIXTURES)

@@ -89,6 +89,7 @@ struct Tile {
   float* af;  // [nA*3][EPB]  force.x force.y torque
   float* tr;  // [nE*4][EPB]  cos(rot) sin(rot) cos(rot+pi/2) sin(rot+pi/2)
   float* fa;  // [nE*3][EPB]  force.x force.y torque accumulators
+  int* bad;   // [EPB]        env has a non-finite pos/rot: no broad-phase skipping (NaN parity)
 };
 
 // ------------------------------------------------------------------------------------
@@ -108,6 +109,7 @@ __global__ __launch_bounds__(256) void step_kernel(DevWorld W, float* __restrict
   T.af = T.st + nE * 6 * EPB;
   T.tr = T.af + nA * 3 * EPB;
   T.fa = T.tr + nE * 4 * EPB;
+  T.bad = (int*)(T.fa + nE * 3 * EPB);
   const long env0 = (long)blockIdx.x * EPB;
 
   // ---- HBM -> LDS: every wave instruction reads one contiguous run of a plane ----
@@ -117,6 +119,7 @@ __global__ __launch_bounds__(256) void step_kernel(DevWorld W, float* __restrict
     const bool ok = env < batch;
     for (int r = r0; r < nE * 6; r += G) T.st[r * EPB + col] = ok ? state[r * ld + env] : 0.f;
     for (int r = r0; r < nA * 3; r += G) T.af[r * EPB + col] = ok ? agent_ft[r * ld + env] : 0.f;
+    if (r0 == 0) T.bad[col] = 0;
   }
   __syncthreads();
 
@@ -137,6 +140,11 @@ __global__ __launch_bounds__(256) void step_kernel(DevWorld W, float* __restrict
     for (int e = g; e < nE; e += G) {
       const DevEntity D = W.ent[e];
       const uint32_t fl = D.flags;
+      {  // the reference lets a non-finite entity poison every pair it is in, however far
+         // apart (cos(inf) = NaN): such environments must not use the distance skip
+        const float px = ST(e, 0), py = ST(e, 1), rt = ST(e, 4);
+        if (!(fabsf(px) < kInf) || !(fabsf(py) < kInf) || !(fabsf(rt) < kInf)) T.bad[el] = 1;
+      }
       if (D.shape != VMAS_SHAPE_SPHERE) {  // the only trig the narrow phase needs
         const float rot = ST(e, 4);
         TR(e, 0) = cosf(rot);
@@ -190,6 +198,7 @@ __global__ __launch_bounds__(256) void step_kernel(DevWorld W, float* __restrict
     __syncthreads();
 
     // ================= phase B: joints, then collision pairs (core.py:2104-2189)
+    const bool may_skip = T.bad[el] == 0;
     for (int ti = g; ti < W.nT; ti += G) {
       const DevTask K = W.task[ti];
       const int a = K.a, b = K.b;
@@ -217,7 +226,7 @@ __global__ __launch_bounds__(256) void step_kernel(DevWorld W, float* __restrict
         if (args.pair_mask && !((args.pair_mask[K.index >> 5] >> (K.index & 31)) & 1u)) continue;
         {  // per-environment conservative broad phase: beyond this no force can be non-zero
           const float dx = pa.x - pb.x, dy = pa.y - pb.y;
-          if (dx * dx + dy * dy > K.thr2) continue;
+          if (may_skip && dx * dx + dy * dy > K.thr2) continue;
         }
         switch (K.type) {
           case VMAS_PAIR_SS: {  // core.py:2294-2339; p0 = r_a + r_b
@@ -637,7 +646,7 @@ int vmas_world_create(const VmasWorldDesc* d, int32_t batch, int32_t device_id, 
   W.c_joint_att = -d->joint_force;    // sign = -1
   W.c_joint_rep = d->joint_force;
   W.ent = w->d_ent; W.task = w->d_task;
-  w->lds_rows = (size_t)W.nE * (6 + 4 + 3) + (size_t)W.nA * 3;
+  w->lds_rows = (size_t)W.nE * (6 + 4 + 3) + (size_t)W.nA * 3 + 1;
   w->lanes = default_lanes(W.nT, W.nE, batch);
   // a tile must fit the 160 KiB LDS of a CU (64 KiB is the default dynamic limit)
   while (w->lanes < 64 && w->lds_rows * (256 / w->lanes) * sizeof(float) > 64 * 1024) w->lanes <<= 1;
