@@ -15,7 +15,7 @@ from golden_util import FIXTURES, compare_state, load, tolerances, ulp_sensitivi
 
 pytestmark = pytest.mark.gpu
 
-LANES = (1, 2, 4, 8, 16, 32, 64)
+LANES = (1, 2, 3, 4, 6, 8)  # waves per 64-env tile
 
 
 def _hip(spec, B, lanes=0):
@@ -50,8 +50,15 @@ def make_batch(g, B, seed):
     """A large seeded batch around the fixture's recorded states (so contacts, joints and
     clamps are active): sample (t, env) columns, jitter poses and forces."""
     rng = np.random.default_rng(seed)
-    t = rng.integers(0, g.T, B)
-    e = rng.integers(0, g.B, B)
+    # only columns whose recorded state is sane: the soup fixtures contain environments the
+    # REFERENCE itself blew up (|x| ~ 1e24, inf, NaN).  Their NaN/inf propagation is pinned by
+    # the teacher-forced golden test above; in a tolerance comparison they are meaningless
+    # (any reordering of an 1e24-sized sum moves the result by more than the state itself).
+    with np.errstate(invalid="ignore"):
+        sane = np.isfinite(g.state0).all(axis=(1, 2)) & (np.abs(g.state0) < 50).all(axis=(1, 2))  # [T, B]
+    cols = np.argwhere(sane)
+    pick = cols[rng.integers(0, len(cols), B)]
+    t, e = pick[:, 0], pick[:, 1]
     st = np.ascontiguousarray(g.state0[t, :, :, e].transpose(1, 2, 0)).astype(np.float32)  # [E,6,B]
     ft = np.ascontiguousarray(g.ft_in[t, :, :, e].transpose(1, 2, 0)).astype(np.float32)
     dyn = np.array([(s.flags & 3) != 0 for s in g.spec.entities])
@@ -104,7 +111,7 @@ def test_hip_matches_oracle_every_lane_count(name):
 
     g = load(name)
     o = Oracle(g.spec)
-    B = 1000  # deliberately not a multiple of 64: exercises the tail
+    B = 1000  # deliberately not a multiple of 64: exercises the tail tile
     st0, ft0, jfr_np, eg_np = make_batch(g, B, seed=3)
     kw = dict(joint_fixed_rot=jfr_np, entity_gravity=eg_np)
     sens = ulp_sensitivity(lambda a, b: o.step(a, b, **kw), st0, ft0)
@@ -256,7 +263,7 @@ def test_hip_error_paths():
     g = load("balance_n3")
     hw = HipWorld(g.spec, 4)
     with pytest.raises(VmasHipError):
-        hw.set_lanes_per_env(3)
+        hw.set_lanes_per_env(9)
     with pytest.raises(VmasHipError):
         hw.step(first_substep=5)
     with pytest.raises(VmasHipError):

@@ -1,32 +1,46 @@
 // vmas_hip.hip - MI355X (gfx950 / CDNA4) implementation of the C ABI in include/vmas_hip.h.
 //
 // One fused kernel advances ALL substeps of World.step() (core.py:1972-2015) for a tile
-// of environments:
+// of 64 environments:
 //
-//   HBM (SoA planes, env fastest)  --coalesced row copy-->  LDS tile [row][env]
-//   per substep, out of LDS:   A  entity lanes : trig + action/friction/gravity prologue
-//                              B  task lanes   : joints, then pairs (narrow phase +
-//                                                penalty force), ds_add_f32 into the
-//                                                per-entity force/torque accumulators
-//                              C  entity lanes : semi-implicit Euler + clamps
-//   LDS tile  --coalesced row copy (dynamic rows only)-->  HBM
+//   HBM (SoA planes, env fastest) --coalesced 256-B rows--> LDS tile [row][64 envs]
+//   once      : trig of every Line/Box entity, "non-finite environment" flag
+//   per substep, out of LDS, no HBM traffic:
+//     B  gather : for every dynamic entity, its prologue force (action/friction/gravity)
+//                 plus the force of every incident joint/pair, accumulated IN THE
+//                 REFERENCE'S ORDER in registers, written to a partial-sum row
+//     C  integrate : semi-implicit Euler + clamps, new trig for the next substep
+//   LDS tile --coalesced rows (dynamic planes only)--> HBM
 //
-// Work decomposition: G lanes cooperate on one environment (template parameter, power
-// of two, 1..64).  A 64-wide wavefront therefore carries 64/G environments; lane l owns
-// environment (l % (64/G)) of its wave and is "worker" g = l / (64/G) inside it.
-// Entities (phases A, C) and tasks (phase B) are dealt round-robin to the G workers.
-// Every environment of a batch has the SAME static world, so lanes with equal g execute
-// the same task type in lock-step: divergence only arises between the G workers, and the
-// task list is type-major (joints, SS, LS, LL, BS, BL, BB - also the reference's
-// accumulation order) so neighbouring workers mostly share a type too.
+// Work decomposition ("one wavefront lane per environment, W wavefronts per tile"):
+//   * lane l of every wave of a block is environment l of the block's 64-env tile, so
+//     EVERYTHING else - which entity, which pair, which shape code, every branch - is
+//     wave-uniform: descriptors live in SGPRs (scalar loads), there is no divergence,
+//     and LDS rows are read 64 consecutive floats at a time (conflict-free).
+//   * the W waves of a block split the tile's work by (entity, incident pair) ITEMS:
+//     each dynamic entity's item list (joints, SS, LS, LL, BS, BL, BB - the reference's
+//     accumulation order, core.py:2176-2189) is cut into segments, segments are dealt to
+//     waves by longest-processing-time-first with a per-type cost model.  A segment sums
+//     into its own LDS row, the entity's owner adds the rows in order: no atomics, bitwise
+//     deterministic, and with one segment per entity it IS the reference's sum order.
+//   * a pair of two dynamic entities is evaluated once per side ("owner computes"); that
+//     re-evaluation is cheaper than cross-wave atomics + the barrier they would need and
+//     keeps the accumulation order fixed.
+//   * per-environment conservative broad phase (bounding circle, or oriented-box distance
+//     for boxes) in front of every narrow phase; a wave skips an item when none of its 64
+//     environments needs it.
 //
-// No MFMA: the path is fp32 elementwise/transcendental work with a 2-vector inner
-// dimension; nothing here is a contraction (BASELINE.json north_star).
+// No MFMA: fp32 elementwise/transcendental work on 2-vectors; nothing is a contraction
+// (BASELINE.json north_star).  The roofline that bounds it is HBM (384 B per env-step for
+// `balance`), see DESIGN.md.
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
+#include <map>
+#include <numeric>
 #include <vector>
 
 #include "../../include/vmas_hip.h"
@@ -35,45 +49,67 @@
 using namespace vmas;
 
 // ------------------------------------------------------------------------------------
-// device-side constant block
+// device-side constant block (all wave-uniform => scalar loads)
 // ------------------------------------------------------------------------------------
-enum : uint32_t {
-  GATE_A_MOV = 1u << 0, GATE_A_ROT = 1u << 1, GATE_B_MOV = 1u << 2, GATE_B_ROT = 1u << 3,
-  GATE_A_HOLLOW = 1u << 4, GATE_B_HOLLOW = 1u << 5, GATE_LOCK = 1u << 6 /* joint: rotate == False */
+constexpr int TILE = 64;       // environments per block = lanes per wave
+constexpr int MAX_WAVES = 8;   // waves (workers) per tile
+constexpr int TASK_JOINT = 6;  // item type next to VMAS_PAIR_*
+
+enum : uint32_t { IT_A_HOLLOW = 1u << 0, IT_B_HOLLOW = 1u << 1, IT_LOCK = 1u << 2 /* joint rotate == False */ };
+
+// One evaluation of a joint/pair FOR ONE SIDE of it.  Static data pre-resolved on the host
+// with the same fp32 operations the reference performs at run time.
+struct DevItem {
+  int32_t type;   // VMAS_PAIR_* or TASK_JOINT
+  int32_t a, b;   // entities in the role order the reference passes them
+  int32_t side;   // 0: accumulate the force on a, 1: on b
+  uint32_t flags; // IT_*
+  int32_t index;  // pair index (mask bit) or joint index (per-env fixed-rotation row)
+  int32_t tra, trb;  // first trig row of a / b (-1: sphere)
+  float thr2;     // (R_a + R_b + LINE_MIN_DIST + slack)^2: bounding-circle skip
+  float reach;    // box items: the other shape's reach + LINE_MIN_DIST + slack (OBB skip)
+  float p0, p1, p2, p3, q0, q1;  // type-specific dims, see build_items()
 };
 
-// One unit of phase-B work, everything static pre-resolved on the host (fp32 ops done
-// exactly as the reference does them at run time).
-struct DevTask {
-  int32_t a, b;
-  int32_t type;   // VMAS_PAIR_* or TASK_JOINT
-  uint32_t gate;  // GATE_*
-  float thr2;     // pairs: (R_a + R_b + LINE_MIN_DIST + slack)^2, per-env conservative skip
-  float p0, p1, p2, p3;  // type-specific dims, see build_tasks()
-  float q0, q1;          // joints: delta_b
-  int32_t index;         // pair index (mask bit) or joint index (per-env fixed_rot row)
+struct DevSegment {
+  int32_t entity;
+  int32_t item_begin, item_end;
+  int32_t first;     // 1: this segment starts from the entity's prologue force
+  int32_t part_row;  // first of 3 partial-sum rows (fx, fy, torque)
 };
-constexpr int TASK_JOINT = 6;
+
+struct DevOwned {  // phase C work unit
+  int32_t entity;
+  int32_t part_row, n_parts;  // partial rows of the entity's segments, in order
+};
 
 struct DevEntity {
   uint32_t flags;
   int32_t shape;
   int32_t agent_index;
+  int32_t tr_row;  // first of 4 trig rows, -1 for spheres
   float mass, inertia, one_minus_drag;
   float max_speed, v_range, lin_friction, ang_friction;
-  float gx, gy;  // constant entity gravity
+  float gx, gy;
   float max_f, f_range, max_t, t_range;
 };
 
 struct DevWorld {
-  int32_t nE, nA, nT, nJ, substeps;
+  int32_t nE, nA, substeps;
+  int32_t row_af, row_tr, row_part, row_bad;  // first LDS row of each region (state starts at 0)
   float sub_dt, gx, gy;
   int32_t has_gravity;
   float xs, ys;  // NaN = unbounded
-  float k, tcf;  // contact_margin, torque_constraint_force
+  float k, tcf;
   float c_coll, c_joint_att, c_joint_rep;  // fp32(sign * force_multiplier)
   const DevEntity* ent;
-  const DevTask* task;
+  const DevItem* items;
+  const DevSegment* segs;
+  const int32_t* wave_seg;  // [W+1] segment ranges per wave
+  const DevOwned* owned;
+  const int32_t* wave_own;  // [W+1] owned-entity ranges per wave
+  const int32_t* trig_ent;  // entities with trig rows
+  int32_t n_trig;
 };
 
 struct DevStepArgs {
@@ -83,232 +119,269 @@ struct DevStepArgs {
   int32_t first_substep, n_substeps;
 };
 
-// rows of the LDS tile
-struct Tile {
-  float* st;  // [nE*6][EPB]  pos.x pos.y vel.x vel.y rot ang_vel
-  float* af;  // [nA*3][EPB]  force.x force.y torque
-  float* tr;  // [nE*4][EPB]  cos(rot) sin(rot) cos(rot+pi/2) sin(rot+pi/2)
-  float* fa;  // [nE*3][EPB]  force.x force.y torque accumulators
-  int* bad;   // [EPB]        env has a non-finite pos/rot: no broad-phase skipping (NaN parity)
-};
+#define ROW(r) lds[(r) * TILE + lane]
+#define ST(e, f) ROW((e) * 6 + (f))
+#define AF(a, f) ROW(W.row_af + (a) * 3 + (f))
+#define TR(base, f) ROW(W.row_tr + (base) + (f))
+
+__device__ __forceinline__ int sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// cos/sin of the rotation(s) the narrow phase needs (physics.py:300-302, 413)
+__device__ __forceinline__ void write_trig(float* lds, const DevWorld& W, int lane, int e, const DevEntity& D) {
+  const float rot = ST(e, 4);
+  TR(D.tr_row, 0) = cosf(rot);
+  TR(D.tr_row, 1) = sinf(rot);
+  if (D.shape == VMAS_SHAPE_BOX) {
+    const float rot2 = rot + kHalfPi;
+    TR(D.tr_row, 2) = cosf(rot2);
+    TR(D.tr_row, 3) = sinf(rot2);
+  }
+}
+
+// squared distance from point p to the solid oriented box (centre c, axes (cs,sn)), 0 inside
+__device__ __forceinline__ float obb_dist2(v2 p, v2 c, float cs, float sn, float half_l, float half_w) {
+  const float dx = p.x - c.x, dy = p.y - c.y;
+  const float lx = fabsf(dx * cs + dy * sn) - half_l;
+  const float ly = fabsf(dy * cs - dx * sn) - half_w;
+  const float ex = fmaxf(lx, 0.f), ey = fmaxf(ly, 0.f);
+  return ex * ex + ey * ey;
+}
+
+// Force (and torque) one item contributes to ITS side.  LEVEL prunes code (and registers):
+// 0: SS LS BS   1: + LL BL joints   2: + BB
+template <int LEVEL>
+__device__ __forceinline__ void eval_item(const DevItem& K, const DevWorld& W, const DevStepArgs& args, float* lds,
+                                          int lane, long env, int batch, long ld, bool may_skip, v2& f_out,
+                                          float& t_out) {
+  const int a = K.a, b = K.b;
+  const v2 pa = V(ST(a, 0), ST(a, 1)), pb = V(ST(b, 0), ST(b, 1));
+  v2 fa = V(0.f, 0.f), fb = V(0.f, 0.f);
+  float ta = 0.f, tb = 0.f;
+  const float k = W.k;
+  if (LEVEL >= 1 && K.type == TASK_JOINT) {  // _vectorized_joint_constraints core.py:2201-2292
+    const float ra = ST(a, 4), rb = ST(b, 4);
+    const v2 pja = pa + rotate(V(K.p0, K.p1), cosf(ra), sinf(ra));  // joints.py:209-216
+    const v2 pjb = pb + rotate(V(K.q0, K.q1), cosf(rb), sinf(rb));
+    const v2 f_att = constraint_force<true>(pja, pjb, K.p2, W.c_joint_att, k);
+    const v2 f_rep = constraint_force<false>(pja, pjb, K.p2, W.c_joint_rep, k);
+    fa = f_att + f_rep;
+    fb = (-f_att) + (-f_rep);
+    ta = vcross(pja - pa, fa);
+    tb = vcross(pjb - pb, fb);
+    if (K.flags & IT_LOCK) {
+      float fr = K.p3;
+      if (args.joint_fixed_rot && env < batch) fr = args.joint_fixed_rot[(long)K.index * ld + env];
+      const float t = constraint_torque(ra, rb + fr, W.tcf);
+      ta = ta + (-t);
+      tb = tb + t;
+    }
+  } else {
+    if (args.pair_mask && !((args.pair_mask[K.index >> 5] >> (K.index & 31)) & 1u)) return;
+    {  // conservative per-environment broad phase: beyond it the force is exactly zero
+      const float dx = pa.x - pb.x, dy = pa.y - pb.y;
+      bool need = !(dx * dx + dy * dy > K.thr2);
+      if (K.type >= VMAS_PAIR_BS && need) {  // a is a box: oriented-box distance is much tighter
+        const float d2 = obb_dist2(pb, pa, TR(K.tra, 0), TR(K.tra, 1), K.p0 * 0.5f, K.p1 * 0.5f);
+        need = !(d2 > K.reach * K.reach);
+      }
+      need = need || !may_skip;
+      if (!__any(need)) return;
+    }
+    switch (K.type) {
+      case VMAS_PAIR_SS: {  // core.py:2294-2339; p0 = r_a + r_b
+        fa = constraint_force<false>(pa, pb, K.p0, W.c_coll, k);
+        fb = -fa;
+      } break;
+      case VMAS_PAIR_LS: {  // a = line, b = sphere; p0 = L/2, p1 = r + LMD  core.py:2341-2392
+        const v2 cp = closest_point_line<true>(pa, TR(K.tra, 0), TR(K.tra, 1), K.p0, pb);
+        fb = constraint_force<false>(pb, cp, K.p1, W.c_coll, k);
+        fa = -fb;
+        ta = vcross(cp - pa, fa);
+      } break;
+      case VMAS_PAIR_BS: {  // a = box, b = sphere; p0 = L, p1 = W, p2 = r + LMD  core.py:2459-2552
+        seg_t be[4];
+        box_edges(pa, TR(K.tra, 0), TR(K.tra, 1), TR(K.tra, 2), TR(K.tra, 3), K.p0, K.p1, be);
+        const v2 cp = closest_point_box(be, pb);
+        v2 ip = cp;
+        float d = 0.f;
+        if (!(K.flags & IT_A_HOLLOW)) ip = inner_point_box(pb, cp, pa, d);
+        fb = constraint_force<false>(pb, ip, K.p2 + d, W.c_coll, k);
+        fa = -fb;
+        ta = vcross(cp - pa, fa);
+      } break;
+      case VMAS_PAIR_LL:
+        if (LEVEL >= 1) {  // p0 = La/2, p1 = Lb/2  core.py:2394-2457
+          seg_t l1 = {pa, TR(K.tra, 0), TR(K.tra, 1), K.p0};
+          seg_t l2 = {pb, TR(K.trb, 0), TR(K.trb, 1), K.p1};
+          v2 qa, qb;
+          closest_points_seg_seg(l1, l2, qa, qb);
+          fa = constraint_force<false>(qa, qb, kLineMinDist, W.c_coll, k);
+          fb = -fa;
+          ta = vcross(qa - pa, fa);
+          tb = vcross(qb - pb, fb);
+        }
+        break;
+      case VMAS_PAIR_BL:
+        if (LEVEL >= 1) {  // a = box, b = line; p0 = L, p1 = W, p2 = Lb/2  core.py:2554-2653
+          seg_t be[4];
+          box_edges(pa, TR(K.tra, 0), TR(K.tra, 1), TR(K.tra, 2), TR(K.tra, 3), K.p0, K.p1, be);
+          seg_t ln = {pb, TR(K.trb, 0), TR(K.trb, 1), K.p2};
+          v2 qb, ql;
+          closest_seg_box(be, ln, qb, ql);
+          v2 ip = qb;
+          float d = 0.f;
+          if (!(K.flags & IT_A_HOLLOW)) ip = inner_point_box(ql, qb, pa, d);
+          fa = constraint_force<false>(ip, ql, kLineMinDist + d, W.c_coll, k);
+          fb = -fa;
+          ta = vcross(qb - pa, fa);
+          tb = vcross(ql - pb, fb);
+        }
+        break;
+      case VMAS_PAIR_BB:
+        if (LEVEL >= 2) {  // p0,p1 = L,W of a; p2,p3 = L,W of b  core.py:2655-2786
+          seg_t ea[4], eb[4];
+          box_edges(pa, TR(K.tra, 0), TR(K.tra, 1), TR(K.tra, 2), TR(K.tra, 3), K.p0, K.p1, ea);
+          box_edges(pb, TR(K.trb, 0), TR(K.trb, 1), TR(K.trb, 2), TR(K.trb, 3), K.p2, K.p3, eb);
+          v2 qa, qb;
+          closest_box_box(ea, eb, qa, qb);
+          v2 ia = qa, ib = qb;
+          float da = 0.f, db = 0.f;
+          if (!(K.flags & IT_A_HOLLOW)) ia = inner_point_box(qb, qa, pa, da);
+          if (!(K.flags & IT_B_HOLLOW)) ib = inner_point_box(qa, qb, pb, db);
+          fa = constraint_force<false>(ia, ib, da + db + kLineMinDist, W.c_coll, k);
+          fb = -fa;
+          ta = vcross(qa - pa, fa);
+          tb = vcross(qb - pb, fb);
+        }
+        break;
+      default: break;
+    }
+  }
+  if (K.side) { f_out = fb; t_out = tb; } else { f_out = fa; t_out = ta; }
+}
 
 // ------------------------------------------------------------------------------------
-// the fused step kernel
+// the fused step kernel: grid = ceil(batch / 64) tiles, block = 64 x W threads
 // ------------------------------------------------------------------------------------
-template <int G>
-__global__ __launch_bounds__(256) void step_kernel(DevWorld W, float* __restrict__ state,
-                                                   float* __restrict__ agent_ft, long ld, int batch,
-                                                   DevStepArgs args) {
-  constexpr int EPB = 256 / G;  // environments per 256-thread block
-  constexpr int EPW = 64 / G;   // environments per wavefront
+template <int LEVEL>
+__global__ __launch_bounds__(TILE* MAX_WAVES) void step_kernel(DevWorld W, float* __restrict__ state,
+                                                               float* __restrict__ agent_ft, long ld, int batch,
+                                                               DevStepArgs args) {
   extern __shared__ float lds[];
-  const int tid = threadIdx.x;
+  const int lane = threadIdx.x & (TILE - 1);
+  const int wv = sgpr(threadIdx.x >> 6);
+  const int nw = sgpr(blockDim.x >> 6);
   const int nE = W.nE, nA = W.nA;
-  Tile T;
-  T.st = lds;
-  T.af = T.st + nE * 6 * EPB;
-  T.tr = T.af + nA * 3 * EPB;
-  T.fa = T.tr + nE * 4 * EPB;
-  T.bad = (int*)(T.fa + nE * 3 * EPB);
-  const long env0 = (long)blockIdx.x * EPB;
+  const long env = (long)blockIdx.x * TILE + lane;
+  const bool live = env < batch;
+  int* bad_row = (int*)(lds + W.row_bad * TILE);
 
-  // ---- HBM -> LDS: every wave instruction reads one contiguous run of a plane ----
-  {
-    const int col = tid % EPB, r0 = tid / EPB;
-    const long env = env0 + col;
-    const bool ok = env < batch;
-    for (int r = r0; r < nE * 6; r += G) T.st[r * EPB + col] = ok ? state[r * ld + env] : 0.f;
-    for (int r = r0; r < nA * 3; r += G) T.af[r * EPB + col] = ok ? agent_ft[r * ld + env] : 0.f;
-    if (r0 == 0) T.bad[col] = 0;
+  // ---- HBM -> LDS: each wave instruction moves one 256-byte run of a plane ----
+  for (int r = wv; r < nE * 6; r += nw) ROW(r) = live ? state[r * ld + env] : 0.f;
+  for (int r = wv; r < nA * 3; r += nw) ROW(W.row_af + r) = live ? agent_ft[r * ld + env] : 0.f;
+  if (wv == 0) bad_row[lane] = 0;
+  __syncthreads();
+
+  // ---- once: trig of Line/Box entities; environments with a non-finite pose may not use
+  //      the distance skip (the reference lets cos(inf) = NaN poison every pair, however far)
+  for (int i = wv; i < W.n_trig; i += nw) {
+    const int e = sgpr(W.trig_ent[i]);
+    write_trig(lds, W, lane, e, W.ent[e]);
+  }
+  for (int e = wv; e < nE; e += nw) {
+    const float px = ST(e, 0), py = ST(e, 1), rt = ST(e, 4);
+    if (!(fabsf(px) < kInf) || !(fabsf(py) < kInf) || !(fabsf(rt) < kInf)) bad_row[lane] = 1;
   }
   __syncthreads();
 
-  const int lane = tid & 63, wv = tid >> 6;
-  const int el = wv * EPW + (lane % EPW);  // environment column of this lane inside the tile
-  const int g = lane / EPW;                // worker index inside the environment
-  const long env = env0 + el;
-  const float sub_dt = W.sub_dt, k = W.k;
-#define ST(e, f) T.st[((e) * 6 + (f)) * EPB + el]
-#define AF(a, f) T.af[((a) * 3 + (f)) * EPB + el]
-#define TR(e, f) T.tr[((e) * 4 + (f)) * EPB + el]
-#define FA(e, f) T.fa[((e) * 3 + (f)) * EPB + el]
-
+  const float sub_dt = W.sub_dt;
   const int s_begin = args.first_substep;
   const int s_end = s_begin + (args.n_substeps > 0 ? args.n_substeps : W.substeps - s_begin);
+  const int seg0 = sgpr(W.wave_seg[wv]), seg1 = sgpr(W.wave_seg[wv + 1]);
+  const int own0 = sgpr(W.wave_own[wv]), own1 = sgpr(W.wave_own[wv + 1]);
+
   for (int substep = s_begin; substep < s_end; ++substep) {
-    // ================= phase A: per-entity trig + force prologue (core.py:1976-2004)
-    for (int e = g; e < nE; e += G) {
-      const DevEntity D = W.ent[e];
-      const uint32_t fl = D.flags;
-      {  // the reference lets a non-finite entity poison every pair it is in, however far
-         // apart (cos(inf) = NaN): such environments must not use the distance skip
-        const float px = ST(e, 0), py = ST(e, 1), rt = ST(e, 4);
-        if (!(fabsf(px) < kInf) || !(fabsf(py) < kInf) || !(fabsf(rt) < kInf)) T.bad[el] = 1;
-      }
-      if (D.shape != VMAS_SHAPE_SPHERE) {  // the only trig the narrow phase needs
-        const float rot = ST(e, 4);
-        TR(e, 0) = cosf(rot);
-        TR(e, 1) = sinf(rot);
-        if (D.shape == VMAS_SHAPE_BOX) {
-          const float rot2 = rot + kHalfPi;  // physics.py:301
-          TR(e, 2) = cosf(rot2);
-          TR(e, 3) = sinf(rot2);
-        }
-      }
+    const bool may_skip = bad_row[lane] == 0;
+    // ================= phase B: gather forces per (entity, segment)
+    for (int si = seg0; si < seg1; ++si) {
+      const DevSegment S = W.segs[si];
+      const int e = S.entity;
       v2 F = V(0.f, 0.f);
       float Tq = 0.f;
-      if (fl & VMAS_F_AGENT) {
-        const int a = D.agent_index;
-        if (fl & VMAS_F_MOVABLE) {  // _apply_action_force core.py:2018-2028
-          v2 f = V(AF(a, 0), AF(a, 1));
-          if (fl & VMAS_F_MAX_F) f = clamp_with_norm(f, D.max_f);
-          if (fl & VMAS_F_F_RANGE) f = V(clamp_t(f.x, D.f_range), clamp_t(f.y, D.f_range));
-          if (fl & (VMAS_F_MAX_F | VMAS_F_F_RANGE)) { AF(a, 0) = f.x; AF(a, 1) = f.y; }
-          F = F + f;
-        }
-        if (fl & VMAS_F_ROTATABLE) {  // _apply_action_torque core.py:2030-2041
-          float t = AF(a, 2);
-          if (fl & VMAS_F_MAX_T) {
-            const float n = fabsf(t);
-            const float nt = (t / n) * D.max_t;
-            t = n > D.max_t ? nt : t;
+      if (S.first) {  // prologue core.py:1995-2004
+        const DevEntity D = W.ent[e];
+        const uint32_t fl = D.flags;
+        if (fl & VMAS_F_AGENT) {
+          const int a = D.agent_index;
+          if (fl & VMAS_F_MOVABLE) {  // _apply_action_force core.py:2018-2028
+            v2 f = V(AF(a, 0), AF(a, 1));
+            if (fl & VMAS_F_MAX_F) f = clamp_with_norm(f, D.max_f);
+            if (fl & VMAS_F_F_RANGE) f = V(clamp_t(f.x, D.f_range), clamp_t(f.y, D.f_range));
+            if (fl & (VMAS_F_MAX_F | VMAS_F_F_RANGE)) { AF(a, 0) = f.x; AF(a, 1) = f.y; }
+            F = F + f;
           }
-          if (fl & VMAS_F_T_RANGE) t = clamp_t(t, D.t_range);
-          if (fl & (VMAS_F_MAX_T | VMAS_F_T_RANGE)) AF(a, 2) = t;
-          Tq = Tq + t;
+          if (fl & VMAS_F_ROTATABLE) {  // _apply_action_torque core.py:2030-2041
+            float t = AF(a, 2);
+            if (fl & VMAS_F_MAX_T) {
+              const float n = fabsf(t);
+              const float nt = (t / n) * D.max_t;
+              t = n > D.max_t ? nt : t;
+            }
+            if (fl & VMAS_F_T_RANGE) t = clamp_t(t, D.t_range);
+            if (fl & (VMAS_F_MAX_T | VMAS_F_T_RANGE)) AF(a, 2) = t;
+            Tq = Tq + t;
+          }
+        }
+        // _apply_friction_force core.py:2054-2102
+        if (fl & VMAS_F_LIN_FRICTION) F = F + friction2(V(ST(e, 2), ST(e, 3)), D.lin_friction, D.mass, sub_dt);
+        if (fl & VMAS_F_ANG_FRICTION) Tq = Tq + friction1(ST(e, 5), D.ang_friction, D.inertia, sub_dt);
+        // _apply_gravity core.py:2043-2052
+        if (fl & VMAS_F_MOVABLE) {
+          if (W.has_gravity) F = F + V(D.mass * W.gx, D.mass * W.gy);
+          if (fl & VMAS_F_GRAVITY) {
+            v2 ge = V(D.gx, D.gy);
+            if (args.entity_gravity && live) {
+              const float* gp = args.entity_gravity + (long)e * 2 * ld + env;
+              ge = V(gp[0], gp[ld]);
+            }
+            F = F + V(D.mass * ge.x, D.mass * ge.y);
+          }
         }
       }
-      // _apply_friction_force core.py:2054-2102
-      if (fl & VMAS_F_LIN_FRICTION) F = F + friction2(V(ST(e, 2), ST(e, 3)), D.lin_friction, D.mass, sub_dt);
-      if (fl & VMAS_F_ANG_FRICTION) Tq = Tq + friction1(ST(e, 5), D.ang_friction, D.inertia, sub_dt);
-      // _apply_gravity core.py:2043-2052
-      if (fl & VMAS_F_MOVABLE) {
-        if (W.has_gravity) F = F + V(D.mass * W.gx, D.mass * W.gy);
-        if (fl & VMAS_F_GRAVITY) {
-          v2 ge = V(D.gx, D.gy);
-          if (args.entity_gravity && env < batch) {
-            const float* gp = args.entity_gravity + (long)e * 2 * ld + env;
-            ge = V(gp[0], gp[ld]);
-          }
-          F = F + V(D.mass * ge.x, D.mass * ge.y);
-        }
+      // joints, then pairs, in the reference's accumulation order (core.py:2176-2199);
+      // the gating of update_env_forces is static and already folded into the item list
+      const uint32_t efl = W.ent[e].flags;
+      for (int ii = S.item_begin; ii < S.item_end; ++ii) {
+        const DevItem K = W.items[ii];
+        v2 f = V(0.f, 0.f);
+        float t = 0.f;
+        eval_item<LEVEL>(K, W, args, lds, lane, env, batch, ld, may_skip, f, t);
+        if (efl & VMAS_F_MOVABLE) F = F + f;
+        if (efl & VMAS_F_ROTATABLE) Tq = Tq + t;
       }
-      FA(e, 0) = F.x; FA(e, 1) = F.y; FA(e, 2) = Tq;
+      ROW(W.row_part + S.part_row + 0) = F.x;
+      ROW(W.row_part + S.part_row + 1) = F.y;
+      ROW(W.row_part + S.part_row + 2) = Tq;
     }
     __syncthreads();
 
-    // ================= phase B: joints, then collision pairs (core.py:2104-2189)
-    const bool may_skip = T.bad[el] == 0;
-    for (int ti = g; ti < W.nT; ti += G) {
-      const DevTask K = W.task[ti];
-      const int a = K.a, b = K.b;
-      const v2 pa = V(ST(a, 0), ST(a, 1)), pb = V(ST(b, 0), ST(b, 1));
-      v2 fa = V(0.f, 0.f), fb = V(0.f, 0.f);
-      float ta = 0.f, tb = 0.f;
-      if (K.type == TASK_JOINT) {  // _vectorized_joint_constraints core.py:2201-2292
-        const float ra = ST(a, 4), rb = ST(b, 4);
-        const v2 pja = pa + rotate(V(K.p0, K.p1), cosf(ra), sinf(ra));  // joints.py:209-216
-        const v2 pjb = pb + rotate(V(K.q0, K.q1), cosf(rb), sinf(rb));
-        const v2 f_att = constraint_force<true>(pja, pjb, K.p2, W.c_joint_att, k);
-        const v2 f_rep = constraint_force<false>(pja, pjb, K.p2, W.c_joint_rep, k);
-        fa = f_att + f_rep;
-        fb = (-f_att) + (-f_rep);
-        ta = vcross(pja - pa, fa);
-        tb = vcross(pjb - pb, fb);
-        if (K.gate & GATE_LOCK) {
-          float fr = K.p3;
-          if (args.joint_fixed_rot && env < batch) fr = args.joint_fixed_rot[(long)K.index * ld + env];
-          const float t = constraint_torque(ra, rb + fr, W.tcf);
-          ta = ta + (-t);
-          tb = tb + t;
-        }
-      } else {
-        if (args.pair_mask && !((args.pair_mask[K.index >> 5] >> (K.index & 31)) & 1u)) continue;
-        {  // per-environment conservative broad phase: beyond this no force can be non-zero
-          const float dx = pa.x - pb.x, dy = pa.y - pb.y;
-          if (may_skip && dx * dx + dy * dy > K.thr2) continue;
-        }
-        switch (K.type) {
-          case VMAS_PAIR_SS: {  // core.py:2294-2339; p0 = r_a + r_b
-            fa = constraint_force<false>(pa, pb, K.p0, W.c_coll, k);
-            fb = -fa;
-          } break;
-          case VMAS_PAIR_LS: {  // a = line, b = sphere; p0 = L/2, p1 = r + LMD  core.py:2341-2392
-            const v2 cp = closest_point_line<true>(pa, TR(a, 0), TR(a, 1), K.p0, pb);
-            fb = constraint_force<false>(pb, cp, K.p1, W.c_coll, k);
-            fa = -fb;
-            ta = vcross(cp - pa, fa);
-          } break;
-          case VMAS_PAIR_LL: {  // p0 = La/2, p1 = Lb/2  core.py:2394-2457
-            seg_t l1 = {pa, TR(a, 0), TR(a, 1), K.p0};
-            seg_t l2 = {pb, TR(b, 0), TR(b, 1), K.p1};
-            v2 qa, qb;
-            closest_points_seg_seg(l1, l2, qa, qb);
-            fa = constraint_force<false>(qa, qb, kLineMinDist, W.c_coll, k);
-            fb = -fa;
-            ta = vcross(qa - pa, fa);
-            tb = vcross(qb - pb, fb);
-          } break;
-          case VMAS_PAIR_BS: {  // a = box, b = sphere; p0 = L, p1 = W, p2 = r + LMD  core.py:2459-2552
-            seg_t be[4];
-            box_edges(pa, TR(a, 0), TR(a, 1), TR(a, 2), TR(a, 3), K.p0, K.p1, be);
-            const v2 cp = closest_point_box(be, pb);
-            v2 ip = cp;
-            float d = 0.f;
-            if (!(K.gate & GATE_A_HOLLOW)) ip = inner_point_box(pb, cp, pa, d);
-            fb = constraint_force<false>(pb, ip, K.p2 + d, W.c_coll, k);
-            fa = -fb;
-            ta = vcross(cp - pa, fa);
-          } break;
-          case VMAS_PAIR_BL: {  // a = box, b = line; p0 = L, p1 = W, p2 = Lb/2  core.py:2554-2653
-            seg_t be[4];
-            box_edges(pa, TR(a, 0), TR(a, 1), TR(a, 2), TR(a, 3), K.p0, K.p1, be);
-            seg_t ln = {pb, TR(b, 0), TR(b, 1), K.p2};
-            v2 qb, ql;
-            closest_seg_box(be, ln, qb, ql);
-            v2 ip = qb;
-            float d = 0.f;
-            if (!(K.gate & GATE_A_HOLLOW)) ip = inner_point_box(ql, qb, pa, d);
-            fa = constraint_force<false>(ip, ql, kLineMinDist + d, W.c_coll, k);
-            fb = -fa;
-            ta = vcross(qb - pa, fa);
-            tb = vcross(ql - pb, fb);
-          } break;
-          case VMAS_PAIR_BB: {  // p0,p1 = L,W of a; p2,p3 = L,W of b  core.py:2655-2786
-            seg_t ea[4], eb[4];
-            box_edges(pa, TR(a, 0), TR(a, 1), TR(a, 2), TR(a, 3), K.p0, K.p1, ea);
-            box_edges(pb, TR(b, 0), TR(b, 1), TR(b, 2), TR(b, 3), K.p2, K.p3, eb);
-            v2 qa, qb;
-            closest_box_box(ea, eb, qa, qb);
-            v2 ia = qa, ib = qb;
-            float da = 0.f, db = 0.f;
-            if (!(K.gate & GATE_A_HOLLOW)) ia = inner_point_box(qb, qa, pa, da);
-            if (!(K.gate & GATE_B_HOLLOW)) ib = inner_point_box(qa, qb, pb, db);
-            fa = constraint_force<false>(ia, ib, da + db + kLineMinDist, W.c_coll, k);
-            fb = -fa;
-            ta = vcross(qa - pa, fa);
-            tb = vcross(qb - pb, fb);
-          } break;
-          default: break;
-        }
-      }
-      // update_env_forces core.py:2191-2199 (LDS float atomics: several workers of one
-      // environment may hit the same entity in the same round)
-      if (K.gate & GATE_A_MOV) { atomicAdd(&FA(a, 0), fa.x); atomicAdd(&FA(a, 1), fa.y); }
-      if (K.gate & GATE_A_ROT) atomicAdd(&FA(a, 2), ta);
-      if (K.gate & GATE_B_MOV) { atomicAdd(&FA(b, 0), fb.x); atomicAdd(&FA(b, 1), fb.y); }
-      if (K.gate & GATE_B_ROT) atomicAdd(&FA(b, 2), tb);
-    }
-    __syncthreads();
-
-    // ================= phase C: _integrate_state core.py:2862-2908
-    for (int e = g; e < nE; e += G) {
+    // ================= phase C: _integrate_state core.py:2862-2908 (+ trig for the next substep)
+    for (int oi = own0; oi < own1; ++oi) {
+      const DevOwned O = W.owned[oi];
+      const int e = O.entity;
       const DevEntity D = W.ent[e];
       const uint32_t fl = D.flags;
+      v2 F = V(ROW(W.row_part + O.part_row), ROW(W.row_part + O.part_row + 1));
+      float Tq = ROW(W.row_part + O.part_row + 2);
+      for (int p = 1; p < O.n_parts; ++p) {
+        F = F + V(ROW(W.row_part + O.part_row + 3 * p), ROW(W.row_part + O.part_row + 3 * p + 1));
+        Tq = Tq + ROW(W.row_part + O.part_row + 3 * p + 2);
+      }
+      bool bad = false;
       if (fl & VMAS_F_MOVABLE) {
         v2 vel = V(ST(e, 2), ST(e, 3));
         if (substep == 0) vel = V(vel.x * D.one_minus_drag, vel.y * D.one_minus_drag);
-        const v2 acc = V(FA(e, 0) / D.mass, FA(e, 1) / D.mass);
+        const v2 acc = V(F.x / D.mass, F.y / D.mass);
         vel = V(vel.x + acc.x * sub_dt, vel.y + acc.y * sub_dt);
         if (fl & VMAS_F_MAX_SPEED) vel = clamp_with_norm(vel, D.max_speed);
         if (fl & VMAS_F_V_RANGE) vel = V(clamp_t(vel.x, D.v_range), clamp_t(vel.y, D.v_range));
@@ -316,45 +389,47 @@ __global__ __launch_bounds__(256) void step_kernel(DevWorld W, float* __restrict
         if (W.xs == W.xs) np.x = clamp_t(np.x, W.xs);
         if (W.ys == W.ys) np.y = clamp_t(np.y, W.ys);
         ST(e, 0) = np.x; ST(e, 1) = np.y; ST(e, 2) = vel.x; ST(e, 3) = vel.y;
+        bad = !(fabsf(np.x) < kInf) || !(fabsf(np.y) < kInf);
       }
       if (fl & VMAS_F_ROTATABLE) {
         float av = ST(e, 5);
         if (substep == 0) av = av * D.one_minus_drag;
-        av = av + (FA(e, 2) / D.inertia) * sub_dt;
-        ST(e, 4) = ST(e, 4) + av * sub_dt;
+        av = av + (Tq / D.inertia) * sub_dt;
+        const float rot = ST(e, 4) + av * sub_dt;
+        ST(e, 4) = rot;
         ST(e, 5) = av;
+        bad = bad || !(fabsf(rot) < kInf);
+        if (D.tr_row >= 0 && substep + 1 < s_end) write_trig(lds, W, lane, e, D);
       }
+      if (bad) bad_row[lane] = 1;
     }
     __syncthreads();
   }
 
   // ---- LDS -> HBM: only the planes the reference rebinds (core.py:2871-2908, 2021-2039)
-  {
-    const int col = tid % EPB, r0 = tid / EPB;
-    const long envc = env0 + col;
-    if (envc < batch) {
-      for (int r = r0; r < nE * 6; r += G) {
-        const uint32_t fl = W.ent[r / 6].flags;
-        const bool dyn = (r % 6 < 4) ? (fl & VMAS_F_MOVABLE) : (fl & VMAS_F_ROTATABLE);
-        if (dyn) state[r * ld + envc] = T.st[r * EPB + col];
+  if (live) {
+    for (int r = wv; r < nE * 6; r += nw) {
+      const uint32_t fl = W.ent[r / 6].flags;
+      const bool dyn = (r % 6 < 4) ? (fl & VMAS_F_MOVABLE) : (fl & VMAS_F_ROTATABLE);
+      if (dyn) state[r * ld + env] = ROW(r);
+    }
+    for (int e = wv; e < nE; e += nw) {
+      const DevEntity D = W.ent[e];
+      if (!(D.flags & VMAS_F_AGENT)) continue;
+      const int a = D.agent_index;
+      if ((D.flags & VMAS_F_MOVABLE) && (D.flags & (VMAS_F_MAX_F | VMAS_F_F_RANGE))) {
+        agent_ft[(a * 3 + 0) * ld + env] = AF(a, 0);
+        agent_ft[(a * 3 + 1) * ld + env] = AF(a, 1);
       }
-      for (int e = 0; e < nE; ++e) {
-        const uint32_t fl = W.ent[e].flags;
-        if (!(fl & VMAS_F_AGENT)) continue;
-        const int a = W.ent[e].agent_index;
-        const bool wf = (fl & VMAS_F_MOVABLE) && (fl & (VMAS_F_MAX_F | VMAS_F_F_RANGE));
-        const bool wt = (fl & VMAS_F_ROTATABLE) && (fl & (VMAS_F_MAX_T | VMAS_F_T_RANGE));
-        for (int f = r0; f < 3; f += G) {
-          if (f < 2 ? wf : wt) agent_ft[(a * 3 + f) * ld + envc] = T.af[(a * 3 + f) * EPB + col];
-        }
-      }
+      if ((D.flags & VMAS_F_ROTATABLE) && (D.flags & (VMAS_F_MAX_T | VMAS_F_T_RANGE)))
+        agent_ft[(a * 3 + 2) * ld + env] = AF(a, 2);
     }
   }
+}
+#undef ROW
 #undef ST
 #undef AF
 #undef TR
-#undef FA
-}
 
 // ------------------------------------------------------------------------------------
 // batch-global broad phase (World.collides core.py:2797-2801)
@@ -487,99 +562,248 @@ static int fail(const char* fmt, ...) {
     if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
 
+template <class T>
+static hipError_t upload(T** dst, const std::vector<T>& src) {
+  hipError_t e = hipMalloc((void**)dst, src.empty() ? 16 : src.size() * sizeof(T));
+  if (e != hipSuccess || src.empty()) return e;
+  return hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice);
+}
+
+// A schedule = how the tile's items are dealt to `nw` waves (see file header).
+struct Sched {
+  int nw = 0;
+  DevWorld dw{};
+  size_t lds_bytes = 0;
+  DevSegment* d_segs = nullptr;
+  int32_t* d_wave_seg = nullptr;
+  DevOwned* d_owned = nullptr;
+  int32_t* d_wave_own = nullptr;
+  void release() {
+    (void)hipFree(d_segs); (void)hipFree(d_wave_seg); (void)hipFree(d_owned); (void)hipFree(d_wave_own);
+    d_segs = nullptr; d_wave_seg = nullptr; d_owned = nullptr; d_wave_own = nullptr;
+  }
+};
+
 struct VmasWorld {
   int device = 0;
   int batch = 0;
-  int lanes = 4;
-  DevWorld dw{};
+  int lanes = 1;  // waves per 64-env tile = lanes cooperating on one environment
+  int level = 0;  // kernel code level (which item types exist)
+  int n_pairs = 0, n_dyn = 0;
+  DevWorld base{};  // schedule-independent part
+  std::vector<VmasEntityDesc> ents;
+  // static item lists
+  std::vector<DevItem> items;
+  std::vector<int> ent_item_begin;  // [nE+1]
+  std::vector<float> item_cost;
+  std::vector<int> trig_ents;
   DevEntity* d_ent = nullptr;
-  DevTask* d_task = nullptr;
+  DevItem* d_items = nullptr;
+  int32_t* d_trig_ent = nullptr;
   DevMaskPair* d_mpairs = nullptr;
-  int n_pairs = 0;
-  int n_dyn = 0;
-  size_t lds_rows = 0;
+  std::map<int, Sched> scheds;
   // lidars
   DevLidar* d_lidars = nullptr;
   DevTarget* d_targets = nullptr;
   float* d_angles = nullptr;
   int n_lidars = 0, max_rays = 0;
-  std::vector<VmasEntityDesc> ents;
 };
 
-static float slack_thr2(float bound_sum) {
-  // forces vanish once shapes are farther apart than LINE_MIN_DIST (see DESIGN.md,
-  // "per-environment broad phase"); 1e-3 absorbs rounding of the closest-point math.
-  float t = bound_sum + kLineMinDist + 1e-3f;
-  return t * t;
+static float type_cost(int type) {
+  // relative narrow-phase cost per item, from instruction counts of the compiled kernel
+  switch (type) {
+    case VMAS_PAIR_SS: return 1.f;
+    case VMAS_PAIR_LS: return 2.f;
+    case VMAS_PAIR_LL: return 8.f;
+    case VMAS_PAIR_BS: return 6.f;
+    case VMAS_PAIR_BL: return 28.f;
+    case VMAS_PAIR_BB: return 220.f;
+    case TASK_JOINT: return 8.f;
+  }
+  return 1.f;
 }
 
-static void build_tasks(const VmasWorldDesc* d, std::vector<DevTask>& tasks) {
+// forces vanish once shapes are farther apart than LINE_MIN_DIST ("per-environment
+// broad phase"); the slack absorbs the rounding of the closest-point arithmetic.
+constexpr float kSkipSlack = 1e-3f;
+
+static void build_items(const VmasWorldDesc* d, VmasWorld* w, const std::vector<int>& tr_row) {
   const VmasEntityDesc* E = d->entities;
-  auto gate_of = [&](int a, int b) {
-    uint32_t g = 0;
-    if (E[a].flags & VMAS_F_MOVABLE) g |= GATE_A_MOV;
-    if (E[a].flags & VMAS_F_ROTATABLE) g |= GATE_A_ROT;
-    if (E[b].flags & VMAS_F_MOVABLE) g |= GATE_B_MOV;
-    if (E[b].flags & VMAS_F_ROTATABLE) g |= GATE_B_ROT;
-    if (E[a].flags & VMAS_F_HOLLOW) g |= GATE_A_HOLLOW;
-    if (E[b].flags & VMAS_F_HOLLOW) g |= GATE_B_HOLLOW;
-    return g;
+  const int nE = d->n_entities;
+  std::vector<std::vector<DevItem>> per(nE);
+  auto dyn = [&](int e) { return (E[e].flags & (VMAS_F_MOVABLE | VMAS_F_ROTATABLE)) != 0; };
+  auto push_sides = [&](DevItem t) {
+    if (dyn(t.a)) { t.side = 0; per[t.a].push_back(t); }
+    if (dyn(t.b)) { t.side = 1; per[t.b].push_back(t); }
   };
-  for (int j = 0; j < d->n_joints; ++j) {
+  for (int j = 0; j < d->n_joints; ++j) {  // joints first (core.py:2176)
     const VmasJointDesc& J = d->joints[j];
-    DevTask t{};
-    t.a = J.a; t.b = J.b; t.type = TASK_JOINT; t.index = j;
-    t.gate = gate_of(J.a, J.b) | (J.rotate ? 0u : GATE_LOCK);
+    DevItem t{};
+    t.type = TASK_JOINT; t.a = J.a; t.b = J.b; t.index = j;
+    t.flags = J.rotate ? 0u : IT_LOCK;
+    t.tra = tr_row[J.a]; t.trb = tr_row[J.b];
     t.p0 = J.delta_a[0]; t.p1 = J.delta_a[1]; t.q0 = J.delta_b[0]; t.q1 = J.delta_b[1];
     t.p2 = J.dist; t.p3 = J.fixed_rotation;
-    tasks.push_back(t);
+    push_sides(t);
   }
-  for (int p = 0; p < d->n_pairs; ++p) {
+  for (int p = 0; p < d->n_pairs; ++p) {  // then pairs, already type-major (core.py:2178-2189)
     const VmasPairDesc& P = d->pairs[p];
-    DevTask t{};
-    t.a = P.a; t.b = P.b; t.type = P.type; t.index = p;
-    t.gate = gate_of(P.a, P.b);
-    t.thr2 = slack_thr2(P.bound_sum);
     const VmasEntityDesc &A = E[P.a], &B = E[P.b];
+    DevItem t{};
+    t.type = P.type; t.a = P.a; t.b = P.b; t.index = p;
+    t.flags = ((A.flags & VMAS_F_HOLLOW) ? IT_A_HOLLOW : 0u) | ((B.flags & VMAS_F_HOLLOW) ? IT_B_HOLLOW : 0u);
+    t.tra = tr_row[P.a]; t.trb = tr_row[P.b];
+    float m = P.bound_sum + kLineMinDist + kSkipSlack;
+    t.thr2 = m * m;
     switch (P.type) {
-      case VMAS_PAIR_SS: {  // force is exactly 0 for dist > r_a + r_b (core.py:2836)
+      case VMAS_PAIR_SS: {  // the force is exactly 0 for dist > r_a + r_b (core.py:2836)
         t.p0 = A.radius + B.radius;
-        float m = t.p0 + 1e-4f;
+        m = t.p0 + 1e-4f;
         t.thr2 = m * m;
       } break;
       case VMAS_PAIR_LS: t.p0 = A.length / 2.f; t.p1 = B.radius + kLineMinDist; break;
       case VMAS_PAIR_LL: t.p0 = A.length / 2.f; t.p1 = B.length / 2.f; break;
-      case VMAS_PAIR_BS: t.p0 = A.length; t.p1 = A.width; t.p2 = B.radius + kLineMinDist; break;
-      case VMAS_PAIR_BL: t.p0 = A.length; t.p1 = A.width; t.p2 = B.length / 2.f; break;
-      case VMAS_PAIR_BB: t.p0 = A.length; t.p1 = A.width; t.p2 = B.length; t.p3 = B.width; break;
+      case VMAS_PAIR_BS:
+        t.p0 = A.length; t.p1 = A.width; t.p2 = B.radius + kLineMinDist;
+        t.reach = B.radius + kLineMinDist + kSkipSlack;
+        break;
+      case VMAS_PAIR_BL:
+        t.p0 = A.length; t.p1 = A.width; t.p2 = B.length / 2.f;
+        t.reach = B.length / 2.f + kLineMinDist + kSkipSlack;
+        break;
+      case VMAS_PAIR_BB:
+        t.p0 = A.length; t.p1 = A.width; t.p2 = B.length; t.p3 = B.width;
+        t.reach = B.bound_radius + kLineMinDist + kSkipSlack;
+        break;
       default: break;
     }
-    tasks.push_back(t);
+    push_sides(t);
   }
-}
-
-static int default_lanes(int n_tasks, int n_entities, int batch) {
-  // enough lanes per environment to (a) put >= ~4 waves on each of the 1024 SIMDs and
-  // (b) keep the serial task chain per lane short; tuned on MI355X.
-  int work = n_tasks + n_entities;
-  int g = 1;
-  while (g < 64 && (g * 6 < work || (long)batch * g < 4096L * 64)) g <<= 1;
-  return g;
-}
-
-template <int G>
-static int launch_step(VmasWorld* w, float* state, float* aft, long ld, const DevStepArgs& a, hipStream_t s) {
-  constexpr int EPB = 256 / G;
-  const size_t lds = w->lds_rows * EPB * sizeof(float);
-  if (lds > 64 * 1024) {
-    static thread_local size_t set_for = 0;
-    if (set_for < lds) {
-      HIP_TRY(hipFuncSetAttribute((const void*)step_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      set_for = lds;
+  w->ent_item_begin.assign(nE + 1, 0);
+  w->items.clear();
+  w->item_cost.clear();
+  w->level = 0;
+  for (int e = 0; e < nE; ++e) {
+    w->ent_item_begin[e] = (int)w->items.size();
+    for (const DevItem& t : per[e]) {
+      w->items.push_back(t);
+      w->item_cost.push_back(type_cost(t.type));
+      if (t.type == VMAS_PAIR_BB) w->level = std::max(w->level, 2);
+      if (t.type == VMAS_PAIR_LL || t.type == VMAS_PAIR_BL || t.type == TASK_JOINT) w->level = std::max(w->level, 1);
     }
   }
-  const int blocks = (w->batch + EPB - 1) / EPB;
-  hipLaunchKernelGGL(step_kernel<G>, dim3(blocks), dim3(256), lds, s, w->dw, state, aft, ld, w->batch, a);
+  w->ent_item_begin[nE] = (int)w->items.size();
+}
+
+// Cut every dynamic entity's item list into segments of about total/nw cost and deal the
+// segments to the waves, heaviest first, always to the least loaded wave.
+static int build_sched(VmasWorld* w, int nw, Sched& S) {
+  const int nE = w->base.nE;
+  std::vector<DevSegment> segs;
+  std::vector<float> seg_cost;
+  std::vector<DevOwned> owned_all;
+  float total = 0.f;
+  for (int e = 0; e < nE; ++e)
+    if (w->ents[e].flags & (VMAS_F_MOVABLE | VMAS_F_ROTATABLE)) {
+      total += 1.f;
+      for (int i = w->ent_item_begin[e]; i < w->ent_item_begin[e + 1]; ++i) total += w->item_cost[i];
+    }
+  const float target = std::max(total / (float)nw, 1.f);
+  for (int e = 0; e < nE; ++e) {
+    if (!(w->ents[e].flags & (VMAS_F_MOVABLE | VMAS_F_ROTATABLE))) continue;
+    const int b = w->ent_item_begin[e], n = w->ent_item_begin[e + 1];
+    DevOwned O{e, 3 * (int)segs.size(), 0};
+    int i = b;
+    bool first = true;
+    do {
+      float c = first ? 1.f : 0.f;
+      int j = i;
+      while (j < n && (j == i || c + w->item_cost[j] <= target)) c += w->item_cost[j++];
+      segs.push_back({e, i, j, first ? 1 : 0, 3 * (int)segs.size()});
+      seg_cost.push_back(c);
+      O.n_parts++;
+      first = false;
+      i = j;
+    } while (i < n);
+    owned_all.push_back(O);
+  }
+  // LPT assignment of segments
+  std::vector<int> order(segs.size());
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return seg_cost[x] > seg_cost[y]; });
+  std::vector<float> load(nw, 0.f);
+  std::vector<std::vector<int>> per_wave(nw);
+  for (int si : order) {
+    int best = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+    load[best] += seg_cost[si];
+    per_wave[best].push_back(si);
+  }
+  std::vector<DevSegment> segs_sorted;
+  std::vector<int32_t> wave_seg(nw + 1, 0);
+  for (int wv = 0; wv < nw; ++wv) {
+    std::sort(per_wave[wv].begin(), per_wave[wv].end());
+    for (int si : per_wave[wv]) segs_sorted.push_back(segs[si]);
+    wave_seg[wv + 1] = (int)segs_sorted.size();
+  }
+  // integration work: round-robin over the waves
+  std::vector<std::vector<DevOwned>> own_w(nw);
+  for (size_t i = 0; i < owned_all.size(); ++i) own_w[i % nw].push_back(owned_all[i]);
+  std::vector<DevOwned> owned;
+  std::vector<int32_t> wave_own(nw + 1, 0);
+  for (int wv = 0; wv < nw; ++wv) {
+    for (auto& o : own_w[wv]) owned.push_back(o);
+    wave_own[wv + 1] = (int)owned.size();
+  }
+  S.nw = nw;
+  HIP_TRY(upload(&S.d_segs, segs_sorted));
+  HIP_TRY(upload(&S.d_wave_seg, wave_seg));
+  HIP_TRY(upload(&S.d_owned, owned));
+  HIP_TRY(upload(&S.d_wave_own, wave_own));
+  S.dw = w->base;
+  S.dw.row_part = S.dw.row_tr + 4 * (int)w->trig_ents.size();
+  S.dw.row_bad = S.dw.row_part + 3 * (int)segs.size();
+  S.dw.segs = S.d_segs; S.dw.wave_seg = S.d_wave_seg; S.dw.owned = S.d_owned; S.dw.wave_own = S.d_wave_own;
+  S.lds_bytes = (size_t)(S.dw.row_bad + 1) * TILE * sizeof(float);
+  return 0;
+}
+
+static int get_sched(VmasWorld* w, int nw, Sched** out) {
+  auto it = w->scheds.find(nw);
+  if (it == w->scheds.end()) {
+    Sched S;
+    if (build_sched(w, nw, S)) return -1;
+    it = w->scheds.emplace(nw, S).first;
+  }
+  *out = &it->second;
+  return 0;
+}
+
+static int default_lanes(const VmasWorld* w) {
+  // waves per tile: enough to give each of the chip's 1024 SIMDs ~4 waves at this batch,
+  // but no more than the tile has independent work for (tuned on MI355X)
+  const long tiles = (w->batch + TILE - 1) / TILE;
+  int work = 0;
+  for (float c : w->item_cost) work += (int)c;
+  work += w->n_dyn;
+  int nw = 1;
+  while (nw < MAX_WAVES && tiles * nw < 4096 && work >= 4 * nw) nw <<= 1;
+  return nw;
+}
+
+template <int LEVEL>
+static int launch_level(VmasWorld* w, Sched* S, float* state, float* aft, long ld, const DevStepArgs& a,
+                        hipStream_t s) {
+  if (S->lds_bytes > 64 * 1024) {
+    static thread_local size_t set_for = 0;
+    if (set_for < S->lds_bytes) {
+      HIP_TRY(hipFuncSetAttribute((const void*)step_kernel<LEVEL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)S->lds_bytes));
+      set_for = S->lds_bytes;
+    }
+  }
+  const int blocks = (w->batch + TILE - 1) / TILE;
+  hipLaunchKernelGGL(step_kernel<LEVEL>, dim3(blocks), dim3(TILE * S->nw), S->lds_bytes, s, S->dw, state, aft, ld,
+                     w->batch, a);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -595,6 +819,13 @@ int vmas_world_create(const VmasWorldDesc* d, int32_t batch, int32_t device_id, 
     return fail("vmas_world_create: desc ABI version %d, library %d", d->abi_version, VMAS_ABI_VERSION);
   if (batch <= 0) return fail("vmas_world_create: batch must be > 0, got %d", batch);
   if (d->n_entities <= 0) return fail("vmas_world_create: world has no entities");
+  for (int p = 0; p < d->n_pairs; ++p)
+    if (d->pairs[p].a < 0 || d->pairs[p].a >= d->n_entities || d->pairs[p].b < 0 || d->pairs[p].b >= d->n_entities ||
+        d->pairs[p].type < 0 || d->pairs[p].type > VMAS_PAIR_BB)
+      return fail("vmas_world_create: pair %d is malformed", p);
+  for (int j = 0; j < d->n_joints; ++j)
+    if (d->joints[j].a < 0 || d->joints[j].a >= d->n_entities || d->joints[j].b < 0 || d->joints[j].b >= d->n_entities)
+      return fail("vmas_world_create: joint %d is malformed", j);
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
   if (device_id < 0 || device_id >= ndev) return fail("vmas_world_create: device %d of %d", device_id, ndev);
@@ -607,6 +838,7 @@ int vmas_world_create(const VmasWorldDesc* d, int32_t batch, int32_t device_id, 
   w->n_pairs = d->n_pairs;
 
   std::vector<DevEntity> ents(d->n_entities);
+  std::vector<int> tr_row(d->n_entities, -1);
   for (int e = 0; e < d->n_entities; ++e) {
     const VmasEntityDesc& s = d->entities[e];
     DevEntity& t = ents[e];
@@ -616,40 +848,47 @@ int vmas_world_create(const VmasWorldDesc* d, int32_t batch, int32_t device_id, 
     t.lin_friction = s.lin_friction; t.ang_friction = s.ang_friction;
     t.gx = s.gravity[0]; t.gy = s.gravity[1];
     t.max_f = s.max_f; t.f_range = s.f_range; t.max_t = s.max_t; t.t_range = s.t_range;
+    t.tr_row = -1;
+    if (s.shape != VMAS_SHAPE_SPHERE) {
+      t.tr_row = tr_row[e] = 4 * (int)w->trig_ents.size();
+      w->trig_ents.push_back(e);
+    }
     if (s.flags & (VMAS_F_MOVABLE | VMAS_F_ROTATABLE)) w->n_dyn++;
     if ((s.flags & VMAS_F_AGENT) && (s.agent_index < 0 || s.agent_index >= d->n_agents)) {
       delete w;
       return fail("vmas_world_create: entity %d has agent_index %d outside [0,%d)", e, s.agent_index, d->n_agents);
     }
   }
-  std::vector<DevTask> tasks;
-  build_tasks(d, tasks);
-  std::vector<DevMaskPair> mp(d->n_pairs);
-  for (int p = 0; p < d->n_pairs; ++p) mp[p] = {d->pairs[p].a, d->pairs[p].b, d->pairs[p].bound_sum};
-
-  auto upload = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
-    hipError_t e = hipMalloc(dst, bytes ? bytes : 16);
-    if (e != hipSuccess) return e;
-    return bytes ? hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
-  };
-  HIP_TRY(upload((void**)&w->d_ent, ents.data(), ents.size() * sizeof(DevEntity)));
-  HIP_TRY(upload((void**)&w->d_task, tasks.data(), tasks.size() * sizeof(DevTask)));
-  HIP_TRY(upload((void**)&w->d_mpairs, mp.data(), mp.size() * sizeof(DevMaskPair)));
-
-  DevWorld& W = w->dw;
-  W.nE = d->n_entities; W.nA = d->n_agents; W.nT = (int)tasks.size(); W.nJ = d->n_joints;
-  W.substeps = d->substeps; W.sub_dt = d->sub_dt;
+  DevWorld& W = w->base;
+  W.nE = d->n_entities; W.nA = d->n_agents; W.substeps = d->substeps; W.sub_dt = d->sub_dt;
   W.gx = d->gravity[0]; W.gy = d->gravity[1]; W.has_gravity = d->has_gravity;
   W.xs = d->x_semidim; W.ys = d->y_semidim;
   W.k = d->contact_margin; W.tcf = d->torque_constraint_force;
-  W.c_coll = d->collision_force;      // sign = +1
-  W.c_joint_att = -d->joint_force;    // sign = -1
+  W.c_coll = d->collision_force;    // sign = +1
+  W.c_joint_att = -d->joint_force;  // sign = -1
   W.c_joint_rep = d->joint_force;
-  W.ent = w->d_ent; W.task = w->d_task;
-  w->lds_rows = (size_t)W.nE * (6 + 4 + 3) + (size_t)W.nA * 3 + 1;
-  w->lanes = default_lanes(W.nT, W.nE, batch);
-  // a tile must fit the 160 KiB LDS of a CU (64 KiB is the default dynamic limit)
-  while (w->lanes < 64 && w->lds_rows * (256 / w->lanes) * sizeof(float) > 64 * 1024) w->lanes <<= 1;
+  W.row_af = W.nE * 6;
+  W.row_tr = W.row_af + W.nA * 3;
+  build_items(d, w, tr_row);
+  std::vector<DevMaskPair> mp(d->n_pairs);
+  for (int p = 0; p < d->n_pairs; ++p) mp[p] = {d->pairs[p].a, d->pairs[p].b, d->pairs[p].bound_sum};
+  std::vector<int32_t> trig(w->trig_ents.begin(), w->trig_ents.end());
+  HIP_TRY(upload(&w->d_ent, ents));
+  HIP_TRY(upload(&w->d_items, w->items));
+  HIP_TRY(upload(&w->d_mpairs, mp));
+  HIP_TRY(upload(&w->d_trig_ent, trig));
+  W.ent = w->d_ent; W.items = w->d_items; W.trig_ent = w->d_trig_ent; W.n_trig = (int)trig.size();
+  w->lanes = default_lanes(w);
+  Sched* S;
+  while (true) {
+    if (get_sched(w, w->lanes, &S)) { vmas_world_destroy(w); return -1; }
+    if (S->lds_bytes <= 160 * 1024 || w->lanes == 1) break;
+    w->lanes >>= 1;  // fewer segments => fewer partial rows
+  }
+  if (S->lds_bytes > 160 * 1024) {
+    vmas_world_destroy(w);
+    return fail("vmas_world_create: a 64-environment tile of this world needs %zu B of LDS (> 160 KiB)", S->lds_bytes);
+  }
   *out = w;
   return 0;
 }
@@ -657,17 +896,21 @@ int vmas_world_create(const VmasWorldDesc* d, int32_t batch, int32_t device_id, 
 void vmas_world_destroy(VmasWorld* w) {
   if (!w) return;
   (void)hipSetDevice(w->device);
-  (void)hipFree(w->d_ent); (void)hipFree(w->d_task); (void)hipFree(w->d_mpairs);
+  for (auto& kv : w->scheds) kv.second.release();
+  (void)hipFree(w->d_ent); (void)hipFree(w->d_items); (void)hipFree(w->d_mpairs); (void)hipFree(w->d_trig_ent);
   (void)hipFree(w->d_lidars); (void)hipFree(w->d_targets); (void)hipFree(w->d_angles);
   delete w;
 }
 
 int vmas_world_set_lanes_per_env(VmasWorld* w, int32_t lanes) {
   if (!w) return fail("vmas_world_set_lanes_per_env: null world");
-  if (lanes == 0) lanes = default_lanes(w->dw.nT, w->dw.nE, w->batch);
-  if (lanes < 1 || lanes > 64 || (lanes & (lanes - 1))) return fail("lanes_per_env must be a power of two in 1..64, got %d", lanes);
-  if (w->lds_rows * (256 / lanes) * sizeof(float) > 160 * 1024)
-    return fail("lanes_per_env=%d needs %zu B of LDS per block (> 160 KiB)", lanes, w->lds_rows * (256 / lanes) * sizeof(float));
+  if (lanes == 0) lanes = default_lanes(w);
+  if (lanes < 1 || lanes > MAX_WAVES) return fail("lanes_per_env must be in 1..%d, got %d", MAX_WAVES, lanes);
+  HIP_TRY(hipSetDevice(w->device));
+  Sched* S;
+  if (get_sched(w, lanes, &S)) return -1;
+  if (S->lds_bytes > 160 * 1024)
+    return fail("lanes_per_env=%d needs %zu B of LDS per tile (> 160 KiB)", lanes, S->lds_bytes);
   w->lanes = lanes;
   return 0;
 }
@@ -675,32 +918,28 @@ int vmas_world_get_lanes_per_env(const VmasWorld* w) { return w ? w->lanes : -1;
 
 int64_t vmas_world_step_bytes_per_env(const VmasWorld* w) {
   if (!w) return -1;
-  return 24LL * w->dw.nE + 12LL * w->dw.nA + 24LL * w->n_dyn;
+  return 24LL * w->base.nE + 12LL * w->base.nA + 24LL * w->n_dyn;
 }
 
 int vmas_world_step(VmasWorld* w, float* state, float* agent_ft, int64_t ld, const VmasStepArgs* args, void* stream) {
   if (!w || !state) return fail("vmas_world_step: null argument");
-  if (w->dw.nA > 0 && !agent_ft) return fail("vmas_world_step: world has agents but agent_ft is null");
+  if (w->base.nA > 0 && !agent_ft) return fail("vmas_world_step: world has agents but agent_ft is null");
   if (ld < w->batch) return fail("vmas_world_step: ld (%lld) < batch (%d)", (long long)ld, w->batch);
   DevStepArgs a{};
-  a.n_substeps = 0;
   if (args) {
     a.pair_mask = args->pair_mask; a.joint_fixed_rot = args->joint_fixed_rot; a.entity_gravity = args->entity_gravity;
     a.first_substep = args->first_substep; a.n_substeps = args->n_substeps;
-    if (a.first_substep < 0 || a.first_substep >= w->dw.substeps)
-      return fail("vmas_world_step: first_substep %d outside [0,%d)", a.first_substep, w->dw.substeps);
+    if (a.first_substep < 0 || a.first_substep >= w->base.substeps)
+      return fail("vmas_world_step: first_substep %d outside [0,%d)", a.first_substep, w->base.substeps);
   }
+  Sched* S;
+  if (get_sched(w, w->lanes, &S)) return -1;
   hipStream_t s = (hipStream_t)stream;
-  switch (w->lanes) {
-    case 1: return launch_step<1>(w, state, agent_ft, ld, a, s);
-    case 2: return launch_step<2>(w, state, agent_ft, ld, a, s);
-    case 4: return launch_step<4>(w, state, agent_ft, ld, a, s);
-    case 8: return launch_step<8>(w, state, agent_ft, ld, a, s);
-    case 16: return launch_step<16>(w, state, agent_ft, ld, a, s);
-    case 32: return launch_step<32>(w, state, agent_ft, ld, a, s);
-    case 64: return launch_step<64>(w, state, agent_ft, ld, a, s);
+  switch (w->level) {
+    case 0: return launch_level<0>(w, S, state, agent_ft, ld, a, s);
+    case 1: return launch_level<1>(w, S, state, agent_ft, ld, a, s);
+    default: return launch_level<2>(w, S, state, agent_ft, ld, a, s);
   }
-  return fail("vmas_world_step: bad lanes_per_env %d", w->lanes);
 }
 
 int vmas_world_step_n(VmasWorld* w, float* state, float* agent_ft, int64_t ld, int64_t ft_step_stride, int32_t n_steps,
@@ -737,24 +976,21 @@ int vmas_world_set_lidars(VmasWorld* w, const VmasLidarDesc* lidars, int32_t n) 
   std::vector<float> da;
   for (int i = 0; i < n; ++i) {
     const VmasLidarDesc& L = lidars[i];
-    if (L.entity < 0 || L.entity >= w->dw.nE || L.n_rays <= 0) return fail("vmas_world_set_lidars: bad sensor %d", i);
+    if (L.entity < 0 || L.entity >= w->base.nE || L.n_rays <= 0) return fail("vmas_world_set_lidars: bad sensor %d", i);
     dl[i] = {L.entity, L.n_rays, L.n_targets, (int)dt.size(), (int)da.size(), L.max_range,
              (float)((double)L.max_range / 2.0)};
     for (int t = 0; t < L.n_targets; ++t) {
       int e = L.targets[t];
-      if (e < 0 || e >= w->dw.nE) return fail("vmas_world_set_lidars: sensor %d target %d out of range", i, e);
+      if (e < 0 || e >= w->base.nE) return fail("vmas_world_set_lidars: sensor %d target %d out of range", i, e);
       const VmasEntityDesc& E = w->ents[e];
       dt.push_back({e, E.shape, E.length, E.width, E.radius});
     }
     for (int r = 0; r < L.n_rays; ++r) da.push_back(L.angles[r]);
     if (L.n_rays > w->max_rays) w->max_rays = L.n_rays;
   }
-  HIP_TRY(hipMalloc((void**)&w->d_lidars, dl.size() * sizeof(DevLidar)));
-  HIP_TRY(hipMemcpy(w->d_lidars, dl.data(), dl.size() * sizeof(DevLidar), hipMemcpyHostToDevice));
-  HIP_TRY(hipMalloc((void**)&w->d_targets, (dt.size() ? dt.size() : 1) * sizeof(DevTarget)));
-  if (!dt.empty()) HIP_TRY(hipMemcpy(w->d_targets, dt.data(), dt.size() * sizeof(DevTarget), hipMemcpyHostToDevice));
-  HIP_TRY(hipMalloc((void**)&w->d_angles, da.size() * sizeof(float)));
-  HIP_TRY(hipMemcpy(w->d_angles, da.data(), da.size() * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(upload(&w->d_lidars, dl));
+  HIP_TRY(upload(&w->d_targets, dt));
+  HIP_TRY(upload(&w->d_angles, da));
   w->n_lidars = n;
   return 0;
 }
