@@ -1,0 +1,22 @@
+# rocprofv3 evidence for bench.py: kernel trace (durations) + PMC passes (separate runs)
+set -u
+OUT=gpurun_out/prof; rm -rf $OUT; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
+CMD="python bench.py --no-cpu-baseline --steps 1000 --warmup 100 ${BENCH_ARGS:-}"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $CMD > $OUT/trace_stdout.log 2>&1
+f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1); echo "== $f"; [ -n "$f" ] && cat "$f" | head -8
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc1 -o bench -- $CMD > $OUT/pmc1_stdout.log 2>&1
+rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc2 -o bench -- $CMD > $OUT/pmc2_stdout.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc3 -o bench -- $CMD > $OUT/pmc3_stdout.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc4 -o bench -- $CMD > $OUT/pmc4_stdout.log 2>&1
+python - <<'PY'
+import csv, glob, collections
+for d in ('pmc1','pmc2','pmc3','pmc4'):
+    fs=glob.glob(f'gpurun_out/prof/{d}/**/*counter_collection.csv', recursive=True)
+    if not fs: print(d,'no csv'); continue
+    acc=collections.defaultdict(list)
+    for r in csv.DictReader(open(fs[0])):
+        if 'step_kernel' in r['Kernel_Name']: acc[r['Counter_Name']].append(float(r['Counter_Value']))
+    for k,v in acc.items(): print(d, k, 'per-dispatch mean %.4g'%(sum(v)/len(v)), 'n', len(v))
+PY
+find $OUT -name "*.csv" -size +3M -delete

@@ -1,0 +1,31 @@
+"""Per-wave phase timeline of one step_kernel launch (VMAS_TRACE=1): s_memtime stamps
+0 start | 1 loads issued+landed | 2 after load barrier | 3 end of gather | 4 after barrier | 5 end"""
+import os, sys, ctypes
+os.environ["VMAS_TRACE"] = "1"
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+import numpy as np, torch
+import bench
+lanes = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 32768
+sc, w = bench.build_world(B, torch.device("cuda", 0), 4, lanes, 0)
+be = w._get_backend()
+forces = bench.make_forces(w, 100, 1234, torch.device("cuda", 0))
+be.step_n(60, forces[:60]); torch.cuda.synchronize()
+be.step_n(1, forces[60:61]); torch.cuda.synchronize()
+tiles = (B + 63) // 64
+buf = np.zeros(tiles * 16 * 8, np.uint64)
+lib = be.lib
+lib.vmas_debug_trace.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
+assert lib.vmas_debug_trace(be._h, buf.ctypes.data_as(ctypes.c_void_p), buf.size) == 0
+t = buf.reshape(tiles, 16, 8).astype(np.int64)[:, :lanes, :6]
+t0 = t[:, :, 0].min()
+print("lanes", lanes, "tiles", tiles, "kernel span (cycles, s_memtime @100MHz?)", t[:, :, 5].max() - t0)
+for b in (0, 1, tiles // 2, tiles - 1):
+    print("tile", b)
+    for wv in range(lanes):
+        r = t[b, wv] - t0
+        print("  wave %2d start %6d | load %6d | bar %6d | gather %6d | bar %6d | integrate %6d" % (wv, r[0], r[1] - r[0], r[2] - r[1], r[3] - r[2], r[4] - r[3], r[5] - r[4]))
+d = t - t[:, :, 0:1]
+print("mean per-phase over all waves:", (t[:, :, 1:] - t[:, :, :-1]).mean(axis=(0, 1)))
+print("max  per-phase over all waves:", (t[:, :, 1:] - t[:, :, :-1]).max(axis=(0, 1)))
+print("start spread:", t[:, :, 0].max() - t0, " end min/max:", t[:, :, 5].min() - t0, t[:, :, 5].max() - t0)

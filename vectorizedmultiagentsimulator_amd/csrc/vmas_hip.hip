@@ -36,6 +36,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -54,40 +55,44 @@ using namespace vmas;
 constexpr int TILE = 64;       // environments per block = lanes per wave
 constexpr int MAX_WAVES = 8;   // waves (workers) per tile
 constexpr int TASK_JOINT = 6;  // item type next to VMAS_PAIR_*
+constexpr int ROWF = TILE;     // floats per LDS row
 
 enum : uint32_t { IT_A_HOLLOW = 1u << 0, IT_B_HOLLOW = 1u << 1, IT_LOCK = 1u << 2 /* joint rotate == False */ };
 
 // One evaluation of a joint/pair FOR ONE SIDE of it.  Static data pre-resolved on the host
-// with the same fp32 operations the reference performs at run time.
+// with the same fp32 operations the reference performs at run time.  All LDS positions are
+// float offsets into the tile, so row accesses become ds_read with an immediate offset.
 struct DevItem {
   int32_t type;   // VMAS_PAIR_* or TASK_JOINT
-  int32_t a, b;   // entities in the role order the reference passes them
   int32_t side;   // 0: accumulate the force on a, 1: on b
   uint32_t flags; // IT_*
   int32_t index;  // pair index (mask bit) or joint index (per-env fixed-rotation row)
-  int32_t tra, trb;  // first trig row of a / b (-1: sphere)
+  int32_t oa, ob;    // tile offsets of the first state row of a / b (role order of the reference)
+  int32_t tra, trb;  // tile offsets of their trig rows (unused for spheres)
   float thr2;     // (R_a + R_b + LINE_MIN_DIST + slack)^2: bounding-circle skip
-  float reach;    // box items: the other shape's reach + LINE_MIN_DIST + slack (OBB skip)
+  float reach;    // box items: the other shape's reach + LINE_MIN_DIST + slack (oriented-box skip)
   float p0, p1, p2, p3, q0, q1;  // type-specific dims, see build_items()
 };
 
 struct DevSegment {
   int32_t entity;
+  int32_t oe;        // tile offset of the entity's first state row
   int32_t item_begin, item_end;
   int32_t first;     // 1: this segment starts from the entity's prologue force
-  int32_t part_row;  // first of 3 partial-sum rows (fx, fy, torque)
+  int32_t part_off;  // tile offset of its 3 partial-sum rows (fx, fy, torque)
 };
 
 struct DevOwned {  // phase C work unit
   int32_t entity;
-  int32_t part_row, n_parts;  // partial rows of the entity's segments, in order
+  int32_t oe;
+  int32_t part_off, n_parts;  // partial rows of the entity's segments, in order
 };
 
 struct DevEntity {
   uint32_t flags;
   int32_t shape;
   int32_t agent_index;
-  int32_t tr_row;  // first of 4 trig rows, -1 for spheres
+  int32_t tr_off;  // tile offset of its 4 trig rows, -1 for spheres
   float mass, inertia, one_minus_drag;
   float max_speed, v_range, lin_friction, ang_friction;
   float gx, gy;
@@ -96,7 +101,7 @@ struct DevEntity {
 
 struct DevWorld {
   int32_t nE, nA, substeps;
-  int32_t row_af, row_tr, row_part, row_bad;  // first LDS row of each region (state starts at 0)
+  int32_t off_af, off_bad;  // tile offsets of the agent force rows and of the flag row
   float sub_dt, gx, gy;
   int32_t has_gravity;
   float xs, ys;  // NaN = unbounded
@@ -108,8 +113,6 @@ struct DevWorld {
   const int32_t* wave_seg;  // [W+1] segment ranges per wave
   const DevOwned* owned;
   const int32_t* wave_own;  // [W+1] owned-entity ranges per wave
-  const int32_t* trig_ent;  // entities with trig rows
-  int32_t n_trig;
 };
 
 struct DevStepArgs {
@@ -117,24 +120,23 @@ struct DevStepArgs {
   const float* joint_fixed_rot;
   const float* entity_gravity;
   int32_t first_substep, n_substeps;
+  int32_t ablate;  // profiling only (env VMAS_ABLATE): 1 skip items, 2 skip integration, 4 skip prologue
 };
 
-#define ROW(r) lds[(r) * TILE + lane]
-#define ST(e, f) ROW((e) * 6 + (f))
-#define AF(a, f) ROW(W.row_af + (a) * 3 + (f))
-#define TR(base, f) ROW(W.row_tr + (base) + (f))
-
 __device__ __forceinline__ int sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ bool finite_f(float x) { return fabsf(x) < kInf; }
 
 // cos/sin of the rotation(s) the narrow phase needs (physics.py:300-302, 413)
-__device__ __forceinline__ void write_trig(float* lds, const DevWorld& W, int lane, int e, const DevEntity& D) {
-  const float rot = ST(e, 4);
-  TR(D.tr_row, 0) = cosf(rot);
-  TR(D.tr_row, 1) = sinf(rot);
-  if (D.shape == VMAS_SHAPE_BOX) {
+__device__ __forceinline__ void write_trig(float* tr, float rot, int shape) {
+  float sn, cs;
+  sincosf(rot, &sn, &cs);  // one range reduction for both (ocml), same values as cosf/sinf
+  tr[0 * ROWF] = cs;
+  tr[1 * ROWF] = sn;
+  if (shape == VMAS_SHAPE_BOX) {
     const float rot2 = rot + kHalfPi;
-    TR(D.tr_row, 2) = cosf(rot2);
-    TR(D.tr_row, 3) = sinf(rot2);
+    sincosf(rot2, &sn, &cs);
+    tr[2 * ROWF] = cs;
+    tr[3 * ROWF] = sn;
   }
 }
 
@@ -147,117 +149,137 @@ __device__ __forceinline__ float obb_dist2(v2 p, v2 c, float cs, float sn, float
   return ex * ex + ey * ey;
 }
 
+// separating-axis lower bound of the distance between a segment (centre p, direction (lc,ls),
+// half length h) and the oriented box: the larger of the two gaps along the box axes
+__device__ __forceinline__ float seg_obb_gap(v2 p, float lc, float ls, float h, v2 c, float cs, float sn, float half_l,
+                                             float half_w) {
+  const float dx = p.x - c.x, dy = p.y - c.y;
+  const float px = dx * cs + dy * sn, py = dy * cs - dx * sn;            // segment centre in the box frame
+  const float ex = fabsf(h * (lc * cs + ls * sn)), ey = fabsf(h * (ls * cs - lc * sn));  // its half extents
+  const float gx = fabsf(px) - ex - half_l, gy = fabsf(py) - ey - half_w;
+  return fmaxf(gx, gy);
+}
+
 // Force (and torque) one item contributes to ITS side.  LEVEL prunes code (and registers):
 // 0: SS LS BS   1: + LL BL joints   2: + BB
 template <int LEVEL>
-__device__ __forceinline__ void eval_item(const DevItem& K, const DevWorld& W, const DevStepArgs& args, float* lds,
-                                          int lane, long env, int batch, long ld, bool may_skip, v2& f_out,
+__device__ __forceinline__ void eval_item(const DevItem& K, const DevWorld& W, const DevStepArgs& args,
+                                          const float* tile, long env, bool live, long ld, bool may_skip, v2& f_out,
                                           float& t_out) {
-  const int a = K.a, b = K.b;
-  const v2 pa = V(ST(a, 0), ST(a, 1)), pb = V(ST(b, 0), ST(b, 1));
-  v2 fa = V(0.f, 0.f), fb = V(0.f, 0.f);
-  float ta = 0.f, tb = 0.f;
+  const float* A = tile + K.oa;
+  const float* B = tile + K.ob;
+  const v2 pa = V(A[0], A[ROWF]), pb = V(B[0], B[ROWF]);
   const float k = W.k;
+  // Every joint/pair applies f to a and exactly -f to b (core.py:2839), so only the force on
+  // a is computed and the b side flips its sign bit.  (Written as an integer xor on purpose:
+  // hipcc 7.2 mis-folds `side ? -f : f` - the negation is dropped - which the golden parity
+  // tests caught.)  Torques use the side's own lever arm.
+  const uint32_t flip = K.side ? 0x80000000u : 0u;
+  auto own = [&](v2 fa) { return V(__uint_as_float(__float_as_uint(fa.x) ^ flip), __uint_as_float(__float_as_uint(fa.y) ^ flip)); };
   if (LEVEL >= 1 && K.type == TASK_JOINT) {  // _vectorized_joint_constraints core.py:2201-2292
-    const float ra = ST(a, 4), rb = ST(b, 4);
-    const v2 pja = pa + rotate(V(K.p0, K.p1), cosf(ra), sinf(ra));  // joints.py:209-216
-    const v2 pjb = pb + rotate(V(K.q0, K.q1), cosf(rb), sinf(rb));
+    const float ra = A[4 * ROWF], rb = B[4 * ROWF];
+    float sa, ca, sb, cb;
+    sincosf(ra, &sa, &ca);
+    sincosf(rb, &sb, &cb);
+    const v2 pja = pa + rotate(V(K.p0, K.p1), ca, sa);  // joints.py:209-216
+    const v2 pjb = pb + rotate(V(K.q0, K.q1), cb, sb);
     const v2 f_att = constraint_force<true>(pja, pjb, K.p2, W.c_joint_att, k);
     const v2 f_rep = constraint_force<false>(pja, pjb, K.p2, W.c_joint_rep, k);
-    fa = f_att + f_rep;
-    fb = (-f_att) + (-f_rep);
-    ta = vcross(pja - pa, fa);
-    tb = vcross(pjb - pb, fb);
+    const v2 f = own(f_att + f_rep);  // (-f_att) + (-f_rep) == -(f_att + f_rep) bitwise
+    float t = vcross(K.side ? (pjb - pb) : (pja - pa), f);
     if (K.flags & IT_LOCK) {
       float fr = K.p3;
-      if (args.joint_fixed_rot && env < batch) fr = args.joint_fixed_rot[(long)K.index * ld + env];
-      const float t = constraint_torque(ra, rb + fr, W.tcf);
-      ta = ta + (-t);
-      tb = tb + t;
+      if (args.joint_fixed_rot && live) fr = args.joint_fixed_rot[(long)K.index * ld + env];
+      const float lock = constraint_torque(ra, rb + fr, W.tcf);
+      t = t + (K.side ? lock : -lock);
     }
-  } else {
-    if (args.pair_mask && !((args.pair_mask[K.index >> 5] >> (K.index & 31)) & 1u)) return;
-    {  // conservative per-environment broad phase: beyond it the force is exactly zero
-      const float dx = pa.x - pb.x, dy = pa.y - pb.y;
-      bool need = !(dx * dx + dy * dy > K.thr2);
-      if (K.type >= VMAS_PAIR_BS && need) {  // a is a box: oriented-box distance is much tighter
-        const float d2 = obb_dist2(pb, pa, TR(K.tra, 0), TR(K.tra, 1), K.p0 * 0.5f, K.p1 * 0.5f);
-        need = !(d2 > K.reach * K.reach);
-      }
-      need = need || !may_skip;
-      if (!__any(need)) return;
-    }
-    switch (K.type) {
-      case VMAS_PAIR_SS: {  // core.py:2294-2339; p0 = r_a + r_b
-        fa = constraint_force<false>(pa, pb, K.p0, W.c_coll, k);
-        fb = -fa;
-      } break;
-      case VMAS_PAIR_LS: {  // a = line, b = sphere; p0 = L/2, p1 = r + LMD  core.py:2341-2392
-        const v2 cp = closest_point_line<true>(pa, TR(K.tra, 0), TR(K.tra, 1), K.p0, pb);
-        fb = constraint_force<false>(pb, cp, K.p1, W.c_coll, k);
-        fa = -fb;
-        ta = vcross(cp - pa, fa);
-      } break;
-      case VMAS_PAIR_BS: {  // a = box, b = sphere; p0 = L, p1 = W, p2 = r + LMD  core.py:2459-2552
-        seg_t be[4];
-        box_edges(pa, TR(K.tra, 0), TR(K.tra, 1), TR(K.tra, 2), TR(K.tra, 3), K.p0, K.p1, be);
-        const v2 cp = closest_point_box(be, pb);
-        v2 ip = cp;
-        float d = 0.f;
-        if (!(K.flags & IT_A_HOLLOW)) ip = inner_point_box(pb, cp, pa, d);
-        fb = constraint_force<false>(pb, ip, K.p2 + d, W.c_coll, k);
-        fa = -fb;
-        ta = vcross(cp - pa, fa);
-      } break;
-      case VMAS_PAIR_LL:
-        if (LEVEL >= 1) {  // p0 = La/2, p1 = Lb/2  core.py:2394-2457
-          seg_t l1 = {pa, TR(K.tra, 0), TR(K.tra, 1), K.p0};
-          seg_t l2 = {pb, TR(K.trb, 0), TR(K.trb, 1), K.p1};
-          v2 qa, qb;
-          closest_points_seg_seg(l1, l2, qa, qb);
-          fa = constraint_force<false>(qa, qb, kLineMinDist, W.c_coll, k);
-          fb = -fa;
-          ta = vcross(qa - pa, fa);
-          tb = vcross(qb - pb, fb);
-        }
-        break;
-      case VMAS_PAIR_BL:
-        if (LEVEL >= 1) {  // a = box, b = line; p0 = L, p1 = W, p2 = Lb/2  core.py:2554-2653
-          seg_t be[4];
-          box_edges(pa, TR(K.tra, 0), TR(K.tra, 1), TR(K.tra, 2), TR(K.tra, 3), K.p0, K.p1, be);
-          seg_t ln = {pb, TR(K.trb, 0), TR(K.trb, 1), K.p2};
-          v2 qb, ql;
-          closest_seg_box(be, ln, qb, ql);
-          v2 ip = qb;
-          float d = 0.f;
-          if (!(K.flags & IT_A_HOLLOW)) ip = inner_point_box(ql, qb, pa, d);
-          fa = constraint_force<false>(ip, ql, kLineMinDist + d, W.c_coll, k);
-          fb = -fa;
-          ta = vcross(qb - pa, fa);
-          tb = vcross(ql - pb, fb);
-        }
-        break;
-      case VMAS_PAIR_BB:
-        if (LEVEL >= 2) {  // p0,p1 = L,W of a; p2,p3 = L,W of b  core.py:2655-2786
-          seg_t ea[4], eb[4];
-          box_edges(pa, TR(K.tra, 0), TR(K.tra, 1), TR(K.tra, 2), TR(K.tra, 3), K.p0, K.p1, ea);
-          box_edges(pb, TR(K.trb, 0), TR(K.trb, 1), TR(K.trb, 2), TR(K.trb, 3), K.p2, K.p3, eb);
-          v2 qa, qb;
-          closest_box_box(ea, eb, qa, qb);
-          v2 ia = qa, ib = qb;
-          float da = 0.f, db = 0.f;
-          if (!(K.flags & IT_A_HOLLOW)) ia = inner_point_box(qb, qa, pa, da);
-          if (!(K.flags & IT_B_HOLLOW)) ib = inner_point_box(qa, qb, pb, db);
-          fa = constraint_force<false>(ia, ib, da + db + kLineMinDist, W.c_coll, k);
-          fb = -fa;
-          ta = vcross(qa - pa, fa);
-          tb = vcross(qb - pb, fb);
-        }
-        break;
-      default: break;
-    }
+    f_out = f;
+    t_out = t;
+    return;
   }
-  if (K.side) { f_out = fb; t_out = tb; } else { f_out = fa; t_out = ta; }
+  if (args.pair_mask && !((args.pair_mask[K.index >> 5] >> (K.index & 31)) & 1u)) return;
+  const float* TA = tile + K.tra;
+  const float* TB = tile + K.trb;
+  {  // conservative per-environment broad phase: beyond it the force is exactly zero
+    const float dx = pa.x - pb.x, dy = pa.y - pb.y;
+    bool need = !(dx * dx + dy * dy > K.thr2);
+    if (K.type >= VMAS_PAIR_BS) {  // a is a box: test against the oriented box, much tighter
+      if (K.type == VMAS_PAIR_BL) {
+        const float gap = seg_obb_gap(pb, TB[0], TB[ROWF], K.p2, pa, TA[0], TA[ROWF], K.p0 * 0.5f, K.p1 * 0.5f);
+        need = need && !(gap > K.reach);
+      } else {
+        const float d2 = obb_dist2(pb, pa, TA[0], TA[ROWF], K.p0 * 0.5f, K.p1 * 0.5f);
+        need = need && !(d2 > K.reach * K.reach);
+      }
+    }
+    need = need || !may_skip;
+    if (!__any(need) || (args.ablate & 32)) return;  // 32: broad phase only (profiling)
+  }
+  switch (K.type) {
+    case VMAS_PAIR_SS: {  // core.py:2294-2339; p0 = r_a + r_b
+      f_out = own(contact_force(pa, pb, K.p0, W.c_coll, k));
+    } break;
+    case VMAS_PAIR_LS: {  // a = line, b = sphere; p0 = L/2, p1 = r + LMD  core.py:2341-2392
+      const v2 cp = closest_point_line<true>(pa, TA[0], TA[ROWF], K.p0, pb);
+      const v2 f = own(-contact_force(pb, cp, K.p1, W.c_coll, k));
+      f_out = f;
+      t_out = K.side ? 0.f : vcross(cp - pa, f);
+    } break;
+    case VMAS_PAIR_BS: {  // a = box, b = sphere; p0 = L, p1 = W, p2 = r + LMD  core.py:2459-2552
+      seg_t be[4];
+      box_edges(pa, TA[0], TA[ROWF], TA[2 * ROWF], TA[3 * ROWF], K.p0, K.p1, be);
+      const v2 cp = closest_point_box(be, pb);
+      v2 ip = cp;
+      float d = 0.f;
+      if (!(K.flags & IT_A_HOLLOW)) ip = inner_point_box(pb, cp, pa, d);
+      const v2 f = own(-contact_force(pb, ip, K.p2 + d, W.c_coll, k));
+      f_out = f;
+      t_out = K.side ? 0.f : vcross(cp - pa, f);
+    } break;
+    case VMAS_PAIR_LL:
+      if (LEVEL >= 1) {  // p0 = La/2, p1 = Lb/2  core.py:2394-2457
+        seg_t l1 = {pa, TA[0], TA[ROWF], K.p0};
+        seg_t l2 = {pb, TB[0], TB[ROWF], K.p1};
+        v2 qa, qb;
+        closest_points_seg_seg(l1, l2, qa, qb);
+        const v2 f = own(contact_force(qa, qb, kLineMinDist, W.c_coll, k));
+        f_out = f;
+        t_out = vcross(K.side ? (qb - pb) : (qa - pa), f);
+      }
+      break;
+    case VMAS_PAIR_BL:
+      if (LEVEL >= 1) {  // a = box, b = line; p0 = L, p1 = W, p2 = Lb/2  core.py:2554-2653
+        seg_t be[4];
+        box_edges(pa, TA[0], TA[ROWF], TA[2 * ROWF], TA[3 * ROWF], K.p0, K.p1, be);
+        seg_t ln = {pb, TB[0], TB[ROWF], K.p2};
+        v2 qb, ql;
+        closest_seg_box(be, ln, qb, ql);
+        v2 ip = qb;
+        float d = 0.f;
+        if (!(K.flags & IT_A_HOLLOW)) ip = inner_point_box(ql, qb, pa, d);
+        const v2 f = own(contact_force(ip, ql, kLineMinDist + d, W.c_coll, k));
+        f_out = f;
+        t_out = vcross(K.side ? (ql - pb) : (qb - pa), f);
+      }
+      break;
+    case VMAS_PAIR_BB:
+      if (LEVEL >= 2) {  // p0,p1 = L,W of a; p2,p3 = L,W of b  core.py:2655-2786
+        seg_t ea[4], eb[4];
+        box_edges(pa, TA[0], TA[ROWF], TA[2 * ROWF], TA[3 * ROWF], K.p0, K.p1, ea);
+        box_edges(pb, TB[0], TB[ROWF], TB[2 * ROWF], TB[3 * ROWF], K.p2, K.p3, eb);
+        v2 qa, qb;
+        closest_box_box(ea, eb, qa, qb);
+        v2 ia = qa, ib = qb;
+        float da = 0.f, db = 0.f;
+        if (!(K.flags & IT_A_HOLLOW)) ia = inner_point_box(qb, qa, pa, da);
+        if (!(K.flags & IT_B_HOLLOW)) ib = inner_point_box(qa, qb, pb, db);
+        const v2 f = own(contact_force(ia, ib, da + db + kLineMinDist, W.c_coll, k));
+        f_out = f;
+        t_out = vcross(K.side ? (qb - pb) : (qa - pa), f);
+      }
+      break;
+    default: break;
+  }
 }
 
 // ------------------------------------------------------------------------------------
@@ -274,23 +296,32 @@ __global__ __launch_bounds__(TILE* MAX_WAVES) void step_kernel(DevWorld W, float
   const int nE = W.nE, nA = W.nA;
   const long env = (long)blockIdx.x * TILE + lane;
   const bool live = env < batch;
-  int* bad_row = (int*)(lds + W.row_bad * TILE);
+  float* tile = lds + lane;  // this lane's column: row r is tile[r * ROWF]
+  int* bad_flag = (int*)(tile + W.off_bad);
 
-  // ---- HBM -> LDS: each wave instruction moves one 256-byte run of a plane ----
-  for (int r = wv; r < nE * 6; r += nw) ROW(r) = live ? state[r * ld + env] : 0.f;
-  for (int r = wv; r < nA * 3; r += nw) ROW(W.row_af + r) = live ? agent_ft[r * ld + env] : 0.f;
-  if (wv == 0) bad_row[lane] = 0;
+  // ---- HBM -> LDS, one entity per wave at a time: six 256-byte row reads in flight, then the
+  //      entity's trig and the non-finite check straight from the registers (no extra barrier)
+  if (wv == 0) *bad_flag = 0;
   __syncthreads();
-
-  // ---- once: trig of Line/Box entities; environments with a non-finite pose may not use
-  //      the distance skip (the reference lets cos(inf) = NaN poison every pair, however far)
-  for (int i = wv; i < W.n_trig; i += nw) {
-    const int e = sgpr(W.trig_ent[i]);
-    write_trig(lds, W, lane, e, W.ent[e]);
-  }
   for (int e = wv; e < nE; e += nw) {
-    const float px = ST(e, 0), py = ST(e, 1), rt = ST(e, 4);
-    if (!(fabsf(px) < kInf) || !(fabsf(py) < kInf) || !(fabsf(rt) < kInf)) bad_row[lane] = 1;
+    const float* src = state + (long)e * 6 * ld + env;
+    float v[6];
+#pragma unroll
+    for (int f = 0; f < 6; ++f) v[f] = live ? src[f * ld] : 0.f;
+    float* dst = tile + e * 6 * ROWF;
+#pragma unroll
+    for (int f = 0; f < 6; ++f) dst[f * ROWF] = v[f];
+    // the reference lets a non-finite pose poison every pair it is in, however far apart
+    // (cos(inf) = NaN): such environments must not use the distance skip
+    if (!finite_f(v[0]) || !finite_f(v[1]) || !finite_f(v[4])) *bad_flag = 1;
+    const int tr_off = sgpr(W.ent[e].tr_off), shape = sgpr(W.ent[e].shape);
+    if (tr_off >= 0 && !(args.ablate & 8)) write_trig(tile + tr_off, v[4], shape);
+  }
+  for (int a = wv; a < nA; a += nw) {
+    const float* src = agent_ft + (long)a * 3 * ld + env;
+    float* dst = tile + W.off_af + a * 3 * ROWF;
+#pragma unroll
+    for (int f = 0; f < 3; ++f) dst[f * ROWF] = live ? src[f * ld] : 0.f;
   }
   __syncthreads();
 
@@ -301,40 +332,52 @@ __global__ __launch_bounds__(TILE* MAX_WAVES) void step_kernel(DevWorld W, float
   const int own0 = sgpr(W.wave_own[wv]), own1 = sgpr(W.wave_own[wv + 1]);
 
   for (int substep = s_begin; substep < s_end; ++substep) {
-    const bool may_skip = bad_row[lane] == 0;
+    const bool may_skip = *bad_flag == 0;
+    const bool last = substep + 1 == s_end;
     // ================= phase B: gather forces per (entity, segment)
     for (int si = seg0; si < seg1; ++si) {
       const DevSegment S = W.segs[si];
       const int e = S.entity;
+      const float* Es = tile + S.oe;
+      const uint32_t efl = W.ent[e].flags;
       v2 F = V(0.f, 0.f);
       float Tq = 0.f;
-      if (S.first) {  // prologue core.py:1995-2004
+      if (S.first && !(args.ablate & 4)) {  // prologue core.py:1995-2004
         const DevEntity D = W.ent[e];
         const uint32_t fl = D.flags;
         if (fl & VMAS_F_AGENT) {
-          const int a = D.agent_index;
+          float* Af = tile + W.off_af + D.agent_index * 3 * ROWF;
           if (fl & VMAS_F_MOVABLE) {  // _apply_action_force core.py:2018-2028
-            v2 f = V(AF(a, 0), AF(a, 1));
-            if (fl & VMAS_F_MAX_F) f = clamp_with_norm(f, D.max_f);
-            if (fl & VMAS_F_F_RANGE) f = V(clamp_t(f.x, D.f_range), clamp_t(f.y, D.f_range));
-            if (fl & (VMAS_F_MAX_F | VMAS_F_F_RANGE)) { AF(a, 0) = f.x; AF(a, 1) = f.y; }
+            v2 f = V(Af[0], Af[ROWF]);
+            if (fl & (VMAS_F_MAX_F | VMAS_F_F_RANGE)) {
+              if (fl & VMAS_F_MAX_F) f = clamp_with_norm(f, D.max_f);
+              if (fl & VMAS_F_F_RANGE) f = V(clamp_t(f.x, D.f_range), clamp_t(f.y, D.f_range));
+              Af[0] = f.x; Af[ROWF] = f.y;
+              if (last && live) {  // the clamped force is written back (core.py:2021-2027)
+                float* gf = agent_ft + (long)D.agent_index * 3 * ld + env;
+                gf[0] = f.x; gf[ld] = f.y;
+              }
+            }
             F = F + f;
           }
           if (fl & VMAS_F_ROTATABLE) {  // _apply_action_torque core.py:2030-2041
-            float t = AF(a, 2);
-            if (fl & VMAS_F_MAX_T) {
-              const float n = fabsf(t);
-              const float nt = (t / n) * D.max_t;
-              t = n > D.max_t ? nt : t;
+            float t = Af[2 * ROWF];
+            if (fl & (VMAS_F_MAX_T | VMAS_F_T_RANGE)) {
+              if (fl & VMAS_F_MAX_T) {
+                const float n = fabsf(t);
+                const float nt = (t / n) * D.max_t;
+                t = n > D.max_t ? nt : t;
+              }
+              if (fl & VMAS_F_T_RANGE) t = clamp_t(t, D.t_range);
+              Af[2 * ROWF] = t;
+              if (last && live) agent_ft[((long)D.agent_index * 3 + 2) * ld + env] = t;
             }
-            if (fl & VMAS_F_T_RANGE) t = clamp_t(t, D.t_range);
-            if (fl & (VMAS_F_MAX_T | VMAS_F_T_RANGE)) AF(a, 2) = t;
             Tq = Tq + t;
           }
         }
         // _apply_friction_force core.py:2054-2102
-        if (fl & VMAS_F_LIN_FRICTION) F = F + friction2(V(ST(e, 2), ST(e, 3)), D.lin_friction, D.mass, sub_dt);
-        if (fl & VMAS_F_ANG_FRICTION) Tq = Tq + friction1(ST(e, 5), D.ang_friction, D.inertia, sub_dt);
+        if (fl & VMAS_F_LIN_FRICTION) F = F + friction2(V(Es[2 * ROWF], Es[3 * ROWF]), D.lin_friction, D.mass, sub_dt);
+        if (fl & VMAS_F_ANG_FRICTION) Tq = Tq + friction1(Es[5 * ROWF], D.ang_friction, D.inertia, sub_dt);
         // _apply_gravity core.py:2043-2052
         if (fl & VMAS_F_MOVABLE) {
           if (W.has_gravity) F = F + V(D.mass * W.gx, D.mass * W.gy);
@@ -348,88 +391,74 @@ __global__ __launch_bounds__(TILE* MAX_WAVES) void step_kernel(DevWorld W, float
           }
         }
       }
-      // joints, then pairs, in the reference's accumulation order (core.py:2176-2199);
-      // the gating of update_env_forces is static and already folded into the item list
-      const uint32_t efl = W.ent[e].flags;
-      for (int ii = S.item_begin; ii < S.item_end; ++ii) {
+      // joints, then pairs, in the reference's accumulation order (core.py:2176-2199)
+      const int i0 = S.item_begin, i1 = (args.ablate & 1) ? S.item_begin : S.item_end;
+      for (int ii = i0; ii < i1; ++ii) {
         const DevItem K = W.items[ii];
         v2 f = V(0.f, 0.f);
         float t = 0.f;
-        eval_item<LEVEL>(K, W, args, lds, lane, env, batch, ld, may_skip, f, t);
+        if (!(args.ablate & 16)) eval_item<LEVEL>(K, W, args, tile, env, live, ld, may_skip, f, t);
+        else f.x = __int_as_float(K.type + K.oa + K.ob + K.index) * 1e-30f;  // descriptor fetch only (profiling)
         if (efl & VMAS_F_MOVABLE) F = F + f;
         if (efl & VMAS_F_ROTATABLE) Tq = Tq + t;
       }
-      ROW(W.row_part + S.part_row + 0) = F.x;
-      ROW(W.row_part + S.part_row + 1) = F.y;
-      ROW(W.row_part + S.part_row + 2) = Tq;
+      float* P = tile + S.part_off;
+      P[0] = F.x; P[ROWF] = F.y; P[2 * ROWF] = Tq;
     }
     __syncthreads();
 
-    // ================= phase C: _integrate_state core.py:2862-2908 (+ trig for the next substep)
-    for (int oi = own0; oi < own1; ++oi) {
+    // ================= phase C: _integrate_state core.py:2862-2908 (+ trig for the next substep,
+    //                   or, after the last substep, the write-back of the entity's planes)
+    for (int oi = own0; oi < ((args.ablate & 2) ? own0 : own1); ++oi) {
       const DevOwned O = W.owned[oi];
       const int e = O.entity;
       const DevEntity D = W.ent[e];
       const uint32_t fl = D.flags;
-      v2 F = V(ROW(W.row_part + O.part_row), ROW(W.row_part + O.part_row + 1));
-      float Tq = ROW(W.row_part + O.part_row + 2);
+      float* Es = tile + O.oe;
+      const float* P = tile + O.part_off;
+      v2 F = V(P[0], P[ROWF]);
+      float Tq = P[2 * ROWF];
       for (int p = 1; p < O.n_parts; ++p) {
-        F = F + V(ROW(W.row_part + O.part_row + 3 * p), ROW(W.row_part + O.part_row + 3 * p + 1));
-        Tq = Tq + ROW(W.row_part + O.part_row + 3 * p + 2);
+        F = F + V(P[3 * p * ROWF], P[(3 * p + 1) * ROWF]);
+        Tq = Tq + P[(3 * p + 2) * ROWF];
       }
+      float* dst = state + (long)e * 6 * ld + env;
       bool bad = false;
       if (fl & VMAS_F_MOVABLE) {
-        v2 vel = V(ST(e, 2), ST(e, 3));
+        v2 vel = V(Es[2 * ROWF], Es[3 * ROWF]);
         if (substep == 0) vel = V(vel.x * D.one_minus_drag, vel.y * D.one_minus_drag);
         const v2 acc = V(F.x / D.mass, F.y / D.mass);
         vel = V(vel.x + acc.x * sub_dt, vel.y + acc.y * sub_dt);
         if (fl & VMAS_F_MAX_SPEED) vel = clamp_with_norm(vel, D.max_speed);
         if (fl & VMAS_F_V_RANGE) vel = V(clamp_t(vel.x, D.v_range), clamp_t(vel.y, D.v_range));
-        v2 np = V(ST(e, 0) + vel.x * sub_dt, ST(e, 1) + vel.y * sub_dt);
+        v2 np = V(Es[0] + vel.x * sub_dt, Es[ROWF] + vel.y * sub_dt);
         if (W.xs == W.xs) np.x = clamp_t(np.x, W.xs);
         if (W.ys == W.ys) np.y = clamp_t(np.y, W.ys);
-        ST(e, 0) = np.x; ST(e, 1) = np.y; ST(e, 2) = vel.x; ST(e, 3) = vel.y;
-        bad = !(fabsf(np.x) < kInf) || !(fabsf(np.y) < kInf);
+        if (last) {
+          if (live) { dst[0] = np.x; dst[ld] = np.y; dst[2 * ld] = vel.x; dst[3 * ld] = vel.y; }
+        } else {
+          Es[0] = np.x; Es[ROWF] = np.y; Es[2 * ROWF] = vel.x; Es[3 * ROWF] = vel.y;
+          bad = !finite_f(np.x) || !finite_f(np.y);
+        }
       }
       if (fl & VMAS_F_ROTATABLE) {
-        float av = ST(e, 5);
+        float av = Es[5 * ROWF];
         if (substep == 0) av = av * D.one_minus_drag;
         av = av + (Tq / D.inertia) * sub_dt;
-        const float rot = ST(e, 4) + av * sub_dt;
-        ST(e, 4) = rot;
-        ST(e, 5) = av;
-        bad = bad || !(fabsf(rot) < kInf);
-        if (D.tr_row >= 0 && substep + 1 < s_end) write_trig(lds, W, lane, e, D);
+        const float rot = Es[4 * ROWF] + av * sub_dt;
+        if (last) {
+          if (live) { dst[4 * ld] = rot; dst[5 * ld] = av; }
+        } else {
+          Es[4 * ROWF] = rot; Es[5 * ROWF] = av;
+          bad = bad || !finite_f(rot);
+          if (D.tr_off >= 0) write_trig(tile + D.tr_off, rot, D.shape);
+        }
       }
-      if (bad) bad_row[lane] = 1;
+      if (bad) *bad_flag = 1;
     }
-    __syncthreads();
-  }
-
-  // ---- LDS -> HBM: only the planes the reference rebinds (core.py:2871-2908, 2021-2039)
-  if (live) {
-    for (int r = wv; r < nE * 6; r += nw) {
-      const uint32_t fl = W.ent[r / 6].flags;
-      const bool dyn = (r % 6 < 4) ? (fl & VMAS_F_MOVABLE) : (fl & VMAS_F_ROTATABLE);
-      if (dyn) state[r * ld + env] = ROW(r);
-    }
-    for (int e = wv; e < nE; e += nw) {
-      const DevEntity D = W.ent[e];
-      if (!(D.flags & VMAS_F_AGENT)) continue;
-      const int a = D.agent_index;
-      if ((D.flags & VMAS_F_MOVABLE) && (D.flags & (VMAS_F_MAX_F | VMAS_F_F_RANGE))) {
-        agent_ft[(a * 3 + 0) * ld + env] = AF(a, 0);
-        agent_ft[(a * 3 + 1) * ld + env] = AF(a, 1);
-      }
-      if ((D.flags & VMAS_F_ROTATABLE) && (D.flags & (VMAS_F_MAX_T | VMAS_F_T_RANGE)))
-        agent_ft[(a * 3 + 2) * ld + env] = AF(a, 2);
-    }
+    if (!last) __syncthreads();
   }
 }
-#undef ROW
-#undef ST
-#undef AF
-#undef TR
 
 // ------------------------------------------------------------------------------------
 // batch-global broad phase (World.collides core.py:2797-2801)
@@ -545,6 +574,12 @@ __global__ __launch_bounds__(256) void lidar_kernel(const DevLidar* __restrict__
   }
 }
 
+// test hook (not part of the ABI): the device softplus on an array, for the accuracy test
+__global__ void softplus_kernel(const float* __restrict__ in, float* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = softplus0(in[i]);
+}
+
 // ------------------------------------------------------------------------------------
 // host side: the C ABI
 // ------------------------------------------------------------------------------------
@@ -585,6 +620,7 @@ struct Sched {
 };
 
 struct VmasWorld {
+  int row_tr = 0;  // first trig row of the tile (after state and agent-force rows)
   int device = 0;
   int batch = 0;
   int lanes = 1;  // waves per 64-env tile = lanes cooperating on one environment
@@ -612,15 +648,15 @@ struct VmasWorld {
 static float type_cost(int type) {
   // relative narrow-phase cost per item, from instruction counts of the compiled kernel
   switch (type) {
-    case VMAS_PAIR_SS: return 1.f;
-    case VMAS_PAIR_LS: return 2.f;
-    case VMAS_PAIR_LL: return 8.f;
-    case VMAS_PAIR_BS: return 6.f;
-    case VMAS_PAIR_BL: return 28.f;
-    case VMAS_PAIR_BB: return 220.f;
-    case TASK_JOINT: return 8.f;
+    case VMAS_PAIR_SS: return 60.f;   // ~130 in contact, ~30 skipped; sphere contacts are rare
+    case VMAS_PAIR_LS: return 160.f;
+    case VMAS_PAIR_LL: return 600.f;
+    case VMAS_PAIR_BS: return 350.f;
+    case VMAS_PAIR_BL: return 2000.f;
+    case VMAS_PAIR_BB: return 15000.f;
+    case TASK_JOINT: return 500.f;
   }
-  return 1.f;
+  return 100.f;
 }
 
 // forces vanish once shapes are farther apart than LINE_MIN_DIST ("per-environment
@@ -632,27 +668,30 @@ static void build_items(const VmasWorldDesc* d, VmasWorld* w, const std::vector<
   const int nE = d->n_entities;
   std::vector<std::vector<DevItem>> per(nE);
   auto dyn = [&](int e) { return (E[e].flags & (VMAS_F_MOVABLE | VMAS_F_ROTATABLE)) != 0; };
-  auto push_sides = [&](DevItem t) {
-    if (dyn(t.a)) { t.side = 0; per[t.a].push_back(t); }
-    if (dyn(t.b)) { t.side = 1; per[t.b].push_back(t); }
+  auto push_sides = [&](DevItem t, int a, int b) {
+    if (dyn(a)) { t.side = 0; per[a].push_back(t); }
+    if (dyn(b)) { t.side = 1; per[b].push_back(t); }
   };
+  auto tr_off = [&](int e) { return tr_row[e] >= 0 ? (w->row_tr + tr_row[e]) * ROWF : 0; };
   for (int j = 0; j < d->n_joints; ++j) {  // joints first (core.py:2176)
     const VmasJointDesc& J = d->joints[j];
     DevItem t{};
-    t.type = TASK_JOINT; t.a = J.a; t.b = J.b; t.index = j;
+    t.type = TASK_JOINT; t.index = j;
+    t.oa = J.a * 6 * ROWF; t.ob = J.b * 6 * ROWF;
     t.flags = J.rotate ? 0u : IT_LOCK;
-    t.tra = tr_row[J.a]; t.trb = tr_row[J.b];
+    t.tra = tr_off(J.a); t.trb = tr_off(J.b);
     t.p0 = J.delta_a[0]; t.p1 = J.delta_a[1]; t.q0 = J.delta_b[0]; t.q1 = J.delta_b[1];
     t.p2 = J.dist; t.p3 = J.fixed_rotation;
-    push_sides(t);
+    push_sides(t, J.a, J.b);
   }
   for (int p = 0; p < d->n_pairs; ++p) {  // then pairs, already type-major (core.py:2178-2189)
     const VmasPairDesc& P = d->pairs[p];
     const VmasEntityDesc &A = E[P.a], &B = E[P.b];
     DevItem t{};
-    t.type = P.type; t.a = P.a; t.b = P.b; t.index = p;
+    t.type = P.type; t.index = p;
+    t.oa = P.a * 6 * ROWF; t.ob = P.b * 6 * ROWF;
     t.flags = ((A.flags & VMAS_F_HOLLOW) ? IT_A_HOLLOW : 0u) | ((B.flags & VMAS_F_HOLLOW) ? IT_B_HOLLOW : 0u);
-    t.tra = tr_row[P.a]; t.trb = tr_row[P.b];
+    t.tra = tr_off(P.a); t.trb = tr_off(P.b);
     float m = P.bound_sum + kLineMinDist + kSkipSlack;
     t.thr2 = m * m;
     switch (P.type) {
@@ -677,7 +716,7 @@ static void build_items(const VmasWorldDesc* d, VmasWorld* w, const std::vector<
         break;
       default: break;
     }
-    push_sides(t);
+    push_sides(t, P.a, P.b);
   }
   w->ent_item_begin.assign(nE + 1, 0);
   w->items.clear();
@@ -705,21 +744,21 @@ static int build_sched(VmasWorld* w, int nw, Sched& S) {
   float total = 0.f;
   for (int e = 0; e < nE; ++e)
     if (w->ents[e].flags & (VMAS_F_MOVABLE | VMAS_F_ROTATABLE)) {
-      total += 1.f;
+      total += 60.f;
       for (int i = w->ent_item_begin[e]; i < w->ent_item_begin[e + 1]; ++i) total += w->item_cost[i];
     }
-  const float target = std::max(total / (float)nw, 1.f);
+  const float target = std::max(total / (float)nw, 100.f);
   for (int e = 0; e < nE; ++e) {
     if (!(w->ents[e].flags & (VMAS_F_MOVABLE | VMAS_F_ROTATABLE))) continue;
     const int b = w->ent_item_begin[e], n = w->ent_item_begin[e + 1];
-    DevOwned O{e, 3 * (int)segs.size(), 0};
+    DevOwned O{e, e * 6 * ROWF, 3 * (int)segs.size(), 0};  // part_off holds the ROW until rebased below
     int i = b;
     bool first = true;
     do {
-      float c = first ? 1.f : 0.f;
+      float c = first ? 60.f : 0.f;
       int j = i;
       while (j < n && (j == i || c + w->item_cost[j] <= target)) c += w->item_cost[j++];
-      segs.push_back({e, i, j, first ? 1 : 0, 3 * (int)segs.size()});
+      segs.push_back({e, e * 6 * ROWF, i, j, first ? 1 : 0, 3 * (int)segs.size()});
       seg_cost.push_back(c);
       O.n_parts++;
       first = false;
@@ -754,16 +793,20 @@ static int build_sched(VmasWorld* w, int nw, Sched& S) {
     for (auto& o : own_w[wv]) owned.push_back(o);
     wave_own[wv + 1] = (int)owned.size();
   }
+  // rows -> tile offsets: [state | agent forces | trig | partial sums | flag]
+  const int row_part = w->row_tr + 4 * (int)w->trig_ents.size();
+  for (auto& sg : segs_sorted) sg.part_off = (row_part + sg.part_off) * ROWF;
+  for (auto& o : owned) o.part_off = (row_part + o.part_off) * ROWF;
   S.nw = nw;
   HIP_TRY(upload(&S.d_segs, segs_sorted));
   HIP_TRY(upload(&S.d_wave_seg, wave_seg));
   HIP_TRY(upload(&S.d_owned, owned));
   HIP_TRY(upload(&S.d_wave_own, wave_own));
   S.dw = w->base;
-  S.dw.row_part = S.dw.row_tr + 4 * (int)w->trig_ents.size();
-  S.dw.row_bad = S.dw.row_part + 3 * (int)segs.size();
+  const int row_bad = row_part + 3 * (int)segs.size();
+  S.dw.off_bad = row_bad * ROWF;
   S.dw.segs = S.d_segs; S.dw.wave_seg = S.d_wave_seg; S.dw.owned = S.d_owned; S.dw.wave_own = S.d_wave_own;
-  S.lds_bytes = (size_t)(S.dw.row_bad + 1) * TILE * sizeof(float);
+  S.lds_bytes = (size_t)(row_bad + 1) * ROWF * sizeof(float);
   return 0;
 }
 
@@ -848,9 +891,9 @@ int vmas_world_create(const VmasWorldDesc* d, int32_t batch, int32_t device_id, 
     t.lin_friction = s.lin_friction; t.ang_friction = s.ang_friction;
     t.gx = s.gravity[0]; t.gy = s.gravity[1];
     t.max_f = s.max_f; t.f_range = s.f_range; t.max_t = s.max_t; t.t_range = s.t_range;
-    t.tr_row = -1;
+    t.tr_off = -1;
     if (s.shape != VMAS_SHAPE_SPHERE) {
-      t.tr_row = tr_row[e] = 4 * (int)w->trig_ents.size();
+      tr_row[e] = 4 * (int)w->trig_ents.size();
       w->trig_ents.push_back(e);
     }
     if (s.flags & (VMAS_F_MOVABLE | VMAS_F_ROTATABLE)) w->n_dyn++;
@@ -867,17 +910,17 @@ int vmas_world_create(const VmasWorldDesc* d, int32_t batch, int32_t device_id, 
   W.c_coll = d->collision_force;    // sign = +1
   W.c_joint_att = -d->joint_force;  // sign = -1
   W.c_joint_rep = d->joint_force;
-  W.row_af = W.nE * 6;
-  W.row_tr = W.row_af + W.nA * 3;
+  W.off_af = W.nE * 6 * ROWF;
+  w->row_tr = W.nE * 6 + W.nA * 3;
+  for (int e = 0; e < d->n_entities; ++e)
+    if (tr_row[e] >= 0) ents[e].tr_off = (w->row_tr + tr_row[e]) * ROWF;
   build_items(d, w, tr_row);
   std::vector<DevMaskPair> mp(d->n_pairs);
   for (int p = 0; p < d->n_pairs; ++p) mp[p] = {d->pairs[p].a, d->pairs[p].b, d->pairs[p].bound_sum};
-  std::vector<int32_t> trig(w->trig_ents.begin(), w->trig_ents.end());
   HIP_TRY(upload(&w->d_ent, ents));
   HIP_TRY(upload(&w->d_items, w->items));
   HIP_TRY(upload(&w->d_mpairs, mp));
-  HIP_TRY(upload(&w->d_trig_ent, trig));
-  W.ent = w->d_ent; W.items = w->d_items; W.trig_ent = w->d_trig_ent; W.n_trig = (int)trig.size();
+  W.ent = w->d_ent; W.items = w->d_items;
   w->lanes = default_lanes(w);
   Sched* S;
   while (true) {
@@ -932,6 +975,10 @@ int vmas_world_step(VmasWorld* w, float* state, float* agent_ft, int64_t ld, con
     if (a.first_substep < 0 || a.first_substep >= w->base.substeps)
       return fail("vmas_world_step: first_substep %d outside [0,%d)", a.first_substep, w->base.substeps);
   }
+  {
+    static const int ablate = getenv("VMAS_ABLATE") ? atoi(getenv("VMAS_ABLATE")) : 0;
+    a.ablate = ablate;
+  }
   Sched* S;
   if (get_sched(w, w->lanes, &S)) return -1;
   hipStream_t s = (hipStream_t)stream;
@@ -940,6 +987,12 @@ int vmas_world_step(VmasWorld* w, float* state, float* agent_ft, int64_t ld, con
     case 1: return launch_level<1>(w, S, state, agent_ft, ld, a, s);
     default: return launch_level<2>(w, S, state, agent_ft, ld, a, s);
   }
+}
+
+int vmas_debug_softplus(const float* in, float* out, int32_t n, void* stream) {
+  hipLaunchKernelGGL(softplus_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, in, out, n);
+  HIP_TRY(hipGetLastError());
+  return 0;
 }
 
 int vmas_world_step_n(VmasWorld* w, float* state, float* agent_ft, int64_t ld, int64_t ft_step_stride, int32_t n_steps,
