@@ -123,7 +123,13 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
-    sc, w = build_world(args.num_envs, device, args.n_agents, args.lanes, seed=rank)
+    from vectorizedmultiagentsimulator_amd.shard import EnvShard, max_over_ranks
+
+    # weak scaling: the global batch is world_size x num_envs, sharded by environment; every
+    # rank steps its own contiguous block, no collective on the step path
+    shard = EnvShard(world_size * args.num_envs, rank, world_size)
+    assert shard.local_envs == args.num_envs
+    sc, w = build_world(shard.local_envs, device, args.n_agents, args.lanes, seed=shard.seed(0))
     be = w._get_backend()
     state0 = w._state.clone()
     forces = make_forces(w, EPISODE, 1234 + rank, device)
@@ -157,10 +163,7 @@ def main():
     wall = t1 - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps  # avg launch-to-launch duration on the stream
 
-    if dist is not None:
-        tt = torch.tensor([wall], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        wall = float(tt.item())
+    wall = max_over_ranks(wall, device)
 
     if rank == 0:
         bytes_per_env = be.step_bytes_per_env()

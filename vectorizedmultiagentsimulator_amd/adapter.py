@@ -1,0 +1,202 @@
+"""Drop-in for a LIVE reference ``World``: ``attach(env_or_world)`` replaces its
+``step`` (vmas/simulator/core.py:1972) - and the ``cast_rays`` made by its Lidar sensors -
+with the MI355X-native path, leaving ``vmas.make_env()`` / ``Environment.step()`` / the
+Scenario untouched (the seam of SURVEY.md section 8b).
+
+How the state is shared
+    The reference keeps every state tensor as a separate ``[B, k]`` attribute and REBINDS it
+    on every write (core.py:222-284, 2871-2908).  ``attach`` allocates the packed buffers of
+    include/vmas_hip.h, copies the current state in, and then re-homes each
+    ``entity.state._pos/_vel/_rot/_ang_vel`` (agents: ``_force/_torque``) as a strided VIEW
+    into the packed buffer.  The seven property setters every Python-side write funnels
+    through (SURVEY.md 8b "Adapter notes") are patched on the *instances' classes* to
+    ``copy_`` into the view instead of rebinding, so scenarios, ``reset_at`` and dynamics keep
+    working and the kernel always sees current data - no gather/scatter per step.
+
+What stays dynamic
+    ``JointConstraint.fixed_rotation`` tensors and per-env entity gravity are re-read
+    every step; mass / friction / filters are re-extracted when ``refresh()`` is called.
+
+``grad_enabled`` worlds are refused (the kernels have no backward), as is a CPU device:
+there is no fallback path.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import torch
+
+from . import _abi as A
+from .spec import WorldSpec, spec_from_world
+
+
+def _default_backend(spec: WorldSpec, batch: int, device, state, agent_ft):
+    from .backend import HipWorld
+
+    return HipWorld(spec, batch, device, state=state, agent_ft=agent_ft)
+
+
+_FIELDS = ("pos", "vel", "rot", "ang_vel", "force", "torque")
+_MARK = "_vmas_amd_attached"
+
+
+def _patch_state_class(cls) -> None:
+    """Make the setters of the reference's EntityState/AgentState write THROUGH when the
+    instance is attached, and behave exactly as before otherwise.
+
+    The class-level property must be replaced (not a subclass): whole-batch ``set_pos`` calls
+    ``EntityState.pos.fset(state, new)`` on the base class explicitly (core.py:745-755)."""
+    for klass in cls.__mro__:
+        for name in _FIELDS:
+            prop = klass.__dict__.get(name)
+            if not isinstance(prop, property) or getattr(prop.fset, "_vmas_amd", False):
+                continue
+
+            def fset(self, value, _orig=prop.fset, _priv="_" + name):
+                if self.__dict__.get(_MARK):
+                    cur = self.__dict__[_priv]
+                    assert (
+                        value.shape[0] == cur.shape[0]
+                    ), f"Internal state must match batch dim, got {value.shape[0]}, expected {cur.shape[0]}"
+                    cur.copy_(value.to(cur.device).reshape(cur.shape))
+                else:
+                    _orig(self, value)
+
+            fset._vmas_amd = True
+            setattr(klass, name, property(prop.fget, fset, prop.fdel, prop.__doc__))
+
+
+class AttachedWorld:
+    """Handle returned by ``attach``; ``detach()`` restores the reference behaviour."""
+
+    def __init__(self, world, backend_factory: Callable = _default_backend, exact_broad_phase: bool = False):
+        self.world = world
+        self.exact_broad_phase = exact_broad_phase
+        self._factory = backend_factory
+        self._orig_step = world.step
+        self._orig_classes = {}
+        self._orig_measures = []
+        self.batch = int(world.batch_dim)
+        self.ld = (self.batch + 63) // 64 * 64
+        self.device = torch.device(world.device)
+        self.spec = spec_from_world(world)
+        nE, nA = self.spec.n_entities, self.spec.n_agents
+        self.state = torch.zeros(nE, A.STATE_FIELDS, self.ld, dtype=torch.float32, device=self.device)
+        self.agent_ft = torch.zeros(max(nA, 1), A.AGENT_FIELDS, self.ld, dtype=torch.float32, device=self.device)
+        self._rehome()
+        self.backend = self._factory(self.spec, self.batch, self.device, self.state, self.agent_ft)
+        world.step = self.step
+        self._patch_lidars()
+
+    # ---- state re-homing ---------------------------------------------------------
+    def _rehome(self):
+        B = self.batch
+        for i, e in enumerate(self.world.entities):
+            st = e.state
+            views = {
+                "_pos": self.state[i, 0:2, :B].T,
+                "_vel": self.state[i, 2:4, :B].T,
+                "_rot": self.state[i, 4:5, :B].T,
+                "_ang_vel": self.state[i, 5:6, :B].T,
+            }
+            for k, v in views.items():
+                v.copy_(getattr(st, k))
+                st.__dict__[k] = v
+            _patch_state_class(type(st))
+            st.__dict__[_MARK] = True
+            self._orig_classes[id(st)] = (st, type(st))
+        for a_i, a in enumerate(self.world.agents):
+            st = a.state
+            fv = self.agent_ft[a_i, 0:2, :B].T
+            tv = self.agent_ft[a_i, 2:3, :B].T
+            if st._force is not None:
+                fv.copy_(st._force)
+            if st._torque is not None:
+                tv.copy_(st._torque)
+            st.__dict__["_force"], st.__dict__["_torque"] = fv, tv
+
+    # ---- per-step dynamic inputs ------------------------------------------------------
+    def _per_env_inputs(self):
+        w, spec = self.world, self.spec
+        jfr = eg = None
+        if any(j.per_env_fixed_rotation for j in spec.joints):
+            jfr = torch.zeros(len(spec.joints), self.ld, dtype=torch.float32, device=self.device)
+            ents = list(w.entities)
+            k = 0
+            for ia, ea in enumerate(ents):
+                for ib in range(ia + 1, len(ents)):
+                    c = w._joints.get(frozenset({ea.name, ents[ib].name}))
+                    if c is None:
+                        continue
+                    fr = c.fixed_rotation
+                    if isinstance(fr, torch.Tensor):
+                        jfr[k, : self.batch] = fr.reshape(-1)
+                    elif fr is not None:
+                        jfr[k, : self.batch] = float(fr)
+                    k += 1
+        if any(e.per_env_gravity for e in spec.entities):
+            eg = torch.zeros(len(spec.entities), 2, self.ld, dtype=torch.float32, device=self.device)
+            for i, e in enumerate(w.entities):
+                if spec.entities[i].per_env_gravity:
+                    eg[i, :, : self.batch] = e.gravity.T
+        return jfr, eg
+
+    # ---- the replaced seam ----------------------------------------------------------
+    def step(self):
+        """World.step() (core.py:1972-2015) on the native path."""
+        w = self.world
+        jfr, eg = self._per_env_inputs()
+        if self.exact_broad_phase:
+            self.backend.step_exact(joint_fixed_rot=jfr, entity_gravity=eg)
+        else:
+            self.backend.step(joint_fixed_rot=jfr, entity_gravity=eg)
+        if w._dim_c > 0:  # _update_comm_state core.py:2910-2913
+            for agent in w._agents:
+                if not agent.silent:
+                    agent.state.c = agent.action.c
+
+    def refresh(self):
+        """Re-extract the static description (after changing masses, filters, ...)."""
+        self.spec = spec_from_world(self.world)
+        self.backend.close()
+        self.backend = self._factory(self.spec, self.batch, self.device, self.state, self.agent_ft)
+
+    # ---- sensors -----------------------------------------------------------------------
+    def _patch_lidars(self):
+        if not self.spec.lidars:
+            return
+        k = 0
+        for agent in self.world.agents:
+            for sensor in agent.sensors:
+                if not hasattr(sensor, "_angles"):
+                    continue
+                idx, n_rays = k, self.spec.lidars[k].n_rays
+                orig = sensor.measure
+                self._orig_measures.append((sensor, orig))
+
+                def measure(vectorized: bool = True, _idx=idx, _n=n_rays, _sensor=sensor):
+                    m = self.backend.cast_rays()[_idx, :_n, : self.batch].T
+                    _sensor._last_measurement = m
+                    return m
+
+                sensor.measure = measure
+                k += 1
+
+    def detach(self):
+        self.world.step = self._orig_step
+        for st, cls in self._orig_classes.values():
+            for k in ("_pos", "_vel", "_rot", "_ang_vel", "_force", "_torque"):
+                if k in st.__dict__ and st.__dict__[k] is not None:
+                    st.__dict__[k] = st.__dict__[k].clone()
+            st.__dict__[_MARK] = False
+        for sensor, orig in self._orig_measures:
+            sensor.measure = orig
+        self.backend.close()
+
+
+def attach(env_or_world, backend_factory: Callable = _default_backend, exact_broad_phase: bool = False) -> AttachedWorld:
+    """Put a reference ``Environment`` (or ``World``) on the MI355X-native physics step."""
+    world = getattr(env_or_world, "world", env_or_world)
+    if getattr(env_or_world, "grad_enabled", False):
+        raise NotImplementedError("grad_enabled=True needs the reference's autograd path; the HIP step has no backward")
+    return AttachedWorld(world, backend_factory, exact_broad_phase)
