@@ -15,7 +15,7 @@ from golden_util import FIXTURES, compare_state, load, tolerances, ulp_sensitivi
 
 pytestmark = pytest.mark.gpu
 
-LANES = (1, 2, 3, 4, 6, 8)  # waves per 64-env tile
+LANES = (1, 2, 3, 4, 6, 8, 12, 16)  # waves per 64-env tile
 
 
 def _hip(spec, B, lanes=0):
@@ -273,7 +273,7 @@ def test_hip_error_paths():
     g = load("balance_n3")
     hw = HipWorld(g.spec, 4)
     with pytest.raises(VmasHipError):
-        hw.set_lanes_per_env(9)
+        hw.set_lanes_per_env(17)
     with pytest.raises(VmasHipError):
         hw.step(first_substep=5)
     with pytest.raises(VmasHipError):

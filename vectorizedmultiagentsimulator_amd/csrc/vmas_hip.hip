@@ -53,7 +53,8 @@ using namespace vmas;
 // device-side constant block (all wave-uniform => scalar loads)
 // ------------------------------------------------------------------------------------
 constexpr int TILE = 64;       // environments per block = lanes per wave
-constexpr int MAX_WAVES = 8;   // waves (workers) per tile
+constexpr int MAX_WAVES = 16;  // waves (workers) per tile (8 for the register-heavy box-box level)
+constexpr int ITEMS_LDS_BUDGET = 48 * 1024;  // stage the item descriptors in LDS when they fit
 constexpr int TASK_JOINT = 6;  // item type next to VMAS_PAIR_*
 constexpr int ROWF = TILE;     // floats per LDS row
 
@@ -107,12 +108,17 @@ struct DevWorld {
   float xs, ys;  // NaN = unbounded
   float k, tcf;
   float c_coll, c_joint_att, c_joint_rep;  // fp32(sign * force_multiplier)
-  const DevEntity* ent;
-  const DevItem* items;
-  const DevSegment* segs;
-  const int32_t* wave_seg;  // [W+1] segment ranges per wave
-  const DevOwned* owned;
-  const int32_t* wave_own;  // [W+1] owned-entity ranges per wave
+  // One descriptor blob per schedule, staged into LDS by the whole block with coalesced loads
+  // while the state rows are in flight.  (Scalar/vector loads of descriptors from a cache that
+  // is cold at every launch cost ~600 cycles per dependent fetch - 2-4 us of a 13 us step.)
+  //   [ents | segs | owned | items]   word offsets below; counters live right after the blob
+  const uint32_t* blob;
+  int32_t blob_words;   // words staged (items only when they fit the LDS budget)
+  int32_t off_blob;     // tile offset (floats) of the blob copy in LDS
+  int32_t b_ent, b_segs, b_owned, b_items;
+  int32_t n_segs, n_owned;
+  int32_t items_in_lds;
+  const DevItem* items;  // global copy, used when the item list is too big for LDS
 };
 
 struct DevStepArgs {
@@ -120,6 +126,7 @@ struct DevStepArgs {
   const float* joint_fixed_rot;
   const float* entity_gravity;
   int32_t first_substep, n_substeps;
+  unsigned long long* trace;  // profiling only (env VMAS_TRACE): per-wave s_memtime stamps
   int32_t ablate;  // profiling only (env VMAS_ABLATE): 1 skip items, 2 skip integration, 4 skip prologue
 };
 
@@ -160,10 +167,49 @@ __device__ __forceinline__ float seg_obb_gap(v2 p, float lc, float ls, float h, 
   return fmaxf(gx, gy);
 }
 
+// Register views of descriptors read from the LDS blob (uniform address => broadcast read):
+// control words go to SGPRs, offsets and float parameters stay in (uniform) VGPRs.
+struct ItemV {
+  int32_t type, side; uint32_t flags; int32_t index;  // scalar
+  int32_t oa, ob, tra, trb;
+  float thr2, reach, p0, p1, p2, p3, q0, q1;
+};
+__device__ __forceinline__ ItemV load_item(const uint32_t* p) {
+  const uint4 w0 = ((const uint4*)p)[0], w1 = ((const uint4*)p)[1], w2 = ((const uint4*)p)[2], w3 = ((const uint4*)p)[3];
+  ItemV K;
+  K.type = sgpr((int)w0.x); K.side = sgpr((int)w0.y); K.flags = (uint32_t)sgpr((int)w0.z); K.index = sgpr((int)w0.w);
+  K.oa = (int)w1.x; K.ob = (int)w1.y; K.tra = (int)w1.z; K.trb = (int)w1.w;
+  K.thr2 = __uint_as_float(w2.x); K.reach = __uint_as_float(w2.y); K.p0 = __uint_as_float(w2.z); K.p1 = __uint_as_float(w2.w);
+  K.p2 = __uint_as_float(w3.x); K.p3 = __uint_as_float(w3.y); K.q0 = __uint_as_float(w3.z); K.q1 = __uint_as_float(w3.w);
+  return K;
+}
+__device__ __forceinline__ ItemV item_from_global(const DevItem& D) {
+  ItemV K;
+  K.type = D.type; K.side = D.side; K.flags = D.flags; K.index = D.index;
+  K.oa = D.oa; K.ob = D.ob; K.tra = D.tra; K.trb = D.trb;
+  K.thr2 = D.thr2; K.reach = D.reach; K.p0 = D.p0; K.p1 = D.p1; K.p2 = D.p2; K.p3 = D.p3; K.q0 = D.q0; K.q1 = D.q1;
+  return K;
+}
+struct EntV {
+  uint32_t flags; int32_t shape, agent_index, tr_off;  // scalar
+  float mass, inertia, one_minus_drag, max_speed, v_range, lin_friction, ang_friction, gx, gy, max_f, f_range, max_t, t_range;
+};
+__device__ __forceinline__ EntV load_ent(const uint32_t* p) {
+  EntV D;
+  D.flags = (uint32_t)sgpr((int)p[0]); D.shape = sgpr((int)p[1]); D.agent_index = sgpr((int)p[2]); D.tr_off = sgpr((int)p[3]);
+  D.mass = __uint_as_float(p[4]); D.inertia = __uint_as_float(p[5]); D.one_minus_drag = __uint_as_float(p[6]);
+  D.max_speed = __uint_as_float(p[7]); D.v_range = __uint_as_float(p[8]);
+  D.lin_friction = __uint_as_float(p[9]); D.ang_friction = __uint_as_float(p[10]);
+  D.gx = __uint_as_float(p[11]); D.gy = __uint_as_float(p[12]);
+  D.max_f = __uint_as_float(p[13]); D.f_range = __uint_as_float(p[14]); D.max_t = __uint_as_float(p[15]); D.t_range = __uint_as_float(p[16]);
+  return D;
+}
+static_assert(sizeof(DevItem) == 64 && sizeof(DevEntity) == 68, "descriptor layout");
+
 // Force (and torque) one item contributes to ITS side.  LEVEL prunes code (and registers):
 // 0: SS LS BS   1: + LL BL joints   2: + BB
 template <int LEVEL>
-__device__ __forceinline__ void eval_item(const DevItem& K, const DevWorld& W, const DevStepArgs& args,
+__device__ __forceinline__ void eval_item(const ItemV& K, const DevWorld& W, const DevStepArgs& args,
                                           const float* tile, long env, bool live, long ld, bool may_skip, v2& f_out,
                                           float& t_out) {
   const float* A = tile + K.oa;
@@ -286,7 +332,7 @@ __device__ __forceinline__ void eval_item(const DevItem& K, const DevWorld& W, c
 // the fused step kernel: grid = ceil(batch / 64) tiles, block = 64 x W threads
 // ------------------------------------------------------------------------------------
 template <int LEVEL>
-__global__ __launch_bounds__(TILE* MAX_WAVES) void step_kernel(DevWorld W, float* __restrict__ state,
+__global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel(DevWorld W, float* __restrict__ state,
                                                                float* __restrict__ agent_ft, long ld, int batch,
                                                                DevStepArgs args) {
   extern __shared__ float lds[];
@@ -296,13 +342,24 @@ __global__ __launch_bounds__(TILE* MAX_WAVES) void step_kernel(DevWorld W, float
   const int nE = W.nE, nA = W.nA;
   const long env = (long)blockIdx.x * TILE + lane;
   const bool live = env < batch;
+#define STAMP(k)                                                                                     \
+  if (args.trace && lane == 0) args.trace[((long)blockIdx.x * 16 + wv) * 8 + (k)] = __builtin_amdgcn_s_memtime()
+  STAMP(0);
   float* tile = lds + lane;  // this lane's column: row r is tile[r * ROWF]
   int* bad_flag = (int*)(tile + W.off_bad);
+  uint32_t* blob = (uint32_t*)(lds + W.off_blob);
+  int* ctr = (int*)(blob + W.blob_words);  // [4] work counters: (substep parity) x (gather, integrate)
+  constexpr int EW = (int)(sizeof(DevEntity) / 4), SW = (int)(sizeof(DevSegment) / 4), OW = (int)(sizeof(DevOwned) / 4),
+                IW = (int)(sizeof(DevItem) / 4);
+
+  // ---- stage the descriptor blob (coalesced) and zero the flag row / counters
+  for (int i = threadIdx.x; i < W.blob_words; i += blockDim.x) blob[i] = W.blob[i];
+  if (threadIdx.x < 4) ctr[threadIdx.x] = 0;
+  if (wv == nw - 1) *bad_flag = 0;
+  __syncthreads();
 
   // ---- HBM -> LDS, one entity per wave at a time: six 256-byte row reads in flight, then the
-  //      entity's trig and the non-finite check straight from the registers (no extra barrier)
-  if (wv == 0) *bad_flag = 0;
-  __syncthreads();
+  //      entity's trig and the non-finite check straight from the registers
   for (int e = wv; e < nE; e += nw) {
     const float* src = state + (long)e * 6 * ld + env;
     float v[6];
@@ -314,7 +371,7 @@ __global__ __launch_bounds__(TILE* MAX_WAVES) void step_kernel(DevWorld W, float
     // the reference lets a non-finite pose poison every pair it is in, however far apart
     // (cos(inf) = NaN): such environments must not use the distance skip
     if (!finite_f(v[0]) || !finite_f(v[1]) || !finite_f(v[4])) *bad_flag = 1;
-    const int tr_off = sgpr(W.ent[e].tr_off), shape = sgpr(W.ent[e].shape);
+    const int shape = sgpr((int)blob[W.b_ent + e * EW + 1]), tr_off = sgpr((int)blob[W.b_ent + e * EW + 3]);
     if (tr_off >= 0 && !(args.ablate & 8)) write_trig(tile + tr_off, v[4], shape);
   }
   for (int a = wv; a < nA; a += nw) {
@@ -323,27 +380,40 @@ __global__ __launch_bounds__(TILE* MAX_WAVES) void step_kernel(DevWorld W, float
 #pragma unroll
     for (int f = 0; f < 3; ++f) dst[f * ROWF] = live ? src[f * ld] : 0.f;
   }
+  STAMP(1);
   __syncthreads();
+  STAMP(2);
 
   const float sub_dt = W.sub_dt;
   const int s_begin = args.first_substep;
   const int s_end = s_begin + (args.n_substeps > 0 ? args.n_substeps : W.substeps - s_begin);
-  const int seg0 = sgpr(W.wave_seg[wv]), seg1 = sgpr(W.wave_seg[wv + 1]);
-  const int own0 = sgpr(W.wave_own[wv]), own1 = sgpr(W.wave_own[wv + 1]);
+  // dynamic work distribution: waves pull the next segment / entity from an LDS counter
+  // (segments are sorted heaviest first).  Results land in per-segment rows, so the force sum
+  // stays deterministic no matter which wave computed what.
+  auto grab = [&](int* c) {
+    int v = 0;
+    if (lane == 0) v = atomicAdd(c, 1);
+    return sgpr(v);
+  };
 
   for (int substep = s_begin; substep < s_end; ++substep) {
     const bool may_skip = *bad_flag == 0;
     const bool last = substep + 1 == s_end;
+    int* c_gather = ctr + 2 * (substep & 1);
+    int* c_integrate = c_gather + 1;
+    if (threadIdx.x < 2) ctr[2 * ((substep + 1) & 1) + threadIdx.x] = 0;  // re-arm the other parity
     // ================= phase B: gather forces per (entity, segment)
-    for (int si = seg0; si < seg1; ++si) {
-      const DevSegment S = W.segs[si];
-      const int e = S.entity;
-      const float* Es = tile + S.oe;
-      const uint32_t efl = W.ent[e].flags;
+    for (int si = grab(c_gather); si < W.n_segs; si = grab(c_gather)) {
+      const uint32_t* sp = blob + W.b_segs + si * SW;
+      const int e = sgpr((int)sp[0]);
+      const float* Es = tile + (int)sp[1];
+      const int i0 = sgpr((int)sp[2]), i1s = sgpr((int)sp[3]), first = sgpr((int)sp[4]);
+      float* P = tile + (int)sp[5];
+      const uint32_t efl = (uint32_t)sgpr((int)blob[W.b_ent + e * EW]);
       v2 F = V(0.f, 0.f);
       float Tq = 0.f;
-      if (S.first && !(args.ablate & 4)) {  // prologue core.py:1995-2004
-        const DevEntity D = W.ent[e];
+      if (first && !(args.ablate & 4)) {  // prologue core.py:1995-2004
+        const EntV D = load_ent(blob + W.b_ent + e * EW);
         const uint32_t fl = D.flags;
         if (fl & VMAS_F_AGENT) {
           float* Af = tile + W.off_af + D.agent_index * 3 * ROWF;
@@ -392,9 +462,9 @@ __global__ __launch_bounds__(TILE* MAX_WAVES) void step_kernel(DevWorld W, float
         }
       }
       // joints, then pairs, in the reference's accumulation order (core.py:2176-2199)
-      const int i0 = S.item_begin, i1 = (args.ablate & 1) ? S.item_begin : S.item_end;
+      const int i1 = (args.ablate & 1) ? i0 : i1s;
       for (int ii = i0; ii < i1; ++ii) {
-        const DevItem K = W.items[ii];
+        const ItemV K = W.items_in_lds ? load_item(blob + W.b_items + ii * IW) : item_from_global(W.items[ii]);
         v2 f = V(0.f, 0.f);
         float t = 0.f;
         if (!(args.ablate & 16)) eval_item<LEVEL>(K, W, args, tile, env, live, ld, may_skip, f, t);
@@ -402,23 +472,26 @@ __global__ __launch_bounds__(TILE* MAX_WAVES) void step_kernel(DevWorld W, float
         if (efl & VMAS_F_MOVABLE) F = F + f;
         if (efl & VMAS_F_ROTATABLE) Tq = Tq + t;
       }
-      float* P = tile + S.part_off;
       P[0] = F.x; P[ROWF] = F.y; P[2 * ROWF] = Tq;
     }
+    STAMP(3);
     __syncthreads();
+    STAMP(4);
 
     // ================= phase C: _integrate_state core.py:2862-2908 (+ trig for the next substep,
     //                   or, after the last substep, the write-back of the entity's planes)
-    for (int oi = own0; oi < ((args.ablate & 2) ? own0 : own1); ++oi) {
-      const DevOwned O = W.owned[oi];
-      const int e = O.entity;
-      const DevEntity D = W.ent[e];
+    const int n_own = (args.ablate & 2) ? 0 : W.n_owned;
+    for (int oi = grab(c_integrate); oi < n_own; oi = grab(c_integrate)) {
+      const uint32_t* op = blob + W.b_owned + oi * OW;
+      const int e = sgpr((int)op[0]);
+      float* Es = tile + (int)op[1];
+      const float* P = tile + (int)op[2];
+      const int n_parts = sgpr((int)op[3]);
+      const EntV D = load_ent(blob + W.b_ent + e * EW);
       const uint32_t fl = D.flags;
-      float* Es = tile + O.oe;
-      const float* P = tile + O.part_off;
       v2 F = V(P[0], P[ROWF]);
       float Tq = P[2 * ROWF];
-      for (int p = 1; p < O.n_parts; ++p) {
+      for (int p = 1; p < n_parts; ++p) {
         F = F + V(P[3 * p * ROWF], P[(3 * p + 1) * ROWF]);
         Tq = Tq + P[(3 * p + 2) * ROWF];
       }
@@ -458,6 +531,7 @@ __global__ __launch_bounds__(TILE* MAX_WAVES) void step_kernel(DevWorld W, float
     }
     if (!last) __syncthreads();
   }
+  STAMP(5);
 }
 
 // ------------------------------------------------------------------------------------
@@ -609,13 +683,10 @@ struct Sched {
   int nw = 0;
   DevWorld dw{};
   size_t lds_bytes = 0;
-  DevSegment* d_segs = nullptr;
-  int32_t* d_wave_seg = nullptr;
-  DevOwned* d_owned = nullptr;
-  int32_t* d_wave_own = nullptr;
+  uint32_t* d_blob = nullptr;
   void release() {
-    (void)hipFree(d_segs); (void)hipFree(d_wave_seg); (void)hipFree(d_owned); (void)hipFree(d_wave_own);
-    d_segs = nullptr; d_wave_seg = nullptr; d_owned = nullptr; d_wave_own = nullptr;
+    (void)hipFree(d_blob);
+    d_blob = nullptr;
   }
 };
 
@@ -628,15 +699,14 @@ struct VmasWorld {
   int n_pairs = 0, n_dyn = 0;
   DevWorld base{};  // schedule-independent part
   std::vector<VmasEntityDesc> ents;
+  std::vector<DevEntity> dev_ents;
   // static item lists
   std::vector<DevItem> items;
   std::vector<int> ent_item_begin;  // [nE+1]
   std::vector<float> item_cost;
   std::vector<int> trig_ents;
-  DevEntity* d_ent = nullptr;
-  DevItem* d_items = nullptr;
-  int32_t* d_trig_ent = nullptr;
   DevMaskPair* d_mpairs = nullptr;
+  unsigned long long* d_trace = nullptr;
   std::map<int, Sched> scheds;
   // lidars
   DevLidar* d_lidars = nullptr;
@@ -652,7 +722,7 @@ static float type_cost(int type) {
     case VMAS_PAIR_LS: return 160.f;
     case VMAS_PAIR_LL: return 600.f;
     case VMAS_PAIR_BS: return 350.f;
-    case VMAS_PAIR_BL: return 2000.f;
+    case VMAS_PAIR_BL: return 600.f;   // ~2000 when executed, but the separating-axis test rejects most
     case VMAS_PAIR_BB: return 15000.f;
     case TASK_JOINT: return 500.f;
   }
@@ -708,7 +778,7 @@ static void build_items(const VmasWorldDesc* d, VmasWorld* w, const std::vector<
         break;
       case VMAS_PAIR_BL:
         t.p0 = A.length; t.p1 = A.width; t.p2 = B.length / 2.f;
-        t.reach = B.length / 2.f + kLineMinDist + kSkipSlack;
+        t.reach = kLineMinDist + kSkipSlack;  // the separating-axis gap already includes the line's extent
         break;
       case VMAS_PAIR_BB:
         t.p0 = A.length; t.p1 = A.width; t.p2 = B.length; t.p3 = B.width;
@@ -747,7 +817,7 @@ static int build_sched(VmasWorld* w, int nw, Sched& S) {
       total += 60.f;
       for (int i = w->ent_item_begin[e]; i < w->ent_item_begin[e + 1]; ++i) total += w->item_cost[i];
     }
-  const float target = std::max(total / (float)nw, 100.f);
+  const float target = std::max(total / (float)(2 * nw), 150.f);
   for (int e = 0; e < nE; ++e) {
     if (!(w->ents[e].flags & (VMAS_F_MOVABLE | VMAS_F_ROTATABLE))) continue;
     const int b = w->ent_item_begin[e], n = w->ent_item_begin[e + 1];
@@ -766,47 +836,53 @@ static int build_sched(VmasWorld* w, int nw, Sched& S) {
     } while (i < n);
     owned_all.push_back(O);
   }
-  // LPT assignment of segments
+  // waves pull segments from a counter at run time: order them heaviest first (dynamic LPT)
   std::vector<int> order(segs.size());
   std::iota(order.begin(), order.end(), 0);
   std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return seg_cost[x] > seg_cost[y]; });
-  std::vector<float> load(nw, 0.f);
-  std::vector<std::vector<int>> per_wave(nw);
-  for (int si : order) {
-    int best = (int)(std::min_element(load.begin(), load.end()) - load.begin());
-    load[best] += seg_cost[si];
-    per_wave[best].push_back(si);
-  }
   std::vector<DevSegment> segs_sorted;
-  std::vector<int32_t> wave_seg(nw + 1, 0);
-  for (int wv = 0; wv < nw; ++wv) {
-    std::sort(per_wave[wv].begin(), per_wave[wv].end());
-    for (int si : per_wave[wv]) segs_sorted.push_back(segs[si]);
-    wave_seg[wv + 1] = (int)segs_sorted.size();
+  for (int si : order) segs_sorted.push_back(segs[si]);
+  std::vector<DevOwned> owned = owned_all;
+  if (getenv("VMAS_DEBUG_SCHED")) {
+    for (int si : order) {
+      fprintf(stderr, "[sched nw=%d] seg cost %.0f {e%d%s", nw, seg_cost[si], segs[si].entity, segs[si].first ? "*" : "");
+      for (int i = segs[si].item_begin; i < segs[si].item_end; ++i)
+        fprintf(stderr, " %s%d-%d", (const char*[]){"SS", "LS", "LL", "BS", "BL", "BB", "J"}[w->items[i].type],
+                w->items[i].oa / (6 * ROWF), w->items[i].ob / (6 * ROWF));
+      fprintf(stderr, "}\n");
+    }
   }
-  // integration work: round-robin over the waves
-  std::vector<std::vector<DevOwned>> own_w(nw);
-  for (size_t i = 0; i < owned_all.size(); ++i) own_w[i % nw].push_back(owned_all[i]);
-  std::vector<DevOwned> owned;
-  std::vector<int32_t> wave_own(nw + 1, 0);
-  for (int wv = 0; wv < nw; ++wv) {
-    for (auto& o : own_w[wv]) owned.push_back(o);
-    wave_own[wv + 1] = (int)owned.size();
-  }
-  // rows -> tile offsets: [state | agent forces | trig | partial sums | flag]
+  // rows -> tile offsets: [state | agent forces | trig | partial sums | flag | blob | counters]
   const int row_part = w->row_tr + 4 * (int)w->trig_ents.size();
   for (auto& sg : segs_sorted) sg.part_off = (row_part + sg.part_off) * ROWF;
   for (auto& o : owned) o.part_off = (row_part + o.part_off) * ROWF;
   S.nw = nw;
-  HIP_TRY(upload(&S.d_segs, segs_sorted));
-  HIP_TRY(upload(&S.d_wave_seg, wave_seg));
-  HIP_TRY(upload(&S.d_owned, owned));
-  HIP_TRY(upload(&S.d_wave_own, wave_own));
   S.dw = w->base;
   const int row_bad = row_part + 3 * (int)segs.size();
   S.dw.off_bad = row_bad * ROWF;
-  S.dw.segs = S.d_segs; S.dw.wave_seg = S.d_wave_seg; S.dw.owned = S.d_owned; S.dw.wave_own = S.d_wave_own;
-  S.lds_bytes = (size_t)(row_bad + 1) * ROWF * sizeof(float);
+  std::vector<uint32_t> blob;
+  auto append = [&](const void* p, size_t bytes) {
+    int at = (int)blob.size();
+    blob.resize(blob.size() + bytes / 4);
+    if (bytes) memcpy(blob.data() + at, p, bytes);
+    return at;
+  };
+  S.dw.b_ent = append(w->dev_ents.data(), w->dev_ents.size() * sizeof(DevEntity));
+  S.dw.b_segs = append(segs_sorted.data(), segs_sorted.size() * sizeof(DevSegment));
+  S.dw.b_owned = append(owned.data(), owned.size() * sizeof(DevOwned));
+  while (blob.size() % 4) blob.push_back(0);  // 16-byte alignment of the item records (ds_read_b128)
+  const size_t item_bytes = w->items.size() * sizeof(DevItem);
+  S.dw.items_in_lds = item_bytes <= (size_t)ITEMS_LDS_BUDGET;
+  S.dw.b_items = (int)blob.size();
+  S.dw.blob_words = (int)blob.size() + (S.dw.items_in_lds ? (int)(item_bytes / 4) : 0);
+  append(w->items.data(), item_bytes);
+  HIP_TRY(upload(&S.d_blob, blob));
+  S.dw.blob = S.d_blob;
+  S.dw.items = (const DevItem*)(S.d_blob + S.dw.b_items);
+  S.dw.n_segs = (int)segs_sorted.size();
+  S.dw.n_owned = (int)owned.size();
+  S.dw.off_blob = (row_bad + 1) * ROWF;
+  S.lds_bytes = ((size_t)(row_bad + 1) * ROWF + S.dw.blob_words + 4) * sizeof(float);
   return 0;
 }
 
@@ -828,8 +904,10 @@ static int default_lanes(const VmasWorld* w) {
   int work = 0;
   for (float c : w->item_cost) work += (int)c;
   work += w->n_dyn;
+  // measured on balance@32768: 8 waves/tile 12.8 us, 16 waves/tile 17.3 us (a 1024-thread block at
+  // ~107 VGPRs leaves room for one tile per CU only), 4 waves 15.6 us
   int nw = 1;
-  while (nw < MAX_WAVES && tiles * nw < 4096 && work >= 4 * nw) nw <<= 1;
+  while (nw < 8 && tiles * nw < 4096 && work >= 150 * nw) nw <<= 1;
   return nw;
 }
 
@@ -917,10 +995,8 @@ int vmas_world_create(const VmasWorldDesc* d, int32_t batch, int32_t device_id, 
   build_items(d, w, tr_row);
   std::vector<DevMaskPair> mp(d->n_pairs);
   for (int p = 0; p < d->n_pairs; ++p) mp[p] = {d->pairs[p].a, d->pairs[p].b, d->pairs[p].bound_sum};
-  HIP_TRY(upload(&w->d_ent, ents));
-  HIP_TRY(upload(&w->d_items, w->items));
+  w->dev_ents = ents;
   HIP_TRY(upload(&w->d_mpairs, mp));
-  W.ent = w->d_ent; W.items = w->d_items;
   w->lanes = default_lanes(w);
   Sched* S;
   while (true) {
@@ -940,7 +1016,7 @@ void vmas_world_destroy(VmasWorld* w) {
   if (!w) return;
   (void)hipSetDevice(w->device);
   for (auto& kv : w->scheds) kv.second.release();
-  (void)hipFree(w->d_ent); (void)hipFree(w->d_items); (void)hipFree(w->d_mpairs); (void)hipFree(w->d_trig_ent);
+  (void)hipFree(w->d_mpairs); (void)hipFree(w->d_trace);
   (void)hipFree(w->d_lidars); (void)hipFree(w->d_targets); (void)hipFree(w->d_angles);
   delete w;
 }
@@ -948,7 +1024,8 @@ void vmas_world_destroy(VmasWorld* w) {
 int vmas_world_set_lanes_per_env(VmasWorld* w, int32_t lanes) {
   if (!w) return fail("vmas_world_set_lanes_per_env: null world");
   if (lanes == 0) lanes = default_lanes(w);
-  if (lanes < 1 || lanes > MAX_WAVES) return fail("lanes_per_env must be in 1..%d, got %d", MAX_WAVES, lanes);
+  const int max_w = w->level >= 2 ? 8 : MAX_WAVES;
+  if (lanes < 1 || lanes > max_w) return fail("lanes_per_env must be in 1..%d for this world, got %d", max_w, lanes);
   HIP_TRY(hipSetDevice(w->device));
   Sched* S;
   if (get_sched(w, lanes, &S)) return -1;
@@ -977,7 +1054,16 @@ int vmas_world_step(VmasWorld* w, float* state, float* agent_ft, int64_t ld, con
   }
   {
     static const int ablate = getenv("VMAS_ABLATE") ? atoi(getenv("VMAS_ABLATE")) : 0;
+    static const int trace = getenv("VMAS_TRACE") ? atoi(getenv("VMAS_TRACE")) : 0;
     a.ablate = ablate;
+    if (trace) {
+      const size_t n = (size_t)((w->batch + TILE - 1) / TILE) * 16 * 8;
+      if (!w->d_trace) {
+        HIP_TRY(hipMalloc((void**)&w->d_trace, n * 8));
+        HIP_TRY(hipMemset(w->d_trace, 0, n * 8));
+      }
+      a.trace = w->d_trace;
+    }
   }
   Sched* S;
   if (get_sched(w, w->lanes, &S)) return -1;
@@ -987,6 +1073,14 @@ int vmas_world_step(VmasWorld* w, float* state, float* agent_ft, int64_t ld, con
     case 1: return launch_level<1>(w, S, state, agent_ft, ld, a, s);
     default: return launch_level<2>(w, S, state, agent_ft, ld, a, s);
   }
+}
+
+// profiling aid, not part of the ABI: copy out the s_memtime stamps of the last launch
+int vmas_debug_trace(VmasWorld* w, unsigned long long* host, int64_t n_words) {
+  if (!w || !w->d_trace) return fail("vmas_debug_trace: tracing is off (set VMAS_TRACE=1)");
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(host, w->d_trace, (size_t)n_words * 8, hipMemcpyDeviceToHost));
+  return 0;
 }
 
 int vmas_debug_softplus(const float* in, float* out, int32_t n, void* stream) {
