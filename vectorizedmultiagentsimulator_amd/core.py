@@ -789,6 +789,35 @@ class World:
                 if not agent.silent:
                     agent.state.c = agent.action.c
 
+    # ---- scenario-side geometric queries (core.py:1788-1969, 2788-2803): batched torch ops
+    def collides(self, a: Entity, b: Entity) -> Tensor:
+        """Per-environment version of the broad-phase test of core.py:2788-2803 ([B] bool; the
+        reference reduces it with ``.any()`` over the batch, a host sync)."""
+        if (not a.collides(b)) or (not b.collides(a)) or a is b:
+            return torch.zeros(self._batch_dim, dtype=torch.bool, device=self._device)
+        if not a.movable and not a.rotatable and not b.movable and not b.rotatable:
+            return torch.zeros(self._batch_dim, dtype=torch.bool, device=self._device)
+        d = torch.linalg.vector_norm(a.state.pos - b.state.pos, dim=-1)
+        return d <= a.shape.circumscribed_radius() + b.shape.circumscribed_radius()
+
+    def get_distance_from_point(self, entity: Entity, test_point_pos: Tensor, env_index: int = None) -> Tensor:
+        from . import geometry
+
+        d = geometry.get_distance_from_point(entity, test_point_pos)
+        return d if env_index is None else d[env_index]
+
+    def get_distance(self, entity_a: Entity, entity_b: Entity, env_index: int = None) -> Tensor:
+        from . import geometry
+
+        d = geometry.get_distance(entity_a, entity_b)
+        return d if env_index is None else d[env_index]
+
+    def is_overlapping(self, entity_a: Entity, entity_b: Entity, env_index: int = None) -> Tensor:
+        from . import geometry
+
+        o = geometry.is_overlapping(entity_a, entity_b)
+        return o if env_index is None else o[env_index]
+
     def cast_rays_all(self) -> Tensor:
         """All Lidar sensors of all agents at once: [n_lidars, max_rays, ld]."""
         return self._get_backend().cast_rays()

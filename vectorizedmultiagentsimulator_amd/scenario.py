@@ -71,3 +71,29 @@ def check_kwargs_consumed(kwargs: dict, warn: bool = True):
         import warnings
 
         warnings.warn(f"Scenario kwargs: {kwargs} passed but not used by the scenario.")
+
+
+def spawn_entities_randomly(entities, world: World, env_index: Optional[int], min_dist_between_entities: float,
+                            x_bounds, y_bounds, occupied_positions: Optional[Tensor] = None, max_tries: int = 64):
+    """ScenarioUtils.spawn_entities_randomly (utils.py:241-319) without the host round trips:
+    the reference loops ``while torch.any(overlaps)``; here a fixed number of rejection rounds
+    runs on the device (each re-draws only the environments that still overlap), which samples
+    the same distribution as long as the placement is not nearly infeasible."""
+    n = 1 if env_index is not None else world.batch_dim
+    dev = world.device
+    if occupied_positions is None:
+        occupied_positions = torch.zeros((n, 0, 2), device=dev)
+
+    def draw():
+        x = torch.empty((n, 1, 1), device=dev, dtype=torch.float32).uniform_(*x_bounds)
+        y = torch.empty((n, 1, 1), device=dev, dtype=torch.float32).uniform_(*y_bounds)
+        return torch.cat([x, y], dim=2)
+
+    for entity in entities:
+        pos = draw()
+        if occupied_positions.shape[1] > 0:
+            for _ in range(max_tries):
+                overlaps = (torch.cdist(occupied_positions, pos) < min_dist_between_entities).squeeze(2).any(dim=1)
+                pos = torch.where(overlaps[:, None, None], draw(), pos)
+        occupied_positions = torch.cat([occupied_positions, pos], dim=1)
+        entity.set_pos(pos.squeeze(1), batch_index=env_index)

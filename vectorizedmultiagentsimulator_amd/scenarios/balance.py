@@ -75,3 +75,42 @@ class Scenario(BaseScenario):
                          dtype=torch.float32),
             batch_index=env_index,
         )
+        # reward bookkeeping (balance.py:202-216)
+        self.compute_on_the_ground()
+        shaping = torch.linalg.vector_norm(self.package.state.pos - self.goal.state.pos, dim=1) * self.shaping_factor
+        if env_index is None:
+            self.global_shaping = shaping
+            self.pos_rew = torch.zeros(w.batch_dim, device=dev, dtype=torch.float32)
+            self.ground_rew = self.pos_rew.clone()
+        else:
+            self.global_shaping[env_index] = shaping[env_index]
+
+    def compute_on_the_ground(self):  # balance.py:218-221
+        w = self.world
+        self.on_the_ground = w.is_overlapping(self.line, self.floor) | w.is_overlapping(self.package, self.floor)
+
+    def reward(self, agent):  # balance.py:223-241
+        if agent is self.world.agents[0]:
+            self.compute_on_the_ground()
+            self.package_dist = torch.linalg.vector_norm(self.package.state.pos - self.goal.state.pos, dim=1)
+            self.ground_rew = torch.where(self.on_the_ground, torch.full_like(self.package_dist, float(self.fall_reward)),
+                                          torch.zeros_like(self.package_dist))
+            global_shaping = self.package_dist * self.shaping_factor
+            self.pos_rew = self.global_shaping - global_shaping
+            self.global_shaping = global_shaping
+        return self.ground_rew + self.pos_rew
+
+    def observation(self, agent):  # balance.py:243-258
+        pkg, line = self.package.state, self.line.state
+        a = agent.state
+        return torch.cat(
+            [a.pos, a.vel, a.pos - pkg.pos, a.pos - line.pos, pkg.pos - self.goal.state.pos, pkg.vel, line.vel,
+             line.ang_vel, line.rot % torch.pi],
+            dim=-1,
+        )
+
+    def done(self):  # balance.py:260-263
+        return self.on_the_ground | self.world.is_overlapping(self.package, self.goal)
+
+    def info(self, agent):
+        return {"pos_rew": self.pos_rew, "ground_rew": self.ground_rew}
