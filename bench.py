@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--n-agents", type=int, default=4)
     ap.add_argument("--lanes", type=int, default=0, help="lanes per environment (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fused", action="store_true",
+                    help="time vmas_world_rollout (persistent launch, state resident in LDS) instead of one launch per step")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -142,7 +144,7 @@ def main():
             if k == 0:
                 w._state.copy_(state0)
             chunk = min(EPISODE - k, n_steps - done)
-            be.step_n(chunk, forces[k : k + chunk])
+            (be.rollout if args.fused else be.step_n)(chunk, forces[k : k + chunk])
             done += chunk
 
     def fence():
@@ -188,6 +190,7 @@ def main():
                 "global_envs": world_size * args.num_envs,
                 "substeps": w.substeps,
                 "lanes_per_env": be.lanes_per_env,
+                "launch": "persistent rollout (vmas_world_rollout)" if args.fused else "one launch per step",
                 "parallelism": f"env-sharded x{world_size}",
             },
             "roofline": {

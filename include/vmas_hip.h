@@ -174,6 +174,13 @@ int vmas_world_step(VmasWorld* w, float* state, float* agent_ft, int64_t ld,
 int vmas_world_step_n(VmasWorld* w, float* state, float* agent_ft, int64_t ld, int64_t ft_step_stride,
                       int32_t n_steps, const VmasStepArgs* args /* may be NULL */, void* stream);
 
+/* Persistent rollout: the same `n_steps` World.step() calls as vmas_world_step_n, bit for bit,
+ * but in ONE launch - the tile of 64 environments stays in LDS between steps, only the agent
+ * forces of step i (at agent_ft + i * ft_step_stride) are read from HBM and the state is written
+ * back once at the end.  For scripted / pre-computed forces (no policy in the loop). */
+int vmas_world_rollout(VmasWorld* w, float* state, float* agent_ft, int64_t ld, int64_t ft_step_stride,
+                       int32_t n_steps, const VmasStepArgs* args /* may be NULL */, void* stream);
+
 /* Batch-global broad phase of World.collides (core.py:2797-2801): mask[p/32] bit
  * p%32 = any_env(|pos_a - pos_b| <= R_a + R_b).  `mask` is zeroed on the stream
  * first.  Only needed for exact small-batch parity; see DESIGN.md. */

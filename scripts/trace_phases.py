@@ -13,11 +13,12 @@ forces = bench.make_forces(w, 100, 1234, torch.device("cuda", 0))
 be.step_n(60, forces[:60]); torch.cuda.synchronize()
 be.step_n(1, forces[60:61]); torch.cuda.synchronize()
 tiles = (B + 63) // 64
-buf = np.zeros(tiles * 16 * 8, np.uint64)
+buf = np.zeros(tiles * 16 * 16, np.uint64)
 lib = be.lib
 lib.vmas_debug_trace.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
 assert lib.vmas_debug_trace(be._h, buf.ctypes.data_as(ctypes.c_void_p), buf.size) == 0
-t = buf.reshape(tiles, 16, 8).astype(np.int64)[:, :lanes, :6]
+full = buf.reshape(tiles, 16, 16).astype(np.int64)[:, :lanes]
+t = full[:, :, :6]
 t0 = t[:, :, 0].min()
 print("lanes", lanes, "tiles", tiles, "kernel span (cycles, s_memtime @100MHz?)", t[:, :, 5].max() - t0)
 for b in (tiles // 2,):
@@ -29,3 +30,11 @@ d = t - t[:, :, 0:1]
 print("mean per-phase over all waves:", (t[:, :, 1:] - t[:, :, :-1]).mean(axis=(0, 1)))
 print("max  per-phase over all waves:", (t[:, :, 1:] - t[:, :, :-1]).max(axis=(0, 1)))
 print("start spread:", t[:, :, 0].max() - t0, " end min/max:", t[:, :, 5].min() - t0, t[:, :, 5].max() - t0)
+
+g = full[:, :, 6:16].astype(np.float64)
+print("gather breakdown, mean cycles per wave: grab+segdesc %.0f | prologue %.0f | SS %.0f (n=%.1f) | LS %.0f (n=%.1f) | BS %.0f (n=%.1f) | other %.0f (n=%.1f)" % (
+    g[:, :, 0].mean(), g[:, :, 1].mean(), g[:, :, 2].mean(), g[:, :, 6].mean(), g[:, :, 3].mean(), g[:, :, 7].mean(),
+    g[:, :, 4].mean(), g[:, :, 8].mean(), g[:, :, 5].mean(), g[:, :, 9].mean()))
+for c, nm in enumerate(("SS", "LS", "BS", "other")):
+    n = g[:, :, 6 + c].sum()
+    if n: print("  per-item %s: %.0f cycles (count per tile %.1f)" % (nm, g[:, :, 2 + c].sum() / n, n / tiles))

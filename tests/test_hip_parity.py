@@ -280,3 +280,28 @@ def test_hip_error_paths():
         hw.cast_rays()
     with pytest.raises(VmasHipError):
         HipWorld(g.spec, 0)
+
+
+@pytest.mark.parametrize("name", ["balance_n4", "navigation_n8", "waterfall", "give_way"])
+def test_persistent_rollout_is_bitwise_equal_to_single_steps(name):
+    """vmas_world_rollout (one launch, state resident in LDS) == n single launches, bit for bit,
+    including the clamped forces written back per step."""
+    g = load(name)
+    B, n = 500, 7
+    st0, ft0, jfr_np, eg_np = make_batch(g, B, seed=21)
+    if jfr_np is not None or eg_np is not None:
+        pytest.skip("per-env joint/gravity inputs are single-step arguments")
+    rng = np.random.default_rng(4)
+    outs = []
+    for mode in ("steps", "rollout"):
+        hw = _hip(g.spec, B)
+        _up(hw, st0, ft0)
+        forces = torch.from_numpy(
+            (ft0[None] * (1 + 0.3 * rng.standard_normal((n,) + ft0.shape))).astype(np.float32)).cuda() if mode == "steps" else forces_saved
+        forces_saved = forces.clone() if mode == "steps" else forces_saved
+        full = torch.zeros(n, *hw.agent_ft.shape, device="cuda")
+        full[:, : ft0.shape[0], :, :B] = forces_saved
+        (hw.step_n if mode == "steps" else hw.rollout)(n, full)
+        outs.append((hw.state.clone(), full.clone()))
+    assert torch.equal(outs[0][0].view(torch.int32), outs[1][0].view(torch.int32))
+    assert torch.equal(outs[0][1].view(torch.int32), outs[1][1].view(torch.int32))

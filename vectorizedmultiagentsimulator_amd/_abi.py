@@ -130,6 +130,7 @@ EXPORTED_SYMBOLS = (
     "vmas_world_destroy",
     "vmas_world_step",
     "vmas_world_step_n",
+    "vmas_world_rollout",
     "vmas_world_pair_mask",
     "vmas_world_set_lidars",
     "vmas_world_cast_rays",
@@ -164,6 +165,8 @@ def load_library() -> C.CDLL:
     lib.vmas_world_step.restype = C.c_int
     lib.vmas_world_step_n.argtypes = [vp, vp, vp, i64, i64, i32, C.POINTER(StepArgs), vp]
     lib.vmas_world_step_n.restype = C.c_int
+    lib.vmas_world_rollout.argtypes = [vp, vp, vp, i64, i64, i32, C.POINTER(StepArgs), vp]
+    lib.vmas_world_rollout.restype = C.c_int
     lib.vmas_world_pair_mask.argtypes = [vp, vp, i64, vp, vp]
     lib.vmas_world_pair_mask.restype = C.c_int
     lib.vmas_world_set_lidars.argtypes = [vp, C.POINTER(LidarDesc), i32]

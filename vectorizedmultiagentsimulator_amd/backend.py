@@ -162,6 +162,20 @@ class HipWorld:
         if rc != 0:
             raise VmasHipError(A.last_error())
 
+    def rollout(self, n_steps: int, forces: Optional[torch.Tensor] = None, stream=None) -> None:
+        """The same steps as ``step_n`` in ONE persistent launch (state stays in LDS)."""
+        if forces is not None:
+            assert forces.shape == (n_steps,) + tuple(self.agent_ft.shape) and forces.is_contiguous()
+            assert forces.device == self.agent_ft.device and forces.dtype == torch.float32
+            ft, stride = forces, self.agent_ft.numel()
+        else:
+            ft, stride = self.agent_ft, 0
+        rc = self.lib.vmas_world_rollout(
+            self._h, self._dptr(self.state), self._dptr(ft), self.ld, stride, int(n_steps), None, self._stream(stream)
+        )
+        if rc != 0:
+            raise VmasHipError(A.last_error())
+
     def pair_mask(self, stream=None) -> torch.Tensor:
         """Batch-global broad phase of World.collides on the current state."""
         rc = self.lib.vmas_world_pair_mask(

@@ -126,6 +126,8 @@ struct DevStepArgs {
   const float* joint_fixed_rot;
   const float* entity_gravity;
   int32_t first_substep, n_substeps;
+  int32_t n_steps;    // > 1: persistent rollout, the tile stays in LDS between steps
+  long ft_stride;     // floats between the agent-force slabs of consecutive steps
   unsigned long long* trace;  // profiling only (env VMAS_TRACE): per-wave s_memtime stamps
   int32_t ablate;  // profiling only (env VMAS_ABLATE): 1 skip items, 2 skip integration, 4 skip prologue
 };
@@ -342,8 +344,14 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
   const int nE = W.nE, nA = W.nA;
   const long env = (long)blockIdx.x * TILE + lane;
   const bool live = env < batch;
+#ifdef VMAS_TRACE  // profiling build only (scripts/trace_phases.py): per-wave s_memtime stamps
 #define STAMP(k)                                                                                     \
-  if (args.trace && lane == 0) args.trace[((long)blockIdx.x * 16 + wv) * 8 + (k)] = __builtin_amdgcn_s_memtime()
+  if (args.trace && lane == 0) args.trace[((long)blockIdx.x * 16 + wv) * 16 + (k)] = __builtin_amdgcn_s_memtime()
+#define TNOW() (args.trace ? __builtin_amdgcn_s_memtime() : 0ull)
+#else
+#define STAMP(k)
+#define TNOW() 0ull
+#endif
   STAMP(0);
   float* tile = lds + lane;  // this lane's column: row r is tile[r * ROWF]
   int* bad_flag = (int*)(tile + W.off_bad);
@@ -354,7 +362,8 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
 
   // ---- stage the descriptor blob (coalesced) and zero the flag row / counters
   for (int i = threadIdx.x; i < W.blob_words; i += blockDim.x) blob[i] = W.blob[i];
-  if (threadIdx.x < 4) ctr[threadIdx.x] = 0;
+  const int first_dyn = (args.ablate & 128) ? 0 : nw;  // 128: profiling toggle, fully dynamic
+  if (threadIdx.x < 4) ctr[threadIdx.x] = first_dyn;  // the first unit of every wave is static (its own index)
   if (wv == nw - 1) *bad_flag = 0;
   __syncthreads();
 
@@ -396,14 +405,34 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
     return sgpr(v);
   };
 
-  for (int substep = s_begin; substep < s_end; ++substep) {
+  const int n_steps = args.n_steps > 1 ? args.n_steps : 1;
+#ifdef VMAS_TRACE
+  unsigned long long acc_grab = 0, acc_pro = 0, acc_item[4] = {0, 0, 0, 0}, cnt_item[4] = {0, 0, 0, 0};
+#endif
+  int it = 0;  // running (step, substep) index: parity selects the live pair of work counters
+  for (int stp = 0; stp < n_steps; ++stp) {
+  float* aft = agent_ft + (long)stp * args.ft_stride;  // this step's agent forces
+  if (stp > 0) {  // persistent rollout: only the agent forces come from HBM, the state never left LDS
+    for (int a = wv; a < nA; a += nw) {
+      const float* src = aft + (long)a * 3 * ld + env;
+      float* dst = tile + W.off_af + a * 3 * ROWF;
+#pragma unroll
+      for (int f = 0; f < 3; ++f) dst[f * ROWF] = live ? src[f * ld] : 0.f;
+    }
+    __syncthreads();
+  }
+  for (int substep = s_begin; substep < s_end; ++substep, ++it) {
     const bool may_skip = *bad_flag == 0;
-    const bool last = substep + 1 == s_end;
-    int* c_gather = ctr + 2 * (substep & 1);
+    const bool last_sub = substep + 1 == s_end;
+    const bool last = last_sub && stp + 1 == n_steps;  // write back to HBM instead of LDS
+    int* c_gather = ctr + 2 * (it & 1);
     int* c_integrate = c_gather + 1;
-    if (threadIdx.x < 2) ctr[2 * ((substep + 1) & 1) + threadIdx.x] = 0;  // re-arm the other parity
+    if (threadIdx.x < 2) ctr[2 * ((it + 1) & 1) + threadIdx.x] = first_dyn;  // re-arm the other parity
     // ================= phase B: gather forces per (entity, segment)
-    for (int si = grab(c_gather); si < W.n_segs; si = grab(c_gather)) {
+#ifdef VMAS_TRACE
+    unsigned long long tg = TNOW();
+#endif
+    for (int si = first_dyn ? wv : grab(c_gather); si < W.n_segs; si = grab(c_gather)) {
       const uint32_t* sp = blob + W.b_segs + si * SW;
       const int e = sgpr((int)sp[0]);
       const float* Es = tile + (int)sp[1];
@@ -412,6 +441,9 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
       const uint32_t efl = (uint32_t)sgpr((int)blob[W.b_ent + e * EW]);
       v2 F = V(0.f, 0.f);
       float Tq = 0.f;
+#ifdef VMAS_TRACE
+      { unsigned long long t1 = TNOW(); acc_grab += t1 - tg; tg = t1; }
+#endif
       if (first && !(args.ablate & 4)) {  // prologue core.py:1995-2004
         const EntV D = load_ent(blob + W.b_ent + e * EW);
         const uint32_t fl = D.flags;
@@ -423,8 +455,8 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
               if (fl & VMAS_F_MAX_F) f = clamp_with_norm(f, D.max_f);
               if (fl & VMAS_F_F_RANGE) f = V(clamp_t(f.x, D.f_range), clamp_t(f.y, D.f_range));
               Af[0] = f.x; Af[ROWF] = f.y;
-              if (last && live) {  // the clamped force is written back (core.py:2021-2027)
-                float* gf = agent_ft + (long)D.agent_index * 3 * ld + env;
+              if (last_sub && live) {  // the clamped force is written back (core.py:2021-2027)
+                float* gf = aft + (long)D.agent_index * 3 * ld + env;
                 gf[0] = f.x; gf[ld] = f.y;
               }
             }
@@ -440,7 +472,7 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
               }
               if (fl & VMAS_F_T_RANGE) t = clamp_t(t, D.t_range);
               Af[2 * ROWF] = t;
-              if (last && live) agent_ft[((long)D.agent_index * 3 + 2) * ld + env] = t;
+              if (last_sub && live) aft[((long)D.agent_index * 3 + 2) * ld + env] = t;
             }
             Tq = Tq + t;
           }
@@ -462,6 +494,9 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
         }
       }
       // joints, then pairs, in the reference's accumulation order (core.py:2176-2199)
+#ifdef VMAS_TRACE
+      { unsigned long long t1 = TNOW(); acc_pro += t1 - tg; tg = t1; }
+#endif
       const int i1 = (args.ablate & 1) ? i0 : i1s;
       for (int ii = i0; ii < i1; ++ii) {
         const ItemV K = W.items_in_lds ? load_item(blob + W.b_items + ii * IW) : item_from_global(W.items[ii]);
@@ -471,9 +506,26 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
         else f.x = __int_as_float(K.type + K.oa + K.ob + K.index) * 1e-30f;  // descriptor fetch only (profiling)
         if (efl & VMAS_F_MOVABLE) F = F + f;
         if (efl & VMAS_F_ROTATABLE) Tq = Tq + t;
+#ifdef VMAS_TRACE
+        if (args.trace) {
+          unsigned long long t1 = TNOW();
+          const int cls = K.type == VMAS_PAIR_SS ? 0 : (K.type == VMAS_PAIR_LS ? 1 : (K.type == VMAS_PAIR_BS ? 2 : 3));
+          acc_item[cls] += t1 - tg; cnt_item[cls] += 1; tg = t1;
+        }
+#endif
       }
       P[0] = F.x; P[ROWF] = F.y; P[2 * ROWF] = Tq;
+#ifdef VMAS_TRACE
+      tg = TNOW();
+#endif
     }
+#ifdef VMAS_TRACE
+    if (args.trace && lane == 0) {
+      unsigned long long* tr = args.trace + ((long)blockIdx.x * 16 + wv) * 16;
+      tr[6] = acc_grab; tr[7] = acc_pro;
+      for (int c = 0; c < 4; ++c) { tr[8 + c] = acc_item[c]; tr[12 + c] = cnt_item[c]; }
+    }
+#endif
     STAMP(3);
     __syncthreads();
     STAMP(4);
@@ -481,7 +533,7 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
     // ================= phase C: _integrate_state core.py:2862-2908 (+ trig for the next substep,
     //                   or, after the last substep, the write-back of the entity's planes)
     const int n_own = (args.ablate & 2) ? 0 : W.n_owned;
-    for (int oi = grab(c_integrate); oi < n_own; oi = grab(c_integrate)) {
+    for (int oi = first_dyn ? wv : grab(c_integrate); oi < n_own; oi = grab(c_integrate)) {
       const uint32_t* op = blob + W.b_owned + oi * OW;
       const int e = sgpr((int)op[0]);
       float* Es = tile + (int)op[1];
@@ -530,6 +582,7 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
       if (bad) *bad_flag = 1;
     }
     if (!last) __syncthreads();
+  }
   }
   STAMP(5);
 }
@@ -752,6 +805,7 @@ static void build_items(const VmasWorldDesc* d, VmasWorld* w, const std::vector<
     t.tra = tr_off(J.a); t.trb = tr_off(J.b);
     t.p0 = J.delta_a[0]; t.p1 = J.delta_a[1]; t.q0 = J.delta_b[0]; t.q1 = J.delta_b[1];
     t.p2 = J.dist; t.p3 = J.fixed_rotation;
+    t.thr2 = kInf;  // joints are never skipped
     push_sides(t, J.a, J.b);
   }
   for (int p = 0; p < d->n_pairs; ++p) {  // then pairs, already type-major (core.py:2178-2189)
@@ -1041,11 +1095,29 @@ int64_t vmas_world_step_bytes_per_env(const VmasWorld* w) {
   return 24LL * w->base.nE + 12LL * w->base.nA + 24LL * w->n_dyn;
 }
 
+static int step_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld, const VmasStepArgs* args, void* stream,
+                     int n_steps, int64_t ft_stride);
+
 int vmas_world_step(VmasWorld* w, float* state, float* agent_ft, int64_t ld, const VmasStepArgs* args, void* stream) {
+  return step_impl(w, state, agent_ft, ld, args, stream, 1, 0);
+}
+
+int vmas_world_rollout(VmasWorld* w, float* state, float* agent_ft, int64_t ld, int64_t ft_step_stride, int32_t n_steps,
+                       const VmasStepArgs* args, void* stream) {
+  if (n_steps <= 0) return fail("vmas_world_rollout: n_steps must be > 0, got %d", n_steps);
+  if (args && (args->first_substep != 0 || args->n_substeps > 0))
+    return fail("vmas_world_rollout: partial substep ranges are only valid for single steps");
+  return step_impl(w, state, agent_ft, ld, args, stream, n_steps, ft_step_stride);
+}
+
+static int step_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld, const VmasStepArgs* args, void* stream,
+                     int n_steps, int64_t ft_stride) {
   if (!w || !state) return fail("vmas_world_step: null argument");
   if (w->base.nA > 0 && !agent_ft) return fail("vmas_world_step: world has agents but agent_ft is null");
   if (ld < w->batch) return fail("vmas_world_step: ld (%lld) < batch (%d)", (long long)ld, w->batch);
   DevStepArgs a{};
+  a.n_steps = n_steps;
+  a.ft_stride = ft_stride;
   if (args) {
     a.pair_mask = args->pair_mask; a.joint_fixed_rot = args->joint_fixed_rot; a.entity_gravity = args->entity_gravity;
     a.first_substep = args->first_substep; a.n_substeps = args->n_substeps;
@@ -1057,7 +1129,7 @@ int vmas_world_step(VmasWorld* w, float* state, float* agent_ft, int64_t ld, con
     static const int trace = getenv("VMAS_TRACE") ? atoi(getenv("VMAS_TRACE")) : 0;
     a.ablate = ablate;
     if (trace) {
-      const size_t n = (size_t)((w->batch + TILE - 1) / TILE) * 16 * 8;
+      const size_t n = (size_t)((w->batch + TILE - 1) / TILE) * 16 * 16;
       if (!w->d_trace) {
         HIP_TRY(hipMalloc((void**)&w->d_trace, n * 8));
         HIP_TRY(hipMemset(w->d_trace, 0, n * 8));
