@@ -618,8 +618,8 @@ struct DevLidar {
 };
 struct DevTarget { int32_t entity, shape; float length, width, radius; };
 
-constexpr int RAY_CHUNK = 8;
 
+template <int RAY_CHUNK>  // rays per thread; blockIdx.z selects the chunk of the sensor's fan
 __global__ __launch_bounds__(256) void lidar_kernel(const DevLidar* __restrict__ lidars,
                                                     const DevTarget* __restrict__ targets,
                                                     const float* __restrict__ angles, int max_rays,
@@ -633,14 +633,13 @@ __global__ __launch_bounds__(256) void lidar_kernel(const DevLidar* __restrict__
   const v2 o = V(sp[0], sp[ld]);
   const float arot = sp[4 * ld];
   const float R = L.max_range;
-  for (int r0 = 0; r0 < L.n_rays; r0 += RAY_CHUNK) {
+  for (int r0 = blockIdx.z * RAY_CHUNK; r0 < L.n_rays; r0 += gridDim.z * RAY_CHUNK) {
     float best[RAY_CHUNK], c[RAY_CHUNK], s[RAY_CHUNK];
 #pragma unroll
     for (int i = 0; i < RAY_CHUNK; ++i) {
       const int r = r0 + i < L.n_rays ? r0 + i : L.n_rays - 1;
       const float th = angles[L.angle_off + r] + arot;  // sensors.py:118
-      c[i] = cosf(th);
-      s[i] = sinf(th);
+      sincosf(th, &s[i], &c[i]);  // one range reduction for both
       best[i] = R;  // core.py:1672-1674
     }
     for (int ti = 0; ti < L.n_targets; ++ti) {
@@ -655,12 +654,16 @@ __global__ __launch_bounds__(256) void lidar_kernel(const DevLidar* __restrict__
           const v2 lp = V(o.x + dir.x * L.half_range, o.y + dir.y * L.half_range);
           const v2 cp = closest_point_line<false>(lp, c[i], s[i], 0.f, tpos);
           const float dn = vnorm(tpos - cp);
-          const float a = Tg.radius * Tg.radius - dn * dn;
-          const float m = __fsqrt_rn(a > 0.f ? a : 1e-8f);
-          float dist = vnorm(cp - o) - m;
           const bool ok = (dn < Tg.radius) && (vdot(u, dir) > 0.f);
-          dist = ok ? dist : R;
-          best[i] = min_t(best[i], dist);
+          // most rays miss (=> max_range, which never lowers the running minimum): the hit
+          // distance, two more square roots, is computed only when some lane of the wave hits
+          if (__any(ok)) {
+            const float a = Tg.radius * Tg.radius - dn * dn;
+            const float m = __fsqrt_rn(a > 0.f ? a : 1e-8f);
+            float dist = vnorm(cp - o) - m;
+            dist = ok ? dist : R;
+            best[i] = min_t(best[i], dist);
+          }
         }
       } else if (Tg.shape == VMAS_SHAPE_BOX) {  // _cast_rays_to_box core.py:1281-1372
         const float trot = tp[4 * ld];
@@ -1217,8 +1220,23 @@ int vmas_world_set_lidars(VmasWorld* w, const VmasLidarDesc* lidars, int32_t n) 
 int vmas_world_cast_rays(VmasWorld* w, const float* state, int64_t ld, float* out, void* stream) {
   if (!w || !state || !out) return fail("vmas_world_cast_rays: null argument");
   if (w->n_lidars <= 0) return fail("vmas_world_cast_rays: no sensors registered (vmas_world_set_lidars)");
-  hipLaunchKernelGGL(lidar_kernel, dim3((w->batch + 255) / 256, w->n_lidars), dim3(256), 0, (hipStream_t)stream,
-                     w->d_lidars, w->d_targets, w->d_angles, w->max_rays, state, (long)ld, w->batch, out);
+  // rays per thread: few when the batch alone cannot fill the chip (latency-bound), more when it
+  // can (each thread then reads its targets once for several rays); VMAS_LIDAR_RPT overrides
+  static const int force_rpt = getenv("VMAS_LIDAR_RPT") ? atoi(getenv("VMAS_LIDAR_RPT")) : 0;
+  const long threads = (long)w->batch * w->n_lidars;
+  int rpt = force_rpt ? force_rpt : (threads >= (1L << 19) ? 4 : 2);  // measured: navigation 8x12 rays, B = 8192 / 65536
+  const dim3 block(256);
+  auto grid = [&](int r) { return dim3((w->batch + 255) / 256, w->n_lidars, (w->max_rays + r - 1) / r); };
+#define LAUNCH_LIDAR(R)                                                                                            \
+  hipLaunchKernelGGL(lidar_kernel<R>, grid(R), block, 0, (hipStream_t)stream, w->d_lidars, w->d_targets, w->d_angles, \
+                     w->max_rays, state, (long)ld, w->batch, out)
+  switch (rpt) {
+    case 1: LAUNCH_LIDAR(1); break;
+    case 2: LAUNCH_LIDAR(2); break;
+    case 4: LAUNCH_LIDAR(4); break;
+    default: LAUNCH_LIDAR(8); break;
+  }
+#undef LAUNCH_LIDAR
   HIP_TRY(hipGetLastError());
   return 0;
 }
