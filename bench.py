@@ -102,12 +102,13 @@ def cpu_baseline(w, forces_cpu, state0_cpu, budget_s=10.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=10000)
+    ap.add_argument("--warmup", type=int, default=500)
     ap.add_argument("--num-envs", type=int, default=32768, help="environments PER GPU")
     ap.add_argument("--n-agents", type=int, default=4)
     ap.add_argument("--lanes", type=int, default=0, help="lanes per environment (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fused", action="store_true", help="skip the secondary persistent-rollout measurement")
     ap.add_argument("--fused", action="store_true",
                     help="time vmas_world_rollout (persistent launch, state resident in LDS) instead of one launch per step")
     args = ap.parse_args()
@@ -167,6 +168,25 @@ def main():
 
     wall = max_over_ranks(wall, device)
 
+    # secondary number (not `value`): the same K steps as ONE persistent launch per episode chunk
+    fused = None
+    if not args.fused and not args.no_fused:
+        def run_fused(n_steps):
+            done = 0
+            while done < n_steps:
+                k = done % EPISODE
+                if k == 0:
+                    w._state.copy_(state0)
+                chunk = min(EPISODE - k, n_steps - done)
+                be.rollout(chunk, forces[k : k + chunk])
+                done += chunk
+        run_fused(EPISODE)
+        fence()
+        tf0 = time.perf_counter()
+        run_fused(args.steps)
+        fence()
+        fused = max_over_ranks(time.perf_counter() - tf0, device)
+
     if rank == 0:
         bytes_per_env = be.step_bytes_per_env()
         ach = bytes_per_env * args.num_envs / (kernel_ms * 1e-3) / 1e9
@@ -205,6 +225,23 @@ def main():
                 "bytes_per_launch": bytes_per_env * args.num_envs,
             },
         }
+        if fused is not None:
+            out["persistent_rollout"] = {
+                "value": world_size * args.num_envs * w.substeps * args.steps / fused,
+                "unit": "env-steps/s",
+                "us_per_step": fused / args.steps * 1e6,
+                "note": "vmas_world_rollout: identical results bit for bit, state stays in LDS between steps "
+                        "(scripted / pre-computed forces only); NOT the headline value",
+            }
+        tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
+        if os.path.exists(tpath):  # HBM bytes per launch from rocprofv3 PMC passes (scripts/gpu_prof.sh)
+            try:
+                tr = json.load(open(tpath))
+                if tr.get("num_envs") == args.num_envs:
+                    out["roofline"]["traffic"] = tr["bytes_per_launch"]
+                    out["roofline"]["traffic_note"] = tr["note"]
+            except Exception:
+                pass
         if world_size == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, forces.cpu().numpy(), state0.cpu().numpy())
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]

@@ -2,7 +2,7 @@
 set -u
 OUT=gpurun_out/prof; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-CMD="python bench.py --no-cpu-baseline --steps 1000 --warmup 100 ${BENCH_ARGS:-}"
+CMD="python bench.py --no-cpu-baseline --no-fused --steps 1000 --warmup 100 ${BENCH_ARGS:-}"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $CMD > $OUT/trace_stdout.log 2>&1
 f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1); echo "== $f"; [ -n "$f" ] && cat "$f" | head -8
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc1 -o bench -- $CMD > $OUT/pmc1_stdout.log 2>&1
@@ -18,5 +18,19 @@ for d in ('pmc1','pmc2','pmc3','pmc4'):
     for r in csv.DictReader(open(fs[0])):
         if 'step_kernel' in r['Kernel_Name']: acc[r['Counter_Name']].append(float(r['Counter_Value']))
     for k,v in acc.items(): print(d, k, 'per-dispatch mean %.4g'%(sum(v)/len(v)), 'n', len(v))
+PY
+python - <<'PY'
+import csv, glob, json, collections
+def mean(d, name):
+    fs=glob.glob(f'gpurun_out/prof/{d}/**/*counter_collection.csv', recursive=True)
+    v=[float(r['Counter_Value']) for r in csv.DictReader(open(fs[0])) if 'step_kernel' in r['Kernel_Name'] and r['Counter_Name']==name]
+    return sum(v)/len(v)
+f, w = mean('pmc3','FETCH_SIZE'), mean('pmc4','WRITE_SIZE')
+json.dump({"num_envs": 32768, "bytes_per_launch": (f + w) * 1024, "fetch_KiB": f, "write_KiB": w,
+           "note": "rocprofv3 FETCH_SIZE + WRITE_SIZE (KiB) per step_kernel launch, separate PMC passes, uncorrected: "
+                   "the guide's 2x FETCH correction is calibrated for 16 B/lane reads, ours are 4 B/lane rows; the state "
+                   "written by step k is still L2-resident when step k+1 reads it, so fetches stay below the 7.9 MB read"},
+          open('gpurun_out/prof/latest_traffic.json','w'))
+print(open('gpurun_out/prof/latest_traffic.json').read())
 PY
 find $OUT -name "*.csv" -size +3M -delete
