@@ -360,7 +360,19 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
   constexpr int EW = (int)(sizeof(DevEntity) / 4), SW = (int)(sizeof(DevSegment) / 4), OW = (int)(sizeof(DevOwned) / 4),
                 IW = (int)(sizeof(DevItem) / 4);
 
-  // ---- stage the descriptor blob (coalesced) and zero the flag row / counters
+  // ---- issue this wave's first entity rows and agent-force rows, THEN stage the descriptor
+  //      blob: the two HBM latencies overlap instead of adding up
+  float v0[6], f0[3];
+  if (wv < nE) {
+    const float* src = state + (long)wv * 6 * ld + env;
+#pragma unroll
+    for (int f = 0; f < 6; ++f) v0[f] = live ? src[f * ld] : 0.f;
+  }
+  if (wv < nA) {
+    const float* src = agent_ft + (long)wv * 3 * ld + env;
+#pragma unroll
+    for (int f = 0; f < 3; ++f) f0[f] = live ? src[f * ld] : 0.f;
+  }
   for (int i = threadIdx.x; i < W.blob_words; i += blockDim.x) blob[i] = W.blob[i];
   const int first_dyn = (args.ablate & 128) ? 0 : nw;  // 128: profiling toggle, fully dynamic
   if (threadIdx.x < 4) ctr[threadIdx.x] = first_dyn;  // the first unit of every wave is static (its own index)
@@ -370,10 +382,15 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
   // ---- HBM -> LDS, one entity per wave at a time: six 256-byte row reads in flight, then the
   //      entity's trig and the non-finite check straight from the registers
   for (int e = wv; e < nE; e += nw) {
-    const float* src = state + (long)e * 6 * ld + env;
     float v[6];
+    if (e == wv) {
 #pragma unroll
-    for (int f = 0; f < 6; ++f) v[f] = live ? src[f * ld] : 0.f;
+      for (int f = 0; f < 6; ++f) v[f] = v0[f];
+    } else {
+      const float* src = state + (long)e * 6 * ld + env;
+#pragma unroll
+      for (int f = 0; f < 6; ++f) v[f] = live ? src[f * ld] : 0.f;
+    }
     float* dst = tile + e * 6 * ROWF;
 #pragma unroll
     for (int f = 0; f < 6; ++f) dst[f * ROWF] = v[f];
@@ -383,7 +400,12 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
     const int shape = sgpr((int)blob[W.b_ent + e * EW + 1]), tr_off = sgpr((int)blob[W.b_ent + e * EW + 3]);
     if (tr_off >= 0 && !(args.ablate & 8)) write_trig(tile + tr_off, v[4], shape);
   }
-  for (int a = wv; a < nA; a += nw) {
+  if (wv < nA) {
+    float* dst = tile + W.off_af + wv * 3 * ROWF;
+#pragma unroll
+    for (int f = 0; f < 3; ++f) dst[f * ROWF] = f0[f];
+  }
+  for (int a = wv + nw; a < nA; a += nw) {
     const float* src = agent_ft + (long)a * 3 * ld + env;
     float* dst = tile + W.off_af + a * 3 * ROWF;
 #pragma unroll
@@ -1010,6 +1032,10 @@ int vmas_world_create(const VmasWorldDesc* d, int32_t batch, int32_t device_id, 
   HIP_TRY(hipSetDevice(device_id));
 
   VmasWorld* w = new VmasWorld();
+  struct Guard {  // destroys the half-built world on every early return below
+    VmasWorld* w;
+    ~Guard() { if (w) vmas_world_destroy(w); }
+  } guard{w};
   w->device = device_id;
   w->batch = batch;
   w->ents.assign(d->entities, d->entities + d->n_entities);
@@ -1033,7 +1059,6 @@ int vmas_world_create(const VmasWorldDesc* d, int32_t batch, int32_t device_id, 
     }
     if (s.flags & (VMAS_F_MOVABLE | VMAS_F_ROTATABLE)) w->n_dyn++;
     if ((s.flags & VMAS_F_AGENT) && (s.agent_index < 0 || s.agent_index >= d->n_agents)) {
-      delete w;
       return fail("vmas_world_create: entity %d has agent_index %d outside [0,%d)", e, s.agent_index, d->n_agents);
     }
   }
@@ -1057,14 +1082,14 @@ int vmas_world_create(const VmasWorldDesc* d, int32_t batch, int32_t device_id, 
   w->lanes = default_lanes(w);
   Sched* S;
   while (true) {
-    if (get_sched(w, w->lanes, &S)) { vmas_world_destroy(w); return -1; }
+    if (get_sched(w, w->lanes, &S)) return -1;
     if (S->lds_bytes <= 160 * 1024 || w->lanes == 1) break;
     w->lanes >>= 1;  // fewer segments => fewer partial rows
   }
   if (S->lds_bytes > 160 * 1024) {
-    vmas_world_destroy(w);
     return fail("vmas_world_create: a 64-environment tile of this world needs %zu B of LDS (> 160 KiB)", S->lds_bytes);
   }
+  guard.w = nullptr;
   *out = w;
   return 0;
 }
@@ -1139,6 +1164,10 @@ static int step_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld, co
       }
       a.trace = w->d_trace;
     }
+  }
+  {
+    int cur = -1;  // the stream belongs to w->device: make it current if the caller's thread is elsewhere
+    if (hipGetDevice(&cur) != hipSuccess || cur != w->device) HIP_TRY(hipSetDevice(w->device));
   }
   Sched* S;
   if (get_sched(w, w->lanes, &S)) return -1;
