@@ -985,8 +985,11 @@ static int default_lanes(const VmasWorld* w) {
   work += w->n_dyn;
   // measured on balance@32768: 8 waves/tile 12.8 us, 16 waves/tile 17.3 us (a 1024-thread block at
   // ~107 VGPRs leaves room for one tile per CU only), 4 waves 15.6 us
+  // ... and in the throughput regime (sweep in DESIGN.md section 6): 131072 envs 36.8 us with 4 waves vs
+  // 41.8 (8) / 47.5 (2); 2097152 envs 463 us (4) vs 572 (8) / 523 (2)
+  const int cap = tiles <= 1024 ? 8 : 4;
   int nw = 1;
-  while (nw < 8 && tiles * nw < 4096 && work >= 150 * nw) nw <<= 1;
+  while (nw < cap && work >= 150 * nw) nw <<= 1;
   return nw;
 }
 

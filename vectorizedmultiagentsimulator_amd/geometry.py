@@ -29,8 +29,7 @@ def closest_point_line(pos: Tensor, rot: Tensor, length, p: Tensor, limit: bool 
     dot = ((pos - p) * u).sum(-1, keepdim=True)
     m = dot.abs()
     if limit:
-        half = torch.as_tensor(length, dtype=pos.dtype, device=pos.device) / 2
-        m = torch.minimum(m, half.reshape(half.shape + (1,) * (m.dim() - half.dim())) if half.dim() else half)
+        m = m.clamp(max=length / 2)  # python scalar: no host->device copy (HIP-graph capturable)
     return pos - torch.sign(dot) * m * u
 
 

@@ -65,6 +65,17 @@ class BaseScenario:
         return
 
 
+def keep(obj, name: str, value: Tensor) -> Tensor:
+    """Persistent per-scenario tensor (shaping caches ...): created once, then updated IN PLACE, so a
+    HIP graph captured over ``Environment.step`` keeps reading and writing the same memory."""
+    cur = getattr(obj, name, None)
+    if isinstance(cur, Tensor) and cur.shape == value.shape and cur.dtype == value.dtype and cur.device == value.device:
+        cur.copy_(value)
+        return cur
+    setattr(obj, name, value.clone())
+    return getattr(obj, name)
+
+
 def check_kwargs_consumed(kwargs: dict, warn: bool = True):
     """utils.py:321-330: unknown scenario kwargs only warn."""
     if kwargs and warn:

@@ -12,7 +12,7 @@ from typing import Optional
 import torch
 
 from ..core import Agent, Box, Landmark, Line, Sphere, World
-from ..scenario import BaseScenario, check_kwargs_consumed
+from ..scenario import BaseScenario, check_kwargs_consumed, keep
 
 
 class Scenario(BaseScenario):
@@ -79,7 +79,7 @@ class Scenario(BaseScenario):
         self.compute_on_the_ground()
         shaping = torch.linalg.vector_norm(self.package.state.pos - self.goal.state.pos, dim=1) * self.shaping_factor
         if env_index is None:
-            self.global_shaping = shaping
+            keep(self, "global_shaping", shaping)
             self.pos_rew = torch.zeros(w.batch_dim, device=dev, dtype=torch.float32)
             self.ground_rew = self.pos_rew.clone()
         else:
@@ -97,7 +97,7 @@ class Scenario(BaseScenario):
                                           torch.zeros_like(self.package_dist))
             global_shaping = self.package_dist * self.shaping_factor
             self.pos_rew = self.global_shaping - global_shaping
-            self.global_shaping = global_shaping
+            keep(self, "global_shaping", global_shaping)
         return self.ground_rew + self.pos_rew
 
     def observation(self, agent):  # balance.py:243-258

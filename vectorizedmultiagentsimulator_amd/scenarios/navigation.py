@@ -9,7 +9,7 @@ from typing import Optional
 import torch
 
 from ..core import Agent, Landmark, Sphere, World
-from ..scenario import BaseScenario, check_kwargs_consumed, spawn_entities_randomly
+from ..scenario import BaseScenario, check_kwargs_consumed, keep, spawn_entities_randomly
 from ..sensors import Lidar
 
 
@@ -74,7 +74,7 @@ class Scenario(BaseScenario):
         for a in w.agents:
             shaping = torch.linalg.vector_norm(a.state.pos - a.goal.state.pos, dim=1) * self.pos_shaping_factor
             if env_index is None:
-                a.pos_shaping = shaping
+                keep(a, "pos_shaping", shaping)
                 a.pos_rew = torch.zeros_like(shaping)
                 a.agent_collision_rew = torch.zeros_like(shaping)
             else:
@@ -88,7 +88,7 @@ class Scenario(BaseScenario):
         agent.on_goal = agent.distance_to_goal < agent.goal.shape.radius
         pos_shaping = agent.distance_to_goal * self.pos_shaping_factor
         agent.pos_rew = agent.pos_shaping - pos_shaping
-        agent.pos_shaping = pos_shaping
+        keep(agent, "pos_shaping", pos_shaping)
         return agent.pos_rew
 
     def reward(self, agent):  # navigation.py:200-230, sync-free

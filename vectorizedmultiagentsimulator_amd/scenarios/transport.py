@@ -7,7 +7,7 @@ from typing import Optional
 import torch
 
 from ..core import Agent, Box, Landmark, Sphere, World
-from ..scenario import BaseScenario, check_kwargs_consumed, spawn_entities_randomly
+from ..scenario import BaseScenario, check_kwargs_consumed, keep, spawn_entities_randomly
 
 
 class Scenario(BaseScenario):
@@ -50,7 +50,7 @@ class Scenario(BaseScenario):
             p.on_goal = w.is_overlapping(p, p.goal)
             shaping = torch.linalg.vector_norm(p.state.pos - p.goal.state.pos, dim=1) * self.shaping_factor
             if env_index is None:
-                p.global_shaping = shaping
+                keep(p, "global_shaping", shaping)
             else:
                 p.global_shaping[env_index] = shaping[env_index]
 
@@ -62,7 +62,7 @@ class Scenario(BaseScenario):
                 p.on_goal = self.world.is_overlapping(p, p.goal)
                 shaping = p.dist_to_goal * self.shaping_factor
                 self.rew = self.rew + torch.where(p.on_goal, torch.zeros_like(shaping), p.global_shaping - shaping)
-                p.global_shaping = shaping
+                keep(p, "global_shaping", shaping)
         return self.rew
 
     def observation(self, agent):  # transport.py:165-182
