@@ -242,6 +242,28 @@ def main():
                     out["roofline"]["traffic_note"] = tr["note"]
             except Exception:
                 pass
+        if world_size == 1 and not args.no_fused:  # informational: the full Environment.step of the same scenario
+            try:
+                from vectorizedmultiagentsimulator_amd.environment import make_env
+
+                env = make_env("balance", num_envs=args.num_envs, device=device, seed=0, validate_actions=False,
+                               graph=True, n_agents=args.n_agents)
+                acts = [env.get_random_action(a) for a in env.agents]
+                for _ in range(5):
+                    env.step(acts)
+                torch.cuda.synchronize()
+                te = time.perf_counter()
+                for _ in range(200):
+                    env.step(acts)
+                torch.cuda.synchronize()
+                te = (time.perf_counter() - te) / 200
+                out["end_to_end_env_step"] = {
+                    "value": args.num_envs / te, "unit": "env-steps/s", "us_per_step": te * 1e6,
+                    "note": "make_env('balance').step(): action ingest + World.step + fused overlap queries + "
+                            "observation/reward/done, replayed as one HIP graph; NOT the headline value",
+                }
+            except Exception as e:  # never let the informational leg break the bench line
+                out["end_to_end_env_step"] = {"error": repr(e)}
         if world_size == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, forces.cpu().numpy(), state0.cpu().numpy())
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]

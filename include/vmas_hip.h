@@ -193,6 +193,18 @@ int vmas_world_set_lidars(VmasWorld* w, const VmasLidarDesc* lidars, int32_t n_l
  * largest n_rays of the registered set. */
 int vmas_world_cast_rays(VmasWorld* w, const float* state, int64_t ld, float* out, void* stream);
 
+/* Scenario-side geometric queries (World.get_distance core.py:1822-1905,
+ * World.is_overlapping core.py:1907-1969) evaluated for a registered list of entity pairs in
+ * ONE launch: out[q * ld + env] = distance, or 1.0f / 0.0f for an overlap query. */
+#define VMAS_QUERY_DISTANCE 0
+#define VMAS_QUERY_OVERLAP 1
+typedef struct VmasQuery {
+  int32_t kind; /* VMAS_QUERY_* */
+  int32_t a, b; /* entity indices, any order (as the caller would pass them) */
+} VmasQuery;
+int vmas_world_set_queries(VmasWorld* w, const VmasQuery* queries, int32_t n_queries);
+int vmas_world_run_queries(VmasWorld* w, const float* state, int64_t ld, float* out, void* stream);
+
 /* Kernel geometry knob: lanes cooperating on one environment (1..64, power of
  * two); 0 = choose from the world size. */
 int vmas_world_set_lanes_per_env(VmasWorld* w, int32_t lanes);

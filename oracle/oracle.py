@@ -53,6 +53,8 @@ def _load():
         lib.vmas_oracle_cast_rays.restype = C.c_int
         lib.vmas_oracle_pair_forces.argtypes = [C.POINTER(A.WorldDesc), i32, vp, i64, i32, vp]
         lib.vmas_oracle_pair_forces.restype = C.c_int
+        lib.vmas_oracle_queries.argtypes = [C.POINTER(A.WorldDesc), i32, vp, i64, C.POINTER(A.Query), i32, vp]
+        lib.vmas_oracle_queries.restype = C.c_int
         lib.vmas_oracle_set_jitter.argtypes = [C.c_uint32]
         lib.vmas_oracle_set_jitter.restype = None
         _lib = lib
@@ -145,5 +147,18 @@ class Oracle:
         batch = ld if batch is None else batch
         out = np.zeros((6, ld), np.float32)
         rc = self.lib.vmas_oracle_pair_forces(C.byref(self.cdesc.world), batch, _ptr(state), ld, p, _ptr(out))
+        assert rc == 0
+        return out
+
+    def queries(self, state: np.ndarray, queries, batch: Optional[int] = None) -> np.ndarray:
+        """[(kind, a, b)] -> [n, ld] distances / overlaps (1.0 / 0.0)."""
+        ld = state.shape[-1]
+        batch = ld if batch is None else batch
+        arr = (A.Query * max(len(queries), 1))()
+        for i, (kind, a, b) in enumerate(queries):
+            arr[i].kind = A.QUERY_OVERLAP if kind == "overlap" else A.QUERY_DISTANCE
+            arr[i].a, arr[i].b = int(a), int(b)
+        out = np.zeros((max(len(queries), 1), ld), np.float32)
+        rc = self.lib.vmas_oracle_queries(C.byref(self.cdesc.world), batch, _ptr(state), ld, arr, len(queries), _ptr(out))
         assert rc == 0
         return out

@@ -595,4 +595,68 @@ int vmas_oracle_pair_forces(const VmasWorldDesc* W, int32_t batch, const float* 
   return 0;
 }
 
+/* World.get_distance core.py:1822-1905 / World.is_overlapping core.py:1907-1969 for one env */
+static float query_env(const VmasWorldDesc* W, const ent_t* S, int kind, int a, int b) {
+  const VmasEntityDesc* E = W->entities;
+  int sa = E[a].shape, sb = E[b].shape;
+  float dist;
+  int overlap = -1;
+  if (sa == VMAS_SHAPE_SPHERE && sb == VMAS_SHAPE_SPHERE) {
+    dist = (vnorm(vsub(S[a].pos, S[b].pos)) - E[a].radius) - E[b].radius;
+  } else if ((sa == VMAS_SHAPE_BOX && sb == VMAS_SHAPE_SPHERE) || (sb == VMAS_SHAPE_BOX && sa == VMAS_SHAPE_SPHERE)) {
+    int bx = sa == VMAS_SHAPE_BOX ? a : b, sp = sa == VMAS_SHAPE_BOX ? b : a;
+    seg_t be[4];
+    box_edges(S[bx].pos, S[bx].rot, E[bx].length, E[bx].width, be);
+    v2 cp = closest_point_box(be, S[sp].pos);
+    float d_sphere_cp = vnorm(vsub(S[sp].pos, cp));
+    float d_sphere_box = vnorm(vsub(S[sp].pos, S[bx].pos));
+    float d_box_cp = vnorm(vsub(S[bx].pos, cp));
+    overlap = (d_sphere_box < d_box_cp) || (d_sphere_cp < E[sp].radius + LINE_MIN_DIST);
+    dist = (d_sphere_cp - LINE_MIN_DIST) - E[sp].radius;
+    if (overlap) dist = -1.f;
+  } else if ((sa == VMAS_SHAPE_LINE && sb == VMAS_SHAPE_SPHERE) || (sb == VMAS_SHAPE_LINE && sa == VMAS_SHAPE_SPHERE)) {
+    int ln = sa == VMAS_SHAPE_LINE ? a : b, sp = sa == VMAS_SHAPE_LINE ? b : a;
+    v2 cp = closest_point_line(S[ln].pos, cosf(S[ln].rot), sinf(S[ln].rot), E[ln].length / 2.f, S[sp].pos, 1);
+    dist = (vnorm(vsub(S[sp].pos, cp)) - LINE_MIN_DIST) - E[sp].radius;
+  } else if (sa == VMAS_SHAPE_LINE && sb == VMAS_SHAPE_LINE) {
+    seg_t l1 = {S[a].pos, cosf(S[a].rot), sinf(S[a].rot), E[a].length / 2.f};
+    seg_t l2 = {S[b].pos, cosf(S[b].rot), sinf(S[b].rot), E[b].length / 2.f};
+    v2 p1, p2;
+    closest_points_seg_seg(&l1, &l2, &p1, &p2);
+    dist = vnorm(vsub(p1, p2)) - LINE_MIN_DIST;
+  } else if ((sa == VMAS_SHAPE_BOX && sb == VMAS_SHAPE_LINE) || (sb == VMAS_SHAPE_BOX && sa == VMAS_SHAPE_LINE)) {
+    int bx = sa == VMAS_SHAPE_BOX ? a : b, ln = sa == VMAS_SHAPE_BOX ? b : a;
+    seg_t be[4];
+    box_edges(S[bx].pos, S[bx].rot, E[bx].length, E[bx].width, be);
+    seg_t l = {S[ln].pos, cosf(S[ln].rot), sinf(S[ln].rot), E[ln].length / 2.f};
+    v2 pb, pl;
+    closest_seg_box(be, &l, &pb, &pl);
+    dist = vnorm(vsub(pb, pl)) - LINE_MIN_DIST;
+  } else {
+    seg_t ea[4], eb[4];
+    box_edges(S[a].pos, S[a].rot, E[a].length, E[a].width, ea);
+    box_edges(S[b].pos, S[b].rot, E[b].length, E[b].width, eb);
+    v2 pa, pb;
+    closest_box_box(ea, eb, &pa, &pb);
+    dist = vnorm(vsub(pa, pb)) - LINE_MIN_DIST;
+  }
+  if (kind == VMAS_QUERY_DISTANCE) return dist;
+  if (overlap < 0) overlap = dist < 0.f;
+  return overlap ? 1.f : 0.f;
+}
+
+int vmas_oracle_queries(const VmasWorldDesc* W, int32_t batch, const float* state, int64_t ld, const VmasQuery* q,
+                        int32_t n, float* out) {
+  if (!W || W->abi_version != VMAS_ABI_VERSION || W->n_entities > MAX_E) return -1;
+  for (int64_t env = 0; env < batch; ++env) {
+    ent_t S[MAX_E];
+    for (int e = 0; e < W->n_entities; ++e) {
+      const float* p = state + (int64_t)e * VMAS_STATE_FIELDS * ld + env;
+      S[e].pos = V(p[0], p[ld]); S[e].vel = V(p[2 * ld], p[3 * ld]); S[e].rot = p[4 * ld]; S[e].ang = p[5 * ld];
+    }
+    for (int i = 0; i < n; ++i) out[(int64_t)i * ld + env] = query_env(W, S, q[i].kind, q[i].a, q[i].b);
+  }
+  return 0;
+}
+
 int vmas_oracle_abi_version(void) { return VMAS_ABI_VERSION; }

@@ -24,6 +24,8 @@ steps of a rollout driven by seeded random actions:
   jfr         [T, J, B]     per-env JointConstraint.fixed_rotation (joints.py:141-144)
   egrav       [T, E, 2, B]  per-env entity gravity (only if some entity has one)
   lidar       [T, L, R, B]  World.cast_rays for every Lidar sensor, measured on state0
+  query       [T, Q, B]     World.get_distance / is_overlapping (1.0/0.0) on state0 for the pairs
+                            listed in `queries` (JSON [(kind, a, b)]), all six shape combinations
   spec        JSON of vectorizedmultiagentsimulator_amd.spec.WorldSpec
 
 Nothing numeric is computed by this repository's code here except the static
@@ -74,7 +76,18 @@ class StepRecorder:
         self.idx = {id(e): i for i, e in enumerate(world.entities)}
         self.pair_index = {frozenset((p.a, p.b)): k for k, p in enumerate(self.spec.pairs)}
         self.words = max((len(self.spec.pairs) + 31) // 32, 1)
-        self.rec = {k: [] for k in ("state0", "ft_in", "masks", "state1", "ft_out", "jfr", "egrav", "lidar", "sub")}
+        self.rec = {k: [] for k in ("state0", "ft_in", "masks", "state1", "ft_out", "jfr", "egrav", "lidar", "sub", "query")}
+        # geometric queries (World.get_distance / is_overlapping): up to 3 entity pairs per
+        # unordered shape combination, both kinds
+        ents = list(world.entities)
+        per_combo = {}
+        for ia, ea in enumerate(ents):
+            for ib in range(ia + 1, len(ents)):
+                key = tuple(sorted((type(ea.shape).__name__, type(ents[ib].shape).__name__)))
+                per_combo.setdefault(key, [])
+                if len(per_combo[key]) < 3:
+                    per_combo[key].append((ia, ib) if (ia + ib) % 2 == 0 else (ib, ia))
+        self.queries = [(kind, a, b) for pairs in per_combo.values() for (a, b) in pairs for kind in ("distance", "overlap")]
         self.count = 0
         self._in_step = False
         self._cur_masks = None
@@ -164,6 +177,14 @@ class StepRecorder:
         lid = self._lidar()
         if lid is not None:
             r["lidar"].append(lid)
+        ents = list(self.world.entities)
+        q = np.zeros((len(self.queries), self.world.batch_dim), np.float32)
+        for i, (kind, a, b) in enumerate(self.queries):
+            if kind == "distance":
+                q[i] = self.world.get_distance(ents[a], ents[b]).detach().numpy()
+            else:
+                q[i] = self.world.is_overlapping(ents[a], ents[b]).to(torch.float32).numpy()
+        r["query"].append(q)
         self._cur_masks = []
         self._cur_sub = []
         self._in_step = True
@@ -183,6 +204,8 @@ class StepRecorder:
     def save(self, name: str):
         arrays = {k: np.stack(v) for k, v in self.rec.items() if v}
         arrays["spec"] = np.array(self.spec.to_json())
+        import json as _json
+        arrays["queries"] = np.array(_json.dumps(self.queries))
         path = os.path.join(HERE, f"{name}.npz")
         np.savez_compressed(path, **arrays)
         T = arrays["state0"].shape[0]

@@ -28,6 +28,8 @@ class Golden:
     egrav: Optional[np.ndarray]  # [T, E, 2, B]
     lidar: Optional[np.ndarray]  # [T, L, R, B]
     sub: Optional[np.ndarray] = None  # [T, S+1, E, 6, B]
+    query: Optional[np.ndarray] = None  # [T, Q, B]
+    queries: Optional[list] = None  # [(kind, a, b)]
 
     @property
     def T(self):
@@ -45,7 +47,8 @@ def load(name: str) -> Golden:
     jfr = g("jfr")
     if jfr is not None and jfr.shape[1] == 0:
         jfr = None
-    return Golden(name, spec, z["state0"], z["ft_in"], z["masks"], z["state1"], z["ft_out"], jfr, g("egrav"), g("lidar"), g("sub"))
+    return Golden(name, spec, z["state0"], z["ft_in"], z["masks"], z["state1"], z["ft_out"], jfr, g("egrav"), g("lidar"), g("sub"), g("query"),
+                  [tuple(q) for q in __import__("json").loads(str(z["queries"]))] if "queries" in z.files else None)
 
 
 def tolerances(spec: WorldSpec):

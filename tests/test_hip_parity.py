@@ -305,3 +305,36 @@ def test_persistent_rollout_is_bitwise_equal_to_single_steps(name):
         outs.append((hw.state.clone(), full.clone()))
     assert torch.equal(outs[0][0].view(torch.int32), outs[1][0].view(torch.int32))
     assert torch.equal(outs[0][1].view(torch.int32), outs[1][1].view(torch.int32))
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_hip_queries_match_reference_and_oracle(name):
+    """vmas_world_run_queries (World.get_distance / is_overlapping, core.py:1822-1969)."""
+    from oracle.oracle import Oracle
+
+    g = load(name)
+    if not g.queries:
+        pytest.skip("no query pairs")
+    o = Oracle(g.spec)
+    hw = _hip(g.spec, g.B)
+    hw.set_queries(g.queries)
+    kinds = np.array([k == "overlap" for k, _, _ in g.queries])
+    flips = 0
+    for t in range(g.T):
+        st = np.ascontiguousarray(g.state0[t])
+        _up(hw, st, np.ascontiguousarray(g.ft_in[t]))
+        out = hw.run_queries()[:, : g.B].cpu().numpy()
+        with np.errstate(invalid="ignore"):
+            ok = np.isfinite(st).all(axis=(0, 1)) & (np.abs(st) < 1e3).all(axis=(0, 1))
+        compare_state(out[~kinds][:, ok], g.query[t][~kinds][:, ok], f"{name}[t={t}] distances vs reference", atol=2e-6, rtol=1e-5)
+        flips += int((out[kinds][:, ok] != g.query[t][kinds][:, ok]).sum())
+    assert flips <= 2, f"{name}: {flips} overlap flags differ from the reference"
+    B = 2000
+    st0, ft0, _, _ = make_batch(g, B, seed=13)
+    hw = _hip(g.spec, B)
+    hw.set_queries(g.queries)
+    _up(hw, st0, ft0)
+    out = hw.run_queries()[:, :B].cpu().numpy()
+    want = o.queries(st0, g.queries)
+    compare_state(out[~kinds], want[~kinds], f"{name} distances vs oracle", atol=2e-6, rtol=1e-5)
+    assert (out[kinds] != want[kinds]).mean() < 1e-4

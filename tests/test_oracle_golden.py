@@ -54,3 +54,24 @@ def test_oracle_lidar_matches_reference(name):
     for t in range(g.T):
         out = o.cast_rays(np.ascontiguousarray(g.state0[t]))
         compare_state(out, g.lidar[t], f"{name}[t={t}] lidar", atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_oracle_queries_match_reference(name):
+    """World.get_distance / World.is_overlapping (core.py:1822-1969) for every shape combination."""
+    g = load(name)
+    if not g.queries:
+        pytest.skip("no query pairs")
+    o = Oracle(g.spec)
+    kinds = np.array([k == "overlap" for k, _, _ in g.queries])
+    flips = 0
+    for t in range(g.T):
+        st = np.ascontiguousarray(g.state0[t])
+        with np.errstate(invalid="ignore"):
+            ok = np.isfinite(st).all(axis=(0, 1)) & (np.abs(st) < 1e3).all(axis=(0, 1))  # sane environments only
+        out = o.queries(st, g.queries)[:, : g.B]
+        want = g.query[t]
+        compare_state(out[~kinds][:, ok], want[~kinds][:, ok], f"{name}[t={t}] distances", atol=2e-6, rtol=1e-5)
+        flips += int((out[kinds][:, ok] != want[kinds][:, ok]).sum())
+    # an overlap flag may flip only where the distance is within rounding of zero
+    assert flips <= 2, f"{name}: {flips} overlap flags differ"

@@ -117,6 +117,13 @@ class LidarDesc(C.Structure):
     ]
 
 
+class Query(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("a", C.c_int32), ("b", C.c_int32)]
+
+
+QUERY_DISTANCE, QUERY_OVERLAP = 0, 1
+
+
 class VmasHipLibraryMissing(ImportError):
     pass
 
@@ -134,6 +141,8 @@ EXPORTED_SYMBOLS = (
     "vmas_world_pair_mask",
     "vmas_world_set_lidars",
     "vmas_world_cast_rays",
+    "vmas_world_set_queries",
+    "vmas_world_run_queries",
     "vmas_world_set_lanes_per_env",
     "vmas_world_get_lanes_per_env",
     "vmas_world_step_bytes_per_env",
@@ -173,6 +182,10 @@ def load_library() -> C.CDLL:
     lib.vmas_world_set_lidars.restype = C.c_int
     lib.vmas_world_cast_rays.argtypes = [vp, vp, i64, vp, vp]
     lib.vmas_world_cast_rays.restype = C.c_int
+    lib.vmas_world_set_queries.argtypes = [vp, C.POINTER(Query), i32]
+    lib.vmas_world_set_queries.restype = C.c_int
+    lib.vmas_world_run_queries.argtypes = [vp, vp, i64, vp, vp]
+    lib.vmas_world_run_queries.restype = C.c_int
     lib.vmas_world_set_lanes_per_env.argtypes = [vp, i32]
     lib.vmas_world_set_lanes_per_env.restype = C.c_int
     lib.vmas_world_get_lanes_per_env.argtypes = [vp]

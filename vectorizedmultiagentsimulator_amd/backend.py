@@ -192,6 +192,25 @@ class HipWorld:
             m = self.pair_mask(stream)
             self.step(m, joint_fixed_rot, entity_gravity, s, 1, stream)
 
+    def set_queries(self, queries) -> None:
+        """Register (kind, a, b) geometric queries: kind "distance" | "overlap", entity indices."""
+        arr = (A.Query * max(len(queries), 1))()
+        for i, (kind, a, b) in enumerate(queries):
+            arr[i].kind = A.QUERY_OVERLAP if kind == "overlap" else A.QUERY_DISTANCE
+            arr[i].a, arr[i].b = int(a), int(b)
+        if self.lib.vmas_world_set_queries(self._h, arr, len(queries)) != 0:
+            raise VmasHipError(A.last_error())
+        self._query_out = torch.zeros(max(len(queries), 1), self.ld, device=self.state.device, dtype=torch.float32)
+
+    def run_queries(self, stream=None) -> torch.Tensor:
+        """All registered queries in one launch: [n_queries, ld] (overlap as 1.0 / 0.0)."""
+        rc = self.lib.vmas_world_run_queries(
+            self._h, self._dptr(self.state), self.ld, self._dptr(self._query_out), self._stream(stream)
+        )
+        if rc != 0:
+            raise VmasHipError(A.last_error())
+        return self._query_out
+
     def cast_rays(self, stream=None) -> torch.Tensor:
         """World.cast_rays for every registered Lidar: [n_lidars, max_rays, ld]."""
         if self._lidar_out is None:

@@ -132,6 +132,7 @@ class EntityState:
             value.shape[0] == v.shape[0]
         ), f"Internal state must match batch dim, got {value.shape[0]}, expected {v.shape[0]}"
         v.copy_(value.to(v.device).reshape(v.shape))
+        self._entity._world._query_cache = None
 
     pos = property(lambda s: s._view("pos"), lambda s, v: s._assign("pos", v))
     vel = property(lambda s: s._view("vel"), lambda s, v: s._assign("vel", v))
@@ -408,6 +409,7 @@ class Entity:
                 view.copy_(new.reshape(1, -1).expand(view.shape))
         else:
             view[batch_index] = new.reshape(-1)
+        self._world._query_cache = None
         self.notify_observers()
 
 
@@ -648,6 +650,10 @@ class World:
         #: (2 launches per substep); False = every static pair evaluated per env
         self.exact_broad_phase = exact_broad_phase
         self._lanes_per_env = lanes_per_env
+        # geometric queries answered by ONE kernel launch per state version (GPU worlds)
+        self._query_list: List[Tuple[str, int, int]] = []
+        self._query_index: Dict[Tuple[str, int, int], int] = {}
+        self._query_cache: Optional[Tensor] = None
 
     # ---- construction ---------------------------------------------------------
     def _register(self, e: Entity):
@@ -699,6 +705,30 @@ class World:
         if self._backend is not None:
             self._backend.close()
         self._backend, self._spec = None, None
+        self._query_cache = None
+        self._queries_registered = False
+
+    def invalidate_queries(self):
+        """Call after writing entity state in place through a view (``e.state.pos[i] = ...``); the
+        setters, ``reset`` and ``step`` do it themselves."""
+        self._query_cache = None
+
+    def _query(self, kind: str, a: Entity, b: Entity) -> Optional[Tensor]:
+        """Row of the fused query kernel for (kind, a, b), or None on non-GPU worlds."""
+        if self._device.type != "cuda":
+            return None
+        key = (kind, a._index, b._index)
+        be = self._get_backend()
+        if key not in self._query_index or not getattr(self, "_queries_registered", False):
+            if key not in self._query_index:
+                self._query_index[key] = len(self._query_list)
+                self._query_list.append(key)
+            be.set_queries(self._query_list)
+            self._queries_registered = True
+            self._query_cache = None
+        if self._query_cache is None:
+            self._query_cache = be.run_queries()
+        return self._query_cache[self._query_index[key], : self._batch_dim]
 
     @property
     def spec(self) -> WorldSpec:
@@ -744,6 +774,7 @@ class World:
         return [a for a in self._agents if a.action_script is not None]
 
     def reset(self, env_index: Optional[int]):
+        self._query_cache = None
         self._packed_state()
         for e in self.entities:
             e._reset(env_index)
@@ -779,6 +810,7 @@ class World:
     def step(self):
         """core.py:1972-2015 as ONE fused kernel launch (or 2 per substep in exact mode)."""
         be = self._get_backend()
+        self._query_cache = None
         jfr, eg = self._per_env_inputs()
         if self.exact_broad_phase:
             be.step_exact(joint_fixed_rot=jfr, entity_gravity=eg)
@@ -809,13 +841,16 @@ class World:
     def get_distance(self, entity_a: Entity, entity_b: Entity, env_index: int = None) -> Tensor:
         from . import geometry
 
-        d = geometry.get_distance(entity_a, entity_b)
+        d = self._query("distance", entity_a, entity_b)
+        if d is None:
+            d = geometry.get_distance(entity_a, entity_b)
         return d if env_index is None else d[env_index]
 
     def is_overlapping(self, entity_a: Entity, entity_b: Entity, env_index: int = None) -> Tensor:
         from . import geometry
 
-        o = geometry.is_overlapping(entity_a, entity_b)
+        q = self._query("overlap", entity_a, entity_b)
+        o = geometry.is_overlapping(entity_a, entity_b) if q is None else q > 0.5
         return o if env_index is None else o[env_index]
 
     def cast_rays_all(self) -> Tensor:

@@ -726,6 +726,69 @@ __global__ __launch_bounds__(256) void lidar_kernel(const DevLidar* __restrict__
   }
 }
 
+// ------------------------------------------------------------------------------------
+// scenario-side queries: World.get_distance core.py:1822-1905, World.is_overlapping core.py:1907-1969
+// one thread per environment, blockIdx.y = query (wave-uniform shape dispatch)
+// ------------------------------------------------------------------------------------
+struct DevQuery {
+  int32_t kind, a, b;      // a/b already ordered (box, sphere) / (line, sphere) / (box, line)
+  int32_t sa, sb;          // shape codes
+  float la, wa, ra, lb, wb, rb;  // length / width / radius of a and b
+};
+
+__global__ __launch_bounds__(256) void query_kernel(const DevQuery* __restrict__ queries, const float* __restrict__ state,
+                                                    long ld, int batch, float* __restrict__ out) {
+  const long env = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= batch) return;
+  const DevQuery Q = queries[blockIdx.y];
+  const float* A = state + (long)Q.a * 6 * ld + env;
+  const float* B = state + (long)Q.b * 6 * ld + env;
+  const v2 pa = V(A[0], A[ld]), pb = V(B[0], B[ld]);
+  float dist;
+  int overlap = -1;
+  if (Q.sa == VMAS_SHAPE_SPHERE) {  // sphere - sphere
+    dist = (vnorm(pa - pb) - Q.ra) - Q.rb;
+  } else if (Q.sa == VMAS_SHAPE_BOX && Q.sb == VMAS_SHAPE_SPHERE) {
+    const float rot = A[4 * ld], rot2 = rot + kHalfPi;
+    seg_t be[4];
+    box_edges(pa, cosf(rot), sinf(rot), cosf(rot2), sinf(rot2), Q.la, Q.wa, be);
+    const v2 cp = closest_point_box(be, pb);
+    const float d_sphere_cp = vnorm(pb - cp), d_sphere_box = vnorm(pb - pa), d_box_cp = vnorm(pa - cp);
+    overlap = (d_sphere_box < d_box_cp) || (d_sphere_cp < Q.rb + kLineMinDist);
+    dist = overlap ? -1.f : (d_sphere_cp - kLineMinDist) - Q.rb;
+  } else if (Q.sa == VMAS_SHAPE_LINE && Q.sb == VMAS_SHAPE_SPHERE) {
+    const float rot = A[4 * ld];
+    const v2 cp = closest_point_line<true>(pa, cosf(rot), sinf(rot), Q.la / 2.f, pb);
+    dist = (vnorm(pb - cp) - kLineMinDist) - Q.rb;
+  } else if (Q.sa == VMAS_SHAPE_LINE) {  // line - line
+    const float r1 = A[4 * ld], r2 = B[4 * ld];
+    seg_t l1 = {pa, cosf(r1), sinf(r1), Q.la / 2.f};
+    seg_t l2 = {pb, cosf(r2), sinf(r2), Q.lb / 2.f};
+    v2 p1, p2;
+    closest_points_seg_seg(l1, l2, p1, p2);
+    dist = vnorm(p1 - p2) - kLineMinDist;
+  } else if (Q.sb == VMAS_SHAPE_LINE) {  // box - line
+    const float rot = A[4 * ld], rot2 = rot + kHalfPi, rl = B[4 * ld];
+    seg_t be[4];
+    box_edges(pa, cosf(rot), sinf(rot), cosf(rot2), sinf(rot2), Q.la, Q.wa, be);
+    seg_t l = {pb, cosf(rl), sinf(rl), Q.lb / 2.f};
+    v2 qb, ql;
+    closest_seg_box(be, l, qb, ql);
+    dist = vnorm(qb - ql) - kLineMinDist;
+  } else {  // box - box
+    const float r1 = A[4 * ld], r1b = r1 + kHalfPi, r2 = B[4 * ld], r2b = r2 + kHalfPi;
+    seg_t ea[4], eb[4];
+    box_edges(pa, cosf(r1), sinf(r1), cosf(r1b), sinf(r1b), Q.la, Q.wa, ea);
+    box_edges(pb, cosf(r2), sinf(r2), cosf(r2b), sinf(r2b), Q.lb, Q.wb, eb);
+    v2 qa, qb;
+    closest_box_box(ea, eb, qa, qb);
+    dist = vnorm(qa - qb) - kLineMinDist;
+  }
+  float r = dist;
+  if (Q.kind == VMAS_QUERY_OVERLAP) r = (overlap < 0 ? (dist < 0.f) : overlap) ? 1.f : 0.f;
+  out[(long)blockIdx.y * ld + env] = r;
+}
+
 // test hook (not part of the ABI): the device softplus on an array, for the accuracy test
 __global__ void softplus_kernel(const float* __restrict__ in, float* __restrict__ out, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -791,6 +854,9 @@ struct VmasWorld {
   DevTarget* d_targets = nullptr;
   float* d_angles = nullptr;
   int n_lidars = 0, max_rays = 0;
+  // queries
+  DevQuery* d_queries = nullptr;
+  int n_queries = 0;
 };
 
 static float type_cost(int type) {
@@ -1102,7 +1168,7 @@ void vmas_world_destroy(VmasWorld* w) {
   (void)hipSetDevice(w->device);
   for (auto& kv : w->scheds) kv.second.release();
   (void)hipFree(w->d_mpairs); (void)hipFree(w->d_trace);
-  (void)hipFree(w->d_lidars); (void)hipFree(w->d_targets); (void)hipFree(w->d_angles);
+  (void)hipFree(w->d_lidars); (void)hipFree(w->d_targets); (void)hipFree(w->d_angles); (void)hipFree(w->d_queries);
   delete w;
 }
 
@@ -1246,6 +1312,38 @@ int vmas_world_set_lidars(VmasWorld* w, const VmasLidarDesc* lidars, int32_t n) 
   HIP_TRY(upload(&w->d_targets, dt));
   HIP_TRY(upload(&w->d_angles, da));
   w->n_lidars = n;
+  return 0;
+}
+
+int vmas_world_set_queries(VmasWorld* w, const VmasQuery* queries, int32_t n) {
+  if (!w || (n > 0 && !queries)) return fail("vmas_world_set_queries: null argument");
+  HIP_TRY(hipSetDevice(w->device));
+  (void)hipFree(w->d_queries);
+  w->d_queries = nullptr;
+  w->n_queries = 0;
+  if (n <= 0) return 0;
+  std::vector<DevQuery> dq(n);
+  for (int i = 0; i < n; ++i) {
+    int a = queries[i].a, b = queries[i].b;
+    if (a < 0 || a >= w->base.nE || b < 0 || b >= w->base.nE || queries[i].kind < 0 || queries[i].kind > 1)
+      return fail("vmas_world_set_queries: query %d is malformed", i);
+    // role order of the reference: (box, sphere), (line, sphere), (box, line)
+    auto rank = [&](int e) { return w->ents[e].shape == VMAS_SHAPE_BOX ? 0 : (w->ents[e].shape == VMAS_SHAPE_LINE ? 1 : 2); };
+    if (rank(a) > rank(b)) std::swap(a, b);
+    const VmasEntityDesc &A = w->ents[a], &B = w->ents[b];
+    dq[i] = {queries[i].kind, a, b, A.shape, B.shape, A.length, A.width, A.radius, B.length, B.width, B.radius};
+  }
+  HIP_TRY(upload(&w->d_queries, dq));
+  w->n_queries = n;
+  return 0;
+}
+
+int vmas_world_run_queries(VmasWorld* w, const float* state, int64_t ld, float* out, void* stream) {
+  if (!w || !state || !out) return fail("vmas_world_run_queries: null argument");
+  if (w->n_queries <= 0) return fail("vmas_world_run_queries: no queries registered (vmas_world_set_queries)");
+  hipLaunchKernelGGL(query_kernel, dim3((w->batch + 255) / 256, w->n_queries), dim3(256), 0, (hipStream_t)stream,
+                     w->d_queries, state, (long)ld, w->batch, out);
+  HIP_TRY(hipGetLastError());
   return 0;
 }
 

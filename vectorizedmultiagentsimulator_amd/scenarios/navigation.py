@@ -102,16 +102,22 @@ class Scenario(BaseScenario):
             self.final_rew = torch.where(all_reached, torch.full_like(self.pos_rew, self.final_reward),
                                          torch.zeros_like(self.pos_rew))
             if self.collisions:
+                # all agent pairs at once (the reference loops over pairs with a host-synchronising
+                # collides() each, navigation.py:218-229): agents are consecutive entities, so their
+                # positions are one [A, 2, B] block of the packed state
+                A_ = len(w.agents)
+                i0 = w.agents[0]._index
+                P = w._packed_state()[i0 : i0 + A_, 0:2, : w.batch_dim]  # [A, 2, B] view
+                diff = P[:, None] - P[None, :]  # [A, A, 2, B]
+                centre = torch.linalg.vector_norm(diff, dim=2)  # [A, A, B]
+                r = self.agent_radius
+                overlap_any = (centre <= r + r).any(dim=-1)  # [A, A]: World.collides' batch-global reduction
+                dist = (centre - r) - r  # World.get_distance for spheres, same operation order
+                hit = overlap_any[:, :, None] & (dist <= self.min_collision_distance)
+                hit = hit & ~torch.eye(A_, dtype=torch.bool, device=w.device)[:, :, None]
+                per_agent = hit.to(torch.float32).sum(dim=1) * self.agent_collision_penalty  # [A, B]
                 for i, a in enumerate(w.agents):
-                    for j, b in enumerate(w.agents):
-                        if i <= j:
-                            continue
-                        # the reference gates on its batch-global collides() (a host sync); the
-                        # same reduction stays on the device here as a 0-dim tensor
-                        hit = (w.collides(a, b).any() & (w.get_distance(a, b) <= self.min_collision_distance)).to(
-                            torch.float32)
-                        a.agent_collision_rew = a.agent_collision_rew + hit * self.agent_collision_penalty
-                        b.agent_collision_rew = b.agent_collision_rew + hit * self.agent_collision_penalty
+                    a.agent_collision_rew = per_agent[i]
         pos_reward = self.pos_rew if self.shared_rew else agent.pos_rew
         return pos_reward + self.final_rew + agent.agent_collision_rew
 
