@@ -338,3 +338,47 @@ def test_hip_queries_match_reference_and_oracle(name):
     want = o.queries(st0, g.queries)
     compare_state(out[~kinds], want[~kinds], f"{name} distances vs oracle", atol=2e-6, rtol=1e-5)
     assert (out[kinds] != want[kinds]).mean() < 1e-4
+
+
+def _tiny_world(kind, B):
+    from vectorizedmultiagentsimulator_amd import core
+
+    if kind == "agents_no_collide":
+        w = core.World(B, "cuda:0", substeps=1)
+        for i in range(2):
+            w.add_agent(core.Agent(f"a{i}", collide=False, shape=core.Sphere(0.05), max_speed=0.3))
+    elif kind == "landmarks_only":  # no agents at all: agent_ft is unused
+        w = core.World(B, "cuda:0", substeps=2, gravity=(0.0, -0.1), y_semidim=0.5)
+        w.add_landmark(core.Landmark("ball", movable=True, shape=core.Sphere(0.05)))
+        w.add_landmark(core.Landmark("bar", movable=True, rotatable=True, shape=core.Line(0.4), mass=2.0))
+        w.add_landmark(core.Landmark("ground", shape=core.Box(2.0, 0.2)))
+    else:  # single entity
+        w = core.World(B, "cuda:0", drag=0.1)
+        w.add_agent(core.Agent("solo", shape=core.Box(0.2, 0.1), f_range=0.4))
+    return w
+
+
+@pytest.mark.parametrize("kind", ["agents_no_collide", "landmarks_only", "single"])
+@pytest.mark.parametrize("B", [1, 63, 64, 65])
+def test_degenerate_worlds_and_batch_sizes(kind, B):
+    """Edge cases: no pairs, no agents, one entity; batches around the 64-env tile boundary."""
+    from oracle.oracle import Oracle
+
+    w = _tiny_world(kind, B)
+    g = torch.Generator(device="cuda:0").manual_seed(B)
+    for e in w.entities:
+        e.set_pos((torch.rand(B, 2, device="cuda:0", generator=g) - 0.5) * 0.6, None)
+        e.set_rot((torch.rand(B, 1, device="cuda:0", generator=g) - 0.5) * 2, None)
+        e.set_vel((torch.rand(B, 2, device="cuda:0", generator=g) - 0.5) * 0.2, None)
+    for a in w.agents:
+        a.state.force = (torch.rand(B, 2, device="cuda:0", generator=g) - 0.5) * 2
+        a.state.torque = (torch.rand(B, 1, device="cuda:0", generator=g) - 0.5) * 0.1
+    o = Oracle(w.spec)
+    st = w._state.cpu().numpy().copy()
+    ft = w._agent_ft.cpu().numpy().copy()[: len(w.agents)]
+    for _ in range(3):
+        o.step(st, ft, batch=B)
+        w.step()
+    got = w._state.cpu().numpy()
+    compare_state(got[:, :, :B], st[:, :, :B], f"{kind} B={B}", atol=1e-5, rtol=1e-5)
+    assert np.array_equal(got[:, :, B:], np.zeros_like(got[:, :, B:])), "padding columns were written"
