@@ -56,6 +56,7 @@ constexpr int TILE = 64;       // environments per block = lanes per wave
 constexpr int MAX_WAVES = 16;  // waves (workers) per tile (8 for the register-heavy box-box level)
 constexpr int ITEMS_LDS_BUDGET = 48 * 1024;  // stage the item descriptors in LDS when they fit
 constexpr int TASK_JOINT = 6;  // item type next to VMAS_PAIR_*
+constexpr int TASK_SSQ = 7;    // up to four sphere-sphere partners of one entity in one record
 constexpr int ROWF = TILE;     // floats per LDS row
 
 enum : uint32_t { IT_A_HOLLOW = 1u << 0, IT_B_HOLLOW = 1u << 1, IT_LOCK = 1u << 2 /* joint rotate == False */ };
@@ -207,6 +208,47 @@ __device__ __forceinline__ EntV load_ent(const uint32_t* p) {
   return D;
 }
 static_assert(sizeof(DevItem) == 64 && sizeof(DevEntity) == 68, "descriptor layout");
+
+// Sphere-sphere partners packed four to a record (same 16 words as a DevItem):
+//   w0: type, n, -, -   w1: own offset, partner offsets 0..2   w2: partner 3, r_sum 0..2
+//   w3: r_sum 3, pair index 0|1<<16, pair index 2|3<<16, -
+// One descriptor fetch and eight position reads in flight instead of four dependent round
+// trips; the forces are added to F one by one, in the reference's order.  Both sides of a
+// sphere pair see force(own, other): cf(a,b) == -cf(b,a) bit for bit, so no sign flip is needed.
+__device__ __forceinline__ void eval_ssq(const uint32_t* p, const DevWorld& W, const DevStepArgs& args,
+                                         const float* tile, bool may_skip, bool movable, v2& F) {
+  const uint4 w0 = ((const uint4*)p)[0], w1 = ((const uint4*)p)[1], w2 = ((const uint4*)p)[2], w3 = ((const uint4*)p)[3];
+  const int n = sgpr((int)w0.y);
+  const float* E = tile + (int)w1.x;
+  const v2 pe = V(E[0], E[ROWF]);
+  const int ob[4] = {(int)w1.y, (int)w1.z, (int)w1.w, (int)w2.x};
+  const float rs[4] = {__uint_as_float(w2.y), __uint_as_float(w2.z), __uint_as_float(w2.w), __uint_as_float(w3.x)};
+  const int idx[4] = {(int)(w3.y & 0xffffu), (int)(w3.y >> 16), (int)(w3.z & 0xffffu), (int)(w3.z >> 16)};
+  v2 po[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float* O = tile + ob[k];
+    po[k] = V(O[0], O[ROWF]);  // unused slots repeat partner 0 on the host: always a valid row
+  }
+  uint32_t needbits = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float dx = pe.x - po[k].x, dy = pe.y - po[k].y;
+    const float m = rs[k] + 1e-4f;  // the force is exactly 0 for dist > r_a + r_b (core.py:2836)
+    bool need = !(dx * dx + dy * dy > m * m) || !may_skip;
+    bool on = k < n;
+    if (args.pair_mask) on = on && ((args.pair_mask[sgpr(idx[k]) >> 5] >> (sgpr(idx[k]) & 31)) & 1u);
+    needbits |= (on && __any(need)) ? (1u << k) : 0u;
+  }
+  if (!needbits || (args.ablate & 32)) return;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (needbits & (1u << k)) {
+      const v2 f = contact_force(pe, po[k], rs[k], W.c_coll, W.k);
+      if (movable) F = F + f;
+    }
+  }
+}
 
 // Force (and torque) one item contributes to ITS side.  LEVEL prunes code (and registers):
 // 0: SS LS BS   1: + LL BL joints   2: + BB
@@ -521,6 +563,10 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
 #endif
       const int i1 = (args.ablate & 1) ? i0 : i1s;
       for (int ii = i0; ii < i1; ++ii) {
+        if (W.items_in_lds && sgpr((int)blob[W.b_items + ii * IW]) == TASK_SSQ) {
+          if (!(args.ablate & 16)) eval_ssq(blob + W.b_items + ii * IW, W, args, tile, may_skip, efl & VMAS_F_MOVABLE, F);
+          continue;
+        }
         const ItemV K = W.items_in_lds ? load_item(blob + W.b_items + ii * IW) : item_from_global(W.items[ii]);
         v2 f = V(0.f, 0.f);
         float t = 0.f;
@@ -937,11 +983,47 @@ static void build_items(const VmasWorldDesc* d, VmasWorld* w, const std::vector<
   w->items.clear();
   w->item_cost.clear();
   w->level = 0;
+  // sphere-sphere partners of one entity are consecutive (type-major order): pack them four to
+  // a record when the item list will live in LDS (the packed form is read from the blob only)
+  const bool pack_ss = (size_t)(2 * d->n_pairs + 2 * d->n_joints) * sizeof(DevItem) <= (size_t)ITEMS_LDS_BUDGET &&
+                       d->n_pairs < 65536 && !getenv("VMAS_NO_SSQ");
+  if (pack_ss) {
+    for (int e = 0; e < nE; ++e) {
+      std::vector<DevItem> packed;
+      size_t i = 0;
+      while (i < per[e].size()) {
+        if (per[e][i].type != VMAS_PAIR_SS) { packed.push_back(per[e][i++]); continue; }
+        size_t j = i;
+        while (j < per[e].size() && per[e][j].type == VMAS_PAIR_SS && j - i < 4) ++j;
+        uint32_t wds[16] = {0};
+        auto fbits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+        const int n = (int)(j - i);
+        int ob[4], idx[4];
+        float rs[4];
+        for (int k = 0; k < 4; ++k) {
+          const DevItem& it = per[e][i + (k < n ? k : 0)];
+          ob[k] = it.side ? it.oa : it.ob;  // the OTHER sphere
+          rs[k] = it.p0;
+          idx[k] = it.index;
+        }
+        wds[0] = TASK_SSQ; wds[1] = (uint32_t)n;
+        wds[4] = (uint32_t)(e * 6 * ROWF); wds[5] = ob[0]; wds[6] = ob[1]; wds[7] = ob[2];
+        wds[8] = ob[3]; wds[9] = fbits(rs[0]); wds[10] = fbits(rs[1]); wds[11] = fbits(rs[2]);
+        wds[12] = fbits(rs[3]); wds[13] = (uint32_t)idx[0] | ((uint32_t)idx[1] << 16);
+        wds[14] = (uint32_t)idx[2] | ((uint32_t)idx[3] << 16);
+        DevItem q;
+        memcpy(&q, wds, sizeof(q));
+        packed.push_back(q);
+        i = j;
+      }
+      per[e].swap(packed);
+    }
+  }
   for (int e = 0; e < nE; ++e) {
     w->ent_item_begin[e] = (int)w->items.size();
     for (const DevItem& t : per[e]) {
       w->items.push_back(t);
-      w->item_cost.push_back(type_cost(t.type));
+      w->item_cost.push_back(t.type == TASK_SSQ ? 40.f + 40.f * (float)t.side /* side word = n */ : type_cost(t.type));
       if (t.type == VMAS_PAIR_BB) w->level = std::max(w->level, 2);
       if (t.type == VMAS_PAIR_LL || t.type == VMAS_PAIR_BL || t.type == TASK_JOINT) w->level = std::max(w->level, 1);
     }
@@ -992,7 +1074,7 @@ static int build_sched(VmasWorld* w, int nw, Sched& S) {
     for (int si : order) {
       fprintf(stderr, "[sched nw=%d] seg cost %.0f {e%d%s", nw, seg_cost[si], segs[si].entity, segs[si].first ? "*" : "");
       for (int i = segs[si].item_begin; i < segs[si].item_end; ++i)
-        fprintf(stderr, " %s%d-%d", (const char*[]){"SS", "LS", "LL", "BS", "BL", "BB", "J"}[w->items[i].type],
+        fprintf(stderr, " %s%d-%d", (const char*[]){"SS", "LS", "LL", "BS", "BL", "BB", "J", "SSQ"}[w->items[i].type],
                 w->items[i].oa / (6 * ROWF), w->items[i].ob / (6 * ROWF));
       fprintf(stderr, "}\n");
     }
