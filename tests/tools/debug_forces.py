@@ -1,5 +1,5 @@
 import sys, os
-sys.path[:0] = [os.path.join(os.path.dirname(__file__), '..'), os.path.join(os.path.dirname(__file__), '..', 'tests')]
+sys.path[:0] = [os.path.join(os.path.dirname(__file__), '..', '..'), os.path.join(os.path.dirname(__file__), '..')]
 import numpy as np, torch
 from golden_util import load
 from oracle.oracle import Oracle
