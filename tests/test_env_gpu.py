@@ -85,3 +85,16 @@ def test_graph_captured_step_equals_eager(name, kw):
         for a, b in zip(r1, r2):
             assert torch.equal(a, b), f"{name} rewards differ at step {t}"
         assert torch.equal(d1, d2)
+
+
+def test_rollout_collect_and_single_rank_gather():
+    from vectorizedmultiagentsimulator_amd.environment import make_env
+    from vectorizedmultiagentsimulator_amd.rollout import collect, gather_rollout
+    from vectorizedmultiagentsimulator_amd.shard import EnvShard
+
+    env = make_env("balance", num_envs=128, device="cuda:0", seed=2, n_agents=3, validate_actions=False)
+    buf = collect(env, lambda obs: [env.get_random_action(a) for a in env.agents], 12)
+    assert buf["obs"].shape == (12, 128, 3, 16) and buf["rew"].shape == (12, 128, 3) and buf["done"].shape == (12, 128)
+    assert torch.isfinite(buf["obs"]).all()
+    g = gather_rollout(buf, EnvShard(128, 0, 1))
+    assert all(torch.equal(g[k], buf[k]) for k in buf)
