@@ -161,6 +161,8 @@ typedef struct VmasWorld VmasWorld;
 /* Build the device-side constant block for one world on one GPU.  `desc` and the
  * arrays it points to are host memory and are copied. */
 int vmas_world_create(const VmasWorldDesc* desc, int32_t batch, int32_t device_id, VmasWorld** out);
+/* Frees device memory (hipFree): must not be called while a stream of this process is being
+ * captured into a HIP graph - the host mirror parks handles released during a capture. */
 void vmas_world_destroy(VmasWorld* w);
 
 /* Replaces World.step() (core.py:1972-2015) for all `batch` environments. */

@@ -228,6 +228,9 @@ def rollout_env(name, scenario, B, steps, every, start=0, seed=0, toward=None, *
     for _ in range(steps):
         acts = []
         for a in env.agents:
+            if toward is None and env.world.dim_c > 0 and not a.silent:
+                acts.append(env.get_random_action(a))  # physical + communication dims
+                continue
             u = a.action.u_range_tensor
             r = torch.rand(B, a.action_size, generator=g) * 2 - 1
             if toward is not None and a.name != toward:
@@ -324,6 +327,16 @@ FIXTURES = {
     "soup_solid": lambda: rollout_soup("soup_solid", 16, 7, rounds=6, steps_per_round=2, hollow=False, spread=0.45),
     "soup_hollow": lambda: rollout_soup("soup_hollow", 16, 11, rounds=6, steps_per_round=2, hollow=True, spread=0.3),
 }
+
+
+# every other in-tree scenario with its default kwargs: the physics step of each world the
+# reference ships is pinned (6 envs, 8 recorded steps out of 40)
+_COVERED = {"balance", "transport", "navigation", "football", "waterfall", "pollock", "reverse_transport", "give_way",
+            "joint_passage", "ball_trajectory", "wind_flocking"}
+for _n in list(vmas.scenarios) + list(vmas.mpe_scenarios) + list(vmas.debug_scenarios):
+    if _n in _COVERED:
+        continue
+    FIXTURES["all_" + _n] = (lambda n=_n: rollout_env("all_" + n, n, 6, 40, 5))
 
 
 if __name__ == "__main__":

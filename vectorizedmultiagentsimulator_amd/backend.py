@@ -28,6 +28,22 @@ def _round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
 
+_PARKED: list = []  # (lib, handle) of worlds released while a HIP-graph capture was in progress
+
+
+def _drain_parked():
+    if not _PARKED:
+        return
+    try:
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            return
+    except Exception:
+        return
+    while _PARKED:
+        lib, h = _PARKED.pop()
+        lib.vmas_world_destroy(h)
+
+
 class HipWorld:
     """One world description instantiated for ``batch`` environments on one GPU."""
 
@@ -72,9 +88,14 @@ class HipWorld:
 
     # ------------------------------------------------------------------ lifecycle
     def close(self):
-        if getattr(self, "_h", None):
-            self.lib.vmas_world_destroy(self._h)
-            self._h = None
+        """Free the native world.  ``hipFree`` is illegal while any stream of the process is being
+        captured into a HIP graph (it invalidates the capture), and the garbage collector can run a
+        ``__del__`` at any point - so a handle released during a capture is parked and freed by the
+        next ``close()`` / constructor that runs outside one."""
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            _PARKED.append((self.lib, h))
+        _drain_parked()
 
     def __del__(self):
         try:
