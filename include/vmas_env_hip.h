@@ -1,0 +1,138 @@
+/* vmas_env_hip.h - C ABI of the fused Environment.step() stages around World.step()
+ * (SURVEY.md section 8f, rows 1 and 2), exported by the same libvmas_hip.so.
+ *
+ * The reference runs, per step and per agent, a few dozen small torch ops on either side of
+ * World.step(): action ingest (`Environment._set_action`, vmas/simulator/environment/
+ * environment.py:616-749, then `Dynamics.process_action`, vmas/simulator/dynamics/
+ * holonomic.py:14-15 / holonomic_with_rot.py) and the scenario's reward / observation / done /
+ * info (vmas/scenarios/balance.py:218-267, transport.py:131-191, navigation.py:200-285).
+ * Each entry point below replaces one of those per-agent Python loops by ONE launch over the
+ * packed state of vmas_hip.h (state[E][6][ld], agent_ft[A][3][ld]).
+ *
+ * Conventions as in vmas_hip.h: plain pointers and sizes, the caller owns every buffer (device
+ * memory unless said otherwise), asynchronous on `stream`, 0 = ok / <0 = error with
+ * vmas_last_error().  Row-major outputs use the reference's own shapes so that the host can
+ * hand out views: obs[a] is a contiguous [batch, obs_dim] matrix, rew[a] a [batch] vector.
+ * Bool outputs are one byte per environment (0/1), i.e. a torch.bool tensor.
+ */
+#ifndef VMAS_ENV_HIP_H
+#define VMAS_ENV_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VMAS_ENV_MAX_AGENTS 32
+#define VMAS_ENV_MAX_PACKAGES 8
+
+/* ---------------------------------------------------------------- action ingest (8f-2) */
+typedef struct VmasActionSlot {
+  const float* action;   /* [batch, action_size] row-major: what the policy produced */
+  float* u_out;          /* [batch, action_size] or NULL: agent.action.u (scaled action) */
+  int32_t action_size;   /* 2 = Holonomic (force), 3 = HolonomicWithRotation (force + torque) */
+  int32_t agent_index;   /* row block of agent_ft */
+  float u_range[3];      /* Agent.action.u_range per dimension (core.py:414-517) */
+  float u_multiplier[3]; /* Agent.action.u_multiplier per dimension */
+} VmasActionSlot;
+
+typedef struct VmasIngestArgs {
+  int32_t n_agents;
+  int32_t clamp;         /* Environment(clamp_actions=...) : clamp to +-u_range instead of asserting */
+  VmasActionSlot agents[VMAS_ENV_MAX_AGENTS];
+} VmasIngestArgs;
+
+#define VMAS_ACTION_ERR_NAN 1u          /* environment.py:621 */
+#define VMAS_ACTION_ERR_OUT_OF_RANGE 2u /* environment.py:651-653 */
+
+/* Continuous-action branch of Environment._set_action + process_action for every policy agent:
+ * agent_ft[agent][0:2] = clamp?(action[:, 0:2]) * u_multiplier, [2] likewise when action_size
+ * is 3.  `err_flags` (one uint32, may be NULL) gets VMAS_ACTION_ERR_* OR-ed in where the
+ * reference would have raised an AssertionError; the host decides when to look at it. */
+int vmas_env_ingest_actions(const VmasIngestArgs* args, int32_t batch, float* agent_ft, int64_t ld,
+                            uint32_t* err_flags, void* stream);
+
+/* ---------------------------------------------------------------- step counter / time limit */
+typedef struct VmasStepLimit {
+  float* steps;     /* [batch] Environment.steps (float, environment.py:107), incremented by 1; may be NULL */
+  float max_steps;  /* done |= steps >= max_steps (environment.py:407-412); < 0 = no limit */
+} VmasStepLimit;
+
+/* ---------------------------------------------------------------- balance (balance.py:218-267) */
+typedef struct VmasBalanceDesc {
+  int32_t n_agents;
+  int32_t goal, package, line, floor, agent0; /* entity indices; agents are agent0 .. agent0+n-1 */
+  float goal_radius, package_radius, line_length, floor_length, floor_width;
+  float shaping_factor, fall_reward;
+} VmasBalanceDesc;
+
+typedef struct VmasBalanceBuffers {
+  float* global_shaping;  /* [batch] in/out: Scenario.global_shaping */
+  float* obs;             /* [n_agents][batch][16] */
+  float* rew;             /* [n_agents][batch] (the reward is shared: every row equal) */
+  float* pos_rew;         /* [batch] info["pos_rew"] */
+  float* ground_rew;      /* [batch] info["ground_rew"] */
+  uint8_t* on_the_ground; /* [batch] Scenario.on_the_ground */
+  uint8_t* done;          /* [batch] */
+  VmasStepLimit limit;
+} VmasBalanceBuffers;
+
+int vmas_balance_post_step(const VmasBalanceDesc* desc, const VmasBalanceBuffers* buf, int32_t batch,
+                           const float* state, int64_t ld, void* stream);
+
+/* ---------------------------------------------------------------- transport (transport.py:131-191) */
+typedef struct VmasTransportDesc {
+  int32_t n_agents, n_packages;
+  int32_t goal, package0, agent0; /* packages are package0 .. package0+n_packages-1 */
+  float goal_radius, package_length, package_width;
+  float shaping_factor;
+} VmasTransportDesc;
+
+typedef struct VmasTransportBuffers {
+  float* global_shaping; /* [n_packages][batch] in/out: package.global_shaping */
+  uint8_t* on_goal;      /* [n_packages][batch] package.on_goal */
+  float* obs;            /* [n_agents][batch][4 + 7 * n_packages] */
+  float* rew;            /* [n_agents][batch] (shared) */
+  uint8_t* done;         /* [batch] */
+  VmasStepLimit limit;
+} VmasTransportBuffers;
+
+int vmas_transport_post_step(const VmasTransportDesc* desc, const VmasTransportBuffers* buf, int32_t batch,
+                             const float* state, int64_t ld, void* stream);
+
+/* ---------------------------------------------------------------- navigation (navigation.py:200-285) */
+typedef struct VmasNavigationDesc {
+  int32_t n_agents;
+  int32_t agent0;                         /* agents are agent0 .. agent0+n-1 */
+  int32_t goal_of[VMAS_ENV_MAX_AGENTS];   /* entity index of agent i's goal */
+  int32_t shared_rew, collisions, observe_all_goals;
+  int32_t n_rays;                         /* rays of each agent's LIDAR (collisions only) */
+  float agent_radius, goal_radius;
+  float pos_shaping_factor, final_reward, agent_collision_penalty, min_collision_distance;
+  float lidar_range;
+} VmasNavigationDesc;
+
+typedef struct VmasNavigationBuffers {
+  float* pos_shaping;       /* [n_agents][batch] in/out: agent.pos_shaping */
+  float* obs;               /* [n_agents][batch][4 + 2*(observe_all_goals ? n_agents : 1) + n_rays] */
+  float* rew;               /* [n_agents][batch] */
+  float* agent_pos_rew;     /* [n_agents][batch] agent.pos_rew */
+  float* pos_rew;           /* [batch] Scenario.pos_rew (sum over agents) */
+  float* final_rew;         /* [batch] */
+  float* collision_rew;     /* [n_agents][batch] agent.agent_collision_rew */
+  uint8_t* done;            /* [batch] */
+  const float* lidar;       /* vmas_world_cast_rays output, sensor l = agent l; NULL without collisions */
+  int64_t lidar_max_rays;
+  const uint32_t* pair_any; /* vmas_world_pair_mask output: World.collides' batch-global reduction */
+  const int32_t* pair_index;/* [n_agents*n_agents] device: static pair index of (i, j), -1 = never collide */
+  VmasStepLimit limit;
+} VmasNavigationBuffers;
+
+int vmas_navigation_post_step(const VmasNavigationDesc* desc, const VmasNavigationBuffers* buf, int32_t batch,
+                              const float* state, int64_t ld, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VMAS_ENV_HIP_H */

@@ -339,6 +339,78 @@ for _n in list(vmas.scenarios) + list(vmas.mpe_scenarios) + list(vmas.debug_scen
     FIXTURES["all_" + _n] = (lambda n=_n: rollout_env("all_" + n, n, 6, 40, 5))
 
 
+# ----------------------------------------------------------------------------
+# Environment.step() outputs of the reference (obs / reward / done / info) for the scenarios
+# that have a fused post-step kernel: `envstep_*.npz`.  state[t] is the packed world state
+# after t steps (state[0] = after reset), state_in[t] what step t+1 started from (differs from
+# state[t] only after a nudge); obs/rew/done/info[t-1] are what env.step returned at step t.  `nudges` teleport entities onto others mid-rollout so that the rare branches
+# (package on goal, all agents on their goals, done) are present.
+# ----------------------------------------------------------------------------
+def rollout_envstep(name, scenario, B, T, toward=None, nudges=(), seed=0, max_steps=None, **kw):
+    torch.manual_seed(seed)
+    env = vmas.make_env(scenario, num_envs=B, device="cpu", seed=seed, continuous_actions=True, max_steps=max_steps, **kw)
+    g = torch.Generator().manual_seed(4321)
+    ents = {e.name: e for e in env.world.entities}
+    states, actions, obs_l, rew_l, done_l = [pack_state(env.world)], [], [], [], []
+    state_in = []
+    infos = {}
+    for t in range(T):
+        for (when, who, where, off, envs) in nudges:
+            if when == t:
+                for b in envs:
+                    ents[who].set_pos(ents[where].state.pos[b] + torch.tensor(off, dtype=torch.float32), batch_index=b)
+                    ents[who].set_vel(torch.zeros(2), batch_index=b)
+        state_in.append(pack_state(env.world))  # what this step starts from (after any nudge)
+        acts = []
+        for a in env.agents:
+            r = (torch.rand(B, a.action_size, generator=g) * 2 - 1)
+            if toward is not None and a.name != toward:
+                d = ents[toward].state.pos - a.state.pos
+                d = d / d.norm(dim=-1, keepdim=True).clamp_min(1e-6)
+                r[:, :2] = 0.8 * d + 0.2 * r[:, :2]
+            acts.append(r * a.action.u_range_tensor)
+        obs, rews, dones, info = env.step(acts)
+        states.append(pack_state(env.world))
+        actions.append(torch.stack(acts).numpy().copy())
+        obs_l.append(torch.stack(obs).numpy().copy())
+        rew_l.append(torch.stack(rews).numpy().copy())
+        done_l.append(dones.numpy().copy())
+        for k in info[0]:
+            infos.setdefault(k, []).append(torch.stack([i[k] for i in info]).numpy().copy())
+    out = dict(state=np.stack(states), state_in=np.stack(state_in), actions=np.stack(actions), obs=np.stack(obs_l), rew=np.stack(rew_l),
+               done=np.stack(done_l), kwargs=np.array(repr(kw)), max_steps=np.array(-1 if max_steps is None else max_steps))
+    for k, v in infos.items():
+        out["info_" + k] = np.stack(v)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(f"{name}: T={T} B={B} obs{out['obs'].shape} done_any={out['done'].any()} "
+          f"rew[{out['rew'].min():.3g},{out['rew'].max():.3g}]")
+
+
+ALL8 = tuple(range(8))
+FIXTURES.update({
+    "envstep_balance": lambda: rollout_envstep(
+        "envstep_balance", "balance", 8, 60, n_agents=4, max_steps=50,
+        nudges=[(20, "package", "goal", (0.01, 0.02), (1, 2)), (30, "package", "floor", (0.3, 0.52), (3,))]),
+    "envstep_balance_n3": lambda: rollout_envstep("envstep_balance_n3", "balance", 4, 40, n_agents=3),
+    "envstep_transport": lambda: rollout_envstep(
+        "envstep_transport", "transport", 8, 50, toward="package 0",
+        nudges=[(15, "package 0", "goal", (0.02, -0.03), (0, 5)), (25, "package 0", "goal", (0.16, 0.0), (2,))]),
+    "envstep_transport_2pkg": lambda: rollout_envstep(
+        "envstep_transport_2pkg", "transport", 8, 50, toward="package 1", n_packages=2, max_steps=45,
+        nudges=[(10, "package 0", "goal", (0.02, -0.03), (0, 1)), (20, "package 1", "goal", (-0.05, 0.05), (1, 2))]),
+    "envstep_navigation": lambda: rollout_envstep(
+        "envstep_navigation", "navigation", 8, 50, toward="agent_0", n_agents=4,
+        nudges=[(12, "agent_1", "goal 1", (0.01, 0.0), (0, 1))] +
+               [(30, f"agent_{i}", f"goal {i}", (0.005 * i, -0.01), (2, 3)) for i in range(4)]),
+    "envstep_navigation_n8_individual": lambda: rollout_envstep(
+        "envstep_navigation_n8_individual", "navigation", 6, 40, toward="agent_0", n_agents=8, shared_rew=False,
+        observe_all_goals=True, max_steps=35),
+    "envstep_navigation_nocoll": lambda: rollout_envstep(
+        "envstep_navigation_nocoll", "navigation", 6, 30, n_agents=3, collisions=False,
+        nudges=[(10, f"agent_{i}", f"goal {i}", (0.0, 0.02), (0,)) for i in range(3)]),
+})
+
+
 if __name__ == "__main__":
     names = sys.argv[1:] or list(FIXTURES)
     torch.set_num_threads(1)

@@ -1,5 +1,5 @@
 """CPU-side checks of the drop-in boundary: libvmas_hip.so loads without a GPU and
-exports every function include/vmas_hip.h declares; struct layouts agree with ctypes."""
+exports every function include/*.h declares; struct layouts agree with ctypes."""
 import ctypes
 import os
 import re
@@ -10,11 +10,11 @@ import pytest
 from vectorizedmultiagentsimulator_amd import _abi
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
-HEADER = os.path.join(ROOT, "include", "vmas_hip.h")
+HEADERS = [os.path.join(ROOT, "include", h) for h in ("vmas_hip.h", "vmas_env_hip.h")]
 
 
 def _declared_functions():
-    src = open(HEADER).read()
+    src = "".join(open(h).read() for h in HEADERS)
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(vmas_[a-z_0-9]+)\s*\(", src)))
 
@@ -53,6 +53,27 @@ def test_struct_sizes_match_the_c_header(tmp_path):
         ctypes.sizeof(_abi.WorldDesc), ctypes.sizeof(_abi.StepArgs), ctypes.sizeof(_abi.LidarDesc),
         _abi.WorldDesc.entities.offset, _abi.LidarDesc.targets.offset,
     ]
+    assert got == want
+
+
+def test_env_struct_sizes_match_the_c_header(tmp_path):
+    """Same for include/vmas_env_hip.h (structs passed by pointer AND copied into kernel arguments)."""
+    names = ["VmasActionSlot", "VmasIngestArgs", "VmasStepLimit", "VmasBalanceDesc", "VmasBalanceBuffers",
+             "VmasTransportDesc", "VmasTransportBuffers", "VmasNavigationDesc", "VmasNavigationBuffers"]
+    prog = tmp_path / "sz.c"
+    prog.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "vmas_env_hip.h"\nint main(){'
+        + "".join(f'printf("%zu ", sizeof({n}));' for n in names)
+        + 'printf("%zu %zu %zu\\n", offsetof(VmasNavigationBuffers, limit), offsetof(VmasNavigationDesc, agent_radius),'
+          " offsetof(VmasIngestArgs, agents));return 0;}\n"
+    )
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(prog)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    py = [_abi.ActionSlot, _abi.IngestArgs, _abi.StepLimit, _abi.BalanceDesc, _abi.BalanceBuffers, _abi.TransportDesc,
+          _abi.TransportBuffers, _abi.NavigationDesc, _abi.NavigationBuffers]
+    want = [ctypes.sizeof(t) for t in py] + [_abi.NavigationBuffers.limit.offset, _abi.NavigationDesc.agent_radius.offset,
+                                             _abi.IngestArgs.agents.offset]
     assert got == want
 
 

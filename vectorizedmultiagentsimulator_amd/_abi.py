@@ -132,6 +132,84 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, "csrc", "libvmas_hip.so")
 
 #: every symbol include/vmas_hip.h declares (checked by tests/test_abi_symbols.py)
+
+# ---------------------------------------------------------------- include/vmas_env_hip.h
+ENV_MAX_AGENTS = 32
+ENV_MAX_PACKAGES = 8
+ACTION_ERR_NAN, ACTION_ERR_OUT_OF_RANGE = 1, 2
+
+
+class ActionSlot(C.Structure):
+    _fields_ = [
+        ("action", C.c_void_p),
+        ("u_out", C.c_void_p),
+        ("action_size", C.c_int32),
+        ("agent_index", C.c_int32),
+        ("u_range", C.c_float * 3),
+        ("u_multiplier", C.c_float * 3),
+    ]
+
+
+class IngestArgs(C.Structure):
+    _fields_ = [("n_agents", C.c_int32), ("clamp", C.c_int32), ("agents", ActionSlot * ENV_MAX_AGENTS)]
+
+
+class StepLimit(C.Structure):
+    _fields_ = [("steps", C.c_void_p), ("max_steps", C.c_float)]
+
+
+class BalanceDesc(C.Structure):
+    _fields_ = [
+        ("n_agents", C.c_int32),
+        ("goal", C.c_int32), ("package", C.c_int32), ("line", C.c_int32), ("floor", C.c_int32), ("agent0", C.c_int32),
+        ("goal_radius", C.c_float), ("package_radius", C.c_float), ("line_length", C.c_float),
+        ("floor_length", C.c_float), ("floor_width", C.c_float),
+        ("shaping_factor", C.c_float), ("fall_reward", C.c_float),
+    ]
+
+
+class BalanceBuffers(C.Structure):
+    _fields_ = [
+        ("global_shaping", C.c_void_p), ("obs", C.c_void_p), ("rew", C.c_void_p), ("pos_rew", C.c_void_p),
+        ("ground_rew", C.c_void_p), ("on_the_ground", C.c_void_p), ("done", C.c_void_p), ("limit", StepLimit),
+    ]
+
+
+class TransportDesc(C.Structure):
+    _fields_ = [
+        ("n_agents", C.c_int32), ("n_packages", C.c_int32),
+        ("goal", C.c_int32), ("package0", C.c_int32), ("agent0", C.c_int32),
+        ("goal_radius", C.c_float), ("package_length", C.c_float), ("package_width", C.c_float),
+        ("shaping_factor", C.c_float),
+    ]
+
+
+class TransportBuffers(C.Structure):
+    _fields_ = [
+        ("global_shaping", C.c_void_p), ("on_goal", C.c_void_p), ("obs", C.c_void_p), ("rew", C.c_void_p),
+        ("done", C.c_void_p), ("limit", StepLimit),
+    ]
+
+
+class NavigationDesc(C.Structure):
+    _fields_ = [
+        ("n_agents", C.c_int32), ("agent0", C.c_int32), ("goal_of", C.c_int32 * ENV_MAX_AGENTS),
+        ("shared_rew", C.c_int32), ("collisions", C.c_int32), ("observe_all_goals", C.c_int32), ("n_rays", C.c_int32),
+        ("agent_radius", C.c_float), ("goal_radius", C.c_float),
+        ("pos_shaping_factor", C.c_float), ("final_reward", C.c_float), ("agent_collision_penalty", C.c_float),
+        ("min_collision_distance", C.c_float), ("lidar_range", C.c_float),
+    ]
+
+
+class NavigationBuffers(C.Structure):
+    _fields_ = [
+        ("pos_shaping", C.c_void_p), ("obs", C.c_void_p), ("rew", C.c_void_p), ("agent_pos_rew", C.c_void_p),
+        ("pos_rew", C.c_void_p), ("final_rew", C.c_void_p), ("collision_rew", C.c_void_p), ("done", C.c_void_p),
+        ("lidar", C.c_void_p), ("lidar_max_rays", C.c_int64), ("pair_any", C.c_void_p), ("pair_index", C.c_void_p),
+        ("limit", StepLimit),
+    ]
+
+
 EXPORTED_SYMBOLS = (
     "vmas_world_create",
     "vmas_world_destroy",
@@ -148,6 +226,11 @@ EXPORTED_SYMBOLS = (
     "vmas_world_step_bytes_per_env",
     "vmas_last_error",
     "vmas_abi_version",
+    # include/vmas_env_hip.h
+    "vmas_env_ingest_actions",
+    "vmas_balance_post_step",
+    "vmas_transport_post_step",
+    "vmas_navigation_post_step",
 )
 
 _lib: Optional[C.CDLL] = None
@@ -192,6 +275,13 @@ def load_library() -> C.CDLL:
     lib.vmas_world_get_lanes_per_env.restype = C.c_int
     lib.vmas_world_step_bytes_per_env.argtypes = [vp]
     lib.vmas_world_step_bytes_per_env.restype = i64
+    lib.vmas_env_ingest_actions.argtypes = [C.POINTER(IngestArgs), i32, vp, i64, vp, vp]
+    lib.vmas_env_ingest_actions.restype = C.c_int
+    for fn, d, b in ((lib.vmas_balance_post_step, BalanceDesc, BalanceBuffers),
+                     (lib.vmas_transport_post_step, TransportDesc, TransportBuffers),
+                     (lib.vmas_navigation_post_step, NavigationDesc, NavigationBuffers)):
+        fn.argtypes = [C.POINTER(d), C.POINTER(b), i32, vp, i64, vp]
+        fn.restype = C.c_int
     lib.vmas_last_error.argtypes = []
     lib.vmas_last_error.restype = C.c_char_p
     lib.vmas_abi_version.argtypes = []

@@ -232,4 +232,66 @@ VD float friction1(float vel, float coeff, float inertia, float sub_dt) {
   return speed == 0.f ? 0.f : f;
 }
 
+// ------------------------------------------------------------------------------------
+// scenario-side queries: World.get_distance core.py:1822-1905, World.is_overlapping core.py:1907-1969
+// for one ordered pair (a, b) = (box, sphere) / (line, sphere) / (box, line) / same-shape, one
+// environment per lane (the shape dispatch is uniform over the wave)
+// ------------------------------------------------------------------------------------
+constexpr int kSphere = 0, kBox = 1, kLine = 2;  // == VMAS_SHAPE_* of include/vmas_hip.h
+
+struct DevQuery {
+  int32_t kind, a, b;            // a/b already ordered as above
+  int32_t sa, sb;                // shape codes
+  float la, wa, ra, lb, wb, rb;  // length / width / radius of a and b
+};
+
+// returns the distance; `overlap` = is_overlapping(a, b)
+VD float pair_distance(const DevQuery& Q, const float* __restrict__ state, long ld, long env, int& overlap) {
+  const float* A = state + (long)Q.a * 6 * ld + env;
+  const float* B = state + (long)Q.b * 6 * ld + env;
+  const v2 pa = V(A[0], A[ld]), pb = V(B[0], B[ld]);
+  float dist;
+  int ov = -1;
+  if (Q.sa == kSphere) {  // sphere - sphere
+    dist = (vnorm(pa - pb) - Q.ra) - Q.rb;
+  } else if (Q.sa == kBox && Q.sb == kSphere) {
+    const float rot = A[4 * ld], rot2 = rot + kHalfPi;
+    seg_t be[4];
+    box_edges(pa, cosf(rot), sinf(rot), cosf(rot2), sinf(rot2), Q.la, Q.wa, be);
+    const v2 cp = closest_point_box(be, pb);
+    const float d_sphere_cp = vnorm(pb - cp), d_sphere_box = vnorm(pb - pa), d_box_cp = vnorm(pa - cp);
+    ov = (d_sphere_box < d_box_cp) || (d_sphere_cp < Q.rb + kLineMinDist);
+    dist = ov ? -1.f : (d_sphere_cp - kLineMinDist) - Q.rb;
+  } else if (Q.sa == kLine && Q.sb == kSphere) {
+    const float rot = A[4 * ld];
+    const v2 cp = closest_point_line<true>(pa, cosf(rot), sinf(rot), Q.la / 2.f, pb);
+    dist = (vnorm(pb - cp) - kLineMinDist) - Q.rb;
+  } else if (Q.sa == kLine) {  // line - line
+    const float r1 = A[4 * ld], r2 = B[4 * ld];
+    seg_t l1 = {pa, cosf(r1), sinf(r1), Q.la / 2.f};
+    seg_t l2 = {pb, cosf(r2), sinf(r2), Q.lb / 2.f};
+    v2 p1, p2;
+    closest_points_seg_seg(l1, l2, p1, p2);
+    dist = vnorm(p1 - p2) - kLineMinDist;
+  } else if (Q.sb == kLine) {  // box - line
+    const float rot = A[4 * ld], rot2 = rot + kHalfPi, rl = B[4 * ld];
+    seg_t be[4];
+    box_edges(pa, cosf(rot), sinf(rot), cosf(rot2), sinf(rot2), Q.la, Q.wa, be);
+    seg_t l = {pb, cosf(rl), sinf(rl), Q.lb / 2.f};
+    v2 qb, ql;
+    closest_seg_box(be, l, qb, ql);
+    dist = vnorm(qb - ql) - kLineMinDist;
+  } else {  // box - box
+    const float r1 = A[4 * ld], r1b = r1 + kHalfPi, r2 = B[4 * ld], r2b = r2 + kHalfPi;
+    seg_t ea[4], eb[4];
+    box_edges(pa, cosf(r1), sinf(r1), cosf(r1b), sinf(r1b), Q.la, Q.wa, ea);
+    box_edges(pb, cosf(r2), sinf(r2), cosf(r2b), sinf(r2b), Q.lb, Q.wb, eb);
+    v2 qa, qb;
+    closest_box_box(ea, eb, qa, qb);
+    dist = vnorm(qa - qb) - kLineMinDist;
+  }
+  overlap = ov < 0 ? (dist < 0.f) : ov;
+  return dist;
+}
+
 }  // namespace vmas

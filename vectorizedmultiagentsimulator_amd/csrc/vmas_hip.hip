@@ -660,20 +660,40 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
 // ------------------------------------------------------------------------------------
 struct DevMaskPair { int32_t a, b; float bound_sum; };
 
-__global__ __launch_bounds__(256) void pair_mask_kernel(const DevMaskPair* __restrict__ pairs, int nP,
+__global__ __launch_bounds__(256) void pair_mask_kernel(const DevMaskPair* __restrict__ pairs, int nP, int nE,
                                                         const float* __restrict__ state, long ld, int batch,
                                                         uint32_t* __restrict__ mask) {
+  extern __shared__ float pos[];  // [nE * 2][T]: each lane's own column (dynamic indexing, no exchange)
+  const int T = blockDim.x;
   const long env = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const bool ok = env < batch;
-  for (int p = 0; p < nP; ++p) {
-    const DevMaskPair P = pairs[p];
-    bool hit = false;
-    if (ok) {
-      const float* sa = state + (long)P.a * 6 * ld + env;
-      const float* sb = state + (long)P.b * 6 * ld + env;
-      hit = norm2(sa[0] - sb[0], sa[ld] - sb[ld]) <= P.bound_sum;
+  const long e = ok ? env : (long)batch - 1;
+  for (int i0 = 0; i0 < nE * 2; i0 += 16) {  // 16 independent coalesced loads in flight, then their LDS stores
+    float t[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int i = i0 + k < nE * 2 ? i0 + k : nE * 2 - 1;
+      t[k] = state[((long)(i >> 1) * 6 + (i & 1)) * ld + e];
     }
-    if (__any(hit) && (threadIdx.x & 63) == 0) atomicOr(&mask[p >> 5], 1u << (p & 31));
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      if (i0 + k < nE * 2) pos[(i0 + k) * T + threadIdx.x] = t[k];
+  }
+  // one word of 32 pairs at a time: the wave ORs its lanes' hits into `bits` and touches global
+  // memory once per word - and only if it would set a bit that is not set yet (the mask only grows,
+  // so a stale read is harmless); every wave hammering one word with atomics cost 35 us at 65536 envs
+  for (int p0 = 0; p0 < nP; p0 += 32) {
+    uint32_t bits = 0;
+    const int n = nP - p0 < 32 ? nP - p0 : 32;
+    for (int k = 0; k < n; ++k) {
+      const DevMaskPair P = pairs[p0 + k];
+      const float* sa = pos + P.a * 2 * T + threadIdx.x;
+      const float* sb = pos + P.b * 2 * T + threadIdx.x;
+      const bool hit = ok && norm2(sa[0] - sb[0], sa[T] - sb[T]) <= P.bound_sum;
+      bits |= (__any(hit) ? 1u : 0u) << k;
+    }
+    if ((threadIdx.x & 63) == 0 && (bits & ~__builtin_nontemporal_load(&mask[p0 >> 5])) != 0u)
+      atomicOr(&mask[p0 >> 5], bits);
   }
 }
 
@@ -811,62 +831,15 @@ __global__ __launch_bounds__(256) void lidar_kernel(const DevLidar* __restrict__
 // scenario-side queries: World.get_distance core.py:1822-1905, World.is_overlapping core.py:1907-1969
 // one thread per environment, blockIdx.y = query (wave-uniform shape dispatch)
 // ------------------------------------------------------------------------------------
-struct DevQuery {
-  int32_t kind, a, b;      // a/b already ordered (box, sphere) / (line, sphere) / (box, line)
-  int32_t sa, sb;          // shape codes
-  float la, wa, ra, lb, wb, rb;  // length / width / radius of a and b
-};
-
 __global__ __launch_bounds__(256) void query_kernel(const DevQuery* __restrict__ queries, const float* __restrict__ state,
                                                     long ld, int batch, float* __restrict__ out) {
   const long env = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (env >= batch) return;
   const DevQuery Q = queries[blockIdx.y];
-  const float* A = state + (long)Q.a * 6 * ld + env;
-  const float* B = state + (long)Q.b * 6 * ld + env;
-  const v2 pa = V(A[0], A[ld]), pb = V(B[0], B[ld]);
-  float dist;
-  int overlap = -1;
-  if (Q.sa == VMAS_SHAPE_SPHERE) {  // sphere - sphere
-    dist = (vnorm(pa - pb) - Q.ra) - Q.rb;
-  } else if (Q.sa == VMAS_SHAPE_BOX && Q.sb == VMAS_SHAPE_SPHERE) {
-    const float rot = A[4 * ld], rot2 = rot + kHalfPi;
-    seg_t be[4];
-    box_edges(pa, cosf(rot), sinf(rot), cosf(rot2), sinf(rot2), Q.la, Q.wa, be);
-    const v2 cp = closest_point_box(be, pb);
-    const float d_sphere_cp = vnorm(pb - cp), d_sphere_box = vnorm(pb - pa), d_box_cp = vnorm(pa - cp);
-    overlap = (d_sphere_box < d_box_cp) || (d_sphere_cp < Q.rb + kLineMinDist);
-    dist = overlap ? -1.f : (d_sphere_cp - kLineMinDist) - Q.rb;
-  } else if (Q.sa == VMAS_SHAPE_LINE && Q.sb == VMAS_SHAPE_SPHERE) {
-    const float rot = A[4 * ld];
-    const v2 cp = closest_point_line<true>(pa, cosf(rot), sinf(rot), Q.la / 2.f, pb);
-    dist = (vnorm(pb - cp) - kLineMinDist) - Q.rb;
-  } else if (Q.sa == VMAS_SHAPE_LINE) {  // line - line
-    const float r1 = A[4 * ld], r2 = B[4 * ld];
-    seg_t l1 = {pa, cosf(r1), sinf(r1), Q.la / 2.f};
-    seg_t l2 = {pb, cosf(r2), sinf(r2), Q.lb / 2.f};
-    v2 p1, p2;
-    closest_points_seg_seg(l1, l2, p1, p2);
-    dist = vnorm(p1 - p2) - kLineMinDist;
-  } else if (Q.sb == VMAS_SHAPE_LINE) {  // box - line
-    const float rot = A[4 * ld], rot2 = rot + kHalfPi, rl = B[4 * ld];
-    seg_t be[4];
-    box_edges(pa, cosf(rot), sinf(rot), cosf(rot2), sinf(rot2), Q.la, Q.wa, be);
-    seg_t l = {pb, cosf(rl), sinf(rl), Q.lb / 2.f};
-    v2 qb, ql;
-    closest_seg_box(be, l, qb, ql);
-    dist = vnorm(qb - ql) - kLineMinDist;
-  } else {  // box - box
-    const float r1 = A[4 * ld], r1b = r1 + kHalfPi, r2 = B[4 * ld], r2b = r2 + kHalfPi;
-    seg_t ea[4], eb[4];
-    box_edges(pa, cosf(r1), sinf(r1), cosf(r1b), sinf(r1b), Q.la, Q.wa, ea);
-    box_edges(pb, cosf(r2), sinf(r2), cosf(r2b), sinf(r2b), Q.lb, Q.wb, eb);
-    v2 qa, qb;
-    closest_box_box(ea, eb, qa, qb);
-    dist = vnorm(qa - qb) - kLineMinDist;
-  }
+  int overlap;
+  const float dist = pair_distance(Q, state, ld, env, overlap);
   float r = dist;
-  if (Q.kind == VMAS_QUERY_OVERLAP) r = (overlap < 0 ? (dist < 0.f) : overlap) ? 1.f : 0.f;
+  if (Q.kind == VMAS_QUERY_OVERLAP) r = overlap ? 1.f : 0.f;
   out[(long)blockIdx.y * ld + env] = r;
 }
 
@@ -886,6 +859,9 @@ static int fail(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
   return -1;
+}
+namespace vmas {
+int host_fail(const char* msg) { return fail("%s", msg); }  // for vmas_env.hip
 }
 #define HIP_TRY(x)                                                                      \
   do {                                                                                  \
@@ -1395,8 +1371,18 @@ int vmas_world_pair_mask(VmasWorld* w, const float* state, int64_t ld, uint32_t*
   const int words = (w->n_pairs + 31) / 32;
   HIP_TRY(hipMemsetAsync(mask, 0, sizeof(uint32_t) * (words ? words : 1), s));
   if (w->n_pairs == 0) return 0;
-  hipLaunchKernelGGL(pair_mask_kernel, dim3((w->batch + 255) / 256), dim3(256), 0, s, w->d_mpairs, w->n_pairs, state,
-                     (long)ld, w->batch, mask);
+  const int T = w->base.nE <= 64 ? 256 : 64;  // threads per block: the block's positions must fit in LDS
+  const size_t lds = (size_t)w->base.nE * 2 * T * sizeof(float);
+  if (lds > 160 * 1024) return fail("vmas_world_pair_mask: %d entities do not fit in LDS", w->base.nE);
+  if (lds > 64 * 1024) {
+    static thread_local size_t set_for = 0;
+    if (set_for < lds) {
+      HIP_TRY(hipFuncSetAttribute((const void*)pair_mask_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      set_for = lds;
+    }
+  }
+  hipLaunchKernelGGL(pair_mask_kernel, dim3((w->batch + T - 1) / T), dim3(T), lds, s, w->d_mpairs, w->n_pairs,
+                     w->base.nE, state, (long)ld, w->batch, mask);
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -36,10 +36,12 @@ class Environment:
         clamp_actions: bool = False,
         validate_actions: bool = True,
         graph: bool = False,
+        fused: Optional[bool] = None,
         **kwargs,
     ):
         self.scenario = scenario
         self.use_graph = graph
+        self.fused = fused
         self._graph = None
         self.num_envs = num_envs
         self.device = torch.device(device)
@@ -54,6 +56,28 @@ class Environment:
         self._lidar_cache: Optional[Tensor] = None
         self.seed(seed)
         self.reset(return_observations=False)
+        self._ingest = self._post = None
+        self._setup_fused()
+
+    def _setup_fused(self):
+        """``fused``: run action ingest and the scenario's reward/observation/done/info as one HIP
+        kernel each (fused.py, include/vmas_env_hip.h) instead of per-agent tensor ops.  ``None`` =
+        wherever the scenario and the agents allow it on a GPU device; ``True`` = required."""
+        if self.fused is False or self.device.type != "cuda":
+            assert not self.fused, "fused=True needs a GPU device"
+            return
+        from . import fused as F
+        why_not = F.ActionIngest.supports(self)
+        if why_not is None:
+            self._ingest = F.ActionIngest(self)
+        make_post = getattr(self.scenario, "make_fused_post", None)
+        if make_post is not None:
+            self._post = make_post(self)  # None when this configuration is not covered by a kernel
+        if self.fused:
+            assert self._ingest is not None, f"fused=True: action path cannot be fused ({why_not})"
+            assert self._post is not None, "fused=True: the scenario has no fused post-step kernel"
+        if self._post is not None:
+            self._post.static_outputs = self.use_graph
 
     batch_dim = property(lambda self: self.num_envs)
 
@@ -172,6 +196,24 @@ class Environment:
 
     def _step_eager(self, actions):
         assert len(actions) == self.n_agents, f"Expecting actions for {self.n_agents}, got {len(actions)} actions"
+        if self._ingest is not None:
+            self._ingest(actions, self.validate_actions)
+        else:
+            self._ingest_torch(actions)
+        self.scenario.pre_step()
+        self.world.step()
+        self.scenario.post_step()
+        self._lidar_cache = None
+        if self._post is not None:  # one launch: reward, observation, done, info, step counter
+            return self._post()
+        self.steps += 1
+        rews = [self.scenario.reward(a).clone() for a in self.agents]
+        obs = self._observations()
+        infos = [self.scenario.info(a) for a in self.agents]
+        dones = self.done()
+        return obs, rews, dones, infos
+
+    def _ingest_torch(self, actions):
         for i, agent in enumerate(self.agents):
             a = actions[i]
             if not isinstance(a, Tensor):
@@ -182,16 +224,6 @@ class Environment:
             self._set_action(a, agent)
         for agent in self.world.agents:  # scripted agents included (environment.py:390-391)
             self.scenario.env_process_action(agent)
-        self.scenario.pre_step()
-        self.world.step()
-        self.scenario.post_step()
-        self.steps += 1
-        self._lidar_cache = None
-        rews = [self.scenario.reward(a).clone() for a in self.agents]
-        obs = self._observations()
-        infos = [self.scenario.info(a) for a in self.agents]
-        dones = self.done()
-        return obs, rews, dones, infos
 
     def _observations(self):
         if any(a.sensors for a in self.world.agents) and self.device.type == "cuda":
@@ -216,6 +248,7 @@ def make_env(
     clamp_actions: bool = False,
     validate_actions: bool = True,
     graph: bool = False,
+    fused: Optional[bool] = None,
     **kwargs,
 ) -> Environment:
     """vmas.make_env(...) for the scenarios shipped in ``vectorizedmultiagentsimulator_amd.scenarios``."""
@@ -228,5 +261,6 @@ def make_env(
         scenario = mod.Scenario()
     return Environment(
         scenario, num_envs=num_envs, device=device, continuous_actions=continuous_actions, max_steps=max_steps,
-        seed=seed, clamp_actions=clamp_actions, validate_actions=validate_actions, graph=graph, **kwargs,
+        seed=seed, clamp_actions=clamp_actions, validate_actions=validate_actions, graph=graph, fused=fused,
+        **kwargs,
     )

@@ -1,0 +1,303 @@
+"""Host side of ``include/vmas_env_hip.h``: the stages of ``Environment.step`` on either side of
+``World.step()`` as one kernel launch each.
+
+* ``ActionIngest``   - ``Environment._set_action`` (environment.py:616-749, continuous branch)
+  followed by ``Holonomic(.WithRotation).process_action`` for every policy agent.
+* ``BalancePost`` / ``TransportPost`` / ``NavigationPost`` - the scenario's
+  reward / observation / done / info (balance.py:218-267, transport.py:131-191,
+  navigation.py:200-285) over the packed state, writing the reference's own output shapes.
+
+Each class owns the descriptor and the scenario's persistent tensors (shaping terms, flags);
+outputs are fresh tensors per call unless ``static_outputs`` (HIP-graph replay) is set.  There is
+no torch fallback in here: the scenario classes keep their tensor-op methods for user code that
+calls ``reward()`` / ``observation()`` directly, the environment uses the kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import torch
+from torch import Tensor
+
+from . import _abi as A
+from .backend import VmasHipError
+from .core import Holonomic, HolonomicWithRotation
+
+
+def _stream(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise VmasHipError(A.last_error())
+
+
+def _per_dim(v, n) -> List[float]:
+    return [float(x) for x in v] if isinstance(v, (list, tuple)) else [float(v)] * n
+
+
+class ActionIngest:
+    """One launch for all agents' ``_set_action`` + ``process_action``."""
+
+    @staticmethod
+    def supports(env) -> Optional[str]:
+        """None if the environment's action path can be fused, else the reason it cannot."""
+        if not env.continuous_actions:
+            return "discrete actions"
+        if len(env.agents) > A.ENV_MAX_AGENTS:
+            return "too many agents"
+        if env.world.scripted_agents:
+            return "scripted agents"
+        from .scenario import BaseScenario
+        if type(env.scenario).process_action is not BaseScenario.process_action:
+            return "scenario overrides process_action"
+        for a in env.agents:
+            if type(a.dynamics) not in (Holonomic, HolonomicWithRotation):
+                return f"dynamics {type(a.dynamics).__name__}"
+            if a.action.u_noise not in (0, 0.0, None):
+                return "action noise"
+            if not a.silent and env.world.dim_c > 0:
+                return "communication actions"
+        return None
+
+    def __init__(self, env):
+        self.env = env
+        self.lib = A.load_library()
+        w = env.world
+        B = env.num_envs
+        self.args = A.IngestArgs()
+        self.args.n_agents = len(env.agents)
+        self.args.clamp = 1 if env.clamp_action else 0
+        self.u = []
+        for i, a in enumerate(env.agents):
+            n = a.action_size
+            s = self.args.agents[i]
+            s.action_size = n
+            s.agent_index = a._agent_index
+            for k, v in enumerate(_per_dim(a.action.u_range, n)):
+                s.u_range[k] = v
+            for k, v in enumerate(_per_dim(a.action.u_multiplier, n)):
+                s.u_multiplier[k] = v
+            u = torch.zeros(B, n, device=env.device, dtype=torch.float32)
+            s.u_out = u.data_ptr()
+            a.action.u = u  # agent.action.u stays readable by scenario code
+            self.u.append(u)
+        self.err = torch.zeros(1, device=env.device, dtype=torch.int32)
+        self._ft = w._packed_agent_ft()
+        self._keep = None
+
+    def __call__(self, actions: List[Tensor], validate: bool):
+        env = self.env
+        held = []
+        for i, (agent, act) in enumerate(zip(env.agents, actions)):
+            if not isinstance(act, Tensor):
+                act = torch.tensor(act, dtype=torch.float32, device=env.device)
+            if act.dim() == 1:
+                act = act.unsqueeze(-1)
+            assert act.shape[0] == env.num_envs, (
+                f"Actions used in input of env must be of len {env.num_envs}, got {act.shape[0]}")
+            assert act.shape[1] == agent.action_size, (
+                f"Agent {agent.name} has wrong action size, got {act.shape[1]}, expected {agent.action_size}")
+            if act.dtype != torch.float32 or act.device != env.device or not act.is_contiguous():
+                act = act.detach().to(device=env.device, dtype=torch.float32).contiguous()
+            held.append(act)
+            self.args.agents[i].action = act.data_ptr()
+        self._keep = held  # the launch is asynchronous: keep the inputs alive until the next call
+        ft = env.world._packed_agent_ft()
+        err = self.err.data_ptr() if validate else None
+        _check(self.lib.vmas_env_ingest_actions(C.byref(self.args), env.num_envs, ft.data_ptr(), ft.shape[-1], err,
+                                                _stream(env.device)))
+        if validate:  # the reference asserts on the host (environment.py:621,651-653): one sync, not 2 per agent
+            flags = int(self.err.item())
+            if flags:
+                self.err.zero_()
+                assert not (flags & A.ACTION_ERR_NAN), "actions contain NaN"
+                raise AssertionError("Physical actions of an agent are out of its range")
+
+
+class _Post:
+    """Shared plumbing of the per-scenario post-step kernels."""
+
+    def __init__(self, env):
+        self.env = env
+        self.lib = A.load_library()
+        self.B = env.num_envs
+        self.dev = env.device
+        self.n = len(env.agents)
+        self.static_outputs = False
+        self._out = None
+
+    def _limit(self) -> A.StepLimit:
+        lim = A.StepLimit()
+        lim.steps = self.env.steps.data_ptr()
+        lim.max_steps = float(self.env.max_steps) if self.env.max_steps is not None else -1.0
+        return lim
+
+    def _outputs(self, obs_dim: int):
+        if self._out is None or not self.static_outputs:
+            self._out = (
+                torch.empty(self.n, self.B, obs_dim, device=self.dev, dtype=torch.float32),
+                torch.empty(self.n, self.B, device=self.dev, dtype=torch.float32),
+                torch.empty(self.B, device=self.dev, dtype=torch.bool),
+            )
+        return self._out
+
+    def _state(self):
+        st = self.env.world._packed_state()
+        return st.data_ptr(), st.shape[-1]
+
+
+class BalancePost(_Post):
+    def __init__(self, env):
+        super().__init__(env)
+        sc = env.scenario
+        d = A.BalanceDesc()
+        d.n_agents = self.n
+        d.goal, d.package, d.line, d.floor = (e._index for e in (sc.goal, sc.package, sc.line, sc.floor))
+        d.agent0 = env.world.agents[0]._index
+        d.goal_radius, d.package_radius = sc.goal.shape.radius, sc.package.shape.radius
+        d.line_length = sc.line.shape.length
+        d.floor_length, d.floor_width = sc.floor.shape.length, sc.floor.shape.width
+        d.shaping_factor, d.fall_reward = sc.shaping_factor, sc.fall_reward
+        self.desc = d
+
+    def __call__(self):
+        sc = self.env.scenario
+        obs, rew, done = self._outputs(16)
+        if not self.static_outputs or getattr(self, "_info", None) is None:
+            self._info = (torch.empty(self.B, device=self.dev), torch.empty(self.B, device=self.dev),
+                          torch.empty(self.B, device=self.dev, dtype=torch.bool))
+        sc.pos_rew, sc.ground_rew, sc.on_the_ground = self._info
+        b = A.BalanceBuffers()
+        b.global_shaping = sc.global_shaping.data_ptr()
+        b.obs, b.rew, b.done = obs.data_ptr(), rew.data_ptr(), done.data_ptr()
+        b.pos_rew, b.ground_rew, b.on_the_ground = (t.data_ptr() for t in self._info)
+        b.limit = self._limit()
+        st, ld = self._state()
+        _check(self.lib.vmas_balance_post_step(C.byref(self.desc), C.byref(b), self.B, st, ld, _stream(self.dev)))
+        infos = [{"pos_rew": sc.pos_rew, "ground_rew": sc.ground_rew} for _ in range(self.n)]
+        return list(obs.unbind(0)), list(rew.unbind(0)), done, infos
+
+
+class TransportPost(_Post):
+    def __init__(self, env):
+        super().__init__(env)
+        sc = env.scenario
+        P = len(sc.packages)
+        assert P <= A.ENV_MAX_PACKAGES
+        d = A.TransportDesc()
+        d.n_agents, d.n_packages = self.n, P
+        d.goal, d.package0, d.agent0 = sc.goal._index, sc.packages[0]._index, env.world.agents[0]._index
+        assert [p._index for p in sc.packages] == list(range(d.package0, d.package0 + P))
+        d.goal_radius = sc.goal.shape.radius
+        d.package_length, d.package_width = sc.packages[0].shape.length, sc.packages[0].shape.width
+        d.shaping_factor = sc.shaping_factor
+        self.desc = d
+        self.P = P
+        # the packages' persistent terms live in one [P, B] block each; the objects hold row views
+        self.global_shaping = torch.stack([p.global_shaping for p in sc.packages]).contiguous()
+        self.on_goal = torch.stack([p.on_goal for p in sc.packages]).contiguous()
+        self._bind()
+
+    def _bind(self):
+        for i, p in enumerate(self.env.scenario.packages):
+            p.global_shaping = self.global_shaping[i]
+            p.on_goal = self.on_goal[i]
+
+    def __call__(self):
+        sc = self.env.scenario
+        for i, p in enumerate(sc.packages):  # reset() may have rebound them
+            if p.global_shaping.data_ptr() != self.global_shaping[i].data_ptr():
+                self.global_shaping[i].copy_(p.global_shaping)
+                p.global_shaping = self.global_shaping[i]
+            if p.on_goal.data_ptr() != self.on_goal[i].data_ptr():
+                self.on_goal[i].copy_(p.on_goal)
+                p.on_goal = self.on_goal[i]
+        obs, rew, done = self._outputs(4 + 7 * self.P)
+        b = A.TransportBuffers()
+        b.global_shaping, b.on_goal = self.global_shaping.data_ptr(), self.on_goal.data_ptr()
+        b.obs, b.rew, b.done = obs.data_ptr(), rew.data_ptr(), done.data_ptr()
+        b.limit = self._limit()
+        st, ld = self._state()
+        _check(self.lib.vmas_transport_post_step(C.byref(self.desc), C.byref(b), self.B, st, ld, _stream(self.dev)))
+        sc.rew = rew[0]
+        return list(obs.unbind(0)), list(rew.unbind(0)), done, [{} for _ in range(self.n)]
+
+
+class NavigationPost(_Post):
+    @staticmethod
+    def supports(env) -> Optional[str]:
+        sc = env.scenario
+        agents = env.world.agents
+        if len(agents) > A.ENV_MAX_AGENTS:
+            return "too many agents"
+        if len({a.shape.radius for a in agents}) != 1 or len({a.goal.shape.radius for a in agents}) != 1:
+            return "non-uniform radii"
+        if sc.collisions and len({(s._angles.shape[0], s._max_range) for a in agents for s in a.sensors}) != 1:
+            return "non-uniform sensors"
+        return None
+
+    def __init__(self, env):
+        super().__init__(env)
+        sc, w = env.scenario, env.world
+        agents = w.agents
+        d = A.NavigationDesc()
+        d.n_agents, d.agent0 = self.n, agents[0]._index
+        assert [a._index for a in agents] == list(range(d.agent0, d.agent0 + self.n))
+        for i, a in enumerate(agents):
+            d.goal_of[i] = a.goal._index
+        d.shared_rew, d.collisions, d.observe_all_goals = int(sc.shared_rew), int(sc.collisions), int(sc.observe_all_goals)
+        d.agent_radius, d.goal_radius = agents[0].shape.radius, agents[0].goal.shape.radius
+        d.pos_shaping_factor, d.final_reward = sc.pos_shaping_factor, sc.final_reward
+        d.agent_collision_penalty, d.min_collision_distance = sc.agent_collision_penalty, sc.min_collision_distance
+        if sc.collisions:
+            s = agents[0].sensors[0]
+            d.n_rays, d.lidar_range = s._angles.shape[0], s._max_range
+        self.desc = d
+        self.obs_dim = 4 + 2 * (self.n if sc.observe_all_goals else 1) + (d.n_rays if sc.collisions else 0)
+        self.pos_shaping = torch.stack([a.pos_shaping for a in agents]).contiguous()
+        for i, a in enumerate(agents):
+            a.pos_shaping = self.pos_shaping[i]
+        if sc.collisions:  # (i, j) -> index in the world's static pair list, for World.collides' global reduction
+            spec = w.spec
+            where = {}
+            for k, p in enumerate(spec.pairs):
+                where[(p.a, p.b)] = where[(p.b, p.a)] = k
+            table = [[where.get((a._index, b._index), -1) for b in agents] for a in agents]
+            self.pair_index = torch.tensor(table, dtype=torch.int32, device=self.dev).contiguous()
+
+    def __call__(self):
+        env, sc, w = self.env, self.env.scenario, self.env.world
+        agents = w.agents
+        for i, a in enumerate(agents):  # reset() may have rebound it
+            if a.pos_shaping.data_ptr() != self.pos_shaping[i].data_ptr():
+                self.pos_shaping[i].copy_(a.pos_shaping)
+                a.pos_shaping = self.pos_shaping[i]
+        obs, rew, done = self._outputs(self.obs_dim)
+        if not self.static_outputs or getattr(self, "_terms", None) is None:
+            self._terms = (torch.empty(self.n, self.B, device=self.dev), torch.empty(self.B, device=self.dev),
+                           torch.empty(self.B, device=self.dev), torch.empty(self.n, self.B, device=self.dev))
+        agent_pos_rew, sc.pos_rew, sc.final_rew, col = self._terms
+        b = A.NavigationBuffers()
+        b.pos_shaping = self.pos_shaping.data_ptr()
+        b.obs, b.rew, b.done = obs.data_ptr(), rew.data_ptr(), done.data_ptr()
+        b.agent_pos_rew, b.pos_rew, b.final_rew, b.collision_rew = (
+            agent_pos_rew.data_ptr(), sc.pos_rew.data_ptr(), sc.final_rew.data_ptr(), col.data_ptr())
+        if sc.collisions:
+            lidar = w.cast_rays_all()  # [n_sensors, max_rays, ld] of the post-step state
+            env._lidar_cache = sc._lidar_cache = lidar
+            pair_any = w._get_backend().pair_mask()
+            b.lidar, b.lidar_max_rays = lidar.data_ptr(), lidar.shape[1]
+            b.pair_any, b.pair_index = pair_any.data_ptr(), self.pair_index.data_ptr()
+        b.limit = self._limit()
+        st, ld = self._state()
+        _check(self.lib.vmas_navigation_post_step(C.byref(self.desc), C.byref(b), self.B, st, ld, _stream(self.dev)))
+        infos = []
+        for i, a in enumerate(agents):
+            a.pos_rew, a.agent_collision_rew = agent_pos_rew[i], col[i]
+        for i, a in enumerate(env.agents):
+            infos.append({"pos_rew": sc.pos_rew if sc.shared_rew else a.pos_rew, "final_rew": sc.final_rew,
+                          "agent_collisions": a.agent_collision_rew})
+        return list(obs.unbind(0)), list(rew.unbind(0)), done, infos

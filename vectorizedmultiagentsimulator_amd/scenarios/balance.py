@@ -114,3 +114,8 @@ class Scenario(BaseScenario):
 
     def info(self, agent):
         return {"pos_rew": self.pos_rew, "ground_rew": self.ground_rew}
+
+    def make_fused_post(self, env):
+        """reward + observation + done + info of every agent as one kernel (fused.BalancePost)."""
+        from ..fused import BalancePost
+        return BalancePost(env)

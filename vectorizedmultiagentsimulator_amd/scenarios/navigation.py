@@ -141,3 +141,8 @@ class Scenario(BaseScenario):
     def info(self, agent):
         return {"pos_rew": self.pos_rew if self.shared_rew else agent.pos_rew, "final_rew": self.final_rew,
                 "agent_collisions": agent.agent_collision_rew}
+
+    def make_fused_post(self, env):
+        """reward + observation (LIDAR included) + done + info as one kernel (fused.NavigationPost)."""
+        from ..fused import NavigationPost
+        return NavigationPost(env) if NavigationPost.supports(env) is None else None

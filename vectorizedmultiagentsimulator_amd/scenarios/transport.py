@@ -47,7 +47,7 @@ class Scenario(BaseScenario):
         min_dist = max(p.shape.circumscribed_radius() + self.goal.shape.radius + 0.01 for p in self.packages)
         spawn_entities_randomly([self.goal] + self.packages, w, env_index, min_dist, b, b, occupied_positions=occupied)
         for p in self.packages:
-            p.on_goal = w.is_overlapping(p, p.goal)
+            keep(p, "on_goal", w.is_overlapping(p, p.goal))
             shaping = torch.linalg.vector_norm(p.state.pos - p.goal.state.pos, dim=1) * self.shaping_factor
             if env_index is None:
                 keep(p, "global_shaping", shaping)
@@ -74,3 +74,11 @@ class Scenario(BaseScenario):
 
     def done(self):
         return torch.stack([p.on_goal for p in self.packages], dim=1).all(dim=-1)
+
+    def make_fused_post(self, env):
+        """reward + observation + done of every agent as one kernel (fused.TransportPost)."""
+        from .. import _abi
+        from ..fused import TransportPost
+        if len(self.packages) > _abi.ENV_MAX_PACKAGES or len(env.agents) > _abi.ENV_MAX_AGENTS:
+            return None
+        return TransportPost(env)
