@@ -20,6 +20,8 @@
 
 #include <stdint.h>
 
+#include "vmas_hip.h"
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -131,6 +133,21 @@ typedef struct VmasNavigationBuffers {
 
 int vmas_navigation_post_step(const VmasNavigationDesc* desc, const VmasNavigationBuffers* buf, int32_t batch,
                               const float* state, int64_t ld, void* stream);
+
+/* ---------------------------------------------------------------- the whole step in one launch
+ * World.step() with the action ingest as its prologue and one scenario's post-step as its
+ * epilogue: the tile of 64 environments a block integrates is still in LDS when the physics is
+ * done, so reward / observation / done are computed from it without a second trip through HBM
+ * and without a second and third launch.  Same results, bit for bit, as
+ *   vmas_env_ingest_actions(ingest) ; vmas_world_step(args) ; vmas_<scenario>_post_step(desc, buffers).
+ * `ingest` may be NULL (agent_ft already holds the forces); `post_desc` / `post_buffers` point to the
+ * VmasBalance* / VmasTransport* pair selected by `post_kind`.  Navigation's post-step needs the
+ * LIDAR and the batch-global collision mask of the NEW state and stays a separate launch. */
+#define VMAS_POST_BALANCE 1
+#define VMAS_POST_TRANSPORT 2
+int vmas_world_step_env(VmasWorld* w, float* state, float* agent_ft, int64_t ld, const VmasStepArgs* args /* may be NULL */,
+                        const VmasIngestArgs* ingest /* may be NULL */, uint32_t* err_flags /* may be NULL */,
+                        int32_t post_kind, const void* post_desc, const void* post_buffers, void* stream);
 
 #ifdef __cplusplus
 }

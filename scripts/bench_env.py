@@ -14,10 +14,10 @@ for fused in (False, True):
             continue
         env = make_env(name, num_envs=B, device="cuda:0", seed=0, validate_actions=False, graph=graph, fused=fused, **kw)
         acts = [env.get_random_action(a) for a in env.agents]
-        for _ in range(5):
+        for _ in range(300 if (graph or fused) else 5):  # (the first few hundred steps carry one-time costs)
             env.step(acts)
         torch.cuda.synchronize()
-        n = 300 if (graph or fused) else 30
+        n = 1000 if (graph or fused) else 30
         t0 = time.perf_counter()
         for _ in range(n):
             env.step(acts)

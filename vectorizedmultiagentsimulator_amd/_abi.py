@@ -137,6 +137,7 @@ LIB_PATH = os.path.join(_PKG_DIR, "csrc", "libvmas_hip.so")
 ENV_MAX_AGENTS = 32
 ENV_MAX_PACKAGES = 8
 ACTION_ERR_NAN, ACTION_ERR_OUT_OF_RANGE = 1, 2
+POST_BALANCE, POST_TRANSPORT = 1, 2
 
 
 class ActionSlot(C.Structure):
@@ -231,6 +232,7 @@ EXPORTED_SYMBOLS = (
     "vmas_balance_post_step",
     "vmas_transport_post_step",
     "vmas_navigation_post_step",
+    "vmas_world_step_env",
 )
 
 _lib: Optional[C.CDLL] = None
@@ -282,6 +284,8 @@ def load_library() -> C.CDLL:
                      (lib.vmas_navigation_post_step, NavigationDesc, NavigationBuffers)):
         fn.argtypes = [C.POINTER(d), C.POINTER(b), i32, vp, i64, vp]
         fn.restype = C.c_int
+    lib.vmas_world_step_env.argtypes = [vp, vp, vp, i64, C.POINTER(StepArgs), C.POINTER(IngestArgs), vp, i32, vp, vp, vp]
+    lib.vmas_world_step_env.restype = C.c_int
     lib.vmas_last_error.argtypes = []
     lib.vmas_last_error.restype = C.c_char_p
     lib.vmas_abi_version.argtypes = []

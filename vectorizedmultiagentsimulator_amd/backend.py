@@ -168,6 +168,25 @@ class HipWorld:
         if rc != 0:
             raise VmasHipError(A.last_error())
 
+    def step_env(self, ingest_args, err_flags: Optional[torch.Tensor], post_kind: int, post_desc, post_buffers,
+                 joint_fixed_rot: Optional[torch.Tensor] = None, entity_gravity: Optional[torch.Tensor] = None,
+                 stream=None) -> None:
+        """World.step() with the action ingest as prologue and a scenario post-step as epilogue, ONE
+        launch (``vmas_world_step_env``, include/vmas_env_hip.h)."""
+        args = None
+        if joint_fixed_rot is not None or entity_gravity is not None:
+            sa = A.StepArgs()
+            sa.joint_fixed_rot = self._dptr(joint_fixed_rot)
+            sa.entity_gravity = self._dptr(entity_gravity)
+            args = C.byref(sa)
+        rc = self.lib.vmas_world_step_env(
+            self._h, self._dptr(self.state), self._dptr(self.agent_ft), self.ld, args,
+            C.byref(ingest_args) if ingest_args is not None else None, self._dptr(err_flags), int(post_kind),
+            C.cast(C.pointer(post_desc), C.c_void_p), C.cast(C.pointer(post_buffers), C.c_void_p), self._stream(stream),
+        )
+        if rc != 0:
+            raise VmasHipError(A.last_error())
+
     def step_n(self, n_steps: int, forces: Optional[torch.Tensor] = None, stream=None) -> None:
         """``n_steps`` World.step() launches enqueued from C.  ``forces`` [n_steps, A, 3, ld]
         (packed like ``agent_ft``) supplies per-step agent forces; None re-uses ``agent_ft``."""

@@ -821,6 +821,15 @@ class World:
                 if not agent.silent:
                     agent.state.c = agent.action.c
 
+    def step_env(self, ingest_args, err_flags, post_kind: int, post_desc, post_buffers):
+        """``step()`` with the environment's action ingest and the scenario's post-step fused into the
+        same launch (fused.py / ``vmas_world_step_env``)."""
+        assert not self.exact_broad_phase and self._dim_c == 0
+        be = self._get_backend()
+        self._query_cache = None
+        jfr, eg = self._per_env_inputs()
+        be.step_env(ingest_args, err_flags, post_kind, post_desc, post_buffers, joint_fixed_rot=jfr, entity_gravity=eg)
+
     # ---- scenario-side geometric queries (core.py:1788-1969, 2788-2803): batched torch ops
     def collides(self, a: Entity, b: Entity) -> Tensor:
         """Per-environment version of the broad-phase test of core.py:2788-2803 ([B] bool; the

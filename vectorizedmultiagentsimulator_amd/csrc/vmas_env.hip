@@ -214,19 +214,60 @@ int waves_for(int n_agents) { return n_agents > 4 ? 8 : 4; }
 
 }  // namespace
 
+// ---- argument validation, shared with vmas_world_step_env (vmas_hip.hip) ----
+namespace vmas {
+
+int check_ingest_args(const VmasIngestArgs* args, int32_t batch, const float* agent_ft, int64_t ld) {
+  if (!args || !agent_ft) return host_fail("action ingest: null argument");
+  if (batch <= 0 || ld < batch) return host_fail("action ingest: bad batch / ld");
+  if (args->n_agents < 0 || args->n_agents > VMAS_ENV_MAX_AGENTS) return host_fail("action ingest: n_agents out of range");
+  for (int a = 0; a < args->n_agents; ++a) {
+    const VmasActionSlot& s = args->agents[a];
+    if (!s.action || s.action_size < 2 || s.action_size > 3 || s.agent_index < 0 || s.agent_index >= VMAS_ENV_MAX_AGENTS)
+      return host_fail("action ingest: malformed action slot");
+  }
+  return 0;
+}
+
+static bool bad_entity(int e, int n_entities) { return e < 0 || (n_entities >= 0 && e >= n_entities); }
+
+int check_balance_args(const VmasBalanceDesc* d, const VmasBalanceBuffers* o, int32_t batch, const float* state, int64_t ld,
+                       int n_entities) {
+  if (!d || !o || !state) return host_fail("balance post-step: null argument");
+  if (batch <= 0 || ld < batch) return host_fail("balance post-step: bad batch / ld");
+  if (d->n_agents < 1 || d->n_agents > VMAS_ENV_MAX_AGENTS) return host_fail("balance post-step: n_agents out of range");
+  if (bad_entity(d->goal, n_entities) || bad_entity(d->package, n_entities) || bad_entity(d->line, n_entities) ||
+      bad_entity(d->floor, n_entities) || bad_entity(d->agent0, n_entities) ||
+      bad_entity(d->agent0 + d->n_agents - 1, n_entities))
+    return host_fail("balance post-step: entity index out of range");
+  if (!o->global_shaping || !o->obs || !o->rew || !o->pos_rew || !o->ground_rew || !o->on_the_ground || !o->done)
+    return host_fail("balance post-step: null buffer");
+  return 0;
+}
+
+int check_transport_args(const VmasTransportDesc* d, const VmasTransportBuffers* o, int32_t batch, const float* state,
+                         int64_t ld, int n_entities) {
+  if (!d || !o || !state) return host_fail("transport post-step: null argument");
+  if (batch <= 0 || ld < batch) return host_fail("transport post-step: bad batch / ld");
+  if (d->n_agents < 1 || d->n_agents > VMAS_ENV_MAX_AGENTS) return host_fail("transport post-step: n_agents out of range");
+  if (d->n_packages < 1 || d->n_packages > VMAS_ENV_MAX_PACKAGES)
+    return host_fail("transport post-step: n_packages out of range");
+  if (bad_entity(d->goal, n_entities) || bad_entity(d->package0, n_entities) ||
+      bad_entity(d->package0 + d->n_packages - 1, n_entities) || bad_entity(d->agent0, n_entities) ||
+      bad_entity(d->agent0 + d->n_agents - 1, n_entities))
+    return host_fail("transport post-step: entity index out of range");
+  if (!o->global_shaping || !o->on_goal || !o->obs || !o->rew || !o->done)
+    return host_fail("transport post-step: null buffer");
+  return 0;
+}
+
+}  // namespace vmas
+
 extern "C" {
 
 int vmas_env_ingest_actions(const VmasIngestArgs* args, int32_t batch, float* agent_ft, int64_t ld, uint32_t* err_flags,
                             void* stream) {
-  if (!args || !agent_ft) return host_fail("vmas_env_ingest_actions: null argument");
-  if (batch <= 0 || ld < batch) return host_fail("vmas_env_ingest_actions: bad batch / ld");
-  if (args->n_agents < 0 || args->n_agents > VMAS_ENV_MAX_AGENTS)
-    return host_fail("vmas_env_ingest_actions: n_agents out of range");
-  for (int a = 0; a < args->n_agents; ++a) {
-    const VmasActionSlot& s = args->agents[a];
-    if (!s.action || s.action_size < 2 || s.action_size > 3 || s.agent_index < 0)
-      return host_fail("vmas_env_ingest_actions: malformed action slot");
-  }
+  if (check_ingest_args(args, batch, agent_ft, ld)) return -1;
   if (args->n_agents == 0) return 0;
   hipLaunchKernelGGL(ingest_kernel, dim3((batch + 255) / 256, args->n_agents), dim3(256), 0, (hipStream_t)stream, *args,
                      batch, agent_ft, (long)ld, err_flags);
@@ -235,11 +276,7 @@ int vmas_env_ingest_actions(const VmasIngestArgs* args, int32_t batch, float* ag
 
 int vmas_balance_post_step(const VmasBalanceDesc* d, const VmasBalanceBuffers* o, int32_t batch, const float* state,
                            int64_t ld, void* stream) {
-  if (!d || !o || !state) return host_fail("vmas_balance_post_step: null argument");
-  if (batch <= 0 || ld < batch) return host_fail("vmas_balance_post_step: bad batch / ld");
-  if (d->n_agents < 1 || d->n_agents > VMAS_ENV_MAX_AGENTS) return host_fail("vmas_balance_post_step: n_agents out of range");
-  if (!o->global_shaping || !o->obs || !o->rew || !o->pos_rew || !o->ground_rew || !o->on_the_ground || !o->done)
-    return host_fail("vmas_balance_post_step: null buffer");
+  if (check_balance_args(d, o, batch, state, ld, -1)) return -1;
   const int nE = std::max({d->goal, d->package, d->line, d->floor, d->agent0 + d->n_agents - 1}) + 1;
   const int nw = waves_for(d->n_agents);
   const size_t lds = ((size_t)nE * 6 * 64 + balance_scratch_floats(nw)) * sizeof(float);
@@ -248,14 +285,7 @@ int vmas_balance_post_step(const VmasBalanceDesc* d, const VmasBalanceBuffers* o
 
 int vmas_transport_post_step(const VmasTransportDesc* d, const VmasTransportBuffers* o, int32_t batch, const float* state,
                              int64_t ld, void* stream) {
-  if (!d || !o || !state) return host_fail("vmas_transport_post_step: null argument");
-  if (batch <= 0 || ld < batch) return host_fail("vmas_transport_post_step: bad batch / ld");
-  if (d->n_agents < 1 || d->n_agents > VMAS_ENV_MAX_AGENTS) return host_fail("vmas_transport_post_step: n_agents out of range");
-  if (d->n_packages < 1 || d->n_packages > VMAS_ENV_MAX_PACKAGES)
-    return host_fail("vmas_transport_post_step: n_packages out of range");
-  if (!o->global_shaping || !o->on_goal || !o->obs || !o->rew || !o->done)
-    return host_fail("vmas_transport_post_step: null buffer");
-  const int D = 4 + 7 * d->n_packages;
+  if (check_transport_args(d, o, batch, state, ld, -1)) return -1;
   const int nE = std::max({d->goal, d->package0 + d->n_packages - 1, d->agent0 + d->n_agents - 1}) + 1;
   const int nw = waves_for(d->n_agents);
   const size_t lds = ((size_t)nE * 6 * 64 + transport_scratch_floats(nw, d->n_packages)) * sizeof(float);

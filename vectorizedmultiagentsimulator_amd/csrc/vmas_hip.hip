@@ -45,7 +45,7 @@
 #include <vector>
 
 #include "../../include/vmas_hip.h"
-#include "vmas_device.h"
+#include "vmas_env_device.h"
 
 using namespace vmas;
 
@@ -132,6 +132,22 @@ struct DevStepArgs {
   unsigned long long* trace;  // profiling only (env VMAS_TRACE): per-wave s_memtime stamps
   int32_t ablate;  // profiling only (env VMAS_ABLATE): 1 skip items, 2 skip integration, 4 skip prologue
 };
+
+// The Environment.step() stages fused around the physics (vmas_world_step_env): action ingest as the
+// kernel's prologue, one scenario's reward / observation / done as its epilogue on the LDS tile.
+enum { ENV_NONE = 0, ENV_BALANCE = 1, ENV_TRANSPORT = 2 };
+struct DevEnv {
+  int32_t has_ingest;
+  int32_t scratch_off;  // floats from the LDS base to the epilogue's scratch (after the step's own LDS)
+  int8_t slot_of_agent[VMAS_ENV_MAX_AGENTS];  // agent index -> action slot, -1 = no action for it
+  uint32_t* err_flags;
+  VmasIngestArgs ingest;
+  union {
+    struct { VmasBalanceDesc d; VmasBalanceBuffers o; } balance;
+    struct { VmasTransportDesc d; VmasTransportBuffers o; } transport;
+  };
+};
+struct NoEnv {};
 
 __device__ __forceinline__ int sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ bool finite_f(float x) { return fabsf(x) < kInf; }
@@ -375,10 +391,10 @@ __device__ __forceinline__ void eval_item(const ItemV& K, const DevWorld& W, con
 // ------------------------------------------------------------------------------------
 // the fused step kernel: grid = ceil(batch / 64) tiles, block = 64 x W threads
 // ------------------------------------------------------------------------------------
-template <int LEVEL>
+template <int LEVEL, int ENV, class EnvArgs>
 __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel(DevWorld W, float* __restrict__ state,
                                                                float* __restrict__ agent_ft, long ld, int batch,
-                                                               DevStepArgs args) {
+                                                               DevStepArgs args, const EnvArgs E) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x & (TILE - 1);
   const int wv = sgpr(threadIdx.x >> 6);
@@ -410,10 +426,36 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
 #pragma unroll
     for (int f = 0; f < 6; ++f) v0[f] = live ? src[f * ld] : 0.f;
   }
-  if (wv < nA) {
-    const float* src = agent_ft + (long)wv * 3 * ld + env;
+  // Environment._set_action + process_action as the prologue: the agent's force rows are computed
+  // from its action tensor (and stored to agent_ft, where scenario code reads agent.state.force)
+  auto load_agent_ft = [&](int a, float* f3) {
+    const float* src = agent_ft + (long)a * 3 * ld + env;
+    if constexpr (ENV != ENV_NONE) {
+      const int slot = E.has_ingest ? E.slot_of_agent[a] : -1;
+      if (slot >= 0) {
+        const VmasActionSlot& S = E.ingest.agents[slot];
+        uint32_t bad = 0;
+        ingest_slot(S, E.ingest.clamp, env, live, agent_ft, ld, f3, bad);
+        if (S.action_size < 3) f3[2] = live ? src[2 * ld] : 0.f;  // Holonomic leaves the torque alone
+        if (E.err_flags != nullptr && bad != 0) atomicOr(E.err_flags, bad);
+        return;
+      }
+    }
 #pragma unroll
-    for (int f = 0; f < 3; ++f) f0[f] = live ? src[f * ld] : 0.f;
+    for (int f = 0; f < 3; ++f) f3[f] = live ? src[f * ld] : 0.f;
+  };
+  if (wv < nA) load_agent_ft(wv, f0);
+  // the epilogue's HBM inputs are requested now, behind the physics
+  [[maybe_unused]] float post_prev = 0.f, post_steps = 0.f;
+  if constexpr (ENV == ENV_BALANCE) {
+    post_prev = live ? E.balance.o.global_shaping[env] : 0.f;
+    if (wv == 0) post_steps = (E.balance.o.limit.steps != nullptr && live) ? E.balance.o.limit.steps[env] : 0.f;
+  }
+  if constexpr (ENV == ENV_TRANSPORT) {
+    float* term = lds + E.scratch_off + lane;
+    for (int p = wv; p < E.transport.d.n_packages; p += nw)
+      term[p * 64] = live ? E.transport.o.global_shaping[(long)p * batch + env] : 0.f;
+    if (wv == 0) post_steps = (E.transport.o.limit.steps != nullptr && live) ? E.transport.o.limit.steps[env] : 0.f;
   }
   for (int i = threadIdx.x; i < W.blob_words; i += blockDim.x) blob[i] = W.blob[i];
   const int first_dyn = (args.ablate & 128) ? 0 : nw;  // 128: profiling toggle, fully dynamic
@@ -448,10 +490,11 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
     for (int f = 0; f < 3; ++f) dst[f * ROWF] = f0[f];
   }
   for (int a = wv + nw; a < nA; a += nw) {
-    const float* src = agent_ft + (long)a * 3 * ld + env;
+    float f3[3];
+    load_agent_ft(a, f3);
     float* dst = tile + W.off_af + a * 3 * ROWF;
 #pragma unroll
-    for (int f = 0; f < 3; ++f) dst[f * ROWF] = live ? src[f * ld] : 0.f;
+    for (int f = 0; f < 3; ++f) dst[f * ROWF] = f3[f];
   }
   STAMP(1);
   __syncthreads();
@@ -629,6 +672,7 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
         if (W.ys == W.ys) np.y = clamp_t(np.y, W.ys);
         if (last) {
           if (live) { dst[0] = np.x; dst[ld] = np.y; dst[2 * ld] = vel.x; dst[3 * ld] = vel.y; }
+          if constexpr (ENV != ENV_NONE) { Es[0] = np.x; Es[ROWF] = np.y; Es[2 * ROWF] = vel.x; Es[3 * ROWF] = vel.y; }
         } else {
           Es[0] = np.x; Es[ROWF] = np.y; Es[2 * ROWF] = vel.x; Es[3 * ROWF] = vel.y;
           bad = !finite_f(np.x) || !finite_f(np.y);
@@ -641,6 +685,7 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
         const float rot = Es[4 * ROWF] + av * sub_dt;
         if (last) {
           if (live) { dst[4 * ld] = rot; dst[5 * ld] = av; }
+          if constexpr (ENV != ENV_NONE) { Es[4 * ROWF] = rot; Es[5 * ROWF] = av; }
         } else {
           Es[4 * ROWF] = rot; Es[5 * ROWF] = av;
           bad = bad || !finite_f(rot);
@@ -653,6 +698,15 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
   }
   }
   STAMP(5);
+  // ---- epilogue: the scenario's reward / observation / done on the tile that is still in LDS
+  if constexpr (ENV != ENV_NONE) {
+    __syncthreads();
+    const TileCtx C(batch);
+    if constexpr (ENV == ENV_BALANCE)
+      balance_post_tile(C, E.balance.d, E.balance.o, batch, lds, lds + E.scratch_off, post_prev, post_steps);
+    if constexpr (ENV == ENV_TRANSPORT)
+      transport_post_tile(C, E.transport.d, E.transport.o, batch, lds, lds + E.scratch_off, post_steps);
+  }
 }
 
 // ------------------------------------------------------------------------------------
@@ -862,6 +916,12 @@ static int fail(const char* fmt, ...) {
 }
 namespace vmas {
 int host_fail(const char* msg) { return fail("%s", msg); }  // for vmas_env.hip
+// argument validation shared with the stand-alone entry points (vmas_env.hip); n_entities < 0 = unknown
+int check_ingest_args(const VmasIngestArgs* args, int32_t batch, const float* agent_ft, int64_t ld);
+int check_balance_args(const VmasBalanceDesc* d, const VmasBalanceBuffers* o, int32_t batch, const float* state, int64_t ld,
+                       int n_entities);
+int check_transport_args(const VmasTransportDesc* d, const VmasTransportBuffers* o, int32_t batch, const float* state,
+                         int64_t ld, int n_entities);
 }
 #define HIP_TRY(x)                                                                      \
   do {                                                                                  \
@@ -1152,23 +1212,39 @@ static int default_lanes(const VmasWorld* w) {
   return nw;
 }
 
-template <int LEVEL>
+template <int LEVEL, int ENV, class EnvArgs>
 static int launch_level(VmasWorld* w, Sched* S, float* state, float* aft, long ld, const DevStepArgs& a,
-                        hipStream_t s) {
-  if (S->lds_bytes > 64 * 1024) {
+                        const EnvArgs& env, size_t extra_lds, hipStream_t s) {
+  const size_t lds = S->lds_bytes + extra_lds;
+  if (lds > 160 * 1024) return fail("vmas_world_step: %zu bytes of LDS per tile exceed the CU's 160 KB", lds);
+  if (lds > 64 * 1024) {
     static thread_local size_t set_for = 0;
-    if (set_for < S->lds_bytes) {
-      HIP_TRY(hipFuncSetAttribute((const void*)step_kernel<LEVEL>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)S->lds_bytes));
-      set_for = S->lds_bytes;
+    if (set_for < lds) {
+      HIP_TRY(hipFuncSetAttribute((const void*)step_kernel<LEVEL, ENV, EnvArgs>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      set_for = lds;
     }
   }
   const int blocks = (w->batch + TILE - 1) / TILE;
-  hipLaunchKernelGGL(step_kernel<LEVEL>, dim3(blocks), dim3(TILE * S->nw), S->lds_bytes, s, S->dw, state, aft, ld,
-                     w->batch, a);
+  hipLaunchKernelGGL((step_kernel<LEVEL, ENV, EnvArgs>), dim3(blocks), dim3(TILE * S->nw), lds, s, S->dw, state, aft, ld,
+                     w->batch, a, env);
   HIP_TRY(hipGetLastError());
   return 0;
 }
+
+template <int ENV, class EnvArgs>
+static int launch_any_level(VmasWorld* w, Sched* S, float* state, float* aft, long ld, const DevStepArgs& a,
+                            const EnvArgs& env, size_t extra_lds, hipStream_t s) {
+  switch (w->level) {
+    case 0: return launch_level<0, ENV>(w, S, state, aft, ld, a, env, extra_lds, s);
+    case 1: return launch_level<1, ENV>(w, S, state, aft, ld, a, env, extra_lds, s);
+    default: return launch_level<2, ENV>(w, S, state, aft, ld, a, env, extra_lds, s);
+  }
+}
+
+static int step_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld, const VmasStepArgs* args, void* stream,
+                     int n_steps, int64_t ft_stride, DevEnv* env = nullptr, int env_kind = ENV_NONE,
+                     size_t scratch_fixed = 0, size_t scratch_per_wave = 0);
 
 extern "C" {
 
@@ -1285,9 +1361,6 @@ int64_t vmas_world_step_bytes_per_env(const VmasWorld* w) {
   return 24LL * w->base.nE + 12LL * w->base.nA + 24LL * w->n_dyn;
 }
 
-static int step_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld, const VmasStepArgs* args, void* stream,
-                     int n_steps, int64_t ft_stride);
-
 int vmas_world_step(VmasWorld* w, float* state, float* agent_ft, int64_t ld, const VmasStepArgs* args, void* stream) {
   return step_impl(w, state, agent_ft, ld, args, stream, 1, 0);
 }
@@ -1300,8 +1373,51 @@ int vmas_world_rollout(VmasWorld* w, float* state, float* agent_ft, int64_t ld, 
   return step_impl(w, state, agent_ft, ld, args, stream, n_steps, ft_step_stride);
 }
 
+int vmas_world_step_env(VmasWorld* w, float* state, float* agent_ft, int64_t ld, const VmasStepArgs* args,
+                        const VmasIngestArgs* ingest, uint32_t* err_flags, int32_t post_kind, const void* post_desc,
+                        const void* post_buffers, void* stream) {
+  if (!w) return fail("vmas_world_step_env: null world");
+  if (args && (args->first_substep != 0 || args->n_substeps > 0))
+    return fail("vmas_world_step_env: partial substep ranges cannot carry an epilogue");
+  if (!post_desc || !post_buffers) return fail("vmas_world_step_env: null post-step descriptor");
+  DevEnv env{};
+  env.err_flags = err_flags;
+  for (int a = 0; a < VMAS_ENV_MAX_AGENTS; ++a) env.slot_of_agent[a] = -1;
+  if (ingest) {
+    if (vmas::check_ingest_args(ingest, w->batch, agent_ft, ld)) return -1;
+    env.has_ingest = 1;
+    env.ingest = *ingest;
+    for (int i = 0; i < ingest->n_agents; ++i) {
+      const int a = ingest->agents[i].agent_index;
+      if (a >= w->base.nA) return fail("vmas_world_step_env: action slot %d names agent %d of %d", i, a, w->base.nA);
+      env.slot_of_agent[a] = (int8_t)i;
+    }
+  }
+  if (post_kind == VMAS_POST_BALANCE) {
+    const auto* d = (const VmasBalanceDesc*)post_desc;
+    const auto* o = (const VmasBalanceBuffers*)post_buffers;
+    if (vmas::check_balance_args(d, o, w->batch, state, ld, w->base.nE)) return -1;
+    env.balance.d = *d;
+    env.balance.o = *o;
+    return step_impl(w, state, agent_ft, ld, args, stream, 1, 0, &env, ENV_BALANCE, balance_scratch_floats(0),
+                     balance_scratch_floats(1) - balance_scratch_floats(0));
+  }
+  if (post_kind == VMAS_POST_TRANSPORT) {
+    const auto* d = (const VmasTransportDesc*)post_desc;
+    const auto* o = (const VmasTransportBuffers*)post_buffers;
+    if (vmas::check_transport_args(d, o, w->batch, state, ld, w->base.nE)) return -1;
+    env.transport.d = *d;
+    env.transport.o = *o;
+    return step_impl(w, state, agent_ft, ld, args, stream, 1, 0, &env, ENV_TRANSPORT,
+                     transport_scratch_floats(0, d->n_packages),
+                     transport_scratch_floats(1, d->n_packages) - transport_scratch_floats(0, d->n_packages));
+  }
+  return fail("vmas_world_step_env: post_kind %d has no fused epilogue", post_kind);
+}
+
 static int step_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld, const VmasStepArgs* args, void* stream,
-                     int n_steps, int64_t ft_stride) {
+                     int n_steps, int64_t ft_stride, DevEnv* env, int env_kind, size_t scratch_fixed,
+                     size_t scratch_per_wave) {
   if (!w || !state) return fail("vmas_world_step: null argument");
   if (w->base.nA > 0 && !agent_ft) return fail("vmas_world_step: world has agents but agent_ft is null");
   if (ld < w->batch) return fail("vmas_world_step: ld (%lld) < batch (%d)", (long long)ld, w->batch);
@@ -1334,11 +1450,12 @@ static int step_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld, co
   Sched* S;
   if (get_sched(w, w->lanes, &S)) return -1;
   hipStream_t s = (hipStream_t)stream;
-  switch (w->level) {
-    case 0: return launch_level<0>(w, S, state, agent_ft, ld, a, s);
-    case 1: return launch_level<1>(w, S, state, agent_ft, ld, a, s);
-    default: return launch_level<2>(w, S, state, agent_ft, ld, a, s);
-  }
+  if (env_kind == ENV_NONE) return launch_any_level<ENV_NONE>(w, S, state, agent_ft, ld, a, NoEnv{}, 0, s);
+  if (S->nw < 2) return fail("vmas_world_step_env: the fused epilogue needs at least 2 waves per tile");
+  env->scratch_off = (int32_t)(S->lds_bytes / sizeof(float));
+  const size_t extra = (scratch_fixed + scratch_per_wave * S->nw) * sizeof(float);
+  if (env_kind == ENV_BALANCE) return launch_any_level<ENV_BALANCE>(w, S, state, agent_ft, ld, a, *env, extra, s);
+  return launch_any_level<ENV_TRANSPORT>(w, S, state, agent_ft, ld, a, *env, extra, s);
 }
 
 // profiling aid, not part of the ABI: copy out the s_memtime stamps of the last launch

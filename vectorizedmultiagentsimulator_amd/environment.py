@@ -57,6 +57,7 @@ class Environment:
         self.seed(seed)
         self.reset(return_observations=False)
         self._ingest = self._post = None
+        self._one_launch = False
         self._setup_fused()
 
     def _setup_fused(self):
@@ -78,6 +79,15 @@ class Environment:
             assert self._post is not None, "fused=True: the scenario has no fused post-step kernel"
         if self._post is not None:
             self._post.static_outputs = self.use_graph
+        # the whole step as ONE launch (vmas_world_step_env): ingest = prologue, post-step = epilogue of
+        # the physics kernel.  Needs the hooks between the stages to be the base class no-ops.
+        w = self.world
+        self._one_launch = (
+            self._ingest is not None and self._post is not None and self._post.kind is not None
+            and type(self.scenario).pre_step is BaseScenario.pre_step
+            and type(self.scenario).post_step is BaseScenario.post_step
+            and not w.exact_broad_phase and w.dim_c == 0
+        )
 
     batch_dim = property(lambda self: self.num_envs)
 
@@ -196,6 +206,15 @@ class Environment:
 
     def _step_eager(self, actions):
         assert len(actions) == self.n_agents, f"Expecting actions for {self.n_agents}, got {len(actions)} actions"
+        if self._one_launch:
+            self._ingest.prepare(actions)
+            desc, buffers, result = self._post.prepare()
+            self.world.step_env(self._ingest.args, self._ingest.err if self.validate_actions else None, self._post.kind,
+                                desc, buffers)
+            self._lidar_cache = None
+            if self.validate_actions:
+                self._ingest.check()
+            return result
         if self._ingest is not None:
             self._ingest(actions, self.validate_actions)
         else:

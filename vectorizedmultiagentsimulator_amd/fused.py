@@ -88,7 +88,8 @@ class ActionIngest:
         self._ft = w._packed_agent_ft()
         self._keep = None
 
-    def __call__(self, actions: List[Tensor], validate: bool):
+    def prepare(self, actions: List[Tensor]):
+        """Check the action tensors and point the slots at them (no launch)."""
         env = self.env
         held = []
         for i, (agent, act) in enumerate(zip(env.agents, actions)):
@@ -105,20 +106,30 @@ class ActionIngest:
             held.append(act)
             self.args.agents[i].action = act.data_ptr()
         self._keep = held  # the launch is asynchronous: keep the inputs alive until the next call
+
+    def check(self):
+        """The reference asserts on the host (environment.py:621,651-653): one sync, not 2 per agent."""
+        flags = int(self.err.item())
+        if flags:
+            self.err.zero_()
+            assert not (flags & A.ACTION_ERR_NAN), "actions contain NaN"
+            raise AssertionError("Physical actions of an agent are out of its range")
+
+    def __call__(self, actions: List[Tensor], validate: bool):
+        env = self.env
+        self.prepare(actions)
         ft = env.world._packed_agent_ft()
         err = self.err.data_ptr() if validate else None
         _check(self.lib.vmas_env_ingest_actions(C.byref(self.args), env.num_envs, ft.data_ptr(), ft.shape[-1], err,
                                                 _stream(env.device)))
-        if validate:  # the reference asserts on the host (environment.py:621,651-653): one sync, not 2 per agent
-            flags = int(self.err.item())
-            if flags:
-                self.err.zero_()
-                assert not (flags & A.ACTION_ERR_NAN), "actions contain NaN"
-                raise AssertionError("Physical actions of an agent are out of its range")
+        if validate:
+            self.check()
 
 
 class _Post:
     """Shared plumbing of the per-scenario post-step kernels."""
+
+    kind = None  # A.POST_*: the post-step can also run as the epilogue of the physics kernel
 
     def __init__(self, env):
         self.env = env
@@ -163,7 +174,10 @@ class BalancePost(_Post):
         d.shaping_factor, d.fall_reward = sc.shaping_factor, sc.fall_reward
         self.desc = d
 
-    def __call__(self):
+    kind = A.POST_BALANCE
+
+    def prepare(self):
+        """(descriptor, buffers, what env.step returns) - outputs allocated, nothing launched."""
         sc = self.env.scenario
         obs, rew, done = self._outputs(16)
         if not self.static_outputs or getattr(self, "_info", None) is None:
@@ -175,10 +189,14 @@ class BalancePost(_Post):
         b.obs, b.rew, b.done = obs.data_ptr(), rew.data_ptr(), done.data_ptr()
         b.pos_rew, b.ground_rew, b.on_the_ground = (t.data_ptr() for t in self._info)
         b.limit = self._limit()
-        st, ld = self._state()
-        _check(self.lib.vmas_balance_post_step(C.byref(self.desc), C.byref(b), self.B, st, ld, _stream(self.dev)))
         infos = [{"pos_rew": sc.pos_rew, "ground_rew": sc.ground_rew} for _ in range(self.n)]
-        return list(obs.unbind(0)), list(rew.unbind(0)), done, infos
+        return self.desc, b, (list(obs.unbind(0)), list(rew.unbind(0)), done, infos)
+
+    def __call__(self):
+        desc, b, result = self.prepare()
+        st, ld = self._state()
+        _check(self.lib.vmas_balance_post_step(C.byref(desc), C.byref(b), self.B, st, ld, _stream(self.dev)))
+        return result
 
 
 class TransportPost(_Post):
@@ -206,7 +224,9 @@ class TransportPost(_Post):
             p.global_shaping = self.global_shaping[i]
             p.on_goal = self.on_goal[i]
 
-    def __call__(self):
+    kind = A.POST_TRANSPORT
+
+    def prepare(self):
         sc = self.env.scenario
         for i, p in enumerate(sc.packages):  # reset() may have rebound them
             if p.global_shaping.data_ptr() != self.global_shaping[i].data_ptr():
@@ -220,10 +240,14 @@ class TransportPost(_Post):
         b.global_shaping, b.on_goal = self.global_shaping.data_ptr(), self.on_goal.data_ptr()
         b.obs, b.rew, b.done = obs.data_ptr(), rew.data_ptr(), done.data_ptr()
         b.limit = self._limit()
-        st, ld = self._state()
-        _check(self.lib.vmas_transport_post_step(C.byref(self.desc), C.byref(b), self.B, st, ld, _stream(self.dev)))
         sc.rew = rew[0]
-        return list(obs.unbind(0)), list(rew.unbind(0)), done, [{} for _ in range(self.n)]
+        return self.desc, b, (list(obs.unbind(0)), list(rew.unbind(0)), done, [{} for _ in range(self.n)])
+
+    def __call__(self):
+        desc, b, result = self.prepare()
+        st, ld = self._state()
+        _check(self.lib.vmas_transport_post_step(C.byref(desc), C.byref(b), self.B, st, ld, _stream(self.dev)))
+        return result
 
 
 class NavigationPost(_Post):
