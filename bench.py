@@ -247,20 +247,22 @@ def main():
                 from vectorizedmultiagentsimulator_amd.environment import make_env
 
                 env = make_env("balance", num_envs=args.num_envs, device=device, seed=0, validate_actions=False,
-                               graph=True, n_agents=args.n_agents)
+                               n_agents=args.n_agents)
                 acts = [env.get_random_action(a) for a in env.agents]
-                for _ in range(5):
+                for _ in range(400):  # (the first few hundred steps carry one-time costs)
                     env.step(acts)
                 torch.cuda.synchronize()
                 te = time.perf_counter()
-                for _ in range(200):
+                for _ in range(1000):
                     env.step(acts)
                 torch.cuda.synchronize()
-                te = (time.perf_counter() - te) / 200
+                te = (time.perf_counter() - te) / 1000
                 out["end_to_end_env_step"] = {
                     "value": args.num_envs / te, "unit": "env-steps/s", "us_per_step": te * 1e6,
-                    "note": "make_env('balance').step(): action ingest + World.step + fused overlap queries + "
-                            "observation/reward/done, replayed as one HIP graph; NOT the headline value",
+                    "launches_per_step": 1 if env._one_launch else None,
+                    "note": "make_env('balance').step() from Python with fresh output tensors every step: action "
+                            "ingest (prologue) + World.step + reward/observation/done/info (epilogue) in ONE kernel "
+                            "launch (vmas_world_step_env); NOT the headline value",
                 }
             except Exception as e:  # never let the informational leg break the bench line
                 out["end_to_end_env_step"] = {"error": repr(e)}

@@ -143,6 +143,7 @@ int vmas_navigation_post_step(const VmasNavigationDesc* desc, const VmasNavigati
  * `ingest` may be NULL (agent_ft already holds the forces); `post_desc` / `post_buffers` point to the
  * VmasBalance* / VmasTransport* pair selected by `post_kind`.  Navigation's post-step needs the
  * LIDAR and the batch-global collision mask of the NEW state and stays a separate launch. */
+#define VMAS_POST_NONE 0 /* prologue only (post_desc / post_buffers NULL): actions -> forces -> World.step() */
 #define VMAS_POST_BALANCE 1
 #define VMAS_POST_TRANSPORT 2
 int vmas_world_step_env(VmasWorld* w, float* state, float* agent_ft, int64_t ld, const VmasStepArgs* args /* may be NULL */,

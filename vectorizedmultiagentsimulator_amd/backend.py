@@ -182,7 +182,8 @@ class HipWorld:
         rc = self.lib.vmas_world_step_env(
             self._h, self._dptr(self.state), self._dptr(self.agent_ft), self.ld, args,
             C.byref(ingest_args) if ingest_args is not None else None, self._dptr(err_flags), int(post_kind),
-            C.cast(C.pointer(post_desc), C.c_void_p), C.cast(C.pointer(post_buffers), C.c_void_p), self._stream(stream),
+            C.cast(C.pointer(post_desc), C.c_void_p) if post_desc is not None else None,
+            C.cast(C.pointer(post_buffers), C.c_void_p) if post_buffers is not None else None, self._stream(stream),
         )
         if rc != 0:
             raise VmasHipError(A.last_error())

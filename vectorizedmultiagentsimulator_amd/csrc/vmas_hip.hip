@@ -135,7 +135,7 @@ struct DevStepArgs {
 
 // The Environment.step() stages fused around the physics (vmas_world_step_env): action ingest as the
 // kernel's prologue, one scenario's reward / observation / done as its epilogue on the LDS tile.
-enum { ENV_NONE = 0, ENV_BALANCE = 1, ENV_TRANSPORT = 2 };
+enum { ENV_NONE = 0, ENV_BALANCE = 1, ENV_TRANSPORT = 2, ENV_INGEST = 3 };  // 3: prologue only
 struct DevEnv {
   int32_t has_ingest;
   int32_t scratch_off;  // floats from the LDS base to the epilogue's scratch (after the step's own LDS)
@@ -1379,7 +1379,9 @@ int vmas_world_step_env(VmasWorld* w, float* state, float* agent_ft, int64_t ld,
   if (!w) return fail("vmas_world_step_env: null world");
   if (args && (args->first_substep != 0 || args->n_substeps > 0))
     return fail("vmas_world_step_env: partial substep ranges cannot carry an epilogue");
-  if (!post_desc || !post_buffers) return fail("vmas_world_step_env: null post-step descriptor");
+  if (post_kind != VMAS_POST_NONE && (!post_desc || !post_buffers))
+    return fail("vmas_world_step_env: null post-step descriptor");
+  if (post_kind == VMAS_POST_NONE && !ingest) return fail("vmas_world_step_env: neither actions nor a post-step given");
   DevEnv env{};
   env.err_flags = err_flags;
   for (int a = 0; a < VMAS_ENV_MAX_AGENTS; ++a) env.slot_of_agent[a] = -1;
@@ -1412,6 +1414,7 @@ int vmas_world_step_env(VmasWorld* w, float* state, float* agent_ft, int64_t ld,
                      transport_scratch_floats(0, d->n_packages),
                      transport_scratch_floats(1, d->n_packages) - transport_scratch_floats(0, d->n_packages));
   }
+  if (post_kind == VMAS_POST_NONE) return step_impl(w, state, agent_ft, ld, args, stream, 1, 0, &env, ENV_INGEST, 0, 0);
   return fail("vmas_world_step_env: post_kind %d has no fused epilogue", post_kind);
 }
 
@@ -1451,10 +1454,12 @@ static int step_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld, co
   if (get_sched(w, w->lanes, &S)) return -1;
   hipStream_t s = (hipStream_t)stream;
   if (env_kind == ENV_NONE) return launch_any_level<ENV_NONE>(w, S, state, agent_ft, ld, a, NoEnv{}, 0, s);
-  if (S->nw < 2) return fail("vmas_world_step_env: the fused epilogue needs at least 2 waves per tile");
+  if (S->nw < 2 && env_kind != ENV_INGEST)
+    return fail("vmas_world_step_env: the fused epilogue needs at least 2 waves per tile");
   env->scratch_off = (int32_t)(S->lds_bytes / sizeof(float));
   const size_t extra = (scratch_fixed + scratch_per_wave * S->nw) * sizeof(float);
   if (env_kind == ENV_BALANCE) return launch_any_level<ENV_BALANCE>(w, S, state, agent_ft, ld, a, *env, extra, s);
+  if (env_kind == ENV_INGEST) return launch_any_level<ENV_INGEST>(w, S, state, agent_ft, ld, a, *env, 0, s);
   return launch_any_level<ENV_TRANSPORT>(w, S, state, agent_ft, ld, a, *env, extra, s);
 }
 

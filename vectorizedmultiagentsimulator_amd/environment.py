@@ -57,7 +57,7 @@ class Environment:
         self.seed(seed)
         self.reset(return_observations=False)
         self._ingest = self._post = None
-        self._one_launch = False
+        self._one_launch = self._ingest_in_step = False
         self._setup_fused()
 
     def _setup_fused(self):
@@ -82,11 +82,13 @@ class Environment:
         # the whole step as ONE launch (vmas_world_step_env): ingest = prologue, post-step = epilogue of
         # the physics kernel.  Needs the hooks between the stages to be the base class no-ops.
         w = self.world
-        self._one_launch = (
-            self._ingest is not None and self._post is not None and self._post.kind is not None
-            and type(self.scenario).pre_step is BaseScenario.pre_step
-            and type(self.scenario).post_step is BaseScenario.post_step
+        self._ingest_in_step = (  # action ingest as the physics kernel's prologue
+            self._ingest is not None and type(self.scenario).pre_step is BaseScenario.pre_step
             and not w.exact_broad_phase and w.dim_c == 0
+        )
+        self._one_launch = (
+            self._ingest_in_step and self._post is not None and self._post.kind is not None
+            and type(self.scenario).post_step is BaseScenario.post_step
         )
 
     batch_dim = property(lambda self: self.num_envs)
@@ -181,6 +183,10 @@ class Environment:
         return self._step_eager(actions)
 
     def _step_graphed(self, actions):
+        if self._one_launch:  # the whole step already is a single kernel: nothing to capture
+            return self._step_eager(actions)
+        if self._ingest_in_step and self._post is not None:
+            return self._step_graphed_post(actions)
         if self._graph is None:
             assert self.device.type == "cuda", "graph=True needs a GPU device"
             assert not self.validate_actions, "graph=True needs validate_actions=False (the asserts are host syncs)"
@@ -189,18 +195,57 @@ class Environment:
                                     for a in self.agents]
             for s_, a in zip(self._static_actions, actions):
                 s_.copy_(a.reshape(s_.shape))
+            persistent = self._persistent_tensors()
+            saved = [t.clone() for t in persistent]
             side = torch.cuda.Stream(self.device)
             side.wait_stream(torch.cuda.current_stream(self.device))
-            with torch.cuda.stream(side):  # warm-up on a side stream (allocations, lazy inits)
+            with torch.cuda.stream(side):  # warm-up on a side stream (allocations, lazy inits) ...
                 for _ in range(3):
                     self._step_eager(self._static_actions)
             torch.cuda.current_stream(self.device).wait_stream(side)
+            for t, s_ in zip(persistent, saved):  # ... undone: this call makes exactly one step, like any other
+                t.copy_(s_)
             self._graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph):
                 self._static_out = self._step_eager(self._static_actions)
-            return self._static_out  # the capture itself does not execute: the caller sees the warm-up state
-        for s_, a in zip(self._static_actions, actions):
-            s_.copy_(a.reshape(s_.shape))
+        else:
+            for s_, a in zip(self._static_actions, actions):
+                s_.copy_(a.reshape(s_.shape))
+        self._graph.replay()
+        return self._static_out
+
+    def _persistent_tensors(self):
+        """Everything a step reads and writes: the packed world state, the step counter and the scenario's
+        in-place tensors (``scenario.keep``)."""
+        ts = [self.world._packed_state(), self.world._packed_agent_ft(), self.steps]
+        for obj in [self.scenario] + list(self.world.entities):
+            ts += [getattr(obj, n) for n in sorted(getattr(obj, "_kept_names", ()))]
+        return ts
+
+    def _step_graphed_post(self, actions):
+        """Prologue + physics as one eager launch (it reads the caller's action tensors directly - no
+        copies into static buffers), the launches after it (LIDAR, collision mask, post-step kernel) as one
+        HIP-graph replay."""
+        assert len(actions) == self.n_agents, f"Expecting actions for {self.n_agents}, got {len(actions)} actions"
+        self._ingest.prepare(actions)
+        self.world.step_env(self._ingest.args, self._ingest.err if self.validate_actions else None, 0, None, None)
+        if self.validate_actions:
+            self._ingest.check()
+        self.scenario.post_step()
+        if self._graph is None:
+            dev = self.device
+            persistent = self._post.persistent_tensors() + [self.steps]
+            saved = [t.clone() for t in persistent]
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):  # warm-up on a side stream (allocations, lazy inits) ...
+                self._post()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            for t, s_ in zip(persistent, saved):  # ... undone: it advanced the shaping terms and the step counter
+                t.copy_(s_)
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._static_out = self._post()
         self._graph.replay()
         return self._static_out
 
@@ -215,12 +260,18 @@ class Environment:
             if self.validate_actions:
                 self._ingest.check()
             return result
-        if self._ingest is not None:
-            self._ingest(actions, self.validate_actions)
+        if self._ingest_in_step:
+            self._ingest.prepare(actions)
+            self.world.step_env(self._ingest.args, self._ingest.err if self.validate_actions else None, 0, None, None)
+            if self.validate_actions:
+                self._ingest.check()
         else:
-            self._ingest_torch(actions)
-        self.scenario.pre_step()
-        self.world.step()
+            if self._ingest is not None:
+                self._ingest(actions, self.validate_actions)
+            else:
+                self._ingest_torch(actions)
+            self.scenario.pre_step()
+            self.world.step()
         self.scenario.post_step()
         self._lidar_cache = None
         if self._post is not None:  # one launch: reward, observation, done, info, step counter

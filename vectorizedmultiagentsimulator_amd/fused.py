@@ -140,6 +140,10 @@ class _Post:
         self.static_outputs = False
         self._out = None
 
+    def persistent_tensors(self) -> List[Tensor]:
+        """Scenario tensors the kernel reads AND writes (shaping terms ...)."""
+        raise NotImplementedError
+
     def _limit(self) -> A.StepLimit:
         lim = A.StepLimit()
         lim.steps = self.env.steps.data_ptr()
@@ -175,6 +179,9 @@ class BalancePost(_Post):
         self.desc = d
 
     kind = A.POST_BALANCE
+
+    def persistent_tensors(self):
+        return [self.env.scenario.global_shaping]
 
     def prepare(self):
         """(descriptor, buffers, what env.step returns) - outputs allocated, nothing launched."""
@@ -225,6 +232,9 @@ class TransportPost(_Post):
             p.on_goal = self.on_goal[i]
 
     kind = A.POST_TRANSPORT
+
+    def persistent_tensors(self):
+        return [self.global_shaping, self.on_goal]
 
     def prepare(self):
         sc = self.env.scenario
@@ -280,10 +290,16 @@ class NavigationPost(_Post):
             s = agents[0].sensors[0]
             d.n_rays, d.lidar_range = s._angles.shape[0], s._max_range
         self.desc = d
+        self._side = None
         self.obs_dim = 4 + 2 * (self.n if sc.observe_all_goals else 1) + (d.n_rays if sc.collisions else 0)
         self.pos_shaping = torch.stack([a.pos_shaping for a in agents]).contiguous()
-        for i, a in enumerate(agents):
-            a.pos_shaping = self.pos_shaping[i]
+        self._shaping_rows = list(self.pos_shaping.unbind(0))
+        self._shaping_ptrs = [r.data_ptr() for r in self._shaping_rows]
+        for a, row in zip(agents, self._shaping_rows):
+            a.pos_shaping = row
+        self._buf = A.NavigationBuffers()
+        self._buf.pos_shaping = self.pos_shaping.data_ptr()
+        self._buf.limit = self._limit()
         if sc.collisions:  # (i, j) -> index in the world's static pair list, for World.collides' global reduction
             spec = w.spec
             where = {}
@@ -291,37 +307,51 @@ class NavigationPost(_Post):
                 where[(p.a, p.b)] = where[(p.b, p.a)] = k
             table = [[where.get((a._index, b._index), -1) for b in agents] for a in agents]
             self.pair_index = torch.tensor(table, dtype=torch.int32, device=self.dev).contiguous()
+            self._buf.pair_index = self.pair_index.data_ptr()
+
+    def persistent_tensors(self):
+        return [self.pos_shaping]
 
     def __call__(self):
         env, sc, w = self.env, self.env.scenario, self.env.world
         agents = w.agents
-        for i, a in enumerate(agents):  # reset() may have rebound it
-            if a.pos_shaping.data_ptr() != self.pos_shaping[i].data_ptr():
-                self.pos_shaping[i].copy_(a.pos_shaping)
-                a.pos_shaping = self.pos_shaping[i]
+        for a, row, ptr in zip(agents, self._shaping_rows, self._shaping_ptrs):  # reset() may have rebound it
+            if a.pos_shaping.data_ptr() != ptr:
+                row.copy_(a.pos_shaping)
+                a.pos_shaping = row
         obs, rew, done = self._outputs(self.obs_dim)
         if not self.static_outputs or getattr(self, "_terms", None) is None:
             self._terms = (torch.empty(self.n, self.B, device=self.dev), torch.empty(self.B, device=self.dev),
                            torch.empty(self.B, device=self.dev), torch.empty(self.n, self.B, device=self.dev))
         agent_pos_rew, sc.pos_rew, sc.final_rew, col = self._terms
-        b = A.NavigationBuffers()
-        b.pos_shaping = self.pos_shaping.data_ptr()
+        b = self._buf
         b.obs, b.rew, b.done = obs.data_ptr(), rew.data_ptr(), done.data_ptr()
         b.agent_pos_rew, b.pos_rew, b.final_rew, b.collision_rew = (
             agent_pos_rew.data_ptr(), sc.pos_rew.data_ptr(), sc.final_rew.data_ptr(), col.data_ptr())
+        main = torch.cuda.current_stream(self.dev)
         if sc.collisions:
-            lidar = w.cast_rays_all()  # [n_sensors, max_rays, ld] of the post-step state
+            # the batch-global collision mask (a short latency-bound kernel) runs beside the LIDAR cast on a
+            # second stream: both only read the new state
+            be = w._get_backend()
+            if self._side is None:
+                self._side = torch.cuda.Stream(self.dev)
+                self._fork, self._join = torch.cuda.Event(), torch.cuda.Event()
+            self._fork.record(main)
+            self._side.wait_event(self._fork)
+            pair_any = be.pair_mask(stream=self._side)
+            self._join.record(self._side)
+            lidar = be.cast_rays(stream=main)  # [n_sensors, max_rays, ld] of the post-step state
             env._lidar_cache = sc._lidar_cache = lidar
-            pair_any = w._get_backend().pair_mask()
+            main.wait_event(self._join)
             b.lidar, b.lidar_max_rays = lidar.data_ptr(), lidar.shape[1]
-            b.pair_any, b.pair_index = pair_any.data_ptr(), self.pair_index.data_ptr()
-        b.limit = self._limit()
-        st, ld = self._state()
-        _check(self.lib.vmas_navigation_post_step(C.byref(self.desc), C.byref(b), self.B, st, ld, _stream(self.dev)))
-        infos = []
-        for i, a in enumerate(agents):
-            a.pos_rew, a.agent_collision_rew = agent_pos_rew[i], col[i]
-        for i, a in enumerate(env.agents):
-            infos.append({"pos_rew": sc.pos_rew if sc.shared_rew else a.pos_rew, "final_rew": sc.final_rew,
-                          "agent_collisions": a.agent_collision_rew})
+            b.pair_any = pair_any.data_ptr()
+        b.limit.steps = env.steps.data_ptr()
+        st = w._packed_state()
+        _check(self.lib.vmas_navigation_post_step(C.byref(self.desc), C.byref(b), self.B, st.data_ptr(), st.shape[-1],
+                                                  main.cuda_stream))
+        pos_rews, cols = agent_pos_rew.unbind(0), col.unbind(0)
+        for a, pr, c in zip(agents, pos_rews, cols):
+            a.pos_rew, a.agent_collision_rew = pr, c
+        infos = [{"pos_rew": sc.pos_rew if sc.shared_rew else a.pos_rew, "final_rew": sc.final_rew,
+                  "agent_collisions": a.agent_collision_rew} for a in env.agents]
         return list(obs.unbind(0)), list(rew.unbind(0)), done, infos

@@ -73,6 +73,7 @@ def keep(obj, name: str, value: Tensor) -> Tensor:
         cur.copy_(value)
         return cur
     setattr(obj, name, value.clone())
+    obj.__dict__.setdefault("_kept_names", set()).add(name)  # Environment snapshots these around a graph warm-up
     return getattr(obj, name)
 
 
