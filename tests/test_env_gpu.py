@@ -90,3 +90,6 @@ def test_rollout_collect_and_single_rank_gather():
     assert torch.isfinite(buf["obs"]).all()
     g = gather_rollout(buf, EnvShard(128, 0, 1))
     assert all(torch.equal(g[k], buf[k]) for k in buf)
+    env = make_env("balance", num_envs=128, device="cuda:0", seed=2, n_agents=3, validate_actions=False, max_steps=5)
+    buf = collect(env, lambda obs: [env.get_random_action(a) for a in env.agents], 12, auto_reset=True)
+    assert buf["done"][4].all() and buf["done"][9].all() and not buf["done"][5].any()  # restarted by the time limit

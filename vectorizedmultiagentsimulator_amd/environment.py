@@ -117,6 +117,39 @@ class Environment:
         self._lidar_cache = None
         return [o[index] for o in self._observations()] if return_observations else None
 
+    def reset_where(self, mask: Tensor, return_observations: bool = True):
+        """Reset exactly the environments where ``mask`` [num_envs] is True - all of them at once, on the
+        device, without a host sync.  (The reference only has ``reset_at(i)``, one Python call per
+        environment - SURVEY.md section 8f-4; a rollout over 32 768 environments resets hundreds per step.)
+
+        A fresh initial state is drawn for every environment by the scenario's own vectorised reset and
+        blended in where the mask is set: the packed world state, the agent forces, the step counter and the
+        scenario's in-place tensors (``scenario.keep``).  Unmasked environments keep their bits."""
+        mask = mask.to(self.device).reshape(self.num_envs).bool()
+        persistent = self._persistent_tensors()
+        saved = [t.clone() for t in persistent]
+        self.scenario.env_reset_world_at(env_index=None)
+        self.steps.zero_()
+        after = self._persistent_tensors()
+        assert len(after) == len(saved) and all(a.data_ptr() == p.data_ptr() for a, p in zip(after, persistent)), (
+            "a full reset must update the scenario's persistent tensors in place (scenario.keep)")
+        B = self.num_envs
+        ld = persistent[0].shape[-1]
+        mask_ld = torch.zeros(ld, dtype=torch.bool, device=self.device)
+        mask_ld[:B] = mask
+        for k, (t, old) in enumerate(zip(persistent, saved)):
+            if k < 2:  # the packed state / agent forces [.., .., ld]: environment = last axis
+                m = mask_ld
+            elif t.shape[0] == B:
+                m = mask.reshape((B,) + (1,) * (t.dim() - 1))
+            else:
+                assert t.shape[-1] == B, f"cannot locate the environment axis of a tensor of shape {tuple(t.shape)}"
+                m = mask
+            t.copy_(torch.where(m, t, old))
+        self.world.invalidate_queries()
+        self._lidar_cache = None
+        return self._observations() if return_observations else None
+
     # ------------------------------------------------------------------ actions
     def get_agent_action_size(self, agent: Agent) -> int:
         return agent.action_size if self.continuous_actions else 1

@@ -16,8 +16,10 @@ from .shard import EnvShard, RolloutGather
 
 
 def collect(env, policy: Callable[[List[Tensor]], List[Tensor]], n_steps: int,
-            obs: Optional[List[Tensor]] = None) -> Dict[str, Tensor]:
-    """Returns {"obs": [T, b, A, D], "rew": [T, b, A], "done": [T, b]} for this shard."""
+            obs: Optional[List[Tensor]] = None, auto_reset: bool = False) -> Dict[str, Tensor]:
+    """Returns {"obs": [T, b, A, D], "rew": [T, b, A], "done": [T, b]} for this shard.  ``auto_reset``:
+    environments that report done are restarted in place (``Environment.reset_where``, no host sync) and
+    the policy sees their fresh observation at the next step; obs[t] is what step t returned."""
     if obs is None:
         obs = env.reset()
     A = len(env.agents)
@@ -35,6 +37,8 @@ def collect(env, policy: Callable[[List[Tensor]], List[Tensor]], n_steps: int,
         out["obs"][t] = torch.stack(obs, dim=1)
         out["rew"][t] = torch.stack(rews, dim=1)
         out["done"][t] = dones
+        if auto_reset:
+            obs = env.reset_where(dones)
     return out
 
 
