@@ -6,7 +6,8 @@ import torch
 from vectorizedmultiagentsimulator_amd.environment import make_env
 name = sys.argv[1] if len(sys.argv) > 1 else "balance"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32768
-kw = {"balance": dict(n_agents=4), "transport": {}, "navigation": dict(n_agents=8)}[name]
+kw = {"balance": dict(n_agents=4), "transport": {}, "navigation": dict(n_agents=8),
+      "football": dict(n_blue_agents=5, n_red_agents=5, ai_red_agents=False)}[name]
 only = os.environ.get("ONLY")  # e.g. ONLY=fused-eager
 for fused in (False, True):
     for graph in (False, True):

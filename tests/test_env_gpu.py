@@ -8,7 +8,7 @@ from golden_util import compare_state, ulp_sensitivity
 pytestmark = pytest.mark.gpu
 
 CASES = [("balance", dict(n_agents=4), 16), ("transport", {}, 11), ("transport", dict(n_packages=2), 18),
-         ("navigation", dict(n_agents=8), 18)]
+         ("navigation", dict(n_agents=8), 18), ("football", dict(n_blue_agents=5, n_red_agents=5, ai_red_agents=False), 88)]
 
 
 @pytest.mark.parametrize("name,kw,obs_dim", CASES)
@@ -52,7 +52,8 @@ def test_discrete_actions_map_like_the_reference():
 
 
 @pytest.mark.parametrize("fused", [False, None])
-@pytest.mark.parametrize("name,kw", [("balance", dict(n_agents=4)), ("transport", {}), ("navigation", dict(n_agents=4))])
+@pytest.mark.parametrize("name,kw", [("balance", dict(n_agents=4)), ("transport", {}), ("navigation", dict(n_agents=4)),
+                                     ("football", dict(n_blue_agents=3, n_red_agents=3, ai_red_agents=False))])
 def test_graph_captured_step_equals_eager(name, kw, fused):
     """Environment(graph=True) gives the same observations / rewards / dones as the eager path, step after
     step, from the very first call (the capture's warm-up steps are undone).  fused=False: the whole

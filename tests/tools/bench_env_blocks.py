@@ -4,7 +4,8 @@ sys.path.insert(0, ".")
 import torch
 from vectorizedmultiagentsimulator_amd.environment import make_env
 name = sys.argv[1] if len(sys.argv) > 1 else "balance"
-kw = {"balance": dict(n_agents=4), "transport": {}, "navigation": dict(n_agents=8)}[name]
+kw = {"balance": dict(n_agents=4), "transport": {}, "navigation": dict(n_agents=8),
+      "football": dict(n_blue_agents=5, n_red_agents=5, ai_red_agents=False)}[name]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32768
 env = make_env(name, num_envs=B, device="cuda:0", seed=0, validate_actions=False, **kw)
 print("one_launch", env._one_launch)
