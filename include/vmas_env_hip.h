@@ -36,13 +36,29 @@ typedef struct VmasActionSlot {
   int32_t action_size;   /* 2 = Holonomic (force), 3 = HolonomicWithRotation (force + torque) */
   int32_t agent_index;   /* row block of agent_ft */
   float u_range[3];      /* Agent.action.u_range per dimension (core.py:414-517) */
-  float u_multiplier[3]; /* Agent.action.u_multiplier per dimension */
+  float u_multiplier[3]; /* Agent.action.u_multiplier per dimension; a scenario's sign flip (football's red
+                            team acts in a mirrored frame, football.py:1050-1057) is folded in as a negative factor */
 } VmasActionSlot;
+
+/* A scripted agent (Agent(action_script=...), core.py:966-982) whose script is known to the library:
+ * its action is computed on the device from the world state instead of by a Python callback. */
+#define VMAS_ENV_MAX_SCRIPTS 4
+#define VMAS_SCRIPT_FOOTBALL_BALL 1 /* football.py:1620-1680: impulse off the pitch border, damped by |vel.y| */
+typedef struct VmasAgentScript {
+  int32_t kind;        /* VMAS_SCRIPT_* */
+  int32_t agent_index; /* row block of agent_ft that receives the force */
+  int32_t entity;      /* entity whose state drives the script (the scripted agent itself) */
+  float* u_out;        /* [batch, 2] or NULL: agent.action.u */
+  float params[8];     /* FOOTBALL_BALL: 2 * agent_size, pitch_width / 2, pitch_length / 2, goal_size / 2
+                          (evaluated in double by the host, like the Python expressions of the reference) */
+} VmasAgentScript;
 
 typedef struct VmasIngestArgs {
   int32_t n_agents;
   int32_t clamp;         /* Environment(clamp_actions=...) : clamp to +-u_range instead of asserting */
   VmasActionSlot agents[VMAS_ENV_MAX_AGENTS];
+  int32_t n_scripts;
+  VmasAgentScript scripts[VMAS_ENV_MAX_SCRIPTS];
 } VmasIngestArgs;
 
 #define VMAS_ACTION_ERR_NAN 1u          /* environment.py:621 */
@@ -52,8 +68,8 @@ typedef struct VmasIngestArgs {
  * agent_ft[agent][0:2] = clamp?(action[:, 0:2]) * u_multiplier, [2] likewise when action_size
  * is 3.  `err_flags` (one uint32, may be NULL) gets VMAS_ACTION_ERR_* OR-ed in where the
  * reference would have raised an AssertionError; the host decides when to look at it. */
-int vmas_env_ingest_actions(const VmasIngestArgs* args, int32_t batch, float* agent_ft, int64_t ld,
-                            uint32_t* err_flags, void* stream);
+int vmas_env_ingest_actions(const VmasIngestArgs* args, int32_t batch, const float* state /* scripts only, else NULL */,
+                            float* agent_ft, int64_t ld, uint32_t* err_flags, void* stream);
 
 /* ---------------------------------------------------------------- step counter / time limit */
 typedef struct VmasStepLimit {
@@ -133,6 +149,34 @@ typedef struct VmasNavigationBuffers {
 
 int vmas_navigation_post_step(const VmasNavigationDesc* desc, const VmasNavigationBuffers* buf, int32_t batch,
                               const float* state, int64_t ld, void* stream);
+
+/* ---------------------------------------------------------------- football (football.py:1121-1515)
+ * the learning-vs-learning game (no heuristic AI, no shooting): agents = blue 0..n_blue-1, red 0..n_red-1,
+ * ball, as consecutive entities from `agent0` and consecutive agent_ft blocks from 0. */
+typedef struct VmasFootballDesc {
+  int32_t n_blue, n_red;
+  int32_t agent0;  /* entity index of blue agent 0; the ball is entity agent0 + n_blue + n_red */
+  int32_t observe_teammates, observe_adversaries, dense_reward;
+  float goal_x;      /* pitch_length / 2 + ball_size / 2: the goal line for the ball and |x| of both goal points */
+  float goal_half;   /* goal_size / 2 */
+  float touch_dist;  /* agent_size + ball_size + 1e-2 (info["touching_ball"]) */
+  float pos_shaping_factor_ball_goal, pos_shaping_factor_agent_ball, distance_to_ball_trigger, scoring_reward;
+} VmasFootballDesc;
+
+typedef struct VmasFootballBuffers {
+  float* pos_shaping;       /* [4][batch] in/out: ball.pos_shaping_blue, _red, pos_shaping_agent_blue, _red */
+  float* obs;               /* [n_blue + n_red][batch][obs_dim], obs_dim = 16 + 8 * observed others */
+  float* rew;               /* [n_blue + n_red][batch] */
+  float* terms;             /* [9][batch] out: sparse_reward_blue, pos_rew_blue, pos_rew_red, pos_rew_agent_blue,
+                               pos_rew_agent_red, min_agent_dist_to_ball_blue, _red, dist_ball_to_goal_blue, _red */
+  uint8_t* touching;        /* [2][batch] out: info["touching_ball"] blue, red */
+  uint8_t* done;            /* [batch] */
+  const float* agent_ft;    /* the agent forces of the step (agent.state.force is observed) */
+  VmasStepLimit limit;
+} VmasFootballBuffers;
+
+int vmas_football_post_step(const VmasFootballDesc* desc, const VmasFootballBuffers* buf, int32_t batch,
+                            const float* state, int64_t ld, void* stream);
 
 /* ---------------------------------------------------------------- the whole step in one launch
  * World.step() with the action ingest as its prologue and one scenario's post-step as its

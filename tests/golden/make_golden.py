@@ -352,7 +352,7 @@ def rollout_envstep(name, scenario, B, T, toward=None, nudges=(), seed=0, max_st
     g = torch.Generator().manual_seed(4321)
     ents = {e.name: e for e in env.world.entities}
     states, actions, obs_l, rew_l, done_l = [pack_state(env.world)], [], [], [], []
-    state_in = []
+    state_in, ft_l = [], []
     infos = {}
     for t in range(T):
         for (when, who, where, off, envs) in nudges:
@@ -371,13 +371,14 @@ def rollout_envstep(name, scenario, B, T, toward=None, nudges=(), seed=0, max_st
             acts.append(r * a.action.u_range_tensor)
         obs, rews, dones, info = env.step(acts)
         states.append(pack_state(env.world))
+        ft_l.append(pack_ft(env.world))  # agent.state.force / torque as the step left them (football observes them)
         actions.append(torch.stack(acts).numpy().copy())
         obs_l.append(torch.stack(obs).numpy().copy())
         rew_l.append(torch.stack(rews).numpy().copy())
         done_l.append(dones.numpy().copy())
         for k in info[0]:
             infos.setdefault(k, []).append(torch.stack([i[k] for i in info]).numpy().copy())
-    out = dict(state=np.stack(states), state_in=np.stack(state_in), actions=np.stack(actions), obs=np.stack(obs_l), rew=np.stack(rew_l),
+    out = dict(state=np.stack(states), state_in=np.stack(state_in), ft=np.stack(ft_l), actions=np.stack(actions), obs=np.stack(obs_l), rew=np.stack(rew_l),
                done=np.stack(done_l), kwargs=np.array(repr(kw)), max_steps=np.array(-1 if max_steps is None else max_steps))
     for k, v in infos.items():
         out["info_" + k] = np.stack(v)
@@ -405,6 +406,14 @@ FIXTURES.update({
     "envstep_navigation_n8_individual": lambda: rollout_envstep(
         "envstep_navigation_n8_individual", "navigation", 6, 40, toward="agent_0", n_agents=8, shared_rew=False,
         observe_all_goals=True, max_steps=35),
+    "envstep_football": lambda: rollout_envstep(
+        "envstep_football", "football", 8, 40, toward="Ball", n_blue_agents=5, n_red_agents=5, ai_red_agents=False,
+        max_steps=36,
+        nudges=[(8, "Ball", "Red Net", (-0.03, 0.05), (0, 1)), (16, "Ball", "Blue Net", (0.02, -0.1), (2,)),
+                (20, "Ball", "Right Top Wall", (-0.01, 0.1), (3, 4)), (24, "Ball", "agent_red_1", (0.03, 0.0), (5,))]),
+    "envstep_football_3v2": lambda: rollout_envstep(
+        "envstep_football_3v2", "football", 6, 30, toward="Ball", n_blue_agents=3, n_red_agents=2, ai_red_agents=False,
+        nudges=[(10, "Ball", "Blue Net", (0.0, 0.0), (0,)), (12, "Ball", "Red Net", (-0.04, 0.0), (1,))]),
     "envstep_navigation_nocoll": lambda: rollout_envstep(
         "envstep_navigation_nocoll", "navigation", 6, 30, n_agents=3, collisions=False,
         nudges=[(10, f"agent_{i}", f"goal {i}", (0.0, 0.02), (0,)) for i in range(3)]),

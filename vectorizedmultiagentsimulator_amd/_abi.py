@@ -151,8 +151,18 @@ class ActionSlot(C.Structure):
     ]
 
 
+ENV_MAX_SCRIPTS = 4
+SCRIPT_FOOTBALL_BALL = 1
+
+
+class AgentScript(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("agent_index", C.c_int32), ("entity", C.c_int32), ("u_out", C.c_void_p),
+                ("params", C.c_float * 8)]
+
+
 class IngestArgs(C.Structure):
-    _fields_ = [("n_agents", C.c_int32), ("clamp", C.c_int32), ("agents", ActionSlot * ENV_MAX_AGENTS)]
+    _fields_ = [("n_agents", C.c_int32), ("clamp", C.c_int32), ("agents", ActionSlot * ENV_MAX_AGENTS),
+                ("n_scripts", C.c_int32), ("scripts", AgentScript * ENV_MAX_SCRIPTS)]
 
 
 class StepLimit(C.Structure):
@@ -189,6 +199,23 @@ class TransportBuffers(C.Structure):
     _fields_ = [
         ("global_shaping", C.c_void_p), ("on_goal", C.c_void_p), ("obs", C.c_void_p), ("rew", C.c_void_p),
         ("done", C.c_void_p), ("limit", StepLimit),
+    ]
+
+
+class FootballDesc(C.Structure):
+    _fields_ = [
+        ("n_blue", C.c_int32), ("n_red", C.c_int32), ("agent0", C.c_int32),
+        ("observe_teammates", C.c_int32), ("observe_adversaries", C.c_int32), ("dense_reward", C.c_int32),
+        ("goal_x", C.c_float), ("goal_half", C.c_float), ("touch_dist", C.c_float),
+        ("pos_shaping_factor_ball_goal", C.c_float), ("pos_shaping_factor_agent_ball", C.c_float),
+        ("distance_to_ball_trigger", C.c_float), ("scoring_reward", C.c_float),
+    ]
+
+
+class FootballBuffers(C.Structure):
+    _fields_ = [
+        ("pos_shaping", C.c_void_p), ("obs", C.c_void_p), ("rew", C.c_void_p), ("terms", C.c_void_p),
+        ("touching", C.c_void_p), ("done", C.c_void_p), ("agent_ft", C.c_void_p), ("limit", StepLimit),
     ]
 
 
@@ -232,6 +259,7 @@ EXPORTED_SYMBOLS = (
     "vmas_balance_post_step",
     "vmas_transport_post_step",
     "vmas_navigation_post_step",
+    "vmas_football_post_step",
     "vmas_world_step_env",
 )
 
@@ -277,11 +305,12 @@ def load_library() -> C.CDLL:
     lib.vmas_world_get_lanes_per_env.restype = C.c_int
     lib.vmas_world_step_bytes_per_env.argtypes = [vp]
     lib.vmas_world_step_bytes_per_env.restype = i64
-    lib.vmas_env_ingest_actions.argtypes = [C.POINTER(IngestArgs), i32, vp, i64, vp, vp]
+    lib.vmas_env_ingest_actions.argtypes = [C.POINTER(IngestArgs), i32, vp, vp, i64, vp, vp]
     lib.vmas_env_ingest_actions.restype = C.c_int
     for fn, d, b in ((lib.vmas_balance_post_step, BalanceDesc, BalanceBuffers),
                      (lib.vmas_transport_post_step, TransportDesc, TransportBuffers),
-                     (lib.vmas_navigation_post_step, NavigationDesc, NavigationBuffers)):
+                     (lib.vmas_navigation_post_step, NavigationDesc, NavigationBuffers),
+                     (lib.vmas_football_post_step, FootballDesc, FootballBuffers)):
         fn.argtypes = [C.POINTER(d), C.POINTER(b), i32, vp, i64, vp]
         fn.restype = C.c_int
     lib.vmas_world_step_env.argtypes = [vp, vp, vp, i64, C.POINTER(StepArgs), C.POINTER(IngestArgs), vp, i32, vp, vp, vp]

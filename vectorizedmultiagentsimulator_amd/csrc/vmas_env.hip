@@ -45,12 +45,15 @@ namespace {
 constexpr int kMaxOwn = VMAS_ENV_MAX_AGENTS / 4;  // agents one wave can own (blocks have >= 4 waves)
 
 // ------------------------------------------------------------------------------------ ingest
-__global__ __launch_bounds__(256) void ingest_kernel(const VmasIngestArgs args, int batch, float* __restrict__ agent_ft,
-                                                     long ld, uint32_t* __restrict__ err) {
+__global__ __launch_bounds__(256) void ingest_kernel(const VmasIngestArgs args, int batch, const float* __restrict__ state,
+                                                     float* __restrict__ agent_ft, long ld, uint32_t* __restrict__ err) {
   const long env = (long)blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t bad = 0;
   float u[3];
-  ingest_slot(args.agents[blockIdx.y], args.clamp, env, env < batch, agent_ft, ld, u, bad);
+  if ((int)blockIdx.y < args.n_agents)
+    ingest_slot(args.agents[blockIdx.y], args.clamp, env, env < batch, agent_ft, ld, u, bad);
+  else
+    run_script(args.scripts[blockIdx.y - args.n_agents], state, env, env < batch, agent_ft, ld, u);
   if (err != nullptr && bad != 0) atomicOr(err, bad);
 }
 
@@ -186,6 +189,152 @@ __global__ __launch_bounds__(512) void navigation_post_kernel(const VmasNavigati
   }
 }
 
+// ------------------------------------------------------------------------------------ football
+// football.py:1121-1515 (learning-vs-learning game).  An observation is 16 + 8 * (observed others) floats
+// - 88 for 5 v 5, 3.5 KB per environment and step over the ten agents: this kernel is a streaming
+// writer.  LDS: rows[(n + 1) * 6][64] (pos, vel, force of every agent and of the ball) | chunk tiles
+// [nw][64][33]: a wave transposes its agent's observation 32 columns at a time, so one store instruction
+// covers two 128-byte row segments.
+constexpr int kChunk = 32;
+
+__global__ __launch_bounds__(512) void football_post_kernel(const VmasFootballDesc d, const VmasFootballBuffers o, int batch,
+                                                            const float* __restrict__ state, long ld) {
+  extern __shared__ float lds[];
+  const TileCtx C(batch);
+  const int n = d.n_blue + d.n_red, ball = n;  // slot of the ball
+  float* rows = lds;                            // rows[(slot * 6 + k) * 64 + lane], k: px py vx vy fx fy
+  float* slab = lds + (n + 1) * 6 * 64 + C.wave * 64 * (kChunk + 1);
+  float* my_row = slab + C.lane * (kChunk + 1);
+
+  stage_rows(C, rows, (n + 1) * 6, [&](int i) {
+    const int slot = i / 6, k = i - slot * 6;
+    return k < 4 ? state[((long)(d.agent0 + slot) * 6 + k) * ld + C.e] : o.agent_ft[((long)slot * 3 + (k - 4)) * ld + C.e];
+  });
+  float prev[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) prev[k] = C.live ? o.pos_shaping[(long)k * batch + C.env] : 0.f;  // (every wave: all need the team rewards)
+  const float steps_in = C.wave == 0 ? load_steps(o.limit, C) : 0.f;
+  __syncthreads();
+  auto G = [&](int slot, int k) { return rows[(slot * 6 + k) * 64 + C.lane]; };
+  auto P2 = [&](int slot, int k) { return V(G(slot, k), G(slot, k + 1)); };
+  const v2 bpos = P2(ball, 0), bvel = P2(ball, 2), bforce = P2(ball, 4);
+
+  // ---- reward football.py:1121-1219 (wave 0 only stores; every wave needs the two team rewards)
+  const bool over_right = bpos.x > d.goal_x, over_left = bpos.x < -d.goal_x;
+  const bool in_mouth = bpos.y <= d.goal_half && bpos.y >= -d.goal_half;
+  const bool blue_score = over_right && in_mouth, red_score = over_left && in_mouth;
+  const float sparse_blue = d.scoring_reward * (blue_score ? 1.f : 0.f) - d.scoring_reward * (red_score ? 1.f : 0.f);
+  float dense[2] = {0.f, 0.f}, term[8];
+  if (d.dense_reward) {
+    const bool ball_moving = vnorm(bvel) > 1e-6f;
+#pragma unroll
+    for (int team = 0; team < 2; ++team) {  // 0 blue (attacks the right goal), 1 red
+      const v2 goal = V(team == 0 ? d.goal_x : -d.goal_x, 0.f);
+      const float shaping = vnorm(bpos - goal) * d.pos_shaping_factor_ball_goal;  // reward_ball_to_goal
+      float min_dist = kInf;                                                       // reward_all_agent_to_ball
+      const int a0 = team == 0 ? 0 : d.n_blue, a1 = team == 0 ? d.n_blue : n;
+      for (int a = a0; a < a1; ++a) min_dist = min_t(min_dist, vnorm(P2(a, 0) - bpos));
+      const float shaping_agent = min_dist * d.pos_shaping_factor_agent_ball;
+      term[team] = shaping; term[2 + team] = shaping_agent; term[4 + team] = min_dist;
+      term[6 + team] = prev[team] - shaping;                                       // ball.pos_rew_<team>
+      const bool quiet = (min_dist < d.distance_to_ball_trigger) || ball_moving;
+      const float rew_agent = quiet ? 0.f : prev[2 + team] - shaping_agent;
+      dense[team] = term[6 + team] + rew_agent;
+      if (C.wave == 0 && C.live) {
+        o.pos_shaping[(long)team * batch + C.env] = shaping;
+        o.pos_shaping[(long)(2 + team) * batch + C.env] = shaping_agent;
+        o.terms[(long)(1 + team) * batch + C.env] = term[6 + team];
+        o.terms[(long)(3 + team) * batch + C.env] = rew_agent;
+        o.terms[(long)(5 + team) * batch + C.env] = min_dist;
+        o.terms[(long)(7 + team) * batch + C.env] = shaping / d.pos_shaping_factor_ball_goal;
+        o.touching[(long)team * batch + C.env] = min_dist <= d.touch_dist ? 1 : 0;
+      }
+    }
+  }
+  if (C.wave == 0) {
+    const bool done = apply_step_limit(o.limit, C, steps_in, blue_score || red_score);
+    if (C.live) {
+      o.terms[C.env] = sparse_blue;
+      o.done[C.env] = done ? 1 : 0;
+    }
+  }
+  const float rew_team[2] = {sparse_blue + dense[0], (0.f - sparse_blue) + dense[1]};
+
+  // ---- observation football.py:1221-1460, agents wave, wave + nw, ...; red agents see everything mirrored in x
+  const int n_adv_b = d.observe_adversaries ? d.n_red : 0, n_adv_r = d.observe_adversaries ? d.n_blue : 0;
+  for (int a = C.wave; a < n; a += C.nw) {
+    const bool blue = a < d.n_blue;
+    const float sx = blue ? 1.f : -1.f;
+    auto M = [&](v2 v) { return V(v.x * sx, v.y); };
+    const v2 goal = V(blue ? d.goal_x : -d.goal_x, 0.f);
+    const v2 pos = P2(a, 0), vel = P2(a, 2), force = P2(a, 4);
+    const int n_adv = blue ? n_adv_b : n_adv_r;
+    const int mate0 = blue ? 0 : d.n_blue, n_team = blue ? d.n_blue : d.n_red;
+    const int n_mates = d.observe_teammates ? n_team - 1 : 0;
+    const int D = 16 + 8 * (n_adv + n_mates);
+    // column c of the observation (see the layout in the reference's observation_base)
+    auto column = [&](int c) -> float {
+      if (c < 16) {
+        v2 v;
+        switch (c >> 1) {
+          case 0: v = M(force); break;
+          case 1: v = M(pos - bpos); break;
+          case 2: v = M(vel - bvel); break;
+          case 3: v = M(bpos - goal); break;
+          case 4: v = M(bvel); break;
+          case 5: v = M(bforce); break;
+          case 6: v = M(pos - goal); break;
+          default: v = M(vel); break;
+        }
+        return (c & 1) ? v.y : v.x;
+      }
+      const int j = (c - 16) >> 3, k = (c - 16) & 7;
+      int other;
+      if (j < n_adv) {
+        other = (blue ? d.n_blue : 0) + j;  // the other team, in order
+      } else {
+        other = mate0 + (j - n_adv);
+        if (other >= a) other += 1;         // my team, skipping myself
+      }
+      v2 v;
+      switch (k >> 1) {
+        case 0: v = M(pos - P2(other, 0)); break;
+        case 1: v = M(vel - P2(other, 2)); break;
+        case 2: v = M(P2(other, 2)); break;
+        default: v = M(P2(other, 4)); break;
+      }
+      return (k & 1) ? v.y : v.x;
+    };
+    float* out = o.obs + ((long)a * batch + C.b0) * D;
+    for (int c0 = 0; c0 < D; c0 += kChunk) {
+      const int w = D - c0 < kChunk ? D - c0 : kChunk;
+      for (int c = 0; c < w; ++c) my_row[c] = column(c0 + c);  // (uniform c: the switch is a scalar branch)
+      wave_lds_fence();
+      const int total = C.n_rows * w;
+      const float inv = 1.f / (float)w;
+      for (int i0 = C.lane; i0 < total; i0 += 256) {
+        float v[4];
+        int dst[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int i = i0 + 64 * k < total ? i0 + 64 * k : total - 1;
+          int r = (int)((float)i * inv);
+          int c = i - r * w;
+          if (c >= w) { c -= w; r += 1; }
+          if (c < 0) { c += w; r -= 1; }
+          v[k] = slab[r * (kChunk + 1) + c];
+          dst[k] = r * D + c0 + c;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (i0 + 64 * k < total) out[dst[k]] = v[k];
+      }
+      wave_lds_fence();
+    }
+    if (C.live) o.rew[(long)a * batch + C.env] = rew_team[blue ? 0 : 1];
+  }
+}
+
 int check_launch(const char* what) {
   const hipError_t e = hipGetLastError();
   if (e == hipSuccess) return 0;
@@ -227,6 +376,12 @@ int check_ingest_args(const VmasIngestArgs* args, int32_t batch, const float* ag
     if (!s.action || s.action_size < 2 || s.action_size > 3 || s.agent_index < 0 || s.agent_index >= VMAS_ENV_MAX_AGENTS)
       return host_fail("action ingest: malformed action slot");
   }
+  if (args->n_scripts < 0 || args->n_scripts > VMAS_ENV_MAX_SCRIPTS) return host_fail("action ingest: n_scripts out of range");
+  for (int i = 0; i < args->n_scripts; ++i) {
+    const VmasAgentScript& s = args->scripts[i];
+    if (s.kind != VMAS_SCRIPT_FOOTBALL_BALL || s.agent_index < 0 || s.agent_index >= VMAS_ENV_MAX_AGENTS || s.entity < 0)
+      return host_fail("action ingest: malformed agent script");
+  }
   return 0;
 }
 
@@ -266,12 +421,13 @@ int check_transport_args(const VmasTransportDesc* d, const VmasTransportBuffers*
 
 extern "C" {
 
-int vmas_env_ingest_actions(const VmasIngestArgs* args, int32_t batch, float* agent_ft, int64_t ld, uint32_t* err_flags,
-                            void* stream) {
+int vmas_env_ingest_actions(const VmasIngestArgs* args, int32_t batch, const float* state, float* agent_ft, int64_t ld,
+                            uint32_t* err_flags, void* stream) {
   if (check_ingest_args(args, batch, agent_ft, ld)) return -1;
-  if (args->n_agents == 0) return 0;
-  hipLaunchKernelGGL(ingest_kernel, dim3((batch + 255) / 256, args->n_agents), dim3(256), 0, (hipStream_t)stream, *args,
-                     batch, agent_ft, (long)ld, err_flags);
+  if (args->n_scripts > 0 && !state) return host_fail("vmas_env_ingest_actions: agent scripts need the world state");
+  if (args->n_agents + args->n_scripts == 0) return 0;
+  hipLaunchKernelGGL(ingest_kernel, dim3((batch + 255) / 256, args->n_agents + args->n_scripts), dim3(256), 0,
+                     (hipStream_t)stream, *args, batch, state, agent_ft, (long)ld, err_flags);
   return check_launch("vmas_env_ingest_actions");
 }
 
@@ -316,6 +472,19 @@ int vmas_navigation_post_step(const VmasNavigationDesc* d, const VmasNavigationB
   const int nw = nw_env ? nw_env : (d->n_agents > 4 && lds_for(8) <= 40 * 1024 ? 8 : 4);
   const size_t lds = lds_for(nw);
   LAUNCH_POST(navigation_post_kernel, nw, lds, "vmas_navigation_post_step", *d, *o, batch, state, (long)ld);
+}
+
+int vmas_football_post_step(const VmasFootballDesc* d, const VmasFootballBuffers* o, int32_t batch, const float* state,
+                            int64_t ld, void* stream) {
+  if (!d || !o || !state) return host_fail("vmas_football_post_step: null argument");
+  if (batch <= 0 || ld < batch) return host_fail("vmas_football_post_step: bad batch / ld");
+  if (d->n_blue < 1 || d->n_red < 1 || d->n_blue + d->n_red + 1 > VMAS_ENV_MAX_AGENTS || d->agent0 < 0)
+    return host_fail("vmas_football_post_step: team sizes out of range");
+  if (!o->pos_shaping || !o->obs || !o->rew || !o->terms || !o->touching || !o->done || !o->agent_ft)
+    return host_fail("vmas_football_post_step: null buffer");
+  const int nw = 4;
+  const size_t lds = ((size_t)(d->n_blue + d->n_red + 1) * 6 * 64 + (size_t)nw * 64 * (kChunk + 1)) * sizeof(float);
+  LAUNCH_POST(football_post_kernel, nw, lds, "vmas_football_post_step", *d, *o, batch, state, (long)ld);
 }
 
 }  // extern "C"

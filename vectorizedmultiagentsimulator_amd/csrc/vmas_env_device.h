@@ -314,4 +314,28 @@ VD void ingest_slot(const VmasActionSlot& S, int clamp, long env, bool live, flo
   }
 }
 
+// A scripted agent whose script the library knows (VmasAgentScript): same contract as ingest_slot.
+VD void run_script(const VmasAgentScript& S, const float* __restrict__ state, long env, bool live,
+                   float* __restrict__ agent_ft, long ld, float u_out[3]) {
+  u_out[0] = u_out[1] = u_out[2] = 0.f;
+  if (!live) return;
+  if (S.kind == VMAS_SCRIPT_FOOTBALL_BALL) {  // ball_action_script football.py:1620-1680
+    const float* E = state + (long)S.entity * 6 * ld + env;
+    const float x = E[0], y = E[ld], vy = E[3 * ld];
+    const float thr = S.params[0], half_w = S.params[1], half_l = S.params[2], half_goal = S.params[3];
+    auto near = [&](float d) { return 1.f - min_t(d, thr) / thr; };  // 1 at the border, 0 from `thr` away
+    const float upper = near(half_w - y), lower = near(half_w + y), right = near(half_l - x), left = near(half_l + x);
+    const float slow = 1.f - min_t(fabsf(vy), 0.3f) / 0.3f;  // (the reference damps BOTH components by |vel.y|)
+    float ax = ((left - right) * slow) * 0.05f;
+    const float ay = ((lower - upper) * slow) * 0.05f;
+    if (y < half_goal && y > -half_goal) ax = 0.f;  // no push along x in front of a goal mouth
+    u_out[0] = ax;
+    u_out[1] = ay;
+  }
+  for (int k = 0; k < 2; ++k) {
+    agent_ft[((long)S.agent_index * 3 + k) * ld + env] = u_out[k];
+    if (S.u_out != nullptr) S.u_out[env * 2 + k] = u_out[k];
+  }
+}
+
 }  // namespace vmas

@@ -139,7 +139,7 @@ enum { ENV_NONE = 0, ENV_BALANCE = 1, ENV_TRANSPORT = 2, ENV_INGEST = 3 };  // 3
 struct DevEnv {
   int32_t has_ingest;
   int32_t scratch_off;  // floats from the LDS base to the epilogue's scratch (after the step's own LDS)
-  int8_t slot_of_agent[VMAS_ENV_MAX_AGENTS];  // agent index -> action slot, -1 = no action for it
+  int8_t slot_of_agent[VMAS_ENV_MAX_AGENTS];  // agent index -> action slot >= 0 | -1 nothing | -2 - i: script i
   uint32_t* err_flags;
   VmasIngestArgs ingest;
   union {
@@ -438,6 +438,11 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
         ingest_slot(S, E.ingest.clamp, env, live, agent_ft, ld, f3, bad);
         if (S.action_size < 3) f3[2] = live ? src[2 * ld] : 0.f;  // Holonomic leaves the torque alone
         if (E.err_flags != nullptr && bad != 0) atomicOr(E.err_flags, bad);
+        return;
+      }
+      if (slot <= -2) {  // a scripted agent: its action comes from the state it is about to be stepped from
+        run_script(E.ingest.scripts[-2 - slot], state, env, live, agent_ft, ld, f3);
+        f3[2] = live ? src[2 * ld] : 0.f;
         return;
       }
     }
@@ -1393,6 +1398,12 @@ int vmas_world_step_env(VmasWorld* w, float* state, float* agent_ft, int64_t ld,
       const int a = ingest->agents[i].agent_index;
       if (a >= w->base.nA) return fail("vmas_world_step_env: action slot %d names agent %d of %d", i, a, w->base.nA);
       env.slot_of_agent[a] = (int8_t)i;
+    }
+    for (int i = 0; i < ingest->n_scripts; ++i) {
+      const int a = ingest->scripts[i].agent_index;
+      if (a >= w->base.nA || ingest->scripts[i].entity >= w->base.nE)
+        return fail("vmas_world_step_env: agent script %d names agent %d / entity %d", i, a, ingest->scripts[i].entity);
+      env.slot_of_agent[a] = (int8_t)(-2 - i);
     }
   }
   if (post_kind == VMAS_POST_BALANCE) {

@@ -48,10 +48,12 @@ class ActionIngest:
             return "discrete actions"
         if len(env.agents) > A.ENV_MAX_AGENTS:
             return "too many agents"
-        if env.world.scripted_agents:
-            return "scripted agents"
         from .scenario import BaseScenario
-        if type(env.scenario).process_action is not BaseScenario.process_action:
+        sc = env.scenario
+        known = {id(s["agent"]) for s in sc.fused_agent_scripts()} if hasattr(sc, "fused_agent_scripts") else set()
+        if any(id(a) not in known for a in env.world.scripted_agents) or len(known) > A.ENV_MAX_SCRIPTS:
+            return "scripted agents"
+        if type(sc).process_action is not BaseScenario.process_action and not hasattr(sc, "fused_action_factors"):
             return "scenario overrides process_action"
         for a in env.agents:
             if type(a.dynamics) not in (Holonomic, HolonomicWithRotation):
@@ -78,11 +80,25 @@ class ActionIngest:
             s.agent_index = a._agent_index
             for k, v in enumerate(_per_dim(a.action.u_range, n)):
                 s.u_range[k] = v
+            # what scenario.process_action does to the scaled action, when it is a per-dimension factor
+            extra = env.scenario.fused_action_factors(a) if hasattr(env.scenario, "fused_action_factors") else None
             for k, v in enumerate(_per_dim(a.action.u_multiplier, n)):
-                s.u_multiplier[k] = v
+                s.u_multiplier[k] = v * (extra[k] if extra is not None else 1.0)
             u = torch.zeros(B, n, device=env.device, dtype=torch.float32)
             s.u_out = u.data_ptr()
             a.action.u = u  # agent.action.u stays readable by scenario code
+            self.u.append(u)
+        scripts = env.scenario.fused_agent_scripts() if hasattr(env.scenario, "fused_agent_scripts") else []
+        self.args.n_scripts = len(scripts)
+        for i, sp in enumerate(scripts):  # scripted agents whose script runs on the device
+            s = self.args.scripts[i]
+            agent = sp["agent"]
+            s.kind, s.agent_index, s.entity = sp["kind"], agent._agent_index, agent._index
+            for k, v in enumerate(sp["params"]):
+                s.params[k] = v
+            u = torch.zeros(B, 2, device=env.device, dtype=torch.float32)
+            s.u_out = u.data_ptr()
+            agent.action.u = u
             self.u.append(u)
         self.err = torch.zeros(1, device=env.device, dtype=torch.int32)
         self._ft = w._packed_agent_ft()
@@ -120,8 +136,8 @@ class ActionIngest:
         self.prepare(actions)
         ft = env.world._packed_agent_ft()
         err = self.err.data_ptr() if validate else None
-        _check(self.lib.vmas_env_ingest_actions(C.byref(self.args), env.num_envs, ft.data_ptr(), ft.shape[-1], err,
-                                                _stream(env.device)))
+        _check(self.lib.vmas_env_ingest_actions(C.byref(self.args), env.num_envs, env.world._packed_state().data_ptr(),
+                                                ft.data_ptr(), ft.shape[-1], err, _stream(env.device)))
         if validate:
             self.check()
 
@@ -354,4 +370,87 @@ class NavigationPost(_Post):
             a.pos_rew, a.agent_collision_rew = pr, c
         infos = [{"pos_rew": sc.pos_rew if sc.shared_rew else a.pos_rew, "final_rew": sc.final_rew,
                   "agent_collisions": a.agent_collision_rew} for a in env.agents]
+        return list(obs.unbind(0)), list(rew.unbind(0)), done, infos
+
+
+class FootballPost(_Post):
+    """football.py:1121-1515 for the learning-vs-learning game (scenarios/football.py)."""
+
+    TERMS = ("sparse_reward_blue", "pos_rew_blue", "pos_rew_red", "pos_rew_agent_blue", "pos_rew_agent_red",
+             "min_agent_dist_to_ball_blue", "min_agent_dist_to_ball_red", "dist_ball_to_goal_blue", "dist_ball_to_goal_red")
+
+    def __init__(self, env):
+        super().__init__(env)
+        sc, w = env.scenario, env.world
+        d = A.FootballDesc()
+        d.n_blue, d.n_red, d.agent0 = len(sc.blue_agents), len(sc.red_agents), sc.blue_agents[0]._index
+        team = sc.blue_agents + sc.red_agents + [sc.ball]
+        assert [a._index for a in team] == list(range(d.agent0, d.agent0 + len(team)))
+        assert [a._agent_index for a in team] == list(range(len(team)))
+        d.observe_teammates, d.observe_adversaries = int(sc.observe_teammates), int(sc.observe_adversaries)
+        d.dense_reward = int(sc.dense_reward)
+        d.goal_x = sc.pitch_length / 2 + sc.ball_size / 2
+        d.goal_half = sc.goal_size / 2
+        d.touch_dist = sc.agent_size + sc.ball_size + 1e-2
+        d.pos_shaping_factor_ball_goal = sc.pos_shaping_factor_ball_goal
+        d.pos_shaping_factor_agent_ball = sc.pos_shaping_factor_agent_ball
+        d.distance_to_ball_trigger, d.scoring_reward = sc.distance_to_ball_trigger, sc.scoring_reward
+        self.desc = d
+        self.obs_dims = [16 + 8 * ((d.n_red if blue else d.n_blue) * d.observe_adversaries
+                                   + ((d.n_blue if blue else d.n_red) - 1) * d.observe_teammates)
+                         for blue in [True] * d.n_blue + [False] * d.n_red]
+        assert len(set(self.obs_dims)) == 1, "the fused kernel writes one [n_agents, batch, obs_dim] block"
+        self.obs_dim = self.obs_dims[0]
+        ball = sc.ball
+        names = ("pos_shaping_blue", "pos_shaping_red", "pos_shaping_agent_blue", "pos_shaping_agent_red")
+        self.pos_shaping = torch.stack([getattr(ball, n) for n in names]).contiguous()
+        self._shaping_rows = list(self.pos_shaping.unbind(0))
+        for n, row in zip(names, self._shaping_rows):  # the ball's shaping terms live in one [4, B] block
+            setattr(ball, n, row)
+        self._shaping_names = names
+
+    def persistent_tensors(self):
+        return [self.pos_shaping]
+
+    def __call__(self):
+        env, sc, w = self.env, self.env.scenario, self.env.world
+        ball = sc.ball
+        for n, row in zip(self._shaping_names, self._shaping_rows):  # reset() may have rebound them
+            cur = getattr(ball, n)
+            if cur.data_ptr() != row.data_ptr():
+                row.copy_(cur)
+                setattr(ball, n, row)
+        obs, rew, done = self._outputs(self.obs_dim)
+        if not self.static_outputs or getattr(self, "_terms", None) is None:
+            self._terms = (torch.empty(len(self.TERMS), self.B, device=self.dev),
+                           torch.empty(2, self.B, device=self.dev, dtype=torch.bool))
+        terms, touching = self._terms
+        b = A.FootballBuffers()
+        b.pos_shaping = self.pos_shaping.data_ptr()
+        b.obs, b.rew, b.done = obs.data_ptr(), rew.data_ptr(), done.data_ptr()
+        b.terms, b.touching = terms.data_ptr(), touching.data_ptr()
+        b.agent_ft = w._packed_agent_ft().data_ptr()
+        b.limit = self._limit()
+        st, ld = self._state()
+        _check(self.lib.vmas_football_post_step(C.byref(self.desc), C.byref(b), self.B, st, ld, _stream(self.dev)))
+        t = dict(zip(self.TERMS, terms.unbind(0)))
+        sc._sparse_reward_blue, sc._done = t["sparse_reward_blue"], done
+        ball.pos_rew_blue, ball.pos_rew_red = t["pos_rew_blue"], t["pos_rew_red"]
+        ball.pos_rew_agent_blue, ball.pos_rew_agent_red = t["pos_rew_agent_blue"], t["pos_rew_agent_red"]
+        sc.min_agent_dist_to_ball_blue, sc.min_agent_dist_to_ball_red = (
+            t["min_agent_dist_to_ball_blue"], t["min_agent_dist_to_ball_red"])
+        ball_pos = ball.state.pos
+        sparse_red = None
+        infos = []
+        for a in env.agents:
+            side = "blue" if a in sc.blue_agents else "red"
+            if side == "red" and sparse_red is None:
+                sparse_red = sc._sparse_reward_red = -t["sparse_reward_blue"]
+            infos.append({
+                "sparse_reward": t["sparse_reward_blue"] if side == "blue" else sparse_red,
+                "ball_goal_pos_rew": t[f"pos_rew_{side}"], "all_agent_ball_pos_rew": t[f"pos_rew_agent_{side}"],
+                "ball_pos": ball_pos, "dist_ball_to_goal": t[f"dist_ball_to_goal_{side}"],
+                "min_agent_dist_to_ball": t[f"min_agent_dist_to_ball_{side}"],
+                "touching_ball": touching[0 if side == "blue" else 1],
+            })
         return list(obs.unbind(0)), list(rew.unbind(0)), done, infos

@@ -315,3 +315,25 @@ class Scenario(BaseScenario):
             "min_agent_dist_to_ball": min_dist,
             "touching_ball": min_dist <= self.agent_size + self.ball_size + 1e-2,
         }
+
+    # ------------------------------------------------------------------ fused stages (fused.py)
+    def fused_action_factors(self, agent: Agent):
+        """What ``process_action`` does, as per-dimension factors for the fused action ingest."""
+        return [-1.0, 1.0] if agent in self.red_agents else None
+
+    def fused_agent_scripts(self):
+        """The scripted ball, for the device-side script (VMAS_SCRIPT_FOOTBALL_BALL)."""
+        from .. import _abi
+        return [dict(kind=_abi.SCRIPT_FOOTBALL_BALL, agent=self.ball,
+                     params=[self.agent_size * 2, self.pitch_width / 2, self.pitch_length / 2, self.goal_size / 2])]
+
+    def make_fused_post(self, env):
+        """reward + observation + done + info of every agent as one kernel (fused.FootballPost)."""
+        from .. import _abi
+        from ..fused import FootballPost
+        n = len(self.blue_agents) + len(self.red_agents)
+        same_dims = self.n_blue_agents == self.n_red_agents or not (self.observe_teammates or self.observe_adversaries) \
+            or (self.observe_teammates and self.observe_adversaries)
+        if not self.dense_reward or n + 1 > _abi.ENV_MAX_AGENTS or not same_dims:
+            return None
+        return FootballPost(env)
