@@ -260,7 +260,10 @@ __global__ __launch_bounds__(512) void football_post_kernel(const VmasFootballDe
   }
   const float rew_team[2] = {sparse_blue + dense[0], (0.f - sparse_blue) + dense[1]};
 
-  // ---- observation football.py:1221-1460, agents wave, wave + nw, ...; red agents see everything mirrored in x
+  // ---- observation football.py:1221-1460, agents wave, wave + nw, ...; red agents see everything mirrored in
+  //      x.  Written chunk by chunk - the 16 own/ball columns, then the observed others four at a time (32
+  //      columns) - through the wave's [64][33] LDS tile; a chunk leaves as float4 stores, two 128-byte row
+  //      segments per instruction.
   const int n_adv_b = d.observe_adversaries ? d.n_red : 0, n_adv_r = d.observe_adversaries ? d.n_blue : 0;
   for (int a = C.wave; a < n; a += C.nw) {
     const bool blue = a < d.n_blue;
@@ -270,66 +273,53 @@ __global__ __launch_bounds__(512) void football_post_kernel(const VmasFootballDe
     const v2 pos = P2(a, 0), vel = P2(a, 2), force = P2(a, 4);
     const int n_adv = blue ? n_adv_b : n_adv_r;
     const int mate0 = blue ? 0 : d.n_blue, n_team = blue ? d.n_blue : d.n_red;
-    const int n_mates = d.observe_teammates ? n_team - 1 : 0;
-    const int D = 16 + 8 * (n_adv + n_mates);
-    // column c of the observation (see the layout in the reference's observation_base)
-    auto column = [&](int c) -> float {
-      if (c < 16) {
-        v2 v;
-        switch (c >> 1) {
-          case 0: v = M(force); break;
-          case 1: v = M(pos - bpos); break;
-          case 2: v = M(vel - bvel); break;
-          case 3: v = M(bpos - goal); break;
-          case 4: v = M(bvel); break;
-          case 5: v = M(bforce); break;
-          case 6: v = M(pos - goal); break;
-          default: v = M(vel); break;
-        }
-        return (c & 1) ? v.y : v.x;
-      }
-      const int j = (c - 16) >> 3, k = (c - 16) & 7;
-      int other;
-      if (j < n_adv) {
-        other = (blue ? d.n_blue : 0) + j;  // the other team, in order
-      } else {
-        other = mate0 + (j - n_adv);
-        if (other >= a) other += 1;         // my team, skipping myself
-      }
-      v2 v;
-      switch (k >> 1) {
-        case 0: v = M(pos - P2(other, 0)); break;
-        case 1: v = M(vel - P2(other, 2)); break;
-        case 2: v = M(P2(other, 2)); break;
-        default: v = M(P2(other, 4)); break;
-      }
-      return (k & 1) ? v.y : v.x;
-    };
+    const int n_others = n_adv + (d.observe_teammates ? n_team - 1 : 0);
+    const int D = 16 + 8 * n_others;
     float* out = o.obs + ((long)a * batch + C.b0) * D;
-    for (int c0 = 0; c0 < D; c0 += kChunk) {
-      const int w = D - c0 < kChunk ? D - c0 : kChunk;
-      for (int c = 0; c < w; ++c) my_row[c] = column(c0 + c);  // (uniform c: the switch is a scalar branch)
+    auto put = [&](int c, v2 v) { my_row[c] = v.x; my_row[c + 1] = v.y; };
+    // the chunk [c0, c0 + w) of the tile -> out; w is a multiple of 8
+    auto flush = [&](int c0, int w) {
       wave_lds_fence();
-      const int total = C.n_rows * w;
-      const float inv = 1.f / (float)w;
-      for (int i0 = C.lane; i0 < total; i0 += 256) {
-        float v[4];
-        int dst[4];
+      const int w4 = w >> 2, total4 = C.n_rows * w4;
+      const float inv = 1.f / (float)w4;
+      for (int i0 = C.lane; i0 < total4; i0 += 128) {
+        float4 v[2];
+        int dst[2];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int i = i0 + 64 * k < total ? i0 + 64 * k : total - 1;
+        for (int k = 0; k < 2; ++k) {
+          const int i = i0 + 64 * k < total4 ? i0 + 64 * k : total4 - 1;
           int r = (int)((float)i * inv);
-          int c = i - r * w;
-          if (c >= w) { c -= w; r += 1; }
-          if (c < 0) { c += w; r -= 1; }
-          v[k] = slab[r * (kChunk + 1) + c];
-          dst[k] = r * D + c0 + c;
+          int c4 = i - r * w4;
+          if (c4 >= w4) { c4 -= w4; r += 1; }
+          if (c4 < 0) { c4 += w4; r -= 1; }
+          const float* src = slab + r * (kChunk + 1) + 4 * c4;
+          v[k] = make_float4(src[0], src[1], src[2], src[3]);
+          dst[k] = r * D + c0 + 4 * c4;
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (i0 + 64 * k < total) out[dst[k]] = v[k];
+        for (int k = 0; k < 2; ++k)
+          if (i0 + 64 * k < total4) *(float4*)(out + dst[k]) = v[k];
       }
       wave_lds_fence();
+    };
+    put(0, M(force)); put(2, M(pos - bpos)); put(4, M(vel - bvel)); put(6, M(bpos - goal));
+    put(8, M(bvel)); put(10, M(bforce)); put(12, M(pos - goal)); put(14, M(vel));
+    flush(0, 16);
+    for (int j0 = 0; j0 < n_others; j0 += 4) {
+      const int m = n_others - j0 < 4 ? n_others - j0 : 4;
+      for (int jj = 0; jj < m; ++jj) {
+        const int j = j0 + jj;
+        int other;
+        if (j < n_adv) {
+          other = (blue ? d.n_blue : 0) + j;  // the other team, in order
+        } else {
+          other = mate0 + (j - n_adv);
+          if (other >= a) other += 1;         // my team, skipping myself
+        }
+        const v2 opos = P2(other, 0), ovel = P2(other, 2), oforce = P2(other, 4);
+        put(8 * jj, M(pos - opos)); put(8 * jj + 2, M(vel - ovel)); put(8 * jj + 4, M(ovel)); put(8 * jj + 6, M(oforce));
+      }
+      flush(16 + 8 * j0, 8 * m);
     }
     if (C.live) o.rew[(long)a * batch + C.env] = rew_team[blue ? 0 : 1];
   }
