@@ -26,10 +26,14 @@ def mean(d, name):
     v=[float(r['Counter_Value']) for r in csv.DictReader(open(fs[0])) if 'step_kernel' in r['Kernel_Name'] and r['Counter_Name']==name]
     return sum(v)/len(v)
 f, w = mean('pmc3','FETCH_SIZE'), mean('pmc4','WRITE_SIZE')
-json.dump({"num_envs": 32768, "bytes_per_launch": (f + w) * 1024, "fetch_KiB": f, "write_KiB": w,
-           "note": "rocprofv3 FETCH_SIZE + WRITE_SIZE (KiB) per step_kernel launch, separate PMC passes, uncorrected: "
-                   "the guide's 2x FETCH correction is calibrated for 16 B/lane reads, ours are 4 B/lane rows; the state "
-                   "written by step k is still L2-resident when step k+1 reads it, so fetches stay below the 7.9 MB read"},
+FETCH_CAL, WRITE_CAL = 2.0, 1.0  # scripts/gpu_calibrate.sh: in our 4 B/lane coalesced pattern FETCH_SIZE reports 0.500 and
+                                  # WRITE_SIZE 1.000 of a known byte count (6 MiB cache-resident and 512 MiB streaming alike)
+json.dump({"num_envs": 32768, "bytes_per_launch": (f * FETCH_CAL + w * WRITE_CAL) * 1024, "fetch_KiB_raw": f, "write_KiB_raw": w,
+           "fetch_calibration": FETCH_CAL, "write_calibration": WRITE_CAL,
+           "note": "rocprofv3 FETCH_SIZE and WRITE_SIZE (KiB) per step_kernel launch, separate PMC passes, corrected as "
+                   "MI355X_MICROARCH.md prescribes (gfx950 FETCH_SIZE counts 64 B per 128-B request): calibrated in this "
+                   "kernel's own access pattern (4 B/lane coalesced rows) with scripts/gpu_calibrate.sh -> FETCH x2.000, "
+                   "WRITE x1.000"},
           open('gpurun_out/prof/latest_traffic.json','w'))
 print(open('gpurun_out/prof/latest_traffic.json').read())
 PY
