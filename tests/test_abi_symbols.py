@@ -118,3 +118,31 @@ def test_product_has_no_cpu_fallback():
             if f.endswith((".py", ".hip", ".h", ".sh")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "vmas_oracle" not in txt, f
+
+
+def test_env_entry_points_report_errors_not_throw(lib):
+    """include/vmas_env_hip.h: malformed arguments come back as -1 + message, without touching a GPU."""
+    import ctypes as C
+
+    args = _abi.IngestArgs()
+    args.n_agents = _abi.ENV_MAX_AGENTS + 1
+    assert lib.vmas_env_ingest_actions(C.byref(args), 8, None, C.c_void_p(64), 64, None, None) == -1
+    assert b"n_agents" in lib.vmas_last_error()
+    args.n_agents = 1  # slot 0 has no action pointer
+    assert lib.vmas_env_ingest_actions(C.byref(args), 8, None, C.c_void_p(64), 64, None, None) == -1
+    assert b"malformed action slot" in lib.vmas_last_error()
+    d, b = _abi.BalanceDesc(), _abi.BalanceBuffers()
+    assert lib.vmas_balance_post_step(C.byref(d), C.byref(b), 8, C.c_void_p(64), 64, None) == -1  # n_agents = 0
+    d.n_agents = 2
+    assert lib.vmas_balance_post_step(C.byref(d), C.byref(b), 8, C.c_void_p(64), 4, None) == -1  # ld < batch
+    assert b"ld" in lib.vmas_last_error()
+    assert lib.vmas_balance_post_step(C.byref(d), C.byref(b), 8, C.c_void_p(64), 64, None) == -1  # null buffers
+    assert b"null buffer" in lib.vmas_last_error()
+    t, tb = _abi.TransportDesc(), _abi.TransportBuffers()
+    t.n_agents, t.n_packages = 2, _abi.ENV_MAX_PACKAGES + 1
+    assert lib.vmas_transport_post_step(C.byref(t), C.byref(tb), 8, C.c_void_p(64), 64, None) == -1
+    n, nb = _abi.NavigationDesc(), _abi.NavigationBuffers()
+    assert lib.vmas_navigation_post_step(C.byref(n), C.byref(nb), 8, C.c_void_p(64), 64, None) == -1
+    f, fb = _abi.FootballDesc(), _abi.FootballBuffers()
+    assert lib.vmas_football_post_step(C.byref(f), C.byref(fb), 8, C.c_void_p(64), 64, None) == -1
+    assert lib.vmas_world_step_env(None, None, None, 64, None, None, None, 1, None, None, None) == -1

@@ -56,7 +56,9 @@ constexpr int TILE = 64;       // environments per block = lanes per wave
 constexpr int MAX_WAVES = 16;  // waves (workers) per tile (8 for the register-heavy box-box level)
 constexpr int ITEMS_LDS_BUDGET = 48 * 1024;  // stage the item descriptors in LDS when they fit
 constexpr int TASK_JOINT = 6;  // item type next to VMAS_PAIR_*
+constexpr float kSkipSlack = 1e-3f;  // fp slack of the conservative broad-phase distances
 constexpr int TASK_SSQ = 7;    // up to four sphere-sphere partners of one entity in one record
+constexpr int TASK_LSQ = 8;    // up to four lines against one (owning) sphere in one record
 constexpr int ROWF = TILE;     // floats per LDS row
 
 enum : uint32_t { IT_A_HOLLOW = 1u << 0, IT_B_HOLLOW = 1u << 1, IT_LOCK = 1u << 2 /* joint rotate == False */ };
@@ -261,6 +263,53 @@ __device__ __forceinline__ void eval_ssq(const uint32_t* p, const DevWorld& W, c
   for (int k = 0; k < 4; ++k) {
     if (needbits & (1u << k)) {
       const v2 f = contact_force(pe, po[k], rs[k], W.c_coll, W.k);
+      if (movable) F = F + f;
+    }
+  }
+}
+
+// Line-sphere pairs seen from the SPHERE (the owner; lines are mostly static walls), four lines to a record:
+//   w0: type, n, own offset, r + LINE_MIN_DIST   w1: line offsets 0|1, 2|3, trig offsets 0|1, 2|3 (16 bit each)
+//   w2: half lengths 0..3   w3: pair index 0|1<<16, 2|3<<16
+// Same arithmetic as the unpacked item (own(-cf(sphere, cp)) with the b-side sign flip == cf(sphere, cp) bit for
+// bit), one descriptor fetch and sixteen operand reads in flight instead of four dependent round trips.
+__device__ __forceinline__ void eval_lsq(const uint32_t* p, const DevWorld& W, const DevStepArgs& args,
+                                         const float* tile, bool may_skip, bool movable, v2& F) {
+  const uint4 w0 = ((const uint4*)p)[0], w1 = ((const uint4*)p)[1], w2 = ((const uint4*)p)[2], w3 = ((const uint4*)p)[3];
+  const int n = sgpr((int)w0.y);
+  const float* E = tile + (int)w0.z;
+  const float dist_min = __uint_as_float(w0.w);
+  const v2 ps = V(E[0], E[ROWF]);
+  const int lo[4] = {(int)(w1.x & 0xffffu), (int)(w1.x >> 16), (int)(w1.y & 0xffffu), (int)(w1.y >> 16)};
+  const int to[4] = {(int)(w1.z & 0xffffu), (int)(w1.z >> 16), (int)(w1.w & 0xffffu), (int)(w1.w >> 16)};
+  const float half[4] = {__uint_as_float(w2.x), __uint_as_float(w2.y), __uint_as_float(w2.z), __uint_as_float(w2.w)};
+  const int idx[4] = {(int)(w3.x & 0xffffu), (int)(w3.x >> 16), (int)(w3.y & 0xffffu), (int)(w3.y >> 16)};
+  v2 pl[4];
+  float cs[4], sn[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {  // unused slots repeat line 0 on the host: always valid rows
+    const float* L = tile + lo[k];
+    const float* T = tile + to[k];
+    pl[k] = V(L[0], L[ROWF]);
+    cs[k] = T[0];
+    sn[k] = T[ROWF];
+  }
+  uint32_t needbits = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float dx = pl[k].x - ps.x, dy = pl[k].y - ps.y;
+    const float m = half[k] + dist_min + kSkipSlack;  // bounding circles: beyond it the force is exactly 0
+    bool need = !(dx * dx + dy * dy > m * m) || !may_skip;
+    bool on = k < n;
+    if (args.pair_mask) on = on && ((args.pair_mask[sgpr(idx[k]) >> 5] >> (sgpr(idx[k]) & 31)) & 1u);
+    needbits |= (on && __any(need)) ? (1u << k) : 0u;
+  }
+  if (!needbits || (args.ablate & 32)) return;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (needbits & (1u << k)) {  // core.py:2341-2392
+      const v2 cp = closest_point_line<true>(pl[k], cs[k], sn[k], half[k], ps);
+      const v2 f = contact_force(ps, cp, dist_min, W.c_coll, W.k);
       if (movable) F = F + f;
     }
   }
@@ -611,8 +660,14 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
 #endif
       const int i1 = (args.ablate & 1) ? i0 : i1s;
       for (int ii = i0; ii < i1; ++ii) {
-        if (W.items_in_lds && sgpr((int)blob[W.b_items + ii * IW]) == TASK_SSQ) {
-          if (!(args.ablate & 16)) eval_ssq(blob + W.b_items + ii * IW, W, args, tile, may_skip, efl & VMAS_F_MOVABLE, F);
+        const int packed_type = W.items_in_lds ? sgpr((int)blob[W.b_items + ii * IW]) : 0;
+        if (packed_type >= TASK_SSQ) {  // packed records exist only in the LDS copy of the item list
+          if (!(args.ablate & 16)) {
+            if (LEVEL > 0 || packed_type == TASK_SSQ)  // (line-sphere records are only built for level-0 worlds)
+              eval_ssq(blob + W.b_items + ii * IW, W, args, tile, may_skip, efl & VMAS_F_MOVABLE, F);
+            else
+              eval_lsq(blob + W.b_items + ii * IW, W, args, tile, may_skip, efl & VMAS_F_MOVABLE, F);
+          }
           continue;
         }
         const ItemV K = W.items_in_lds ? load_item(blob + W.b_items + ii * IW) : item_from_global(W.items[ii]);
@@ -997,7 +1052,6 @@ static float type_cost(int type) {
 
 // forces vanish once shapes are farther apart than LINE_MIN_DIST ("per-environment
 // broad phase"); the slack absorbs the rounding of the closest-point arithmetic.
-constexpr float kSkipSlack = 1e-3f;
 
 static void build_items(const VmasWorldDesc* d, VmasWorld* w, const std::vector<int>& tr_row) {
   const VmasEntityDesc* E = d->entities;
@@ -1094,12 +1148,53 @@ static void build_items(const VmasWorldDesc* d, VmasWorld* w, const std::vector<
       }
       per[e].swap(packed);
     }
+    // ... and likewise the lines a SPHERE owner meets (its side of line-sphere pairs: force only, no torque) -
+    // in worlds of spheres, lines and boxes-vs-spheres only (kernel level 0, e.g. football's 110 wall pairs):
+    // the level-1/2 kernels are register-bound and do not carry the extra code
+    bool level0 = true;
+    for (int e = 0; e < nE; ++e)
+      for (const DevItem& t : per[e])
+        if (t.type == VMAS_PAIR_LL || t.type == VMAS_PAIR_BL || t.type == VMAS_PAIR_BB || t.type == TASK_JOINT) level0 = false;
+    for (int e = 0; e < nE && level0 && !getenv("VMAS_NO_LSQ"); ++e) {
+      std::vector<DevItem> packed;
+      size_t i = 0;
+      auto packable = [](const DevItem& it) {
+        return it.type == VMAS_PAIR_LS && it.side == 1 && it.oa >= 0 && it.oa < 65536 && it.tra >= 0 && it.tra < 65536;
+      };
+      while (i < per[e].size()) {
+        if (!packable(per[e][i])) { packed.push_back(per[e][i++]); continue; }
+        size_t j = i;
+        while (j < per[e].size() && packable(per[e][j]) && j - i < 4) ++j;
+        if (j - i < 2) { packed.push_back(per[e][i++]); continue; }  // a lone line is cheaper as a plain item
+        uint32_t wds[16] = {0};
+        auto fbits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+        const int n = (int)(j - i);
+        uint32_t lo[4], to[4], idx[4];
+        float half[4];
+        for (int k = 0; k < 4; ++k) {
+          const DevItem& it = per[e][i + (k < n ? k : 0)];
+          lo[k] = (uint32_t)it.oa; to[k] = (uint32_t)it.tra; half[k] = it.p0; idx[k] = (uint32_t)it.index;
+        }
+        wds[0] = TASK_LSQ; wds[1] = (uint32_t)n; wds[2] = (uint32_t)per[e][i].ob; wds[3] = fbits(per[e][i].p1);
+        wds[4] = lo[0] | (lo[1] << 16); wds[5] = lo[2] | (lo[3] << 16);
+        wds[6] = to[0] | (to[1] << 16); wds[7] = to[2] | (to[3] << 16);
+        for (int k = 0; k < 4; ++k) wds[8 + k] = fbits(half[k]);
+        wds[12] = idx[0] | (idx[1] << 16); wds[13] = idx[2] | (idx[3] << 16);
+        DevItem q;
+        memcpy(&q, wds, sizeof(q));
+        packed.push_back(q);
+        i = j;
+      }
+      per[e].swap(packed);
+    }
   }
   for (int e = 0; e < nE; ++e) {
     w->ent_item_begin[e] = (int)w->items.size();
     for (const DevItem& t : per[e]) {
       w->items.push_back(t);
-      w->item_cost.push_back(t.type == TASK_SSQ ? 40.f + 40.f * (float)t.side /* side word = n */ : type_cost(t.type));
+      w->item_cost.push_back(t.type == TASK_SSQ   ? 40.f + 40.f * (float)t.side /* side word = n */
+                             : t.type == TASK_LSQ ? 40.f + 70.f * (float)t.side
+                                                  : type_cost(t.type));
       if (t.type == VMAS_PAIR_BB) w->level = std::max(w->level, 2);
       if (t.type == VMAS_PAIR_LL || t.type == VMAS_PAIR_BL || t.type == TASK_JOINT) w->level = std::max(w->level, 1);
     }
