@@ -31,6 +31,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <map>
 
 #include "../../include/vmas_env_hip.h"
 #include "vmas_env_device.h"
@@ -337,8 +338,12 @@ template <class K>
 int ensure_lds(K kernel, size_t bytes, const char* what) {
   if (bytes <= 64 * 1024) return 0;
   if (bytes > 160 * 1024) return host_fail("observation too wide for one LDS tile");
+  static std::map<const void*, size_t> set_for;  // per kernel: the opt-in is sticky, ask once per size
+  size_t& have = set_for[(const void*)kernel];
+  if (have >= bytes) return 0;
   if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
     return host_fail(what);
+  have = bytes;
   return 0;
 }
 
