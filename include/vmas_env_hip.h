@@ -38,6 +38,9 @@ typedef struct VmasActionSlot {
   float u_range[3];      /* Agent.action.u_range per dimension (core.py:414-517) */
   float u_multiplier[3]; /* Agent.action.u_multiplier per dimension; a scenario's sign flip (football's red
                             team acts in a mirrored frame, football.py:1050-1057) is folded in as a negative factor */
+  const int64_t* action_index; /* discrete actions (Environment(continuous_actions=False), environment.py:657-705):
+                                  [batch] flat indices, decoded per dimension with `nvec`; NULL = continuous */
+  int32_t nvec[3];             /* Agent.discrete_action_nvec */
 } VmasActionSlot;
 
 /* A scripted agent (Agent(action_script=...), core.py:966-982) whose script is known to the library:

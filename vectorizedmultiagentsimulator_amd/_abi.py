@@ -148,6 +148,8 @@ class ActionSlot(C.Structure):
         ("agent_index", C.c_int32),
         ("u_range", C.c_float * 3),
         ("u_multiplier", C.c_float * 3),
+        ("action_index", C.c_void_p),
+        ("nvec", C.c_int32 * 3),
     ]
 
 

@@ -368,8 +368,11 @@ int check_ingest_args(const VmasIngestArgs* args, int32_t batch, const float* ag
   if (args->n_agents < 0 || args->n_agents > VMAS_ENV_MAX_AGENTS) return host_fail("action ingest: n_agents out of range");
   for (int a = 0; a < args->n_agents; ++a) {
     const VmasActionSlot& s = args->agents[a];
-    if (!s.action || s.action_size < 2 || s.action_size > 3 || s.agent_index < 0 || s.agent_index >= VMAS_ENV_MAX_AGENTS)
+    if ((!s.action && !s.action_index) || s.action_size < 2 || s.action_size > 3 || s.agent_index < 0 ||
+        s.agent_index >= VMAS_ENV_MAX_AGENTS)
       return host_fail("action ingest: malformed action slot");
+    for (int k = 0; s.action_index && k < s.action_size; ++k)
+      if (s.nvec[k] < 2) return host_fail("action ingest: discrete_action_nvec entries must be >= 2");
   }
   if (args->n_scripts < 0 || args->n_scripts > VMAS_ENV_MAX_SCRIPTS) return host_fail("action ingest: n_scripts out of range");
   for (int i = 0; i < args->n_scripts; ++i) {

@@ -299,10 +299,32 @@ VD void ingest_slot(const VmasActionSlot& S, int clamp, long env, bool live, flo
                     float u_out[3], uint32_t& bad) {
   u_out[0] = u_out[1] = u_out[2] = 0.f;
   if (!live) return;
+  long flat = 0;
+  if (S.action_index != nullptr) {  // flat index -> per-dimension index -> [-u_range, u_range] (environment.py:657-705)
+    flat = S.action_index[env];
+    long total = 1;
+    for (int k = 0; k < S.action_size; ++k) total *= S.nvec[k];
+    if (flat < 0 || flat >= total) {
+      bad |= VMAS_ACTION_ERR_OUT_OF_RANGE;
+      flat = 0;
+    }
+  }
   for (int k = 0; k < S.action_size; ++k) {
-    float u = S.action[env * S.action_size + k];
+    float u;
+    if (S.action_index != nullptr) {
+      long m = 1;
+      for (int j = k + 1; j < S.action_size; ++j) m *= S.nvec[j];
+      const int n = S.nvec[k];
+      int a = (int)(flat / m);
+      flat = flat % m;
+      if (n & 1) a = a == 0 ? n / 2 : (a <= n / 2 ? a - 1 : a);  // odd count: index 0 is "stay"
+      u = ((float)a / (float)(n - 1)) * (2.f * S.u_range[k]) - S.u_range[k];
+    } else {
+      u = S.action[env * S.action_size + k];
+    }
     if (u != u) bad |= VMAS_ACTION_ERR_NAN;
-    if (clamp) {
+    if (S.action_index != nullptr) {
+    } else if (clamp) {
       u = max_t(min_t(u, S.u_range[k]), -S.u_range[k]);  // torch.maximum(torch.minimum(u, r), -r)
     } else if (fabsf(u) > S.u_range[k]) {
       bad |= VMAS_ACTION_ERR_OUT_OF_RANGE;

@@ -44,8 +44,6 @@ class ActionIngest:
     @staticmethod
     def supports(env) -> Optional[str]:
         """None if the environment's action path can be fused, else the reason it cannot."""
-        if not env.continuous_actions:
-            return "discrete actions"
         if len(env.agents) > A.ENV_MAX_AGENTS:
             return "too many agents"
         from .scenario import BaseScenario
@@ -84,6 +82,9 @@ class ActionIngest:
             extra = env.scenario.fused_action_factors(a) if hasattr(env.scenario, "fused_action_factors") else None
             for k, v in enumerate(_per_dim(a.action.u_multiplier, n)):
                 s.u_multiplier[k] = v * (extra[k] if extra is not None else 1.0)
+            if not env.continuous_actions:
+                for k, nv in enumerate(a.discrete_action_nvec):
+                    s.nvec[k] = int(nv)
             u = torch.zeros(B, n, device=env.device, dtype=torch.float32)
             s.u_out = u.data_ptr()
             a.action.u = u  # agent.action.u stays readable by scenario code
@@ -115,12 +116,16 @@ class ActionIngest:
                 act = act.unsqueeze(-1)
             assert act.shape[0] == env.num_envs, (
                 f"Actions used in input of env must be of len {env.num_envs}, got {act.shape[0]}")
-            assert act.shape[1] == agent.action_size, (
-                f"Agent {agent.name} has wrong action size, got {act.shape[1]}, expected {agent.action_size}")
-            if act.dtype != torch.float32 or act.device != env.device or not act.is_contiguous():
-                act = act.detach().to(device=env.device, dtype=torch.float32).contiguous()
+            want = env.get_agent_action_size(agent)
+            assert act.shape[1] == want, f"Agent {agent.name} has wrong action size, got {act.shape[1]}, expected {want}"
+            dtype = torch.float32 if env.continuous_actions else torch.int64
+            if act.dtype != dtype or act.device != env.device or not act.is_contiguous():
+                act = act.detach().to(device=env.device, dtype=dtype).contiguous()
             held.append(act)
-            self.args.agents[i].action = act.data_ptr()
+            if env.continuous_actions:
+                self.args.agents[i].action = act.data_ptr()
+            else:
+                self.args.agents[i].action_index = act.data_ptr()
         self._keep = held  # the launch is asynchronous: keep the inputs alive until the next call
 
     def check(self):
