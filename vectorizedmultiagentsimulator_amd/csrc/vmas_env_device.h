@@ -144,7 +144,7 @@ constexpr int kBalanceObsDim = 16;
 __host__ __device__ inline size_t balance_scratch_floats(int nw) { return 2 * 64 + kBalanceObsDim * 64 + (size_t)nw * 64 * (kBalanceObsDim | 1); }
 
 VD void balance_post_tile(const TileCtx& C, const VmasBalanceDesc& d, const VmasBalanceBuffers& o, int batch,
-                          const float* rows, float* scratch, float prev_shaping, float steps_in) {
+                          const float* rows, float* scratch, float prev_shaping, float steps_in, int ablate = 0) {
   constexpr int D = kBalanceObsDim;
   float* flags = scratch;
   int* tab = (int*)(flags + 2 * 64);
@@ -158,7 +158,8 @@ VD void balance_post_tile(const TileCtx& C, const VmasBalanceDesc& d, const Vmas
   //   wave 1: is_overlapping(package, floor), the box-sphere rule (core.py:1932-1961)
   // each skipped when no lane's body can reach the floor box (outside distance of its centre to the
   // box > its reach: conservative, fp slack included, NaN counts as near).
-  if (C.wave < 2) {
+  if (C.wave < 2 && (ablate & 1)) flags[C.wave * 64 + C.lane] = 0.f;  // profiling: queries off
+  if (C.wave < 2 && !(ablate & 1)) {
     const v2 floor = P2(d.floor, 0);
     const float floor_rot = R(d.floor, 4);
     float fs, fc;
@@ -213,7 +214,7 @@ VD void balance_post_tile(const TileCtx& C, const VmasBalanceDesc& d, const Vmas
   // observation balance.py:243-258, agents wave, wave + nw, ...
   const v2 pkg_vel = P2(d.package, 2), line_vel = P2(d.line, 2), pkg_goal_rel = pkg - goal;
   const float line_av = R(d.line, 5), rot_mod = remainder_pi(R(d.line, 4));
-  for (int a = C.wave; a < d.n_agents; a += C.nw) {
+  for (int a = C.wave; a < d.n_agents && !(ablate & 2); a += C.nw) {  // (2: profiling, observations off)
     const v2 p = P2(d.agent0 + a, 0), v = P2(d.agent0 + a, 2);
     T.put(0, p); T.put(2, v); T.put(4, p - pkg); T.put(6, p - line); T.put(8, pkg_goal_rel);
     T.put(10, pkg_vel); T.put(12, line_vel); T.put(14, line_av); T.put(15, rot_mod);

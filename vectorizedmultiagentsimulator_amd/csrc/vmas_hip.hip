@@ -140,6 +140,7 @@ struct DevStepArgs {
 enum { ENV_NONE = 0, ENV_BALANCE = 1, ENV_TRANSPORT = 2, ENV_INGEST = 3 };  // 3: prologue only
 struct DevEnv {
   int32_t has_ingest;
+  int32_t ablate;       // profiling only (env VMAS_ENV_ABLATE)
   int32_t scratch_off;  // floats from the LDS base to the epilogue's scratch (after the step's own LDS)
   int8_t slot_of_agent[VMAS_ENV_MAX_AGENTS];  // agent index -> action slot >= 0 | -1 nothing | -2 - i: script i
   uint32_t* err_flags;
@@ -480,7 +481,7 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
   auto load_agent_ft = [&](int a, float* f3) {
     const float* src = agent_ft + (long)a * 3 * ld + env;
     if constexpr (ENV != ENV_NONE) {
-      const int slot = E.has_ingest ? E.slot_of_agent[a] : -1;
+      const int slot = (E.has_ingest && !(E.ablate & 8)) ? E.slot_of_agent[a] : -1;
       if (slot >= 0) {
         const VmasActionSlot& S = E.ingest.agents[slot];
         uint32_t bad = 0;
@@ -763,7 +764,8 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
     __syncthreads();
     const TileCtx C(batch);
     if constexpr (ENV == ENV_BALANCE)
-      balance_post_tile(C, E.balance.d, E.balance.o, batch, lds, lds + E.scratch_off, post_prev, post_steps);
+      if (!(E.ablate & 4))  // profiling (VMAS_ENV_ABLATE): 1 queries off, 2 observations off, 4 epilogue off, 8 prologue off
+        balance_post_tile(C, E.balance.d, E.balance.o, batch, lds, lds + E.scratch_off, post_prev, post_steps, E.ablate);
     if constexpr (ENV == ENV_TRANSPORT)
       transport_post_tile(C, E.transport.d, E.transport.o, batch, lds, lds + E.scratch_off, post_steps);
   }
@@ -1483,6 +1485,8 @@ int vmas_world_step_env(VmasWorld* w, float* state, float* agent_ft, int64_t ld,
     return fail("vmas_world_step_env: null post-step descriptor");
   if (post_kind == VMAS_POST_NONE && !ingest) return fail("vmas_world_step_env: neither actions nor a post-step given");
   DevEnv env{};
+  static const int env_ablate = getenv("VMAS_ENV_ABLATE") ? atoi(getenv("VMAS_ENV_ABLATE")) : 0;
+  env.ablate = env_ablate;
   env.err_flags = err_flags;
   for (int a = 0; a < VMAS_ENV_MAX_AGENTS; ++a) env.slot_of_agent[a] = -1;
   if (ingest) {

@@ -90,6 +90,8 @@ class Environment:
             self._ingest_in_step and self._post is not None and self._post.kind is not None
             and type(self.scenario).post_step is BaseScenario.post_step
         )
+        if self._ingest_in_step:
+            self._launch = F.StepLauncher(self, self._ingest)
 
     batch_dim = property(lambda self: self.num_envs)
 
@@ -261,7 +263,7 @@ class Environment:
         HIP-graph replay."""
         assert len(actions) == self.n_agents, f"Expecting actions for {self.n_agents}, got {len(actions)} actions"
         self._ingest.prepare(actions)
-        self.world.step_env(self._ingest.args, self._ingest.err if self.validate_actions else None, 0, None, None)
+        self._launch(0, None, None, self.validate_actions)
         if self.validate_actions:
             self._ingest.check()
         self.scenario.post_step()
@@ -287,15 +289,14 @@ class Environment:
         if self._one_launch:
             self._ingest.prepare(actions)
             desc, buffers, result = self._post.prepare()
-            self.world.step_env(self._ingest.args, self._ingest.err if self.validate_actions else None, self._post.kind,
-                                desc, buffers)
+            self._launch(self._post.kind, desc, buffers, self.validate_actions)
             self._lidar_cache = None
             if self.validate_actions:
                 self._ingest.check()
             return result
         if self._ingest_in_step:
             self._ingest.prepare(actions)
-            self.world.step_env(self._ingest.args, self._ingest.err if self.validate_actions else None, 0, None, None)
+            self._launch(0, None, None, self.validate_actions)
             if self.validate_actions:
                 self._ingest.check()
         else:

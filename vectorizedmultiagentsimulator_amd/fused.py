@@ -147,6 +147,46 @@ class ActionIngest:
             self.check()
 
 
+class StepLauncher:
+    """``vmas_world_step_env`` with every argument that does not change between steps marshalled once
+    (world handle, buffer pointers, the ingest struct): the Python side of a one-launch step is then
+    pointer updates + one foreign call.  Re-binds itself when the world rebuilt its backend."""
+
+    def __init__(self, env, ingest: "ActionIngest"):
+        self.env, self.ingest = env, ingest
+        self.fn = A.load_library().vmas_world_step_env
+        self._be = None
+
+    def _bind(self):
+        w = self.env.world
+        be = self._be = w._get_backend()
+        self._h = be._h
+        self._st, self._ft, self._ld = C.c_void_p(be.state.data_ptr()), C.c_void_p(be.agent_ft.data_ptr()), be.ld
+        spec = w.spec
+        self._per_env = any(j.per_env_fixed_rotation for j in spec.joints) or any(e.per_env_gravity for e in spec.entities)
+        self._ing = C.byref(self.ingest.args)
+        self._err = C.c_void_p(self.ingest.err.data_ptr())
+        self._dev = self.env.device
+
+    def __call__(self, kind: int, desc, buffers, validate: bool):
+        w = self.env.world
+        if self._be is None or w._backend is not self._be:
+            self._bind()
+        w._query_cache = None
+        args = None
+        if self._per_env:
+            jfr, eg = w._per_env_inputs()
+            sa = A.StepArgs()
+            sa.joint_fixed_rot = jfr.data_ptr() if jfr is not None else None
+            sa.entity_gravity = eg.data_ptr() if eg is not None else None
+            args = C.byref(sa)
+        rc = self.fn(self._h, self._st, self._ft, self._ld, args, self._ing, self._err if validate else None, kind,
+                     C.byref(desc) if desc is not None else None, C.byref(buffers) if buffers is not None else None,
+                     torch.cuda.current_stream(self._dev).cuda_stream)
+        if rc != 0:
+            raise VmasHipError(A.last_error())
+
+
 class _Post:
     """Shared plumbing of the per-scenario post-step kernels."""
 
@@ -170,6 +210,14 @@ class _Post:
         lim.steps = self.env.steps.data_ptr()
         lim.max_steps = float(self.env.max_steps) if self.env.max_steps is not None else -1.0
         return lim
+
+    def _buffers(self, cls):
+        """The kernel's buffer struct, built once; per step only the pointers that change are rewritten."""
+        b = getattr(self, "_b", None)
+        if b is None:
+            b = self._b = cls()
+            b.limit = self._limit()
+        return b
 
     def _outputs(self, obs_dim: int):
         if self._out is None or not self.static_outputs:
@@ -212,11 +260,10 @@ class BalancePost(_Post):
             self._info = (torch.empty(self.B, device=self.dev), torch.empty(self.B, device=self.dev),
                           torch.empty(self.B, device=self.dev, dtype=torch.bool))
         sc.pos_rew, sc.ground_rew, sc.on_the_ground = self._info
-        b = A.BalanceBuffers()
+        b = self._buffers(A.BalanceBuffers)
         b.global_shaping = sc.global_shaping.data_ptr()
         b.obs, b.rew, b.done = obs.data_ptr(), rew.data_ptr(), done.data_ptr()
         b.pos_rew, b.ground_rew, b.on_the_ground = (t.data_ptr() for t in self._info)
-        b.limit = self._limit()
         infos = [{"pos_rew": sc.pos_rew, "ground_rew": sc.ground_rew} for _ in range(self.n)]
         return self.desc, b, (list(obs.unbind(0)), list(rew.unbind(0)), done, infos)
 
@@ -267,10 +314,9 @@ class TransportPost(_Post):
                 self.on_goal[i].copy_(p.on_goal)
                 p.on_goal = self.on_goal[i]
         obs, rew, done = self._outputs(4 + 7 * self.P)
-        b = A.TransportBuffers()
+        b = self._buffers(A.TransportBuffers)
         b.global_shaping, b.on_goal = self.global_shaping.data_ptr(), self.on_goal.data_ptr()
         b.obs, b.rew, b.done = obs.data_ptr(), rew.data_ptr(), done.data_ptr()
-        b.limit = self._limit()
         sc.rew = rew[0]
         return self.desc, b, (list(obs.unbind(0)), list(rew.unbind(0)), done, [{} for _ in range(self.n)])
 
