@@ -138,20 +138,24 @@ VD bool apply_step_limit(const VmasStepLimit& lim, const TileCtx& C, float steps
 
 // ------------------------------------------------------------------------------------ balance
 // balance.py:218-267.  scratch: flags[2][64] (line-floor, package-floor) | tab[16][64] | tiles[nw][64][17].
-// Preconditions: `rows` complete and visible to the block; the caller loaded prev_shaping
-// (Scenario.global_shaping) and steps_in for this lane.  Contains two block barriers.
+// Preconditions: `rows` complete and the flush table built (balance_build_table), both visible to the block;
+// the caller loaded prev_shaping (Scenario.global_shaping) and steps_in for this lane.  One block barrier: the
+// two overlap queries (waves 0 and 1) run beside the observations of the other waves, the reward follows it.
 constexpr int kBalanceObsDim = 16;
+VD void balance_build_table(const TileCtx& C, float* scratch) {
+  build_flush_table(C, (int*)(scratch + 2 * 64), kBalanceObsDim, kBalanceObsDim | 1);
+}
 __host__ __device__ inline size_t balance_scratch_floats(int nw) { return 2 * 64 + kBalanceObsDim * 64 + (size_t)nw * 64 * (kBalanceObsDim | 1); }
 
 VD void balance_post_tile(const TileCtx& C, const VmasBalanceDesc& d, const VmasBalanceBuffers& o, int batch,
-                          const float* rows, float* scratch, float prev_shaping, float steps_in, int ablate = 0) {
+                          const float* rows, float* scratch, float prev_shaping, float steps_in, int ablate = 0,
+                          const float* floor_trig = nullptr /* this lane's cos, sin, cos2, sin2 rows (stride 64) */) {
   constexpr int D = kBalanceObsDim;
   float* flags = scratch;
   int* tab = (int*)(flags + 2 * 64);
   const ObsTile T = obs_tile(C, (float*)(tab + D * 64), tab, D);
   auto R = [&](int ent, int f) { return rows[(ent * 6 + f) * 64 + C.lane]; };
   auto P2 = [&](int ent, int f) { return V(R(ent, f), R(ent, f + 1)); };
-  build_flush_table(C, tab, D, D | 1);
 
   // phase 1: compute_on_the_ground balance.py:218-221, one query per wave:
   //   wave 0: is_overlapping(line, floor) = World.get_distance(box, line) < 0 (core.py:1880-1893)
@@ -163,7 +167,12 @@ VD void balance_post_tile(const TileCtx& C, const VmasBalanceDesc& d, const Vmas
     const v2 floor = P2(d.floor, 0);
     const float floor_rot = R(d.floor, 4);
     float fs, fc;
-    sincosf(floor_rot, &fs, &fc);
+    if (floor_trig != nullptr) {  // the physics kernel keeps cos/sin of every box in its tile
+      fc = floor_trig[0];
+      fs = floor_trig[64];
+    } else {
+      sincosf(floor_rot, &fs, &fc);
+    }
     const bool is_line = C.wave == 0;
     const v2 body = P2(is_line ? d.line : d.package, 0);
     const float reach = (is_line ? d.line_length / 2.f : d.package_radius) + kLineMinDist + 1e-3f;
@@ -171,7 +180,12 @@ VD void balance_post_tile(const TileCtx& C, const VmasBalanceDesc& d, const Vmas
     int hit = 0;
     if (__any(near)) {
       float fs2, fc2;
-      sincosf(floor_rot + kHalfPi, &fs2, &fc2);
+      if (floor_trig != nullptr) {
+        fc2 = floor_trig[128];
+        fs2 = floor_trig[192];
+      } else {
+        sincosf(floor_rot + kHalfPi, &fs2, &fc2);
+      }
       seg_t be[4];
       box_edges(floor, fc, fs, fc2, fs2, d.floor_length, d.floor_width, be);
       if (is_line) {
@@ -189,10 +203,22 @@ VD void balance_post_tile(const TileCtx& C, const VmasBalanceDesc& d, const Vmas
     }
     flags[C.wave * 64 + C.lane] = hit ? 1.f : 0.f;
   }
+
+  // observation balance.py:243-258 (needs no query result): agent a on wave (a + 2) mod nw, so that with more
+  // waves than agents + 2 the observations are written while waves 0 and 1 are still in their queries
+  const v2 pkg = P2(d.package, 0), goal = P2(d.goal, 0), line = P2(d.line, 0);
+  const v2 pkg_vel = P2(d.package, 2), line_vel = P2(d.line, 2), pkg_goal_rel = pkg - goal;
+  const float line_av = R(d.line, 5), rot_mod = remainder_pi(R(d.line, 4));
+  const int first = (C.wave + C.nw - (2 % C.nw)) % C.nw;
+  for (int a = first; a < d.n_agents && !(ablate & 2); a += C.nw) {  // (2: profiling, observations off)
+    const v2 p = P2(d.agent0 + a, 0), v = P2(d.agent0 + a, 2);
+    T.put(0, p); T.put(2, v); T.put(4, p - pkg); T.put(6, p - line); T.put(8, pkg_goal_rel);
+    T.put(10, pkg_vel); T.put(12, line_vel); T.put(14, line_av); T.put(15, rot_mod);
+    T.flush(o.obs + ((long)a * batch + C.b0) * D, C.n_rows);
+  }
   __syncthreads();
 
-  // phase 2: reward balance.py:223-241 (every wave: a handful of operations; wave 0 stores it)
-  const v2 pkg = P2(d.package, 0), goal = P2(d.goal, 0), line = P2(d.line, 0);
+  // phase 2: reward balance.py:223-241 (every wave: a handful of operations; wave 0 stores the shared terms)
   const bool on_ground = flags[C.lane] != 0.f || flags[64 + C.lane] != 0.f;
   const float package_dist = vnorm(pkg - goal);
   const float ground_rew = on_ground ? d.fall_reward : 0.f;
@@ -210,17 +236,8 @@ VD void balance_post_tile(const TileCtx& C, const VmasBalanceDesc& d, const Vmas
       o.done[C.env] = done ? 1 : 0;
     }
   }
-
-  // observation balance.py:243-258, agents wave, wave + nw, ...
-  const v2 pkg_vel = P2(d.package, 2), line_vel = P2(d.line, 2), pkg_goal_rel = pkg - goal;
-  const float line_av = R(d.line, 5), rot_mod = remainder_pi(R(d.line, 4));
-  for (int a = C.wave; a < d.n_agents && !(ablate & 2); a += C.nw) {  // (2: profiling, observations off)
-    const v2 p = P2(d.agent0 + a, 0), v = P2(d.agent0 + a, 2);
-    T.put(0, p); T.put(2, v); T.put(4, p - pkg); T.put(6, p - line); T.put(8, pkg_goal_rel);
-    T.put(10, pkg_vel); T.put(12, line_vel); T.put(14, line_av); T.put(15, rot_mod);
-    T.flush(o.obs + ((long)a * batch + C.b0) * D, C.n_rows);
-    if (C.live) o.rew[(long)a * batch + C.env] = rew;
-  }
+  if (C.live)
+    for (int a = first; a < d.n_agents; a += C.nw) o.rew[(long)a * batch + C.env] = rew;
 }
 
 // ------------------------------------------------------------------------------------ transport

@@ -142,7 +142,9 @@ struct DevEnv {
   int32_t has_ingest;
   int32_t ablate;       // profiling only (env VMAS_ENV_ABLATE)
   int32_t scratch_off;  // floats from the LDS base to the epilogue's scratch (after the step's own LDS)
-  int8_t slot_of_agent[VMAS_ENV_MAX_AGENTS];  // agent index -> action slot >= 0 | -1 nothing | -2 - i: script i
+  // `ingest.agents` is re-ordered by the host: slot a belongs to AGENT a (action == action_index == NULL: no action
+  // for it), so the prologue reads its slot with one kernarg fetch, no indirection.  Scripts: agent -> script or -1.
+  int8_t script_of_agent[VMAS_ENV_MAX_AGENTS];
   uint32_t* err_flags;
   VmasIngestArgs ingest;
   union {
@@ -481,17 +483,17 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
   auto load_agent_ft = [&](int a, float* f3) {
     const float* src = agent_ft + (long)a * 3 * ld + env;
     if constexpr (ENV != ENV_NONE) {
-      const int slot = (E.has_ingest && !(E.ablate & 8)) ? E.slot_of_agent[a] : -1;
-      if (slot >= 0) {
-        const VmasActionSlot& S = E.ingest.agents[slot];
+      const bool on = E.has_ingest && !(E.ablate & 8);
+      const VmasActionSlot& S = E.ingest.agents[a];
+      if (on && (S.action != nullptr || S.action_index != nullptr)) {
         uint32_t bad = 0;
         ingest_slot(S, E.ingest.clamp, env, live, agent_ft, ld, f3, bad);
         if (S.action_size < 3) f3[2] = live ? src[2 * ld] : 0.f;  // Holonomic leaves the torque alone
         if (E.err_flags != nullptr && bad != 0) atomicOr(E.err_flags, bad);
         return;
       }
-      if (slot <= -2) {  // a scripted agent: its action comes from the state it is about to be stepped from
-        run_script(E.ingest.scripts[-2 - slot], state, env, live, agent_ft, ld, f3);
+      if (on && E.ingest.n_scripts > 0 && E.script_of_agent[a] >= 0) {  // scripted: driven by the state about to be stepped
+        run_script(E.ingest.scripts[E.script_of_agent[a]], state, env, live, agent_ft, ld, f3);
         f3[2] = live ? src[2 * ld] : 0.f;
         return;
       }
@@ -504,6 +506,7 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
   [[maybe_unused]] float post_prev = 0.f, post_steps = 0.f;
   if constexpr (ENV == ENV_BALANCE) {
     post_prev = live ? E.balance.o.global_shaping[env] : 0.f;
+    balance_build_table(TileCtx(batch), lds + E.scratch_off);  // (published by the load barrier below)
     if (wv == 0) post_steps = (E.balance.o.limit.steps != nullptr && live) ? E.balance.o.limit.steps[env] : 0.f;
   }
   if constexpr (ENV == ENV_TRANSPORT) {
@@ -765,7 +768,13 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
     const TileCtx C(batch);
     if constexpr (ENV == ENV_BALANCE)
       if (!(E.ablate & 4))  // profiling (VMAS_ENV_ABLATE): 1 queries off, 2 observations off, 4 epilogue off, 8 prologue off
-        balance_post_tile(C, E.balance.d, E.balance.o, batch, lds, lds + E.scratch_off, post_prev, post_steps, E.ablate);
+      {
+        // the floor's cos/sin rows of the tile are current if it cannot rotate (they are not refreshed after the last substep)
+        const uint32_t ffl = (uint32_t)sgpr((int)blob[W.b_ent + E.balance.d.floor * EW]);
+        const int tr_off = sgpr((int)blob[W.b_ent + E.balance.d.floor * EW + 3]);
+        balance_post_tile(C, E.balance.d, E.balance.o, batch, lds, lds + E.scratch_off, post_prev, post_steps, E.ablate,
+                          (tr_off >= 0 && !(ffl & VMAS_F_ROTATABLE)) ? tile + tr_off : nullptr);
+      }
     if constexpr (ENV == ENV_TRANSPORT)
       transport_post_tile(C, E.transport.d, E.transport.o, batch, lds, lds + E.scratch_off, post_steps);
   }
@@ -1488,21 +1497,24 @@ int vmas_world_step_env(VmasWorld* w, float* state, float* agent_ft, int64_t ld,
   static const int env_ablate = getenv("VMAS_ENV_ABLATE") ? atoi(getenv("VMAS_ENV_ABLATE")) : 0;
   env.ablate = env_ablate;
   env.err_flags = err_flags;
-  for (int a = 0; a < VMAS_ENV_MAX_AGENTS; ++a) env.slot_of_agent[a] = -1;
+  for (int a = 0; a < VMAS_ENV_MAX_AGENTS; ++a) env.script_of_agent[a] = -1;
   if (ingest) {
     if (vmas::check_ingest_args(ingest, w->batch, agent_ft, ld)) return -1;
     env.has_ingest = 1;
-    env.ingest = *ingest;
-    for (int i = 0; i < ingest->n_agents; ++i) {
+    env.ingest.clamp = ingest->clamp;
+    env.ingest.n_agents = w->base.nA;
+    env.ingest.n_scripts = ingest->n_scripts;
+    for (int i = 0; i < ingest->n_agents; ++i) {  // slot of agent a at index a (zero-initialised slots: no action)
       const int a = ingest->agents[i].agent_index;
       if (a >= w->base.nA) return fail("vmas_world_step_env: action slot %d names agent %d of %d", i, a, w->base.nA);
-      env.slot_of_agent[a] = (int8_t)i;
+      env.ingest.agents[a] = ingest->agents[i];
     }
     for (int i = 0; i < ingest->n_scripts; ++i) {
       const int a = ingest->scripts[i].agent_index;
       if (a >= w->base.nA || ingest->scripts[i].entity >= w->base.nE)
         return fail("vmas_world_step_env: agent script %d names agent %d / entity %d", i, a, ingest->scripts[i].entity);
-      env.slot_of_agent[a] = (int8_t)(-2 - i);
+      env.ingest.scripts[i] = ingest->scripts[i];
+      env.script_of_agent[a] = (int8_t)i;
     }
   }
   if (post_kind == VMAS_POST_BALANCE) {
