@@ -17,11 +17,8 @@ constexpr float kLineMinDist = (float)(4.0 / 6e2);                         // ut
 constexpr float kHalfPi = (float)(3.14159265358979323846 / 2.0);           // torch.pi / 2 -> fp32
 constexpr float kInf = __builtin_huge_valf();
 
-struct v2 { float x, y; };
+typedef float v2 __attribute__((ext_vector_type(2)));  // (+, -, unary - are element-wise: v_pk_add_f32 where they pair up)
 VD v2 V(float x, float y) { v2 r; r.x = x; r.y = y; return r; }
-VD v2 operator+(v2 a, v2 b) { return V(a.x + b.x, a.y + b.y); }
-VD v2 operator-(v2 a, v2 b) { return V(a.x - b.x, a.y - b.y); }
-VD v2 operator-(v2 a) { return V(-a.x, -a.y); }
 VD float norm2(float x, float y) { return __fsqrt_rn(__fmaf_rn(y, y, x * x)); }
 VD float vnorm(v2 a) { return norm2(a.x, a.y); }
 VD float vdot(v2 a, v2 b) { return a.x * b.x + a.y * b.y; }               // (a*b).sum(-1)

@@ -59,6 +59,7 @@ constexpr int TASK_JOINT = 6;  // item type next to VMAS_PAIR_*
 constexpr float kSkipSlack = 1e-3f;  // fp slack of the conservative broad-phase distances
 constexpr int TASK_SSQ = 7;    // up to four sphere-sphere partners of one entity in one record
 constexpr int TASK_LSQ = 8;    // up to four lines against one (owning) sphere in one record
+constexpr int TASK_SSP = 9;    // up to four SHARED sphere-sphere pairs (both spheres dynamic) in one record
 constexpr int ROWF = TILE;     // floats per LDS row
 
 enum : uint32_t { IT_A_HOLLOW = 1u << 0, IT_B_HOLLOW = 1u << 1, IT_LOCK = 1u << 2 /* joint rotate == False */ };
@@ -68,7 +69,8 @@ enum : uint32_t { IT_A_HOLLOW = 1u << 0, IT_B_HOLLOW = 1u << 1, IT_LOCK = 1u << 
 // float offsets into the tile, so row accesses become ds_read with an immediate offset.
 struct DevItem {
   int32_t type;   // VMAS_PAIR_* or TASK_JOINT
-  int32_t side;   // 0: accumulate the force on a, 1: on b
+  int32_t side;   // low 2 bits  0: the force on a, 1: on b, 2: SHARED - evaluated once, results to the LDS rows at
+                  // tile offset (side >> 2): [fx fy] of a, then the torque on a, then the torque on b
   uint32_t flags; // IT_*
   int32_t index;  // pair index (mask bit) or joint index (per-env fixed-rotation row)
   int32_t oa, ob;    // tile offsets of the first state row of a / b (role order of the reference)
@@ -79,7 +81,7 @@ struct DevItem {
 };
 
 struct DevSegment {
-  int32_t entity;
+  int32_t entity;    // -1: a run of shared pairs/joints (no prologue, no partial rows; every item has its own rows)
   int32_t oe;        // tile offset of the entity's first state row
   int32_t item_begin, item_end;
   int32_t first;     // 1: this segment starts from the entity's prologue force
@@ -90,6 +92,10 @@ struct DevOwned {  // phase C work unit
   int32_t entity;
   int32_t oe;
   int32_t part_off, n_parts;  // partial rows of the entity's segments, in order
+  // then the entity's side of every shared pair/joint it is in, in the reference's accumulation order; one word each:
+  //   bits 0..15 row of [fx fy] | bit 16 side (1: the entity is b, the force flips its sign) | bits 17..18 row delta
+  //   of its torque (0: none)
+  int32_t ref_begin, n_refs;
 };
 
 struct DevEntity {
@@ -118,7 +124,7 @@ struct DevWorld {
   const uint32_t* blob;
   int32_t blob_words;   // words staged (items only when they fit the LDS budget)
   int32_t off_blob;     // tile offset (floats) of the blob copy in LDS
-  int32_t b_ent, b_segs, b_owned, b_items;
+  int32_t b_ent, b_segs, b_owned, b_refs, b_items;
   int32_t n_segs, n_owned;
   int32_t items_in_lds;
   const DevItem* items;  // global copy, used when the item list is too big for LDS
@@ -318,12 +324,55 @@ __device__ __forceinline__ void eval_lsq(const uint32_t* p, const DevWorld& W, c
   }
 }
 
+// SHARED sphere-sphere pairs (both spheres dynamic), four pairs to a record, each evaluated ONCE: the force on a goes
+// to the pair's two LDS rows, b's owner reads it with the sign flipped (cf(a,b) == -cf(b,a) bit for bit).
+//   w0: type, n, tile offset of the first pair's rows (pair k: + 2k rows), -
+//   w1: a offsets 0|1<<16, 2|3<<16, b offsets 0|1<<16, 2|3<<16   w2: r_sum 0..3   w3: pair index 0|1<<16, 2|3<<16
+__device__ __forceinline__ void eval_ssp(const uint32_t* p, const DevWorld& W, const DevStepArgs& args, float* tile,
+                                         bool may_skip) {
+  const uint4 w0 = ((const uint4*)p)[0], w1 = ((const uint4*)p)[1], w2 = ((const uint4*)p)[2], w3 = ((const uint4*)p)[3];
+  const int n = sgpr((int)w0.y);
+  float* R = tile + (int)w0.z;
+  const int oa[4] = {(int)(w1.x & 0xffffu), (int)(w1.x >> 16), (int)(w1.y & 0xffffu), (int)(w1.y >> 16)};
+  const int ob[4] = {(int)(w1.z & 0xffffu), (int)(w1.z >> 16), (int)(w1.w & 0xffffu), (int)(w1.w >> 16)};
+  const float rs[4] = {__uint_as_float(w2.x), __uint_as_float(w2.y), __uint_as_float(w2.z), __uint_as_float(w2.w)};
+  const int idx[4] = {(int)(w3.x & 0xffffu), (int)(w3.x >> 16), (int)(w3.y & 0xffffu), (int)(w3.y >> 16)};
+  v2 pa[4], pb[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {  // unused slots repeat pair 0 on the host: always valid rows
+    const float* A = tile + oa[k];
+    const float* B = tile + ob[k];
+    pa[k] = V(A[0], A[ROWF]);
+    pb[k] = V(B[0], B[ROWF]);
+  }
+  uint32_t needbits = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float dx = pa[k].x - pb[k].x, dy = pa[k].y - pb[k].y;
+    const float m = rs[k] + 1e-4f;  // the force is exactly 0 for dist > r_a + r_b (core.py:2836)
+    bool need = !(dx * dx + dy * dy > m * m) || !may_skip;
+    bool on = k < n;
+    if (args.pair_mask) on = on && ((args.pair_mask[sgpr(idx[k]) >> 5] >> (sgpr(idx[k]) & 31)) & 1u);
+    needbits |= (on && __any(need)) ? (1u << k) : 0u;
+  }
+  if (args.ablate & 32) needbits = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (k < n) {
+      v2 f = V(0.f, 0.f);
+      if (needbits & (1u << k)) f = contact_force(pa[k], pb[k], rs[k], W.c_coll, W.k);
+      R[(2 * k) * ROWF] = f.x;
+      R[(2 * k + 1) * ROWF] = f.y;
+    }
+  }
+}
+
 // Force (and torque) one item contributes to ITS side.  LEVEL prunes code (and registers):
 // 0: SS LS BS   1: + LL BL joints   2: + BB
 template <int LEVEL>
 __device__ __forceinline__ void eval_item(const ItemV& K, const DevWorld& W, const DevStepArgs& args,
                                           const float* tile, long env, bool live, long ld, bool may_skip, v2& f_out,
-                                          float& t_out) {
+                                          float& t_out, float& tb_out) {
   const float* A = tile + K.oa;
   const float* B = tile + K.ob;
   const v2 pa = V(A[0], A[ROWF]), pb = V(B[0], B[ROWF]);
@@ -332,8 +381,17 @@ __device__ __forceinline__ void eval_item(const ItemV& K, const DevWorld& W, con
   // a is computed and the b side flips its sign bit.  (Written as an integer xor on purpose:
   // hipcc 7.2 mis-folds `side ? -f : f` - the negation is dropped - which the golden parity
   // tests caught.)  Torques use the side's own lever arm.
-  const uint32_t flip = K.side ? 0x80000000u : 0u;
+  // A SHARED item (side 2, both entities dynamic) is evaluated once: f_out/t_out are a's, tb_out is the torque on b.
+  const int side = K.side & 3;
+  const uint32_t flip = side == 1 ? 0x80000000u : 0u;
   auto own = [&](v2 fa) { return V(__uint_as_float(__float_as_uint(fa.x) ^ flip), __uint_as_float(__float_as_uint(fa.y) ^ flip)); };
+  auto neg = [&](v2 fa) { return V(__uint_as_float(__float_as_uint(fa.x) ^ 0x80000000u), __uint_as_float(__float_as_uint(fa.y) ^ 0x80000000u)); };
+  // torques of a pair whose force on a is fa: each side's own lever arm, b's with the flipped force
+  auto levers = [&](v2 lever_a, v2 lever_b, v2 fa) {
+    if (side != 1) t_out = vcross(lever_a, fa);
+    if (side == 1) t_out = vcross(lever_b, neg(fa));
+    if (side == 2) tb_out = vcross(lever_b, neg(fa));
+  };
   if (LEVEL >= 1 && K.type == TASK_JOINT) {  // _vectorized_joint_constraints core.py:2201-2292
     const float ra = A[4 * ROWF], rb = B[4 * ROWF];
     float sa, ca, sb, cb;
@@ -343,16 +401,16 @@ __device__ __forceinline__ void eval_item(const ItemV& K, const DevWorld& W, con
     const v2 pjb = pb + rotate(V(K.q0, K.q1), cb, sb);
     const v2 f_att = constraint_force<true>(pja, pjb, K.p2, W.c_joint_att, k);
     const v2 f_rep = constraint_force<false>(pja, pjb, K.p2, W.c_joint_rep, k);
-    const v2 f = own(f_att + f_rep);  // (-f_att) + (-f_rep) == -(f_att + f_rep) bitwise
-    float t = vcross(K.side ? (pjb - pb) : (pja - pa), f);
+    const v2 fa = f_att + f_rep;  // (-f_att) + (-f_rep) == -(f_att + f_rep) bitwise
+    levers(pja - pa, pjb - pb, fa);
     if (K.flags & IT_LOCK) {
       float fr = K.p3;
       if (args.joint_fixed_rot && live) fr = args.joint_fixed_rot[(long)K.index * ld + env];
       const float lock = constraint_torque(ra, rb + fr, W.tcf);
-      t = t + (K.side ? lock : -lock);
+      t_out = t_out + (side == 1 ? lock : -lock);
+      if (side == 2) tb_out = tb_out + lock;
     }
-    f_out = f;
-    t_out = t;
+    f_out = own(fa);
     return;
   }
   if (args.pair_mask && !((args.pair_mask[K.index >> 5] >> (K.index & 31)) & 1u)) return;
@@ -381,7 +439,7 @@ __device__ __forceinline__ void eval_item(const ItemV& K, const DevWorld& W, con
       const v2 cp = closest_point_line<true>(pa, TA[0], TA[ROWF], K.p0, pb);
       const v2 f = own(-contact_force(pb, cp, K.p1, W.c_coll, k));
       f_out = f;
-      t_out = K.side ? 0.f : vcross(cp - pa, f);
+      t_out = side == 1 ? 0.f : vcross(cp - pa, f);
     } break;
     case VMAS_PAIR_BS: {  // a = box, b = sphere; p0 = L, p1 = W, p2 = r + LMD  core.py:2459-2552
       seg_t be[4];
@@ -392,7 +450,7 @@ __device__ __forceinline__ void eval_item(const ItemV& K, const DevWorld& W, con
       if (!(K.flags & IT_A_HOLLOW)) ip = inner_point_box(pb, cp, pa, d);
       const v2 f = own(-contact_force(pb, ip, K.p2 + d, W.c_coll, k));
       f_out = f;
-      t_out = K.side ? 0.f : vcross(cp - pa, f);
+      t_out = side == 1 ? 0.f : vcross(cp - pa, f);
     } break;
     case VMAS_PAIR_LL:
       if (LEVEL >= 1) {  // p0 = La/2, p1 = Lb/2  core.py:2394-2457
@@ -400,9 +458,9 @@ __device__ __forceinline__ void eval_item(const ItemV& K, const DevWorld& W, con
         seg_t l2 = {pb, TB[0], TB[ROWF], K.p1};
         v2 qa, qb;
         closest_points_seg_seg(l1, l2, qa, qb);
-        const v2 f = own(contact_force(qa, qb, kLineMinDist, W.c_coll, k));
-        f_out = f;
-        t_out = vcross(K.side ? (qb - pb) : (qa - pa), f);
+        const v2 fa = contact_force(qa, qb, kLineMinDist, W.c_coll, k);
+        f_out = own(fa);
+        levers(qa - pa, qb - pb, fa);
       }
       break;
     case VMAS_PAIR_BL:
@@ -415,9 +473,9 @@ __device__ __forceinline__ void eval_item(const ItemV& K, const DevWorld& W, con
         v2 ip = qb;
         float d = 0.f;
         if (!(K.flags & IT_A_HOLLOW)) ip = inner_point_box(ql, qb, pa, d);
-        const v2 f = own(contact_force(ip, ql, kLineMinDist + d, W.c_coll, k));
-        f_out = f;
-        t_out = vcross(K.side ? (ql - pb) : (qb - pa), f);
+        const v2 fa = contact_force(ip, ql, kLineMinDist + d, W.c_coll, k);
+        f_out = own(fa);
+        levers(qb - pa, ql - pb, fa);
       }
       break;
     case VMAS_PAIR_BB:
@@ -431,9 +489,9 @@ __device__ __forceinline__ void eval_item(const ItemV& K, const DevWorld& W, con
         float da = 0.f, db = 0.f;
         if (!(K.flags & IT_A_HOLLOW)) ia = inner_point_box(qb, qa, pa, da);
         if (!(K.flags & IT_B_HOLLOW)) ib = inner_point_box(qa, qb, pb, db);
-        const v2 f = own(contact_force(ia, ib, da + db + kLineMinDist, W.c_coll, k));
-        f_out = f;
-        t_out = vcross(K.side ? (qb - pb) : (qa - pa), f);
+        const v2 fa = contact_force(ia, ib, da + db + kLineMinDist, W.c_coll, k);
+        f_out = own(fa);
+        levers(qa - pa, qb - pb, fa);
       }
       break;
     default: break;
@@ -602,6 +660,27 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
       const int e = sgpr((int)sp[0]);
       const float* Es = tile + (int)sp[1];
       const int i0 = sgpr((int)sp[2]), i1s = sgpr((int)sp[3]), first = sgpr((int)sp[4]);
+      if (e < 0) {  // a run of SHARED pairs/joints (both entities dynamic): evaluated once, both owners read the rows in phase C
+        const int i1u = (args.ablate & 1) ? i0 : i1s;
+        for (int ii = i0; ii < i1u; ++ii) {
+          const uint32_t* ip = blob + W.b_items + ii * IW;
+          if (sgpr((int)ip[0]) == TASK_SSP) {
+            eval_ssp(ip, W, args, tile, may_skip);
+            continue;
+          }
+          const ItemV K = load_item(ip);
+          v2 f = V(0.f, 0.f);
+          float ta = 0.f, tb = 0.f;
+          if (!(args.ablate & 16)) eval_item<LEVEL>(K, W, args, tile, env, live, ld, may_skip, f, ta, tb);
+          float* R = tile + (K.side >> 2);
+          R[0] = f.x; R[ROWF] = f.y; R[2 * ROWF] = ta;
+          if (K.type != VMAS_PAIR_LS && K.type != VMAS_PAIR_BS) R[3 * ROWF] = tb;  // (b is a sphere: no torque row)
+        }
+#ifdef VMAS_TRACE
+        tg = TNOW();
+#endif
+        continue;
+      }
       float* P = tile + (int)sp[5];
       const uint32_t efl = (uint32_t)sgpr((int)blob[W.b_ent + e * EW]);
       v2 F = V(0.f, 0.f);
@@ -676,8 +755,8 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
         }
         const ItemV K = W.items_in_lds ? load_item(blob + W.b_items + ii * IW) : item_from_global(W.items[ii]);
         v2 f = V(0.f, 0.f);
-        float t = 0.f;
-        if (!(args.ablate & 16)) eval_item<LEVEL>(K, W, args, tile, env, live, ld, may_skip, f, t);
+        float t = 0.f, t_unused = 0.f;
+        if (!(args.ablate & 16)) eval_item<LEVEL>(K, W, args, tile, env, live, ld, may_skip, f, t, t_unused);
         else f.x = __int_as_float(K.type + K.oa + K.ob + K.index) * 1e-30f;  // descriptor fetch only (profiling)
         if (efl & VMAS_F_MOVABLE) F = F + f;
         if (efl & VMAS_F_ROTATABLE) Tq = Tq + t;
@@ -721,6 +800,33 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
       for (int p = 1; p < n_parts; ++p) {
         F = F + V(P[3 * p * ROWF], P[(3 * p + 1) * ROWF]);
         Tq = Tq + P[(3 * p + 2) * ROWF];
+      }
+      {  // the entity's side of the shared pairs/joints, in the reference's order (core.py:2176-2199)
+        // (four references per fetch, all their rows requested before the first add: one LDS round trip per four pairs)
+        const int r0 = sgpr((int)op[4]), nr = sgpr((int)op[5]);
+        for (int r = 0; r < nr; r += 4) {
+          const uint4 q = *(const uint4*)(blob + W.b_refs + r0 + r);  // (ref_begin is a multiple of 4, the tail is padded)
+          const uint32_t ref[4] = {(uint32_t)sgpr((int)q.x), (uint32_t)sgpr((int)q.y), (uint32_t)sgpr((int)q.z),
+                                   (uint32_t)sgpr((int)q.w)};
+          float fx[4], fy[4], tq[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float* R = tile + (ref[k] & 0xffffu) * ROWF;  // (padding repeats a valid row)
+            const int td = (int)((ref[k] >> 17) & 3u);
+            fx[k] = R[0];
+            fy[k] = R[ROWF];
+            tq[k] = R[td * ROWF];
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if (r + k < nr) {
+              const uint32_t flip = (ref[k] & 0x10000u) << 15;  // b's side: -f
+              if (fl & VMAS_F_MOVABLE)
+                F = F + V(__uint_as_float(__float_as_uint(fx[k]) ^ flip), __uint_as_float(__float_as_uint(fy[k]) ^ flip));
+              if (((ref[k] >> 17) & 3u) && (fl & VMAS_F_ROTATABLE)) Tq = Tq + tq[k];
+            }
+          }
+        }
       }
       float* dst = state + (long)e * 6 * ld + env;
       bool bad = false;
@@ -1028,10 +1134,20 @@ struct VmasWorld {
   int n_pairs = 0, n_dyn = 0;
   DevWorld base{};  // schedule-independent part
   std::vector<VmasEntityDesc> ents;
+  std::vector<VmasPairDesc> pairs;     // copies of the creation-time description: the item lists can be rebuilt
+  std::vector<VmasJointDesc> joints;   // (without shared rows) if a launch needs more LDS than the tile has left
+  std::vector<int> tr_row;
+  int share_mode = 0;
   std::vector<DevEntity> dev_ents;
   // static item lists
   std::vector<DevItem> items;
   std::vector<int> ent_item_begin;  // [nE+1]
+  // pairs/joints of two dynamic entities are evaluated ONCE ("shared"): their items follow the entities' own items,
+  // their results live in LDS rows [row_shared, row_shared + n_shared_rows) that both owners read in phase C
+  int unit_item_begin = 0, row_shared = 0, n_shared_rows = 0;
+  std::vector<uint32_t> refs;       // per entity, reference order: row | side << 16 | torque row delta << 17
+  std::vector<int> ent_ref_begin;   // [nE+1]
+  std::vector<int> ent_ref_count;   // [nE]
   std::vector<float> item_cost;
   std::vector<int> trig_ents;
   DevMaskPair* d_mpairs = nullptr;
@@ -1064,18 +1180,44 @@ static float type_cost(int type) {
 // forces vanish once shapes are farther apart than LINE_MIN_DIST ("per-environment
 // broad phase"); the slack absorbs the rounding of the closest-point arithmetic.
 
-static void build_items(const VmasWorldDesc* d, VmasWorld* w, const std::vector<int>& tr_row) {
-  const VmasEntityDesc* E = d->entities;
-  const int nE = d->n_entities;
+// share_mode: 0 every side evaluates its own copy of a pair | 1 pairs/joints of two dynamic entities are evaluated once,
+// except sphere-sphere pairs | 2 those too
+static void build_items(VmasWorld* w, int share_mode) {
+  const std::vector<int>& tr_row = w->tr_row;
+  w->share_mode = share_mode;
+  const VmasEntityDesc* E = w->ents.data();
+  const int nE = (int)w->ents.size();
+  const int n_pairs = (int)w->pairs.size(), n_joints = (int)w->joints.size();
   std::vector<std::vector<DevItem>> per(nE);
   auto dyn = [&](int e) { return (E[e].flags & (VMAS_F_MOVABLE | VMAS_F_ROTATABLE)) != 0; };
+  // sphere-sphere partners of one entity are consecutive (type-major order): pack them four to
+  // a record when the item list will live in LDS (the packed form is read from the blob only)
+  const bool pack_ss = (size_t)(2 * n_pairs + 2 * n_joints) * sizeof(DevItem) <= (size_t)ITEMS_LDS_BUDGET &&
+                       n_pairs < 65536 && !getenv("VMAS_NO_SSQ");
+  // ... and a pair/joint of TWO dynamic entities is evaluated once for both (same condition: blob records only)
+  const bool share = share_mode > 0 && pack_ss && nE * 6 * ROWF < 65536;
+  std::vector<DevItem> units;
+  std::vector<std::vector<uint32_t>> ent_refs(nE);
+  w->row_shared = w->row_tr + 4 * (int)w->trig_ents.size();
+  int shared_rows = 0;
   auto push_sides = [&](DevItem t, int a, int b) {
+    if (share && dyn(a) && dyn(b) && (t.type != VMAS_PAIR_SS || share_mode > 1)) {
+      const bool no_tq = t.type == VMAS_PAIR_SS;
+      const int n_rows = no_tq ? 2 : ((t.type == VMAS_PAIR_LS || t.type == VMAS_PAIR_BS) ? 3 : 4);
+      const int row = w->row_shared + shared_rows;
+      shared_rows += n_rows;
+      t.side = 2 | ((row * ROWF) << 2);
+      units.push_back(t);
+      ent_refs[a].push_back((uint32_t)row | (no_tq ? 0u : (2u << 17)));
+      ent_refs[b].push_back((uint32_t)row | (1u << 16) | (n_rows == 4 ? (3u << 17) : 0u));
+      return;
+    }
     if (dyn(a)) { t.side = 0; per[a].push_back(t); }
     if (dyn(b)) { t.side = 1; per[b].push_back(t); }
   };
   auto tr_off = [&](int e) { return tr_row[e] >= 0 ? (w->row_tr + tr_row[e]) * ROWF : 0; };
-  for (int j = 0; j < d->n_joints; ++j) {  // joints first (core.py:2176)
-    const VmasJointDesc& J = d->joints[j];
+  for (int j = 0; j < n_joints; ++j) {  // joints first (core.py:2176)
+    const VmasJointDesc& J = w->joints[j];
     DevItem t{};
     t.type = TASK_JOINT; t.index = j;
     t.oa = J.a * 6 * ROWF; t.ob = J.b * 6 * ROWF;
@@ -1086,8 +1228,8 @@ static void build_items(const VmasWorldDesc* d, VmasWorld* w, const std::vector<
     t.thr2 = kInf;  // joints are never skipped
     push_sides(t, J.a, J.b);
   }
-  for (int p = 0; p < d->n_pairs; ++p) {  // then pairs, already type-major (core.py:2178-2189)
-    const VmasPairDesc& P = d->pairs[p];
+  for (int p = 0; p < n_pairs; ++p) {  // then pairs, already type-major (core.py:2178-2189)
+    const VmasPairDesc& P = w->pairs[p];
     const VmasEntityDesc &A = E[P.a], &B = E[P.b];
     DevItem t{};
     t.type = P.type; t.index = p;
@@ -1124,10 +1266,6 @@ static void build_items(const VmasWorldDesc* d, VmasWorld* w, const std::vector<
   w->items.clear();
   w->item_cost.clear();
   w->level = 0;
-  // sphere-sphere partners of one entity are consecutive (type-major order): pack them four to
-  // a record when the item list will live in LDS (the packed form is read from the blob only)
-  const bool pack_ss = (size_t)(2 * d->n_pairs + 2 * d->n_joints) * sizeof(DevItem) <= (size_t)ITEMS_LDS_BUDGET &&
-                       d->n_pairs < 65536 && !getenv("VMAS_NO_SSQ");
   if (pack_ss) {
     for (int e = 0; e < nE; ++e) {
       std::vector<DevItem> packed;
@@ -1166,6 +1304,8 @@ static void build_items(const VmasWorldDesc* d, VmasWorld* w, const std::vector<
     for (int e = 0; e < nE; ++e)
       for (const DevItem& t : per[e])
         if (t.type == VMAS_PAIR_LL || t.type == VMAS_PAIR_BL || t.type == VMAS_PAIR_BB || t.type == TASK_JOINT) level0 = false;
+    for (const DevItem& t : units)
+      if (t.type == VMAS_PAIR_LL || t.type == VMAS_PAIR_BL || t.type == VMAS_PAIR_BB || t.type == TASK_JOINT) level0 = false;
     for (int e = 0; e < nE && level0 && !getenv("VMAS_NO_LSQ"); ++e) {
       std::vector<DevItem> packed;
       size_t i = 0;
@@ -1211,6 +1351,51 @@ static void build_items(const VmasWorldDesc* d, VmasWorld* w, const std::vector<
     }
   }
   w->ent_item_begin[nE] = (int)w->items.size();
+  // shared items behind the entities' own: consecutive sphere-sphere pairs packed four to a record
+  w->unit_item_begin = (int)w->items.size();
+  w->n_shared_rows = shared_rows;
+  for (size_t i = 0; i < units.size();) {
+    if (units[i].type != VMAS_PAIR_SS) {
+      w->items.push_back(units[i]);
+      w->item_cost.push_back(type_cost(units[i].type));
+      if (units[i].type == VMAS_PAIR_BB) w->level = std::max(w->level, 2);
+      if (units[i].type == VMAS_PAIR_LL || units[i].type == VMAS_PAIR_BL || units[i].type == TASK_JOINT)
+        w->level = std::max(w->level, 1);
+      ++i;
+      continue;
+    }
+    size_t j = i;
+    while (j < units.size() && units[j].type == VMAS_PAIR_SS && j - i < 4) ++j;  // (their rows are consecutive: 2 each)
+    const int n = (int)(j - i);
+    auto fbits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+    uint32_t oa[4], ob[4], idx[4];
+    float rs[4];
+    for (int k = 0; k < 4; ++k) {
+      const DevItem& it = units[i + (k < n ? k : 0)];
+      oa[k] = (uint32_t)it.oa; ob[k] = (uint32_t)it.ob; rs[k] = it.p0; idx[k] = (uint32_t)it.index;
+    }
+    uint32_t wds[16] = {0};
+    wds[0] = TASK_SSP; wds[1] = (uint32_t)n; wds[2] = (uint32_t)(units[i].side >> 2);
+    wds[4] = oa[0] | (oa[1] << 16); wds[5] = oa[2] | (oa[3] << 16);
+    wds[6] = ob[0] | (ob[1] << 16); wds[7] = ob[2] | (ob[3] << 16);
+    for (int k = 0; k < 4; ++k) wds[8 + k] = fbits(rs[k]);
+    wds[12] = idx[0] | (idx[1] << 16); wds[13] = idx[2] | (idx[3] << 16);
+    DevItem q;
+    memcpy(&q, wds, sizeof(q));
+    w->items.push_back(q);
+    w->item_cost.push_back(40.f + 50.f * (float)n);
+    i = j;
+  }
+  w->ent_ref_begin.assign(nE + 1, 0);
+  w->refs.clear();
+  w->ent_ref_count.assign(nE, 0);
+  for (int e = 0; e < nE; ++e) {  // fetched four at a time: every entity's run starts at a multiple of 4, padded with its last reference
+    w->ent_ref_begin[e] = (int)w->refs.size();
+    w->ent_ref_count[e] = (int)ent_refs[e].size();
+    w->refs.insert(w->refs.end(), ent_refs[e].begin(), ent_refs[e].end());
+    while (w->refs.size() % 4) w->refs.push_back(ent_refs[e].back());
+  }
+  w->ent_ref_begin[nE] = (int)w->refs.size();
 }
 
 // Cut every dynamic entity's item list into segments of about total/nw cost and deal the
@@ -1226,11 +1411,12 @@ static int build_sched(VmasWorld* w, int nw, Sched& S) {
       total += 60.f;
       for (int i = w->ent_item_begin[e]; i < w->ent_item_begin[e + 1]; ++i) total += w->item_cost[i];
     }
+  for (size_t i = (size_t)w->unit_item_begin; i < w->items.size(); ++i) total += w->item_cost[i];
   const float target = std::max(total / (float)(2 * nw), 150.f);
   for (int e = 0; e < nE; ++e) {
     if (!(w->ents[e].flags & (VMAS_F_MOVABLE | VMAS_F_ROTATABLE))) continue;
     const int b = w->ent_item_begin[e], n = w->ent_item_begin[e + 1];
-    DevOwned O{e, e * 6 * ROWF, 3 * (int)segs.size(), 0};  // part_off holds the ROW until rebased below
+    DevOwned O{e, e * 6 * ROWF, 3 * (int)segs.size(), 0, w->ent_ref_begin[e], w->ent_ref_count[e]};  // part_off holds the ROW until rebased below
     int i = b;
     bool first = true;
     do {
@@ -1245,6 +1431,15 @@ static int build_sched(VmasWorld* w, int nw, Sched& S) {
     } while (i < n);
     owned_all.push_back(O);
   }
+  const int n_ent_segs = (int)segs.size();
+  for (int i = w->unit_item_begin, n = (int)w->items.size(); i < n;) {  // runs of shared items: no prologue, no partial rows
+    float c = 0.f;
+    int j = i;
+    while (j < n && (j == i || c + w->item_cost[j] <= target)) c += w->item_cost[j++];
+    segs.push_back({-1, 0, i, j, 0, 0});
+    seg_cost.push_back(c);
+    i = j;
+  }
   // waves pull segments from a counter at run time: order them heaviest first (dynamic LPT)
   std::vector<int> order(segs.size());
   std::iota(order.begin(), order.end(), 0);
@@ -1253,21 +1448,26 @@ static int build_sched(VmasWorld* w, int nw, Sched& S) {
   for (int si : order) segs_sorted.push_back(segs[si]);
   std::vector<DevOwned> owned = owned_all;
   if (getenv("VMAS_DEBUG_SCHED")) {
+    fprintf(stderr, "[sched nw=%d] %d own + %d shared items, %d shared rows, %zu refs\n", nw, w->unit_item_begin,
+            (int)w->items.size() - w->unit_item_begin, w->n_shared_rows, w->refs.size());
     for (int si : order) {
       fprintf(stderr, "[sched nw=%d] seg cost %.0f {e%d%s", nw, seg_cost[si], segs[si].entity, segs[si].first ? "*" : "");
       for (int i = segs[si].item_begin; i < segs[si].item_end; ++i)
-        fprintf(stderr, " %s%d-%d", (const char*[]){"SS", "LS", "LL", "BS", "BL", "BB", "J", "SSQ"}[w->items[i].type],
-                w->items[i].oa / (6 * ROWF), w->items[i].ob / (6 * ROWF));
+        if (w->items[i].type >= TASK_SSQ)
+          fprintf(stderr, " %s(n=%d)", (const char*[]){"SSQ", "LSQ", "SSP"}[w->items[i].type - TASK_SSQ], w->items[i].side);
+        else
+          fprintf(stderr, " %s%d-%d", (const char*[]){"SS", "LS", "LL", "BS", "BL", "BB", "J"}[w->items[i].type],
+                  w->items[i].oa / (6 * ROWF), w->items[i].ob / (6 * ROWF));
       fprintf(stderr, "}\n");
     }
   }
   // rows -> tile offsets: [state | agent forces | trig | partial sums | flag | blob | counters]
-  const int row_part = w->row_tr + 4 * (int)w->trig_ents.size();
-  for (auto& sg : segs_sorted) sg.part_off = (row_part + sg.part_off) * ROWF;
+  const int row_part = w->row_shared + w->n_shared_rows;
+  for (auto& sg : segs_sorted) sg.part_off = sg.entity < 0 ? 0 : (row_part + sg.part_off) * ROWF;
   for (auto& o : owned) o.part_off = (row_part + o.part_off) * ROWF;
   S.nw = nw;
   S.dw = w->base;
-  const int row_bad = row_part + 3 * (int)segs.size();
+  const int row_bad = row_part + 3 * n_ent_segs;
   S.dw.off_bad = row_bad * ROWF;
   std::vector<uint32_t> blob;
   auto append = [&](const void* p, size_t bytes) {
@@ -1279,6 +1479,8 @@ static int build_sched(VmasWorld* w, int nw, Sched& S) {
   S.dw.b_ent = append(w->dev_ents.data(), w->dev_ents.size() * sizeof(DevEntity));
   S.dw.b_segs = append(segs_sorted.data(), segs_sorted.size() * sizeof(DevSegment));
   S.dw.b_owned = append(owned.data(), owned.size() * sizeof(DevOwned));
+  while (blob.size() % 4) blob.push_back(0);  // (ds_read_b128 of four references)
+  S.dw.b_refs = append(w->refs.data(), w->refs.size() * sizeof(uint32_t));
   while (blob.size() % 4) blob.push_back(0);  // 16-byte alignment of the item records (ds_read_b128)
   const size_t item_bytes = w->items.size() * sizeof(DevItem);
   S.dw.items_in_lds = item_bytes <= (size_t)ITEMS_LDS_BUDGET;
@@ -1292,6 +1494,15 @@ static int build_sched(VmasWorld* w, int nw, Sched& S) {
   S.dw.n_owned = (int)owned.size();
   S.dw.off_blob = (row_bad + 1) * ROWF;
   S.lds_bytes = ((size_t)(row_bad + 1) * ROWF + S.dw.blob_words + 4) * sizeof(float);
+  if (getenv("VMAS_DEBUG_SCHED")) fprintf(stderr, "[sched nw=%d] %d segments, LDS %zu B per tile\n", nw, (int)segs.size(), S.lds_bytes);
+  return 0;
+}
+
+// rebuild the item lists without shared rows (all cached schedules are dropped)
+static int unshare(VmasWorld* w) {
+  for (auto& kv : w->scheds) kv.second.release();
+  w->scheds.clear();
+  build_items(w, 0);
   return 0;
 }
 
@@ -1388,6 +1599,8 @@ int vmas_world_create(const VmasWorldDesc* d, int32_t batch, int32_t device_id, 
   w->device = device_id;
   w->batch = batch;
   w->ents.assign(d->entities, d->entities + d->n_entities);
+  w->pairs.assign(d->pairs, d->pairs + d->n_pairs);
+  w->joints.assign(d->joints, d->joints + d->n_joints);
   w->n_pairs = d->n_pairs;
 
   std::vector<DevEntity> ents(d->n_entities);
@@ -1423,17 +1636,49 @@ int vmas_world_create(const VmasWorldDesc* d, int32_t batch, int32_t device_id, 
   w->row_tr = W.nE * 6 + W.nA * 3;
   for (int e = 0; e < d->n_entities; ++e)
     if (tr_row[e] >= 0) ents[e].tr_off = (w->row_tr + tr_row[e]) * ROWF;
-  build_items(d, w, tr_row);
+  w->tr_row = tr_row;
   std::vector<DevMaskPair> mp(d->n_pairs);
   for (int p = 0; p < d->n_pairs; ++p) mp[p] = {d->pairs[p].a, d->pairs[p].b, d->pairs[p].bound_sum};
   w->dev_ents = ents;
   HIP_TRY(upload(&w->d_mpairs, mp));
-  w->lanes = default_lanes(w);
-  Sched* S;
-  while (true) {
-    if (get_sched(w, w->lanes, &S)) return -1;
-    if (S->lds_bytes <= 160 * 1024 || w->lanes == 1) break;
-    w->lanes >>= 1;  // fewer segments => fewer partial rows
+  // Which pairs are evaluated once (shared rows in LDS) is decided by what the rows cost in OCCUPANCY: a batch with more
+  // tiles than CUs lives on two resident tiles per CU, so the rows may not push a tile beyond half the CU's LDS unless the
+  // unshared tile is already there; a batch of at most one tile per CU has the LDS to itself.  (Measured, DESIGN.md:
+  // football at 16384 envs 31.1 -> 28.8 us with everything shared, at 131072 envs 224 -> 351 us.)
+  static const int share_env = getenv("VMAS_SHARE") ? atoi(getenv("VMAS_SHARE")) : -1;  // (A/B measurements)
+  int n_cu = 256;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+  }
+  const long tiles = ((long)batch + TILE - 1) / TILE;
+  auto tiles_per_cu = [](size_t lds) { return lds > 160 * 1024 ? 0 : (int)std::min<size_t>(8, 160 * 1024 / lds); };
+  Sched* S = nullptr;
+  auto try_mode = [&](int mode) -> int {  // builds the items and the default schedule; returns resident tiles per CU (0: does not fit)
+    for (auto& kv : w->scheds) kv.second.release();
+    w->scheds.clear();
+    build_items(w, mode);
+    w->lanes = default_lanes(w);
+    while (true) {
+      if (get_sched(w, w->lanes, &S)) return -1;
+      if (S->lds_bytes <= 160 * 1024 || w->lanes == 1) break;
+      w->lanes >>= 1;  // fewer segments => fewer partial rows
+    }
+    return tiles_per_cu(S->lds_bytes);
+  };
+  if (share_env >= 0) {
+    if (try_mode(share_env) < 0) return -1;
+  } else {
+    const int base = try_mode(0);
+    if (base < 0) return -1;
+    const int want = (int)std::min<long>(std::min(base, 2), (tiles + n_cu - 1) / n_cu);
+    for (int mode = 2; mode >= 1; --mode) {
+      const int r = try_mode(mode);
+      if (r < 0) return -1;
+      if (w->n_shared_rows == 0) { mode = 1; }  // nothing to share at this mode: the lower modes are the same world
+      if (r >= want && r > 0) break;
+      if (mode == 1 && try_mode(0) < 0) return -1;
+    }
   }
   if (S->lds_bytes > 160 * 1024) {
     return fail("vmas_world_create: a 64-environment tile of this world needs %zu B of LDS (> 160 KiB)", S->lds_bytes);
@@ -1460,6 +1705,7 @@ int vmas_world_set_lanes_per_env(VmasWorld* w, int32_t lanes) {
   HIP_TRY(hipSetDevice(w->device));
   Sched* S;
   if (get_sched(w, lanes, &S)) return -1;
+  if (S->lds_bytes > 160 * 1024 && w->n_shared_rows > 0 && (unshare(w) || get_sched(w, lanes, &S))) return -1;
   if (S->lds_bytes > 160 * 1024)
     return fail("lanes_per_env=%d needs %zu B of LDS per tile (> 160 KiB)", lanes, S->lds_bytes);
   w->lanes = lanes;
@@ -1578,8 +1824,12 @@ static int step_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld, co
   if (env_kind == ENV_NONE) return launch_any_level<ENV_NONE>(w, S, state, agent_ft, ld, a, NoEnv{}, 0, s);
   if (S->nw < 2 && env_kind != ENV_INGEST)
     return fail("vmas_world_step_env: the fused epilogue needs at least 2 waves per tile");
+  size_t extra = (scratch_fixed + scratch_per_wave * S->nw) * sizeof(float);
+  if (S->lds_bytes + extra > 160 * 1024 && w->n_shared_rows > 0) {  // the epilogue's scratch needs the shared rows' LDS
+    if (unshare(w) || get_sched(w, w->lanes, &S)) return -1;
+    extra = (scratch_fixed + scratch_per_wave * S->nw) * sizeof(float);
+  }
   env->scratch_off = (int32_t)(S->lds_bytes / sizeof(float));
-  const size_t extra = (scratch_fixed + scratch_per_wave * S->nw) * sizeof(float);
   if (env_kind == ENV_BALANCE) return launch_any_level<ENV_BALANCE>(w, S, state, agent_ft, ld, a, *env, extra, s);
   if (env_kind == ENV_INGEST) return launch_any_level<ENV_INGEST>(w, S, state, agent_ft, ld, a, *env, 0, s);
   return launch_any_level<ENV_TRANSPORT>(w, S, state, agent_ft, ld, a, *env, extra, s);
