@@ -19,7 +19,32 @@ constexpr float kInf = __builtin_huge_valf();
 
 typedef float v2 __attribute__((ext_vector_type(2)));  // (+, -, unary - are element-wise: v_pk_add_f32 where they pair up)
 VD v2 V(float x, float y) { v2 r; r.x = x; r.y = y; return r; }
-VD float norm2(float x, float y) { return __fsqrt_rn(__fmaf_rn(y, y, x * x)); }
+// IEEE sqrt and division as hipcc expands them for gfx950, minus the exponent-range scaffolding:
+//  * sqrt: the compiler wraps v_sqrt_f32 in a denormal-input rescue (cmp, cndmask, ldexp, ..., cndmask, ldexp: 6 VALU per
+//    root).  Arguments here are squared lengths; one below 2^-126 means a distance below 1e-19, which every caller treats
+//    as zero anyway (core.py:2836-2838).  The bare instruction gives the same bits for every normal input.
+//  * division: v_div_scale x2, v_rcp, Newton step, two quotient corrections, v_div_fmas, v_div_fixup (12 VALU).  The
+//    scaling only acts when an exponent sits at the edge of the format; without it the SAME instruction sequence needs 9,
+//    and quotients that share a denominator (x/n, y/n) share its refined reciprocal: 6 each.  v_div_fixup keeps the IEEE
+//    results for 0, inf and NaN operands.  Same bits as a/b whenever div_scale would not have scaled.
+VD float sqrt_n(float x) { return __builtin_amdgcn_sqrtf(x); }
+struct rcp_t { float b, y; };
+VD rcp_t rcp_of(float b) {
+  float y = __builtin_amdgcn_rcpf(b);
+  const float e = __builtin_fmaf(-b, y, 1.f);
+  y = __builtin_fmaf(e, y, y);
+  rcp_t r; r.b = b; r.y = y;
+  return r;
+}
+VD float operator/(float a, rcp_t d) {
+  float q = a * d.y;
+  float r = __builtin_fmaf(-d.b, q, a);
+  q = __builtin_fmaf(r, d.y, q);
+  r = __builtin_fmaf(-d.b, q, a);
+  q = __builtin_fmaf(r, d.y, q);
+  return __builtin_amdgcn_div_fixupf(q, d.b, a);
+}
+VD float norm2(float x, float y) { return sqrt_n(__fmaf_rn(y, y, x * x)); }
 VD float vnorm(v2 a) { return norm2(a.x, a.y); }
 VD float vdot(v2 a, v2 b) { return a.x * b.x + a.y * b.y; }               // (a*b).sum(-1)
 VD float vcross(v2 a, v2 b) { return a.x * b.y - a.y * b.x; }             // utils.py:193-197
@@ -32,7 +57,8 @@ VD v2 rotate(v2 v, float c, float s) { return V(v.x * c - v.y * s, v.x * s + v.y
 // TorchUtils.clamp_with_norm utils.py:167-173
 VD v2 clamp_with_norm(v2 t, float max_norm) {
   float n = vnorm(t);
-  v2 nt = V((t.x / n) * max_norm, (t.y / n) * max_norm);
+  const rcp_t rn = rcp_of(n);
+  v2 nt = V((t.x / rn) * max_norm, (t.y / rn) * max_norm);
   return n > max_norm ? nt : t;
 }
 
@@ -43,7 +69,12 @@ VD v2 clamp_with_norm(v2 t, float max_norm) {
 VD float log1p_unit(float y) {
   const float u = 1.f + y;
   const float e = y - (u - 1.f);
-  return logf(u) + e * __builtin_amdgcn_rcpf(u);
+  // logf(u) as ocml evaluates it for a normal, finite u (here u is in [1, 2]): log2 times ln2 as a two-term product
+  const float r = __builtin_amdgcn_logf(u);
+  const float h = 0x1.62e42ep-1f * r;
+  float l = __builtin_fmaf(r, 0x1.62e42ep-1f, -h);
+  l = __builtin_fmaf(r, 0x1.efa39ep-25f, l);
+  return (h + l) + e * __builtin_amdgcn_rcpf(u);
 }
 // torch.logaddexp(0, x): max(0, x) + log1p(exp(-|x|))
 VD float softplus0(float x) { return max_t(0.f, x) + log1p_unit(expf(-fabsf(0.f - x))); }
@@ -55,8 +86,8 @@ VD v2 constraint_force(v2 pa, v2 pb, float dist_min, float c, float k) {
   v2 d = pa - pb;
   float dist = vnorm(d);
   float sign = ATTRACTIVE ? -1.f : 1.f;
-  float pen = softplus0((dist_min - dist) * sign / k) * k;
-  float den = dist > 0.f ? dist : 1e-8f;
+  float pen = softplus0((dist_min - dist) * sign / rcp_of(k)) * k;
+  const rcp_t den = rcp_of(dist > 0.f ? dist : 1e-8f);
   v2 f = V(c * d.x / den * pen, c * d.y / den * pen);
   bool zero = dist < 1e-6f;
   zero = zero || (ATTRACTIVE ? (dist < dist_min) : (dist > dist_min));
@@ -70,8 +101,8 @@ VD v2 contact_force(v2 pa, v2 pb, float dist_min, float c, float k) {
   const v2 d = pa - pb;
   const float dist = vnorm(d);
   if (!__any(!(dist > dist_min))) return V(0.f, 0.f);
-  const float pen = softplus0((dist_min - dist) / k) * k;  // sign = +1
-  const float den = dist > 0.f ? dist : 1e-8f;
+  const float pen = softplus0((dist_min - dist) / rcp_of(k)) * k;  // sign = +1
+  const rcp_t den = rcp_of(dist > 0.f ? dist : 1e-8f);
   const v2 f = V(c * d.x / den * pen, c * d.y / den * pen);
   const bool zero = (dist < 1e-6f) || (dist > dist_min);
   return zero ? V(0.f, 0.f) : f;
@@ -136,8 +167,9 @@ VD v2 inner_point_box(v2 outside, v2 surface, v2 box_pos, float& depth) {
   v2 v = surface - outside;
   v2 u = box_pos - surface;
   float n = vnorm(v);
-  float xm = vdot(v, u) / n;
-  v2 x = V((v.x / n) * xm, (v.y / n) * xm);
+  const rcp_t rn = rcp_of(n);
+  float xm = vdot(v, u) / rn;
+  v2 x = V((v.x / rn) * xm, (v.y / rn) * xm);
   bool z = n == 0.f;
   x = z ? surface : x;
   xm = z ? 0.f : xm;
@@ -153,7 +185,8 @@ VD void closest_points_seg_seg(const seg_t& l1, const seg_t& l2, v2& p1, v2& p2)
   v2 b1 = l2.pos + xy2, b2 = l2.pos - xy2;
   v2 r = a2 - a1, s = b2 - b1, qp = b1 - a1;
   float cqpr = vcross(qp, r), cqps = vcross(qp, s), crs = vcross(r, s);
-  float u = cqpr / crs, t = cqps / crs;
+  const rcp_t rc = rcp_of(crs);
+  float u = cqpr / rc, t = cqps / rc;
   bool hit = (crs != 0.f) && (0.f <= u) && (u <= 1.f) && (0.f <= t) && (t <= 1.f);
   v2 pi = V(a1.x + t * r.x, a1.y + t * r.y);
   v2 q1 = V(kInf, kInf), q2 = V(kInf, kInf);

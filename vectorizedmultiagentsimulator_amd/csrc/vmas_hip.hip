@@ -833,7 +833,8 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
       if (fl & VMAS_F_MOVABLE) {
         v2 vel = V(Es[2 * ROWF], Es[3 * ROWF]);
         if (substep == 0) vel = V(vel.x * D.one_minus_drag, vel.y * D.one_minus_drag);
-        const v2 acc = V(F.x / D.mass, F.y / D.mass);
+        const rcp_t rm = rcp_of(D.mass);
+        const v2 acc = V(F.x / rm, F.y / rm);
         vel = V(vel.x + acc.x * sub_dt, vel.y + acc.y * sub_dt);
         if (fl & VMAS_F_MAX_SPEED) vel = clamp_with_norm(vel, D.max_speed);
         if (fl & VMAS_F_V_RANGE) vel = V(clamp_t(vel.x, D.v_range), clamp_t(vel.y, D.v_range));
@@ -992,7 +993,7 @@ __global__ __launch_bounds__(256) void lidar_kernel(const DevLidar* __restrict__
           const float dn = vnorm(tpos - cp);
           const bool ok = (dn < Tg.radius) && (vdot(u, dir) > 0.f);
           const float a = Tg.radius * Tg.radius - dn * dn;
-          const float m = __fsqrt_rn(a > 0.f ? a : 1e-8f);
+          const float m = sqrt_n(a > 0.f ? a : 1e-8f);
           float dist = vnorm(cp - o) - m;
           dist = ok ? dist : R;
           best[i] = min_t(best[i], dist);
@@ -1014,7 +1015,7 @@ __global__ __launch_bounds__(256) void lidar_kernel(const DevLidar* __restrict__
           const float dn = vnorm(tpos - cp);
           const bool ok = (dn < Tg.radius) && (vdot(u, dir) > 0.f);
           const float a = Tg.radius * Tg.radius - dn * dn;
-          const float m = __fsqrt_rn(a > 0.f ? a : 1e-8f);
+          const float m = sqrt_n(a > 0.f ? a : 1e-8f);
           float dist = vnorm(cp - o) - m;
           dist = ok ? dist : R;
           best[i] = min_t(best[i], dist);
