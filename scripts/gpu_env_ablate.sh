@@ -1,3 +1,5 @@
+# (the VMAS_ABLATE / VMAS_ENV_ABLATE knobs only exist in -DVMAS_PROFILE builds; the product library is rebuilt at the end)
+VMAS_HIPCC_EXTRA=-DVMAS_PROFILE bash vectorizedmultiagentsimulator_amd/csrc/build.sh > /dev/null 2>&1
 # kernel duration of the one-launch balance step with pieces of the prologue / epilogue switched off
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -12,3 +14,4 @@ for r in csv.DictReader(open(sys.argv[2])):
         print(f"ablate {sys.argv[1]}: {float(r['AverageNs'])/1000:.2f} us ({r['Calls']} calls)")
 PY
 done
+bash vectorizedmultiagentsimulator_amd/csrc/build.sh > /dev/null 2>&1

@@ -1,3 +1,5 @@
+# (the VMAS_ABLATE / VMAS_ENV_ABLATE knobs only exist in -DVMAS_PROFILE builds; the product library is rebuilt at the end)
+VMAS_HIPCC_EXTRA=-DVMAS_PROFILE bash vectorizedmultiagentsimulator_amd/csrc/build.sh > /dev/null 2>&1
 # dynamic instruction counts per wave of step_kernel under the VMAS_ABLATE profiling toggles
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 for A in ${ABL:-0 1 16 32 2 3 15}; do
@@ -13,3 +15,4 @@ w=sum(acc['SQ_WAVES'])/len(acc['SQ_WAVES'])
 print('ablate', sys.argv[1], ' '.join('%s %.0f'%(k.replace('SQ_INSTS_',''), sum(v)/len(v)/w) for k,v in sorted(acc.items()) if k!='SQ_WAVES'), 'waves %d'%w)
 PY
 done
+bash vectorizedmultiagentsimulator_amd/csrc/build.sh > /dev/null 2>&1

@@ -234,6 +234,7 @@ VD void closest_seg_box(const seg_t be[4], const seg_t& line, v2& p_box, v2& p_l
 VD void closest_box_box(const seg_t ea[4], const seg_t eb[4], v2& pa, v2& pb) {
   v2 qa = V(kInf, kInf), qb = V(kInf, kInf);
   float best = kInf;
+#pragma unroll 1  // (32 segment-segment solves: unrolled they cost 90 KB of code and every VGPR the wave has)
   for (int i = 0; i < 4; ++i) {  // A's edges against box B -> (on B, on A's edge)
     v2 on_b, on_a;
     closest_seg_box(eb, ea[i], on_b, on_a);
@@ -241,6 +242,7 @@ VD void closest_box_box(const seg_t ea[4], const seg_t eb[4], v2& pa, v2& pb) {
     bool cl = d < best;
     qa = cl ? on_a : qa; qb = cl ? on_b : qb; best = cl ? d : best;
   }
+#pragma unroll 1
   for (int i = 0; i < 4; ++i) {  // B's edges against box A -> (on A, on B's edge)
     v2 on_a, on_b;
     closest_seg_box(ea, eb[i], on_a, on_b);

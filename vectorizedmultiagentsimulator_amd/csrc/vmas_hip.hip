@@ -111,7 +111,12 @@ struct DevEntity {
 
 struct DevWorld {
   int32_t nE, nA, substeps;
-  int32_t off_af, off_bad;  // tile offsets of the agent force rows and of the flag row
+  int32_t off_af;  // tile offset of the agent force rows
+  // Which entities need cos/sin rows (bit e: a Line or a Box | a Box), straight from the kernel arguments so that the load
+  // phase does not wait for the descriptor blob: entity e's four trig rows start at row_tr + 4 * popcount(trig_mask below e).
+  // trig_in_args == 0: more than 64 entities, shapes and offsets come from the blob behind a barrier of their own.
+  unsigned long long trig_mask, box_mask;
+  int32_t trig_in_args, row_tr;
   float sub_dt, gx, gy;
   int32_t has_gravity;
   float xs, ys;  // NaN = unbounded
@@ -160,8 +165,21 @@ struct DevEnv {
 };
 struct NoEnv {};
 
+// Profiling knobs (env VMAS_ABLATE / VMAS_ENV_ABLATE) exist only in -DVMAS_PROFILE builds (scripts/gpu_ablate.sh): in the
+// product build they are the literal 0, so their tests - and the scalar register that carried them through every loop -
+// are compiled out.
+#ifdef VMAS_PROFILE
+#define ABLATE(a) ((a).ablate)
+#else
+#define ABLATE(a) 0
+#endif
+
 __device__ __forceinline__ int sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ bool finite_f(float x) { return fabsf(x) < kInf; }
+// A pair may be skipped only on a FINITE squared distance beyond its bound: a NaN or an infinite operand must reach the
+// narrow phase, where the reference's own arithmetic decides (inf * 0, cos(inf) ... = NaN poisons the pair however far
+// apart the shapes are).  Together with the NaN checks on the cos rows of Lines and Boxes this is why no separate
+// "environment has a non-finite pose" flag is needed.
+__device__ __forceinline__ bool far_apart(float d2, float thr2) { return d2 > thr2 && d2 < kInf; }
 
 // cos/sin of the rotation(s) the narrow phase needs (physics.py:300-302, 413)
 __device__ __forceinline__ void write_trig(float* tr, float rot, int shape) {
@@ -243,7 +261,7 @@ static_assert(sizeof(DevItem) == 64 && sizeof(DevEntity) == 68, "descriptor layo
 // trips; the forces are added to F one by one, in the reference's order.  Both sides of a
 // sphere pair see force(own, other): cf(a,b) == -cf(b,a) bit for bit, so no sign flip is needed.
 __device__ __forceinline__ void eval_ssq(const uint32_t* p, const DevWorld& W, const DevStepArgs& args,
-                                         const float* tile, bool may_skip, bool movable, v2& F) {
+                                         const float* tile, bool movable, v2& F) {
   const uint4 w0 = ((const uint4*)p)[0], w1 = ((const uint4*)p)[1], w2 = ((const uint4*)p)[2], w3 = ((const uint4*)p)[3];
   const int n = sgpr((int)w0.y);
   const float* E = tile + (int)w1.x;
@@ -262,12 +280,12 @@ __device__ __forceinline__ void eval_ssq(const uint32_t* p, const DevWorld& W, c
   for (int k = 0; k < 4; ++k) {
     const float dx = pe.x - po[k].x, dy = pe.y - po[k].y;
     const float m = rs[k] + 1e-4f;  // the force is exactly 0 for dist > r_a + r_b (core.py:2836)
-    bool need = !(dx * dx + dy * dy > m * m) || !may_skip;
+    bool need = !far_apart(dx * dx + dy * dy, m * m);
     bool on = k < n;
     if (args.pair_mask) on = on && ((args.pair_mask[sgpr(idx[k]) >> 5] >> (sgpr(idx[k]) & 31)) & 1u);
     needbits |= (on && __any(need)) ? (1u << k) : 0u;
   }
-  if (!needbits || (args.ablate & 32)) return;
+  if (!needbits || (ABLATE(args) & 32)) return;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     if (needbits & (1u << k)) {
@@ -283,7 +301,7 @@ __device__ __forceinline__ void eval_ssq(const uint32_t* p, const DevWorld& W, c
 // Same arithmetic as the unpacked item (own(-cf(sphere, cp)) with the b-side sign flip == cf(sphere, cp) bit for
 // bit), one descriptor fetch and sixteen operand reads in flight instead of four dependent round trips.
 __device__ __forceinline__ void eval_lsq(const uint32_t* p, const DevWorld& W, const DevStepArgs& args,
-                                         const float* tile, bool may_skip, bool movable, v2& F) {
+                                         const float* tile, bool movable, v2& F) {
   const uint4 w0 = ((const uint4*)p)[0], w1 = ((const uint4*)p)[1], w2 = ((const uint4*)p)[2], w3 = ((const uint4*)p)[3];
   const int n = sgpr((int)w0.y);
   const float* E = tile + (int)w0.z;
@@ -308,12 +326,12 @@ __device__ __forceinline__ void eval_lsq(const uint32_t* p, const DevWorld& W, c
   for (int k = 0; k < 4; ++k) {
     const float dx = pl[k].x - ps.x, dy = pl[k].y - ps.y;
     const float m = half[k] + dist_min + kSkipSlack;  // bounding circles: beyond it the force is exactly 0
-    bool need = !(dx * dx + dy * dy > m * m) || !may_skip;
+    bool need = !far_apart(dx * dx + dy * dy, m * m) || cs[k] != cs[k];  // (cos of a non-finite rotation is NaN)
     bool on = k < n;
     if (args.pair_mask) on = on && ((args.pair_mask[sgpr(idx[k]) >> 5] >> (sgpr(idx[k]) & 31)) & 1u);
     needbits |= (on && __any(need)) ? (1u << k) : 0u;
   }
-  if (!needbits || (args.ablate & 32)) return;
+  if (!needbits || (ABLATE(args) & 32)) return;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     if (needbits & (1u << k)) {  // core.py:2341-2392
@@ -328,8 +346,7 @@ __device__ __forceinline__ void eval_lsq(const uint32_t* p, const DevWorld& W, c
 // to the pair's two LDS rows, b's owner reads it with the sign flipped (cf(a,b) == -cf(b,a) bit for bit).
 //   w0: type, n, tile offset of the first pair's rows (pair k: + 2k rows), -
 //   w1: a offsets 0|1<<16, 2|3<<16, b offsets 0|1<<16, 2|3<<16   w2: r_sum 0..3   w3: pair index 0|1<<16, 2|3<<16
-__device__ __forceinline__ void eval_ssp(const uint32_t* p, const DevWorld& W, const DevStepArgs& args, float* tile,
-                                         bool may_skip) {
+__device__ __forceinline__ void eval_ssp(const uint32_t* p, const DevWorld& W, const DevStepArgs& args, float* tile) {
   const uint4 w0 = ((const uint4*)p)[0], w1 = ((const uint4*)p)[1], w2 = ((const uint4*)p)[2], w3 = ((const uint4*)p)[3];
   const int n = sgpr((int)w0.y);
   float* R = tile + (int)w0.z;
@@ -350,12 +367,12 @@ __device__ __forceinline__ void eval_ssp(const uint32_t* p, const DevWorld& W, c
   for (int k = 0; k < 4; ++k) {
     const float dx = pa[k].x - pb[k].x, dy = pa[k].y - pb[k].y;
     const float m = rs[k] + 1e-4f;  // the force is exactly 0 for dist > r_a + r_b (core.py:2836)
-    bool need = !(dx * dx + dy * dy > m * m) || !may_skip;
+    bool need = !far_apart(dx * dx + dy * dy, m * m);
     bool on = k < n;
     if (args.pair_mask) on = on && ((args.pair_mask[sgpr(idx[k]) >> 5] >> (sgpr(idx[k]) & 31)) & 1u);
     needbits |= (on && __any(need)) ? (1u << k) : 0u;
   }
-  if (args.ablate & 32) needbits = 0;
+  if (ABLATE(args) & 32) needbits = 0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     if (k < n) {
@@ -371,8 +388,8 @@ __device__ __forceinline__ void eval_ssp(const uint32_t* p, const DevWorld& W, c
 // 0: SS LS BS   1: + LL BL joints   2: + BB
 template <int LEVEL>
 __device__ __forceinline__ void eval_item(const ItemV& K, const DevWorld& W, const DevStepArgs& args,
-                                          const float* tile, long env, bool live, long ld, bool may_skip, v2& f_out,
-                                          float& t_out, float& tb_out) {
+                                          const float* tile, long env, bool live, long ld, v2& f_out, float& t_out,
+                                          float& tb_out) {
   const float* A = tile + K.oa;
   const float* B = tile + K.ob;
   const v2 pa = V(A[0], A[ROWF]), pb = V(B[0], B[ROWF]);
@@ -418,7 +435,7 @@ __device__ __forceinline__ void eval_item(const ItemV& K, const DevWorld& W, con
   const float* TB = tile + K.trb;
   {  // conservative per-environment broad phase: beyond it the force is exactly zero
     const float dx = pa.x - pb.x, dy = pa.y - pb.y;
-    bool need = !(dx * dx + dy * dy > K.thr2);
+    bool need = !far_apart(dx * dx + dy * dy, K.thr2);
     if (K.type >= VMAS_PAIR_BS) {  // a is a box: test against the oriented box, much tighter
       if (K.type == VMAS_PAIR_BL) {
         const float gap = seg_obb_gap(pb, TB[0], TB[ROWF], K.p2, pa, TA[0], TA[ROWF], K.p0 * 0.5f, K.p1 * 0.5f);
@@ -428,8 +445,10 @@ __device__ __forceinline__ void eval_item(const ItemV& K, const DevWorld& W, con
         need = need && !(d2 > K.reach * K.reach);
       }
     }
-    need = need || !may_skip;
-    if (!__any(need) || (args.ablate & 32)) return;  // 32: broad phase only (profiling)
+    // a Line/Box with a non-finite rotation has NaN edges at any distance
+    if (K.type != VMAS_PAIR_SS) need = need || TA[0] != TA[0];
+    if (K.type == VMAS_PAIR_LL || K.type == VMAS_PAIR_BL || K.type == VMAS_PAIR_BB) need = need || TB[0] != TB[0];
+    if (!__any(need) || (ABLATE(args) & 32)) return;  // 32: broad phase only (profiling)
   }
   switch (K.type) {
     case VMAS_PAIR_SS: {  // core.py:2294-2339; p0 = r_a + r_b
@@ -522,7 +541,6 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
 #endif
   STAMP(0);
   float* tile = lds + lane;  // this lane's column: row r is tile[r * ROWF]
-  int* bad_flag = (int*)(tile + W.off_bad);
   uint32_t* blob = (uint32_t*)(lds + W.off_blob);
   int* ctr = (int*)(blob + W.blob_words);  // [4] work counters: (substep parity) x (gather, integrate)
   constexpr int EW = (int)(sizeof(DevEntity) / 4), SW = (int)(sizeof(DevSegment) / 4), OW = (int)(sizeof(DevOwned) / 4),
@@ -541,7 +559,7 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
   auto load_agent_ft = [&](int a, float* f3) {
     const float* src = agent_ft + (long)a * 3 * ld + env;
     if constexpr (ENV != ENV_NONE) {
-      const bool on = E.has_ingest && !(E.ablate & 8);
+      const bool on = E.has_ingest && !(ABLATE(E) & 8);
       const VmasActionSlot& S = E.ingest.agents[a];
       if (on && (S.action != nullptr || S.action_index != nullptr)) {
         uint32_t bad = 0;
@@ -573,14 +591,26 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
       term[p * 64] = live ? E.transport.o.global_shaping[(long)p * batch + env] : 0.f;
     if (wv == 0) post_steps = (E.transport.o.limit.steps != nullptr && live) ? E.transport.o.limit.steps[env] : 0.f;
   }
-  for (int i = threadIdx.x; i < W.blob_words; i += blockDim.x) blob[i] = W.blob[i];
-  const int first_dyn = (args.ablate & 128) ? 0 : nw;  // 128: profiling toggle, fully dynamic
+  {  // the descriptor blob, 16 bytes per thread and up to four requests in flight before the first LDS write (a plain
+     // copy loop waits for every load before it issues the next: one full HBM latency per iteration)
+    const uint4* src = (const uint4*)W.blob;
+    uint4* dst = (uint4*)blob;
+    const int n4 = W.blob_words >> 2;  // (the host pads the blob to a multiple of four words)
+    const int nt = blockDim.x;
+    for (int i0 = threadIdx.x; i0 < n4; i0 += 4 * nt) {
+      const int i1 = i0 + nt, i2 = i0 + 2 * nt, i3 = i0 + 3 * nt;
+      const uint4 a = src[i0], b = src[i1 < n4 ? i1 : i0], c = src[i2 < n4 ? i2 : i0], d = src[i3 < n4 ? i3 : i0];
+      dst[i0] = a;
+      if (i1 < n4) dst[i1] = b;
+      if (i2 < n4) dst[i2] = c;
+      if (i3 < n4) dst[i3] = d;
+    }
+  }
+  const int first_dyn = (ABLATE(args) & 128) ? 0 : nw;  // 128: profiling toggle, fully dynamic
   if (threadIdx.x < 4) ctr[threadIdx.x] = first_dyn;  // the first unit of every wave is static (its own index)
-  if (wv == nw - 1) *bad_flag = 0;
-  __syncthreads();
 
   // ---- HBM -> LDS, one entity per wave at a time: six 256-byte row reads in flight, then the
-  //      entity's trig and the non-finite check straight from the registers
+  //      entity's trig straight from the registers
   for (int e = wv; e < nE; e += nw) {
     float v[6];
     if (e == wv) {
@@ -596,9 +626,10 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
     for (int f = 0; f < 6; ++f) dst[f * ROWF] = v[f];
     // the reference lets a non-finite pose poison every pair it is in, however far apart
     // (cos(inf) = NaN): such environments must not use the distance skip
-    if (!finite_f(v[0]) || !finite_f(v[1]) || !finite_f(v[4])) *bad_flag = 1;
-    const int shape = sgpr((int)blob[W.b_ent + e * EW + 1]), tr_off = sgpr((int)blob[W.b_ent + e * EW + 3]);
-    if (tr_off >= 0 && !(args.ablate & 8)) write_trig(tile + tr_off, v[4], shape);
+    if (W.trig_in_args && ((W.trig_mask >> e) & 1ull) && !(ABLATE(args) & 8)) {
+      const int tr_row = W.row_tr + 4 * __builtin_popcountll(W.trig_mask & ((1ull << e) - 1ull));
+      write_trig(tile + tr_row * ROWF, v[4], ((W.box_mask >> e) & 1ull) ? VMAS_SHAPE_BOX : VMAS_SHAPE_LINE);
+    }
   }
   if (wv < nA) {
     float* dst = tile + W.off_af + wv * 3 * ROWF;
@@ -614,6 +645,13 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
   }
   STAMP(1);
   __syncthreads();
+  if (!W.trig_in_args) {  // (more than 64 entities: shapes and offsets from the blob, rotations from the tile)
+    for (int e = wv; e < nE && !(ABLATE(args) & 8); e += nw) {
+      const int shape = sgpr((int)blob[W.b_ent + e * EW + 1]), tr_off = sgpr((int)blob[W.b_ent + e * EW + 3]);
+      if (tr_off >= 0) write_trig(tile + tr_off, tile[(e * 6 + 4) * ROWF], shape);
+    }
+    __syncthreads();
+  }
   STAMP(2);
 
   const float sub_dt = W.sub_dt;
@@ -645,7 +683,6 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
     __syncthreads();
   }
   for (int substep = s_begin; substep < s_end; ++substep, ++it) {
-    const bool may_skip = *bad_flag == 0;
     const bool last_sub = substep + 1 == s_end;
     const bool last = last_sub && stp + 1 == n_steps;  // write back to HBM instead of LDS
     int* c_gather = ctr + 2 * (it & 1);
@@ -661,17 +698,17 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
       const float* Es = tile + (int)sp[1];
       const int i0 = sgpr((int)sp[2]), i1s = sgpr((int)sp[3]), first = sgpr((int)sp[4]);
       if (e < 0) {  // a run of SHARED pairs/joints (both entities dynamic): evaluated once, both owners read the rows in phase C
-        const int i1u = (args.ablate & 1) ? i0 : i1s;
+        const int i1u = (ABLATE(args) & 1) ? i0 : i1s;
         for (int ii = i0; ii < i1u; ++ii) {
           const uint32_t* ip = blob + W.b_items + ii * IW;
           if (sgpr((int)ip[0]) == TASK_SSP) {
-            eval_ssp(ip, W, args, tile, may_skip);
+            eval_ssp(ip, W, args, tile);
             continue;
           }
           const ItemV K = load_item(ip);
           v2 f = V(0.f, 0.f);
           float ta = 0.f, tb = 0.f;
-          if (!(args.ablate & 16)) eval_item<LEVEL>(K, W, args, tile, env, live, ld, may_skip, f, ta, tb);
+          if (!(ABLATE(args) & 16)) eval_item<LEVEL>(K, W, args, tile, env, live, ld, f, ta, tb);
           float* R = tile + (K.side >> 2);
           R[0] = f.x; R[ROWF] = f.y; R[2 * ROWF] = ta;
           if (K.type != VMAS_PAIR_LS && K.type != VMAS_PAIR_BS) R[3 * ROWF] = tb;  // (b is a sphere: no torque row)
@@ -688,7 +725,7 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
 #ifdef VMAS_TRACE
       { unsigned long long t1 = TNOW(); acc_grab += t1 - tg; tg = t1; }
 #endif
-      if (first && !(args.ablate & 4)) {  // prologue core.py:1995-2004
+      if (first && !(ABLATE(args) & 4)) {  // prologue core.py:1995-2004
         const EntV D = load_ent(blob + W.b_ent + e * EW);
         const uint32_t fl = D.flags;
         if (fl & VMAS_F_AGENT) {
@@ -741,22 +778,22 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
 #ifdef VMAS_TRACE
       { unsigned long long t1 = TNOW(); acc_pro += t1 - tg; tg = t1; }
 #endif
-      const int i1 = (args.ablate & 1) ? i0 : i1s;
+      const int i1 = (ABLATE(args) & 1) ? i0 : i1s;
       for (int ii = i0; ii < i1; ++ii) {
         const int packed_type = W.items_in_lds ? sgpr((int)blob[W.b_items + ii * IW]) : 0;
         if (packed_type >= TASK_SSQ) {  // packed records exist only in the LDS copy of the item list
-          if (!(args.ablate & 16)) {
+          if (!(ABLATE(args) & 16)) {
             if (LEVEL > 0 || packed_type == TASK_SSQ)  // (line-sphere records are only built for level-0 worlds)
-              eval_ssq(blob + W.b_items + ii * IW, W, args, tile, may_skip, efl & VMAS_F_MOVABLE, F);
+              eval_ssq(blob + W.b_items + ii * IW, W, args, tile, efl & VMAS_F_MOVABLE, F);
             else
-              eval_lsq(blob + W.b_items + ii * IW, W, args, tile, may_skip, efl & VMAS_F_MOVABLE, F);
+              eval_lsq(blob + W.b_items + ii * IW, W, args, tile, efl & VMAS_F_MOVABLE, F);
           }
           continue;
         }
         const ItemV K = W.items_in_lds ? load_item(blob + W.b_items + ii * IW) : item_from_global(W.items[ii]);
         v2 f = V(0.f, 0.f);
         float t = 0.f, t_unused = 0.f;
-        if (!(args.ablate & 16)) eval_item<LEVEL>(K, W, args, tile, env, live, ld, may_skip, f, t, t_unused);
+        if (!(ABLATE(args) & 16)) eval_item<LEVEL>(K, W, args, tile, env, live, ld, f, t, t_unused);
         else f.x = __int_as_float(K.type + K.oa + K.ob + K.index) * 1e-30f;  // descriptor fetch only (profiling)
         if (efl & VMAS_F_MOVABLE) F = F + f;
         if (efl & VMAS_F_ROTATABLE) Tq = Tq + t;
@@ -786,7 +823,7 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
 
     // ================= phase C: _integrate_state core.py:2862-2908 (+ trig for the next substep,
     //                   or, after the last substep, the write-back of the entity's planes)
-    const int n_own = (args.ablate & 2) ? 0 : W.n_owned;
+    const int n_own = (ABLATE(args) & 2) ? 0 : W.n_owned;
     for (int oi = first_dyn ? wv : grab(c_integrate); oi < n_own; oi = grab(c_integrate)) {
       const uint32_t* op = blob + W.b_owned + oi * OW;
       const int e = sgpr((int)op[0]);
@@ -829,7 +866,6 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
         }
       }
       float* dst = state + (long)e * 6 * ld + env;
-      bool bad = false;
       if (fl & VMAS_F_MOVABLE) {
         v2 vel = V(Es[2 * ROWF], Es[3 * ROWF]);
         if (substep == 0) vel = V(vel.x * D.one_minus_drag, vel.y * D.one_minus_drag);
@@ -846,7 +882,6 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
           if constexpr (ENV != ENV_NONE) { Es[0] = np.x; Es[ROWF] = np.y; Es[2 * ROWF] = vel.x; Es[3 * ROWF] = vel.y; }
         } else {
           Es[0] = np.x; Es[ROWF] = np.y; Es[2 * ROWF] = vel.x; Es[3 * ROWF] = vel.y;
-          bad = !finite_f(np.x) || !finite_f(np.y);
         }
       }
       if (fl & VMAS_F_ROTATABLE) {
@@ -859,11 +894,9 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
           if constexpr (ENV != ENV_NONE) { Es[4 * ROWF] = rot; Es[5 * ROWF] = av; }
         } else {
           Es[4 * ROWF] = rot; Es[5 * ROWF] = av;
-          bad = bad || !finite_f(rot);
           if (D.tr_off >= 0) write_trig(tile + D.tr_off, rot, D.shape);
         }
       }
-      if (bad) *bad_flag = 1;
     }
     if (!last) __syncthreads();
   }
@@ -874,12 +907,12 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
     __syncthreads();
     const TileCtx C(batch);
     if constexpr (ENV == ENV_BALANCE)
-      if (!(E.ablate & 4))  // profiling (VMAS_ENV_ABLATE): 1 queries off, 2 observations off, 4 epilogue off, 8 prologue off
+      if (!(ABLATE(E) & 4))  // profiling (VMAS_ENV_ABLATE): 1 queries off, 2 observations off, 4 epilogue off, 8 prologue off
       {
         // the floor's cos/sin rows of the tile are current if it cannot rotate (they are not refreshed after the last substep)
         const uint32_t ffl = (uint32_t)sgpr((int)blob[W.b_ent + E.balance.d.floor * EW]);
         const int tr_off = sgpr((int)blob[W.b_ent + E.balance.d.floor * EW + 3]);
-        balance_post_tile(C, E.balance.d, E.balance.o, batch, lds, lds + E.scratch_off, post_prev, post_steps, E.ablate,
+        balance_post_tile(C, E.balance.d, E.balance.o, batch, lds, lds + E.scratch_off, post_prev, post_steps, ABLATE(E),
                           (tr_off >= 0 && !(ffl & VMAS_F_ROTATABLE)) ? tile + tr_off : nullptr);
       }
     if constexpr (ENV == ENV_TRANSPORT)
@@ -1469,7 +1502,6 @@ static int build_sched(VmasWorld* w, int nw, Sched& S) {
   S.nw = nw;
   S.dw = w->base;
   const int row_bad = row_part + 3 * n_ent_segs;
-  S.dw.off_bad = row_bad * ROWF;
   std::vector<uint32_t> blob;
   auto append = [&](const void* p, size_t bytes) {
     int at = (int)blob.size();
@@ -1486,15 +1518,15 @@ static int build_sched(VmasWorld* w, int nw, Sched& S) {
   const size_t item_bytes = w->items.size() * sizeof(DevItem);
   S.dw.items_in_lds = item_bytes <= (size_t)ITEMS_LDS_BUDGET;
   S.dw.b_items = (int)blob.size();
-  S.dw.blob_words = (int)blob.size() + (S.dw.items_in_lds ? (int)(item_bytes / 4) : 0);
+  S.dw.blob_words = (int)blob.size() + (S.dw.items_in_lds ? (int)(item_bytes / 4) : 0);  // (a multiple of 4: 16-byte staging)
   append(w->items.data(), item_bytes);
   HIP_TRY(upload(&S.d_blob, blob));
   S.dw.blob = S.d_blob;
   S.dw.items = (const DevItem*)(S.d_blob + S.dw.b_items);
   S.dw.n_segs = (int)segs_sorted.size();
   S.dw.n_owned = (int)owned.size();
-  S.dw.off_blob = (row_bad + 1) * ROWF;
-  S.lds_bytes = ((size_t)(row_bad + 1) * ROWF + S.dw.blob_words + 4) * sizeof(float);
+  S.dw.off_blob = row_bad * ROWF;  // (row_bad: the first row after the partial sums)
+  S.lds_bytes = ((size_t)row_bad * ROWF + S.dw.blob_words + 4) * sizeof(float);  // + work counters
   if (getenv("VMAS_DEBUG_SCHED")) fprintf(stderr, "[sched nw=%d] %d segments, LDS %zu B per tile\n", nw, (int)segs.size(), S.lds_bytes);
   return 0;
 }
@@ -1637,6 +1669,14 @@ int vmas_world_create(const VmasWorldDesc* d, int32_t batch, int32_t device_id, 
   w->row_tr = W.nE * 6 + W.nA * 3;
   for (int e = 0; e < d->n_entities; ++e)
     if (tr_row[e] >= 0) ents[e].tr_off = (w->row_tr + tr_row[e]) * ROWF;
+  W.row_tr = w->row_tr;
+  W.trig_in_args = d->n_entities <= 64;
+  W.trig_mask = W.box_mask = 0ull;
+  for (int e : w->trig_ents)
+    if (W.trig_in_args) {
+      W.trig_mask |= 1ull << e;
+      if (d->entities[e].shape == VMAS_SHAPE_BOX) W.box_mask |= 1ull << e;
+    }
   w->tr_row = tr_row;
   std::vector<DevMaskPair> mp(d->n_pairs);
   for (int p = 0; p < d->n_pairs; ++p) mp[p] = {d->pairs[p].a, d->pairs[p].b, d->pairs[p].bound_sum};
