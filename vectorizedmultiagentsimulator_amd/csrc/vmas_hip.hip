@@ -520,10 +520,18 @@ __device__ __forceinline__ void eval_item(const ItemV& K, const DevWorld& W, con
 // ------------------------------------------------------------------------------------
 // the fused step kernel: grid = ceil(batch / 64) tiles, block = 64 x W threads
 // ------------------------------------------------------------------------------------
-template <int LEVEL, int ENV, class EnvArgs>
+// PLAIN: the launch has none of the optional inputs (recorded pair mask, per-environment joint rotations / entity gravity,
+// a partial substep range, a multi-step rollout) - their tests, and the scalar registers that would carry the pointers
+// through every loop of a kernel that is short of them, are compiled out.
+template <int LEVEL, int ENV, class EnvArgs, bool PLAIN>
 __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel(DevWorld W, float* __restrict__ state,
                                                                float* __restrict__ agent_ft, long ld, int batch,
-                                                               DevStepArgs args, const EnvArgs E) {
+                                                               DevStepArgs args_in, const EnvArgs E) {
+  DevStepArgs args = args_in;
+  if constexpr (PLAIN) {
+    args.pair_mask = nullptr; args.joint_fixed_rot = nullptr; args.entity_gravity = nullptr;
+    args.first_substep = 0; args.n_substeps = 0; args.n_steps = 1; args.ft_stride = 0;
+  }
   extern __shared__ float lds[];
   const int lane = threadIdx.x & (TILE - 1);
   const int wv = sgpr(threadIdx.x >> 6);
@@ -1572,17 +1580,25 @@ static int launch_level(VmasWorld* w, Sched* S, float* state, float* aft, long l
                         const EnvArgs& env, size_t extra_lds, hipStream_t s) {
   const size_t lds = S->lds_bytes + extra_lds;
   if (lds > 160 * 1024) return fail("vmas_world_step: %zu bytes of LDS per tile exceed the CU's 160 KB", lds);
+  const bool plain = !a.pair_mask && !a.joint_fixed_rot && !a.entity_gravity && a.first_substep == 0 && a.n_substeps <= 0 &&
+                     a.n_steps <= 1;
   if (lds > 64 * 1024) {
     static thread_local size_t set_for = 0;
     if (set_for < lds) {
-      HIP_TRY(hipFuncSetAttribute((const void*)step_kernel<LEVEL, ENV, EnvArgs>,
+      HIP_TRY(hipFuncSetAttribute((const void*)step_kernel<LEVEL, ENV, EnvArgs, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      HIP_TRY(hipFuncSetAttribute((const void*)step_kernel<LEVEL, ENV, EnvArgs, false>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       set_for = lds;
     }
   }
   const int blocks = (w->batch + TILE - 1) / TILE;
-  hipLaunchKernelGGL((step_kernel<LEVEL, ENV, EnvArgs>), dim3(blocks), dim3(TILE * S->nw), lds, s, S->dw, state, aft, ld,
-                     w->batch, a, env);
+  if (plain)
+    hipLaunchKernelGGL((step_kernel<LEVEL, ENV, EnvArgs, true>), dim3(blocks), dim3(TILE * S->nw), lds, s, S->dw, state, aft,
+                       ld, w->batch, a, env);
+  else
+    hipLaunchKernelGGL((step_kernel<LEVEL, ENV, EnvArgs, false>), dim3(blocks), dim3(TILE * S->nw), lds, s, S->dw, state, aft,
+                       ld, w->batch, a, env);
   HIP_TRY(hipGetLastError());
   return 0;
 }
