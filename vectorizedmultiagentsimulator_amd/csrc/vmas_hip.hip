@@ -523,14 +523,20 @@ __device__ __forceinline__ void eval_item(const ItemV& K, const DevWorld& W, con
 // PLAIN: the launch has none of the optional inputs (recorded pair mask, per-environment joint rotations / entity gravity,
 // a partial substep range, a multi-step rollout) - their tests, and the scalar registers that would carry the pointers
 // through every loop of a kernel that is short of them, are compiled out.
-template <int LEVEL, int ENV, class EnvArgs, bool PLAIN>
-__global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel(DevWorld W, float* __restrict__ state,
+// The same holds for: a batch of whole tiles (no per-load "is this lane a live environment" predication), an item list that
+// lives in the LDS blob, and (PLAIN == 2) a world with one substep per step (the between-substeps write-back to LDS and
+// its trig are dead code).
+template <int LEVEL, int ENV, class EnvArgs, int PLAIN>
+__global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel(DevWorld W_in, float* __restrict__ state,
                                                                float* __restrict__ agent_ft, long ld, int batch,
                                                                DevStepArgs args_in, const EnvArgs E) {
   DevStepArgs args = args_in;
-  if constexpr (PLAIN) {
+  DevWorld W = W_in;
+  if constexpr (PLAIN != 0) {
     args.pair_mask = nullptr; args.joint_fixed_rot = nullptr; args.entity_gravity = nullptr;
     args.first_substep = 0; args.n_substeps = 0; args.n_steps = 1; args.ft_stride = 0;
+    W.items_in_lds = 1;
+    if constexpr (PLAIN == 2) W.substeps = 1;
   }
   extern __shared__ float lds[];
   const int lane = threadIdx.x & (TILE - 1);
@@ -538,7 +544,7 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
   const int nw = sgpr(blockDim.x >> 6);
   const int nE = W.nE, nA = W.nA;
   const long env = (long)blockIdx.x * TILE + lane;
-  const bool live = env < batch;
+  const bool live = PLAIN != 0 || env < batch;
 #ifdef VMAS_TRACE  // profiling build only (scripts/trace_phases.py): per-wave s_memtime stamps
 #define STAMP(k)                                                                                     \
   if (args.trace && lane == 0) args.trace[((long)blockIdx.x * 16 + wv) * 16 + (k)] = __builtin_amdgcn_s_memtime()
@@ -1581,23 +1587,29 @@ static int launch_level(VmasWorld* w, Sched* S, float* state, float* aft, long l
   const size_t lds = S->lds_bytes + extra_lds;
   if (lds > 160 * 1024) return fail("vmas_world_step: %zu bytes of LDS per tile exceed the CU's 160 KB", lds);
   const bool plain = !a.pair_mask && !a.joint_fixed_rot && !a.entity_gravity && a.first_substep == 0 && a.n_substeps <= 0 &&
-                     a.n_steps <= 1;
+                     a.n_steps <= 1 && w->batch % TILE == 0 && S->dw.items_in_lds;
+  const int mode = !plain ? 0 : (S->dw.substeps == 1 ? 2 : 1);
   if (lds > 64 * 1024) {
     static thread_local size_t set_for = 0;
     if (set_for < lds) {
-      HIP_TRY(hipFuncSetAttribute((const void*)step_kernel<LEVEL, ENV, EnvArgs, true>,
+      HIP_TRY(hipFuncSetAttribute((const void*)step_kernel<LEVEL, ENV, EnvArgs, 0>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      HIP_TRY(hipFuncSetAttribute((const void*)step_kernel<LEVEL, ENV, EnvArgs, false>,
+      HIP_TRY(hipFuncSetAttribute((const void*)step_kernel<LEVEL, ENV, EnvArgs, 1>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      HIP_TRY(hipFuncSetAttribute((const void*)step_kernel<LEVEL, ENV, EnvArgs, 2>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       set_for = lds;
     }
   }
   const int blocks = (w->batch + TILE - 1) / TILE;
-  if (plain)
-    hipLaunchKernelGGL((step_kernel<LEVEL, ENV, EnvArgs, true>), dim3(blocks), dim3(TILE * S->nw), lds, s, S->dw, state, aft,
+  if (mode == 2)
+    hipLaunchKernelGGL((step_kernel<LEVEL, ENV, EnvArgs, 2>), dim3(blocks), dim3(TILE * S->nw), lds, s, S->dw, state, aft,
+                       ld, w->batch, a, env);
+  else if (mode == 1)
+    hipLaunchKernelGGL((step_kernel<LEVEL, ENV, EnvArgs, 1>), dim3(blocks), dim3(TILE * S->nw), lds, s, S->dw, state, aft,
                        ld, w->batch, a, env);
   else
-    hipLaunchKernelGGL((step_kernel<LEVEL, ENV, EnvArgs, false>), dim3(blocks), dim3(TILE * S->nw), lds, s, S->dw, state, aft,
+    hipLaunchKernelGGL((step_kernel<LEVEL, ENV, EnvArgs, 0>), dim3(blocks), dim3(TILE * S->nw), lds, s, S->dw, state, aft,
                        ld, w->batch, a, env);
   HIP_TRY(hipGetLastError());
   return 0;
