@@ -88,15 +88,23 @@ struct DevSegment {
   int32_t part_off;  // tile offset of its 3 partial-sum rows (fx, fy, torque)
 };
 
-struct DevOwned {  // phase C work unit
+struct DevOwned {  // phase C work unit: everything the integration of one entity needs, ONE LDS round trip (6 x 16 bytes)
   int32_t entity;
   int32_t oe;
   int32_t part_off, n_parts;  // partial rows of the entity's segments, in order
-  // then the entity's side of every shared pair/joint it is in, in the reference's accumulation order; one word each:
+  // the entity's side of every shared pair/joint it is in, in the reference's accumulation order; one word each:
   //   bits 0..15 row of [fx fy] | bit 16 side (1: the entity is b, the force flips its sign) | bits 17..18 row delta
-  //   of its torque (0: none)
+  //   of its torque (0: none).  The first eight are inlined below, the rest follow at blob[b_refs + ref_begin + 8].
   int32_t ref_begin, n_refs;
+  uint32_t flags;
+  int32_t shape;
+  int32_t tr_off;
+  float mass, inertia, one_minus_drag;
+  float max_speed, v_range;
+  uint32_t pad[2];
+  uint32_t refs8[8];
 };
+static_assert(sizeof(DevOwned) == 96, "DevOwned is read as six uint4");
 
 struct DevEntity {
   uint32_t flags;
@@ -839,56 +847,79 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
     //                   or, after the last substep, the write-back of the entity's planes)
     const int n_own = (ABLATE(args) & 2) ? 0 : W.n_owned;
     for (int oi = first_dyn ? wv : grab(c_integrate); oi < n_own; oi = grab(c_integrate)) {
-      const uint32_t* op = blob + W.b_owned + oi * OW;
-      const int e = sgpr((int)op[0]);
-      float* Es = tile + (int)op[1];
-      const float* P = tile + (int)op[2];
-      const int n_parts = sgpr((int)op[3]);
-      const EntV D = load_ent(blob + W.b_ent + e * EW);
-      const uint32_t fl = D.flags;
+      const uint4* op = (const uint4*)(blob + W.b_owned + oi * OW);
+      const uint4 o0 = op[0], o1 = op[1], o2 = op[2], o3 = op[3], q0 = op[4], q1 = op[5];
+      const int e = sgpr((int)o0.x);
+      float* Es = tile + (int)o0.y;
+      const float* P = tile + (int)o0.z;
+      const int n_parts = sgpr((int)o0.w);
+      const int r0 = sgpr((int)o1.x), nr = sgpr((int)o1.y);
+      const uint32_t fl = (uint32_t)sgpr((int)o1.z);
+      struct { int32_t shape, tr_off; float mass, inertia, one_minus_drag, max_speed, v_range; } D;
+      D.shape = sgpr((int)o1.w); D.tr_off = sgpr((int)o2.x);
+      D.mass = __uint_as_float(o2.y); D.inertia = __uint_as_float(o2.z); D.one_minus_drag = __uint_as_float(o2.w);
+      D.max_speed = __uint_as_float(o3.x); D.v_range = __uint_as_float(o3.y);
+      const uint32_t ref[8] = {(uint32_t)sgpr((int)q0.x), (uint32_t)sgpr((int)q0.y), (uint32_t)sgpr((int)q0.z),
+                               (uint32_t)sgpr((int)q0.w), (uint32_t)sgpr((int)q1.x), (uint32_t)sgpr((int)q1.y),
+                               (uint32_t)sgpr((int)q1.z), (uint32_t)sgpr((int)q1.w)};
+      // second round trip: the entity's state, its first partial row and the rows of its first eight shared pairs
+      float es[6];
+#pragma unroll
+      for (int f = 0; f < 6; ++f) es[f] = Es[f * ROWF];
       v2 F = V(P[0], P[ROWF]);
       float Tq = P[2 * ROWF];
-      for (int p = 1; p < n_parts; ++p) {
-        F = F + V(P[3 * p * ROWF], P[(3 * p + 1) * ROWF]);
-        Tq = Tq + P[(3 * p + 2) * ROWF];
-      }
-      {  // the entity's side of the shared pairs/joints, in the reference's order (core.py:2176-2199)
-        // (four references per fetch, all their rows requested before the first add: one LDS round trip per four pairs)
-        const int r0 = sgpr((int)op[4]), nr = sgpr((int)op[5]);
-        for (int r = 0; r < nr; r += 4) {
-          const uint4 q = *(const uint4*)(blob + W.b_refs + r0 + r);  // (ref_begin is a multiple of 4, the tail is padded)
-          const uint32_t ref[4] = {(uint32_t)sgpr((int)q.x), (uint32_t)sgpr((int)q.y), (uint32_t)sgpr((int)q.z),
-                                   (uint32_t)sgpr((int)q.w)};
-          float fx[4], fy[4], tq[4];
+      float fx[8], fy[8], tq[8];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
+      for (int c = 0; c < 2; ++c)
+        if (nr > 4 * c) {
+#pragma unroll
+          for (int k = 4 * c; k < 4 * c + 4; ++k) {
             const float* R = tile + (ref[k] & 0xffffu) * ROWF;  // (padding repeats a valid row)
             const int td = (int)((ref[k] >> 17) & 3u);
             fx[k] = R[0];
             fy[k] = R[ROWF];
             tq[k] = R[td * ROWF];
           }
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            if (r + k < nr) {
-              const uint32_t flip = (ref[k] & 0x10000u) << 15;  // b's side: -f
-              if (fl & VMAS_F_MOVABLE)
-                F = F + V(__uint_as_float(__float_as_uint(fx[k]) ^ flip), __uint_as_float(__float_as_uint(fy[k]) ^ flip));
-              if (((ref[k] >> 17) & 3u) && (fl & VMAS_F_ROTATABLE)) Tq = Tq + tq[k];
-            }
-          }
         }
+      for (int p = 1; p < n_parts; ++p) {
+        F = F + V(P[3 * p * ROWF], P[(3 * p + 1) * ROWF]);
+        Tq = Tq + P[(3 * p + 2) * ROWF];
+      }
+      // the entity's side of the shared pairs/joints, in the reference's order (core.py:2176-2199)
+      auto add_ref = [&](uint32_t rf, float x, float y, float t) {
+        const uint32_t flip = (rf & 0x10000u) << 15;  // b's side: -f
+        if (fl & VMAS_F_MOVABLE) F = F + V(__uint_as_float(__float_as_uint(x) ^ flip), __uint_as_float(__float_as_uint(y) ^ flip));
+        if (((rf >> 17) & 3u) && (fl & VMAS_F_ROTATABLE)) Tq = Tq + t;
+      };
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (k < nr) add_ref(ref[k], fx[k], fy[k], tq[k]);
+      for (int r = 8; r < nr; r += 4) {  // (more than eight: four references per fetch, their rows requested together)
+        const uint4 q = *(const uint4*)(blob + W.b_refs + r0 + r);  // (ref_begin is a multiple of 4, the tail is padded)
+        const uint32_t rf[4] = {(uint32_t)sgpr((int)q.x), (uint32_t)sgpr((int)q.y), (uint32_t)sgpr((int)q.z),
+                                (uint32_t)sgpr((int)q.w)};
+        float gx[4], gy[4], gt[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float* R = tile + (rf[k] & 0xffffu) * ROWF;
+          gx[k] = R[0];
+          gy[k] = R[ROWF];
+          gt[k] = R[((rf[k] >> 17) & 3u) * ROWF];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (r + k < nr) add_ref(rf[k], gx[k], gy[k], gt[k]);
       }
       float* dst = state + (long)e * 6 * ld + env;
       if (fl & VMAS_F_MOVABLE) {
-        v2 vel = V(Es[2 * ROWF], Es[3 * ROWF]);
+        v2 vel = V(es[2], es[3]);
         if (substep == 0) vel = V(vel.x * D.one_minus_drag, vel.y * D.one_minus_drag);
         const rcp_t rm = rcp_of(D.mass);
         const v2 acc = V(F.x / rm, F.y / rm);
         vel = V(vel.x + acc.x * sub_dt, vel.y + acc.y * sub_dt);
         if (fl & VMAS_F_MAX_SPEED) vel = clamp_with_norm(vel, D.max_speed);
         if (fl & VMAS_F_V_RANGE) vel = V(clamp_t(vel.x, D.v_range), clamp_t(vel.y, D.v_range));
-        v2 np = V(Es[0] + vel.x * sub_dt, Es[ROWF] + vel.y * sub_dt);
+        v2 np = V(es[0] + vel.x * sub_dt, es[1] + vel.y * sub_dt);
         if (W.xs == W.xs) np.x = clamp_t(np.x, W.xs);
         if (W.ys == W.ys) np.y = clamp_t(np.y, W.ys);
         if (last) {
@@ -899,10 +930,10 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
         }
       }
       if (fl & VMAS_F_ROTATABLE) {
-        float av = Es[5 * ROWF];
+        float av = es[5];
         if (substep == 0) av = av * D.one_minus_drag;
         av = av + (Tq / D.inertia) * sub_dt;
-        const float rot = Es[4 * ROWF] + av * sub_dt;
+        const float rot = es[4] + av * sub_dt;
         if (last) {
           if (live) { dst[4 * ld] = rot; dst[5 * ld] = av; }
           if constexpr (ENV != ENV_NONE) { Es[4 * ROWF] = rot; Es[5 * ROWF] = av; }
@@ -1464,7 +1495,19 @@ static int build_sched(VmasWorld* w, int nw, Sched& S) {
   for (int e = 0; e < nE; ++e) {
     if (!(w->ents[e].flags & (VMAS_F_MOVABLE | VMAS_F_ROTATABLE))) continue;
     const int b = w->ent_item_begin[e], n = w->ent_item_begin[e + 1];
-    DevOwned O{e, e * 6 * ROWF, 3 * (int)segs.size(), 0, w->ent_ref_begin[e], w->ent_ref_count[e]};  // part_off holds the ROW until rebased below
+    DevOwned O{};
+    O.entity = e; O.oe = e * 6 * ROWF; O.part_off = 3 * (int)segs.size();  // part_off holds the ROW until rebased below
+    O.ref_begin = w->ent_ref_begin[e]; O.n_refs = w->ent_ref_count[e];
+    {
+      const DevEntity& DE = w->dev_ents[e];
+      O.flags = DE.flags; O.shape = DE.shape; O.tr_off = DE.tr_off;
+      O.mass = DE.mass; O.inertia = DE.inertia; O.one_minus_drag = DE.one_minus_drag;
+      O.max_speed = DE.max_speed; O.v_range = DE.v_range;
+      for (int k = 0; k < 8; ++k) {  // (padding repeats the last valid reference; none at all: row 0, never added)
+        const int nr = O.n_refs;
+        O.refs8[k] = nr > 0 ? w->refs[O.ref_begin + std::min(k, nr - 1)] : 0u;
+      }
+    }
     int i = b;
     bool first = true;
     do {
@@ -1525,6 +1568,7 @@ static int build_sched(VmasWorld* w, int nw, Sched& S) {
   };
   S.dw.b_ent = append(w->dev_ents.data(), w->dev_ents.size() * sizeof(DevEntity));
   S.dw.b_segs = append(segs_sorted.data(), segs_sorted.size() * sizeof(DevSegment));
+  while (blob.size() % 4) blob.push_back(0);  // (ds_read_b128 of the owned records)
   S.dw.b_owned = append(owned.data(), owned.size() * sizeof(DevOwned));
   while (blob.size() % 4) blob.push_back(0);  // (ds_read_b128 of four references)
   S.dw.b_refs = append(w->refs.data(), w->refs.size() * sizeof(uint32_t));
