@@ -197,6 +197,13 @@ int vmas_world_step_env(VmasWorld* w, float* state, float* agent_ft, int64_t ld,
                         const VmasIngestArgs* ingest /* may be NULL */, uint32_t* err_flags /* may be NULL */,
                         int32_t post_kind, const void* post_desc, const void* post_buffers, void* stream);
 
+/* Tells the library that this world's steps will be vmas_world_step_env launches with the `post_kind` epilogue
+ * (`n_packages`: transport only), whose observation staging needs LDS beside the physics tile: the library's choice of
+ * waves per tile and of shared pair rows (vmas_hip.h, "lanes per env") is re-made with that LDS included, instead of
+ * falling back at the first launch that does not fit.  Optional; call it before the first step.  The reference has no
+ * counterpart (kernel geometry). */
+int vmas_world_reserve_epilogue(VmasWorld* w, int32_t post_kind, int32_t n_packages);
+
 #ifdef __cplusplus
 }
 #endif

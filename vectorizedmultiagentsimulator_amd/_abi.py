@@ -263,6 +263,7 @@ EXPORTED_SYMBOLS = (
     "vmas_navigation_post_step",
     "vmas_football_post_step",
     "vmas_world_step_env",
+    "vmas_world_reserve_epilogue",
 )
 
 _lib: Optional[C.CDLL] = None
@@ -317,6 +318,8 @@ def load_library() -> C.CDLL:
         fn.restype = C.c_int
     lib.vmas_world_step_env.argtypes = [vp, vp, vp, i64, C.POINTER(StepArgs), C.POINTER(IngestArgs), vp, i32, vp, vp, vp]
     lib.vmas_world_step_env.restype = C.c_int
+    lib.vmas_world_reserve_epilogue.argtypes = [vp, i32, i32]
+    lib.vmas_world_reserve_epilogue.restype = C.c_int
     lib.vmas_last_error.argtypes = []
     lib.vmas_last_error.restype = C.c_char_p
     lib.vmas_abi_version.argtypes = []

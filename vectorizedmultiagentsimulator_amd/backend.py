@@ -108,6 +108,12 @@ class HipWorld:
         if self.lib.vmas_world_set_lanes_per_env(self._h, int(lanes)) != 0:
             raise VmasHipError(A.last_error())
 
+    def reserve_epilogue(self, post_kind: int, n_packages: int = 0):
+        """The steps of this world will be one-launch Environment.step calls with this post-step epilogue: let the
+        library choose its kernel geometry with the epilogue's LDS included (include/vmas_env_hip.h)."""
+        if self.lib.vmas_world_reserve_epilogue(self._h, int(post_kind), int(n_packages)) != 0:
+            raise VmasHipError(A.last_error())
+
     @property
     def lanes_per_env(self) -> int:
         return self.lib.vmas_world_get_lanes_per_env(self._h)

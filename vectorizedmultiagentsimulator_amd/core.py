@@ -743,6 +743,9 @@ class World:
             self._packed_state()
             self._backend = HipWorld(self.spec, self._batch_dim, self._device, lanes_per_env=self._lanes_per_env,
                                      state=self._state, agent_ft=self._agent_ft)
+            hint = getattr(self, "epilogue_hint", None)  # (post_kind, n_packages), set by scenarios with a fused post-step
+            if hint is not None and not self._lanes_per_env:
+                self._backend.reserve_epilogue(*hint)
         return self._backend
 
     # ---- reference API ---------------------------------------------------------------

@@ -1217,6 +1217,8 @@ struct VmasWorld {
   std::vector<VmasJointDesc> joints;   // (without shared rows) if a launch needs more LDS than the tile has left
   std::vector<int> tr_row;
   int share_mode = 0;
+  int n_cu = 256;
+  size_t reserve_fixed = 0, reserve_per_wave = 0;  // LDS (bytes) of a fused epilogue beside the tile (vmas_world_reserve_epilogue)
   std::vector<DevEntity> dev_ents;
   // static item lists
   std::vector<DevItem> items;
@@ -1608,21 +1610,84 @@ static int get_sched(VmasWorld* w, int nw, Sched** out) {
   return 0;
 }
 
-static int default_lanes(const VmasWorld* w) {
-  // waves per tile: enough to give each of the chip's 1024 SIMDs ~4 waves at this batch,
-  // but no more than the tile has independent work for (tuned on MI355X)
-  const long tiles = (w->batch + TILE - 1) / TILE;
+// Waves per 64-environment tile ("lanes per env") for the item lists as they are now.  The model, fitted to the sweeps in
+// what counts is how many waves of this kernel RUN per CU,
+//     running(nw) = min(tiles the CU can hold, tiles the batch gives it) x nw,
+// where a CU holds min(160 KB / LDS per tile, max waves per CU / nw) tiles.  Largest running() wins; on a tie, more waves
+// per tile if every tile of the batch is resident at once (latency regime: the tile's dependent chain gets shorter -
+// football at 16384 envs 23.6 us with 8 waves, 18.7 with 16), fewer if not (throughput regime: less synchronisation per
+// tile - balance at 1 M envs 156 us with 4 waves, 191 with 8), and a choice that keeps all tiles resident beats one that
+// does not (balance at 32768 envs: 8.2 us with 2 x 8 waves per CU, 11.2 with 1 x 16).
+struct LaneChoice { int nw = 0; long running = 0; bool resident = false; size_t lds = 0; };
+static int choose_lanes(VmasWorld* w, int n_cu, LaneChoice* out) {
+  const long tiles = ((long)w->batch + TILE - 1) / TILE;
+  const long need = (tiles + n_cu - 1) / n_cu;  // tiles per CU the batch asks for
   int work = 0;
   for (float c : w->item_cost) work += (int)c;
   work += w->n_dyn;
-  // measured on balance@32768: 8 waves/tile 12.8 us, 16 waves/tile 17.3 us (a 1024-thread block at
-  // ~107 VGPRs leaves room for one tile per CU only), 4 waves 15.6 us
-  // ... and in the throughput regime (sweep in DESIGN.md section 6): 131072 envs 36.8 us with 4 waves vs
-  // 41.8 (8) / 47.5 (2); 2097152 envs 463 us (4) vs 572 (8) / 523 (2)
-  const int cap = tiles <= 1024 ? 8 : 4;
-  int nw = 1;
-  while (nw < cap && work >= 150 * nw) nw <<= 1;
-  return nw;
+  const int max_w = w->level >= 2 ? 8 : MAX_WAVES;     // (the box-box kernel is compiled for 512-thread blocks)
+  const int waves_per_cu = w->level >= 2 ? 8 : 16;     // by VGPRs: 2 / 4 waves per SIMD
+  LaneChoice best;
+  for (int nw = 1; nw <= max_w; nw <<= 1) {
+    if (nw > 1 && work < 150 * (nw / 2)) break;  // no more waves than the tile has independent work for
+    Sched* S;
+    if (get_sched(w, nw, &S)) return -1;
+    const size_t lds = S->lds_bytes + w->reserve_fixed + w->reserve_per_wave * nw;
+    if (lds > 160 * 1024) continue;
+    const long hold = std::min<long>((long)(160 * 1024 / lds), waves_per_cu / nw);
+    if (hold < 1) continue;
+    LaneChoice c;
+    c.nw = nw; c.lds = lds;
+    c.running = std::min(hold, need) * nw;
+    c.resident = hold >= need;
+    bool better;
+    if (best.nw == 0) better = true;
+    else if (c.running != best.running) better = c.running > best.running;
+    else if (c.resident != best.resident) better = c.resident;
+    else better = c.resident;  // tie: the larger nw (visited later) in the latency regime, the smaller in the throughput regime
+    if (better) best = c;
+  }
+  *out = best;
+  return 0;
+}
+
+// Which pairs are evaluated once (shared rows in LDS: mode 2 all of them, 1 all but sphere-sphere, 0 none) and how many
+// waves work on a tile are chosen TOGETHER, by the number of waves the choice keeps running per CU (choose_lanes): the
+// shared rows cost LDS, i.e. resident tiles.  Ties: co-resident tiles first; then, if the batch is resident at once, more
+// waves per tile, else fewer; then the higher mode.  (Measured, DESIGN.md: football at 16384 envs 31.1 -> 28.8 us with
+// everything shared, at 131072 envs - two resident tiles per CU without the rows, one with - 224 -> 351 us.)
+static int select_config(VmasWorld* w) {
+  static const int share_env = getenv("VMAS_SHARE") ? atoi(getenv("VMAS_SHARE")) : -1;  // (A/B measurements)
+  int best_mode = -1;
+  LaneChoice best;
+  for (int mode = 2; mode >= 0; --mode) {
+    if (share_env >= 0 && mode != share_env) continue;
+    for (auto& kv : w->scheds) kv.second.release();
+    w->scheds.clear();
+    build_items(w, mode);
+    if (mode > 0 && w->n_shared_rows == 0 && share_env < 0) continue;  // nothing to share at this mode: same world as a lower one
+    LaneChoice c;
+    if (choose_lanes(w, w->n_cu, &c)) return -1;
+    if (c.nw == 0) continue;
+    bool better;
+    if (best_mode < 0) better = true;
+    else if (c.running != best.running) better = c.running > best.running;
+    else if (c.resident != best.resident) better = c.resident;
+    else if (c.nw != best.nw) better = c.resident ? c.nw > best.nw : c.nw < best.nw;
+    else better = false;  // same geometry: the higher mode (visited first) stays
+    if (better) {
+      best = c;
+      best_mode = mode;
+    }
+  }
+  if (best_mode < 0) return fail("a 64-environment tile of this world does not fit the CU's 160 KiB of LDS");
+  if (w->share_mode != best_mode) {
+    for (auto& kv : w->scheds) kv.second.release();
+    w->scheds.clear();
+    build_items(w, best_mode);
+  }
+  w->lanes = best.nw;
+  return 0;
 }
 
 template <int LEVEL, int ENV, class EnvArgs>
@@ -1754,45 +1819,13 @@ int vmas_world_create(const VmasWorldDesc* d, int32_t batch, int32_t device_id, 
   for (int p = 0; p < d->n_pairs; ++p) mp[p] = {d->pairs[p].a, d->pairs[p].b, d->pairs[p].bound_sum};
   w->dev_ents = ents;
   HIP_TRY(upload(&w->d_mpairs, mp));
-  // Which pairs are evaluated once (shared rows in LDS) is decided by what the rows cost in OCCUPANCY: a batch with more
-  // tiles than CUs lives on two resident tiles per CU, so the rows may not push a tile beyond half the CU's LDS unless the
-  // unshared tile is already there; a batch of at most one tile per CU has the LDS to itself.  (Measured, DESIGN.md:
-  // football at 16384 envs 31.1 -> 28.8 us with everything shared, at 131072 envs 224 -> 351 us.)
-  static const int share_env = getenv("VMAS_SHARE") ? atoi(getenv("VMAS_SHARE")) : -1;  // (A/B measurements)
-  int n_cu = 256;
   {
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) w->n_cu = prop.multiProcessorCount;
   }
-  const long tiles = ((long)batch + TILE - 1) / TILE;
-  auto tiles_per_cu = [](size_t lds) { return lds > 160 * 1024 ? 0 : (int)std::min<size_t>(8, 160 * 1024 / lds); };
+  if (select_config(w)) return -1;
   Sched* S = nullptr;
-  auto try_mode = [&](int mode) -> int {  // builds the items and the default schedule; returns resident tiles per CU (0: does not fit)
-    for (auto& kv : w->scheds) kv.second.release();
-    w->scheds.clear();
-    build_items(w, mode);
-    w->lanes = default_lanes(w);
-    while (true) {
-      if (get_sched(w, w->lanes, &S)) return -1;
-      if (S->lds_bytes <= 160 * 1024 || w->lanes == 1) break;
-      w->lanes >>= 1;  // fewer segments => fewer partial rows
-    }
-    return tiles_per_cu(S->lds_bytes);
-  };
-  if (share_env >= 0) {
-    if (try_mode(share_env) < 0) return -1;
-  } else {
-    const int base = try_mode(0);
-    if (base < 0) return -1;
-    const int want = (int)std::min<long>(std::min(base, 2), (tiles + n_cu - 1) / n_cu);
-    for (int mode = 2; mode >= 1; --mode) {
-      const int r = try_mode(mode);
-      if (r < 0) return -1;
-      if (w->n_shared_rows == 0) { mode = 1; }  // nothing to share at this mode: the lower modes are the same world
-      if (r >= want && r > 0) break;
-      if (mode == 1 && try_mode(0) < 0) return -1;
-    }
-  }
+  if (get_sched(w, w->lanes, &S)) return -1;
   if (S->lds_bytes > 160 * 1024) {
     return fail("vmas_world_create: a 64-environment tile of this world needs %zu B of LDS (> 160 KiB)", S->lds_bytes);
   }
@@ -1812,7 +1845,12 @@ void vmas_world_destroy(VmasWorld* w) {
 
 int vmas_world_set_lanes_per_env(VmasWorld* w, int32_t lanes) {
   if (!w) return fail("vmas_world_set_lanes_per_env: null world");
-  if (lanes == 0) lanes = default_lanes(w);
+  if (lanes == 0) {
+    LaneChoice c;
+    if (choose_lanes(w, w->n_cu, &c)) return -1;
+    if (c.nw == 0) return fail("vmas_world_set_lanes_per_env: no waves-per-tile setting fits the LDS");
+    lanes = c.nw;
+  }
   const int max_w = w->level >= 2 ? 8 : MAX_WAVES;
   if (lanes < 1 || lanes > max_w) return fail("lanes_per_env must be in 1..%d for this world, got %d", max_w, lanes);
   HIP_TRY(hipSetDevice(w->device));
@@ -1825,6 +1863,23 @@ int vmas_world_set_lanes_per_env(VmasWorld* w, int32_t lanes) {
   return 0;
 }
 int vmas_world_get_lanes_per_env(const VmasWorld* w) { return w ? w->lanes : -1; }
+
+int vmas_world_reserve_epilogue(VmasWorld* w, int32_t post_kind, int32_t n_packages) {
+  if (!w) return fail("vmas_world_reserve_epilogue: null world");
+  size_t f0 = 0, f1 = 0;
+  if (post_kind == VMAS_POST_BALANCE) {
+    f0 = balance_scratch_floats(0); f1 = balance_scratch_floats(1);
+  } else if (post_kind == VMAS_POST_TRANSPORT) {
+    if (n_packages < 1) return fail("vmas_world_reserve_epilogue: transport needs n_packages >= 1, got %d", n_packages);
+    f0 = transport_scratch_floats(0, n_packages); f1 = transport_scratch_floats(1, n_packages);
+  } else if (post_kind != VMAS_POST_NONE) {
+    return fail("vmas_world_reserve_epilogue: post_kind %d has no fused epilogue", post_kind);
+  }
+  HIP_TRY(hipSetDevice(w->device));
+  w->reserve_fixed = f0 * sizeof(float);
+  w->reserve_per_wave = (f1 - f0) * sizeof(float);
+  return select_config(w);
+}
 
 int64_t vmas_world_step_bytes_per_env(const VmasWorld* w) {
   if (!w) return -1;

@@ -41,6 +41,7 @@ class Scenario(BaseScenario):
         world.add_landmark(self.line)
         self.floor = Landmark(name="floor", collide=True, shape=Box(length=10, width=1))
         world.add_landmark(self.floor)
+        world.epilogue_hint = (1, 0)  # VMAS_POST_BALANCE: Environment.step is one launch with the post-step as its epilogue
         return world
 
     def reset_world_at(self, env_index: Optional[int] = None):

@@ -35,6 +35,7 @@ class Scenario(BaseScenario):
             p.goal = self.goal
             self.packages.append(p)
             world.add_landmark(p)
+        world.epilogue_hint = (2, self.n_packages)  # VMAS_POST_TRANSPORT (one-launch Environment.step)
         return world
 
     def reset_world_at(self, env_index: Optional[int] = None):
