@@ -529,7 +529,7 @@ __device__ __forceinline__ void eval_item(const ItemV& K, const DevWorld& W, con
 // the fused step kernel: grid = ceil(batch / 64) tiles, block = 64 x W threads
 // ------------------------------------------------------------------------------------
 // PLAIN: the launch has none of the optional inputs (recorded pair mask, per-environment joint rotations / entity gravity,
-// a partial substep range, a multi-step rollout) - their tests, and the scalar registers that would carry the pointers
+// a partial substep range) - their tests, and the scalar registers that would carry the pointers
 // through every loop of a kernel that is short of them, are compiled out.
 // The same holds for: a batch of whole tiles (no per-load "is this lane a live environment" predication), an item list that
 // lives in the LDS blob, and (PLAIN == 2) a world with one substep per step (the between-substeps write-back to LDS and
@@ -542,9 +542,9 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
   DevWorld W = W_in;
   if constexpr (PLAIN != 0) {
     args.pair_mask = nullptr; args.joint_fixed_rot = nullptr; args.entity_gravity = nullptr;
-    args.first_substep = 0; args.n_substeps = 0; args.n_steps = 1; args.ft_stride = 0;
+    args.first_substep = 0; args.n_substeps = 0;
     W.items_in_lds = 1;
-    if constexpr (PLAIN == 2) W.substeps = 1;
+    if constexpr (PLAIN == 2) { W.substeps = 1; args.n_steps = 1; args.ft_stride = 0; }  // (PLAIN == 1 also serves rollouts)
   }
   extern __shared__ float lds[];
   const int lane = threadIdx.x & (TILE - 1);
@@ -1696,8 +1696,8 @@ static int launch_level(VmasWorld* w, Sched* S, float* state, float* aft, long l
   const size_t lds = S->lds_bytes + extra_lds;
   if (lds > 160 * 1024) return fail("vmas_world_step: %zu bytes of LDS per tile exceed the CU's 160 KB", lds);
   const bool plain = !a.pair_mask && !a.joint_fixed_rot && !a.entity_gravity && a.first_substep == 0 && a.n_substeps <= 0 &&
-                     a.n_steps <= 1 && w->batch % TILE == 0 && S->dw.items_in_lds;
-  const int mode = !plain ? 0 : (S->dw.substeps == 1 ? 2 : 1);
+                     w->batch % TILE == 0 && S->dw.items_in_lds;
+  const int mode = !plain ? 0 : ((S->dw.substeps == 1 && a.n_steps <= 1) ? 2 : 1);
   if (lds > 64 * 1024) {
     static thread_local size_t set_for = 0;
     if (set_for < lds) {
