@@ -207,8 +207,9 @@ typedef struct VmasQuery {
 int vmas_world_set_queries(VmasWorld* w, const VmasQuery* queries, int32_t n_queries);
 int vmas_world_run_queries(VmasWorld* w, const float* state, int64_t ld, float* out, void* stream);
 
-/* Kernel geometry knob: lanes cooperating on one environment (1..64, power of
- * two); 0 = choose from the world size. */
+/* Kernel geometry knob: waves cooperating on one 64-environment tile ("lanes per environment", 1..16, 1..8 for
+ * worlds with box-box pairs); 0 = the library's choice: together with which pairs are evaluated once into shared LDS
+ * rows it maximises the waves running per CU for this world and batch (`select_config`). */
 int vmas_world_set_lanes_per_env(VmasWorld* w, int32_t lanes);
 int vmas_world_get_lanes_per_env(const VmasWorld* w);
 

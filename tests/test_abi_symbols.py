@@ -146,3 +146,5 @@ def test_env_entry_points_report_errors_not_throw(lib):
     f, fb = _abi.FootballDesc(), _abi.FootballBuffers()
     assert lib.vmas_football_post_step(C.byref(f), C.byref(fb), 8, C.c_void_p(64), 64, None) == -1
     assert lib.vmas_world_step_env(None, None, None, 64, None, None, None, 1, None, None, None) == -1
+    assert lib.vmas_world_reserve_epilogue(None, 1, 0) == -1
+    assert b"null world" in lib.vmas_last_error()

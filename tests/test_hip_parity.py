@@ -143,6 +143,53 @@ def test_hip_matches_oracle_every_lane_count(name):
         hw.close()
 
 
+@pytest.mark.parametrize("name", FIXTURES)
+def test_hip_plain_kernels_match_oracle(name):
+    """Whole-tile batches without optional per-environment inputs run on the PLAIN specialisations of the step
+    kernel (no lane predication, no mask / joint-rotation / gravity pointers; one-substep worlds on their own
+    variant): same comparison against the oracle as the general kernel, for the library's own geometry choice
+    and for forced waves-per-tile settings - plus bitwise agreement of a two-step rollout (PLAIN = 1) with two
+    single steps."""
+    from oracle.oracle import Oracle
+
+    g = load(name)
+    o = Oracle(g.spec)
+    B = 1024
+    st0, ft0, jfr_np, eg_np = make_batch(g, B, seed=11)
+    if jfr_np is not None or eg_np is not None:
+        pytest.skip("fixture needs per-environment joint rotations / gravity: general kernel only")
+    sens = ulp_sensitivity(lambda a, b: o.step(a, b), st0, ft0)
+    want_s, want_f = st0.copy(), ft0.copy()
+    o.step(want_s, want_f)
+    with np.errstate(invalid="ignore"):
+        ok = (np.isfinite(want_s) & (np.abs(want_s) < 1e3)).all(axis=(0, 1))
+    for lanes in (0, 4, 16):
+        try:
+            hw = _hip(g.spec, B, lanes)
+        except Exception as e:  # geometry not available for this world (LDS size / register level)
+            assert "LDS" in str(e) or "lanes_per_env must be" in str(e), e
+            continue
+        _up(hw, st0, ft0)
+        hw.step()
+        st, ft = _down(hw, B, g.spec.n_agents)
+        err = np.abs(st[:, :, ok] - want_s[:, :, ok])
+        lim = 1e-5 + 1e-5 * np.abs(want_s[:, :, ok]) + 8 * sens[:, :, ok]
+        frac = (err > lim).mean()
+        assert frac <= (1e-3 if name.startswith("soup") else 0.0), (
+            f"{name} lanes={lanes}: {int((err > lim).sum())} of {err.size} values off, max err {err.max():.3e}")
+        compare_state(ft[:, :, ok], want_f[:, :, ok], f"{name} lanes={lanes} agent_ft", atol=1e-6, rtol=1e-6)
+        if lanes == 0:  # rollout of two steps == two single steps, bit for bit (same forces both steps)
+            _up(hw, st0, ft0)
+            hw.rollout(2)
+            roll = hw.state.clone()
+            _up(hw, st0, ft0)
+            hw.step()
+            hw.step()
+            two = hw.state.clone()
+            assert torch.equal(roll.view(torch.int32), two.view(torch.int32)), f"{name}: rollout != single steps"
+        hw.close()
+
+
 @pytest.mark.parametrize("name", ["balance_n4", "waterfall", "pollock", "soup_solid"])
 def test_hip_is_deterministic(name):
     g = load(name)
