@@ -531,9 +531,9 @@ __device__ __forceinline__ void eval_item(const ItemV& K, const DevWorld& W, con
 // PLAIN: the launch has none of the optional inputs (recorded pair mask, per-environment joint rotations / entity gravity,
 // a partial substep range) - their tests, and the scalar registers that would carry the pointers
 // through every loop of a kernel that is short of them, are compiled out.
-// The same holds for: a batch of whole tiles (no per-load "is this lane a live environment" predication), an item list that
-// lives in the LDS blob, and (PLAIN == 2) a world with one substep per step (the between-substeps write-back to LDS and
-// its trig are dead code).
+// The same holds for: planes padded to whole tiles (ld >= 64 * tiles: no per-load "is this lane a live environment"
+// predication - only the stores of the last tile are masked), an item list that lives in the LDS blob, (PLAIN >= 2) a world with one substep per step (the between-substeps write-back to
+// LDS and its trig are dead code) and (PLAIN == 3) a batch of whole tiles (no store predication either).
 template <int LEVEL, int ENV, class EnvArgs, int PLAIN>
 __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel(DevWorld W_in, float* __restrict__ state,
                                                                float* __restrict__ agent_ft, long ld, int batch,
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
     args.pair_mask = nullptr; args.joint_fixed_rot = nullptr; args.entity_gravity = nullptr;
     args.first_substep = 0; args.n_substeps = 0;
     W.items_in_lds = 1;
-    if constexpr (PLAIN == 2) { W.substeps = 1; args.n_steps = 1; args.ft_stride = 0; }  // (PLAIN == 1 also serves rollouts)
+    if constexpr (PLAIN >= 2) { W.substeps = 1; args.n_steps = 1; args.ft_stride = 0; }  // (PLAIN == 1 also serves rollouts)
   }
   extern __shared__ float lds[];
   const int lane = threadIdx.x & (TILE - 1);
@@ -552,7 +552,10 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
   const int nw = sgpr(blockDim.x >> 6);
   const int nE = W.nE, nA = W.nA;
   const long env = (long)blockIdx.x * TILE + lane;
-  const bool live = PLAIN != 0 || env < batch;
+  const bool live = PLAIN == 3 || env < batch;  // guards every store and every load from a buffer that is not padded to ld
+                                          // (PLAIN == 3: the batch is a whole number of tiles, every lane is an environment)
+  const bool lv = PLAIN != 0 || live;     // loads from state / agent_ft: PLAIN launches have ld >= 64 * tiles, so the tail
+                                          // lanes of the last tile read the padding columns (harmless) without predication
 #ifdef VMAS_TRACE  // profiling build only (scripts/trace_phases.py): per-wave s_memtime stamps
 #define STAMP(k)                                                                                     \
   if (args.trace && lane == 0) args.trace[((long)blockIdx.x * 16 + wv) * 16 + (k)] = __builtin_amdgcn_s_memtime()
@@ -574,7 +577,7 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
   if (wv < nE) {
     const float* src = state + (long)wv * 6 * ld + env;
 #pragma unroll
-    for (int f = 0; f < 6; ++f) v0[f] = live ? src[f * ld] : 0.f;
+    for (int f = 0; f < 6; ++f) v0[f] = lv ? src[f * ld] : 0.f;
   }
   // Environment._set_action + process_action as the prologue: the agent's force rows are computed
   // from its action tensor (and stored to agent_ft, where scenario code reads agent.state.force)
@@ -586,18 +589,18 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
       if (on && (S.action != nullptr || S.action_index != nullptr)) {
         uint32_t bad = 0;
         ingest_slot(S, E.ingest.clamp, env, live, agent_ft, ld, f3, bad);
-        if (S.action_size < 3) f3[2] = live ? src[2 * ld] : 0.f;  // Holonomic leaves the torque alone
+        if (S.action_size < 3) f3[2] = lv ? src[2 * ld] : 0.f;  // Holonomic leaves the torque alone
         if (E.err_flags != nullptr && bad != 0) atomicOr(E.err_flags, bad);
         return;
       }
       if (on && E.ingest.n_scripts > 0 && E.script_of_agent[a] >= 0) {  // scripted: driven by the state about to be stepped
         run_script(E.ingest.scripts[E.script_of_agent[a]], state, env, live, agent_ft, ld, f3);
-        f3[2] = live ? src[2 * ld] : 0.f;
+        f3[2] = lv ? src[2 * ld] : 0.f;
         return;
       }
     }
 #pragma unroll
-    for (int f = 0; f < 3; ++f) f3[f] = live ? src[f * ld] : 0.f;
+    for (int f = 0; f < 3; ++f) f3[f] = lv ? src[f * ld] : 0.f;
   };
   if (wv < nA) load_agent_ft(wv, f0);
   // the epilogue's HBM inputs are requested now, behind the physics
@@ -641,7 +644,7 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
     } else {
       const float* src = state + (long)e * 6 * ld + env;
 #pragma unroll
-      for (int f = 0; f < 6; ++f) v[f] = live ? src[f * ld] : 0.f;
+      for (int f = 0; f < 6; ++f) v[f] = lv ? src[f * ld] : 0.f;
     }
     float* dst = tile + e * 6 * ROWF;
 #pragma unroll
@@ -700,7 +703,7 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
       const float* src = aft + (long)a * 3 * ld + env;
       float* dst = tile + W.off_af + a * 3 * ROWF;
 #pragma unroll
-      for (int f = 0; f < 3; ++f) dst[f * ROWF] = live ? src[f * ld] : 0.f;
+      for (int f = 0; f < 3; ++f) dst[f * ROWF] = lv ? src[f * ld] : 0.f;
     }
     __syncthreads();
   }
@@ -1690,14 +1693,16 @@ static int select_config(VmasWorld* w) {
   return 0;
 }
 
+static inline int blocks_of(int batch) { return (batch + TILE - 1) / TILE; }
+
 template <int LEVEL, int ENV, class EnvArgs>
 static int launch_level(VmasWorld* w, Sched* S, float* state, float* aft, long ld, const DevStepArgs& a,
                         const EnvArgs& env, size_t extra_lds, hipStream_t s) {
   const size_t lds = S->lds_bytes + extra_lds;
   if (lds > 160 * 1024) return fail("vmas_world_step: %zu bytes of LDS per tile exceed the CU's 160 KB", lds);
   const bool plain = !a.pair_mask && !a.joint_fixed_rot && !a.entity_gravity && a.first_substep == 0 && a.n_substeps <= 0 &&
-                     w->batch % TILE == 0 && S->dw.items_in_lds;
-  const int mode = !plain ? 0 : ((S->dw.substeps == 1 && a.n_steps <= 1) ? 2 : 1);
+                     ld >= (long)blocks_of(w->batch) * TILE && S->dw.items_in_lds;
+  const int mode = !plain ? 0 : ((S->dw.substeps == 1 && a.n_steps <= 1) ? (w->batch % TILE == 0 ? 3 : 2) : 1);
   if (lds > 64 * 1024) {
     static thread_local size_t set_for = 0;
     if (set_for < lds) {
@@ -1707,11 +1712,16 @@ static int launch_level(VmasWorld* w, Sched* S, float* state, float* aft, long l
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       HIP_TRY(hipFuncSetAttribute((const void*)step_kernel<LEVEL, ENV, EnvArgs, 2>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      HIP_TRY(hipFuncSetAttribute((const void*)step_kernel<LEVEL, ENV, EnvArgs, 3>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       set_for = lds;
     }
   }
   const int blocks = (w->batch + TILE - 1) / TILE;
-  if (mode == 2)
+  if (mode == 3)
+    hipLaunchKernelGGL((step_kernel<LEVEL, ENV, EnvArgs, 3>), dim3(blocks), dim3(TILE * S->nw), lds, s, S->dw, state, aft,
+                       ld, w->batch, a, env);
+  else if (mode == 2)
     hipLaunchKernelGGL((step_kernel<LEVEL, ENV, EnvArgs, 2>), dim3(blocks), dim3(TILE * S->nw), lds, s, S->dw, state, aft,
                        ld, w->batch, a, env);
   else if (mode == 1)
