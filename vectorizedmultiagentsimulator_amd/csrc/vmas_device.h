@@ -215,17 +215,37 @@ VD void closest_points_seg_seg(const seg_t& l1, const seg_t& l2, v2& p1, v2& p2)
   p2 = hit ? pi : q2;
 }
 
-// physics._get_closest_line_box physics.py:328-382 -> (on box, on line)
+// physics._get_closest_line_box physics.py:328-382 -> (on box, on line): the closest pair over the four edges, strict <
+// in edge order.  An edge is only SOLVED if it can win.  In the box frame the segment's centre (px, py) and half
+// extents (ex, ey) give, per edge, a lower bound of its distance to the segment (distance of the segment's interval to
+// the edge's supporting line), and the distance of the segment's centre to the perimeter is an upper bound of the
+// winning distance; an edge whose bound exceeds it (with slack for the rounding of both sides) cannot be the minimum for
+// any lane of the wave and is skipped - exactly: the edges that are solved are compared in the reference's order.
+// (balance: the line over the 10 x 1 floor solves the top edge only: 3 of 4 segment-segment solves gone.)  A NaN
+// anywhere makes every test fail towards "solve".
 VD void closest_seg_box(const seg_t be[4], const seg_t& line, v2& p_box, v2& p_line) {
+  const float c = be[2].c, s = be[2].s, hl = be[2].half, hw = be[0].half;  // (physics.py:298-325: edges 2, 3 run along the box)
+  const float dx = line.pos.x - (be[0].pos.x + be[1].pos.x) * 0.5f, dy = line.pos.y - (be[0].pos.y + be[1].pos.y) * 0.5f;
+  const float px = dx * c + dy * s, py = dy * c - dx * s;
+  const float ex = fabsf(line.half * (line.c * c + line.s * s)), ey = fabsf(line.half * (line.s * c - line.c * s));
+  const float ax = fabsf(px) - hl, ay = fabsf(py) - hw;
+  const float ox = fmaxf(ax, 0.f), oy = fmaxf(ay, 0.f);
+  const float inside = (ax <= 0.f && ay <= 0.f) ? fminf(0.f - ax, 0.f - ay) : 0.f;
+  const float ub = sqrt_n(ox * ox + oy * oy) + inside;
+  const float thr = ub + 1e-4f * ub + 1e-5f * (1.f + hl + hw + fabsf(px) + fabsf(py));
+  const float lb[4] = {fmaxf(px - ex - hl, hl - px - ex), fmaxf(0.f - px - ex - hl, hl + px - ex),
+                       fmaxf(py - ey - hw, hw - py - ey), fmaxf(0.f - py - ey - hw, hw + py - ey)};
   v2 qb = V(kInf, kInf), ql = V(kInf, kInf);
   float best = kInf;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    v2 pb, pl;
-    closest_points_seg_seg(be[i], line, pb, pl);
-    float d = vnorm(pb - pl);
-    bool cl = d < best;
-    qb = cl ? pb : qb; ql = cl ? pl : ql; best = cl ? d : best;
+    if (__any(!(lb[i] > thr))) {
+      v2 pb, pl;
+      closest_points_seg_seg(be[i], line, pb, pl);
+      float d = vnorm(pb - pl);
+      bool cl = d < best;
+      qb = cl ? pb : qb; ql = cl ? pl : ql; best = cl ? d : best;
+    }
   }
   p_box = qb; p_line = ql;
 }
