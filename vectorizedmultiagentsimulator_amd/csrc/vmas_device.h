@@ -147,17 +147,30 @@ VD void box_edges(v2 pos, float c, float s, float c2, float s2, float length, fl
   e[2].c = e[3].c = c;  e[2].s = e[3].s = s;  e[2].half = e[3].half = hl;
 }
 
-// physics._get_closest_point_box physics.py:263-295
+// physics._get_closest_point_box physics.py:263-295: nearest perimeter point over the four edges, strict < in edge
+// order.  As in closest_seg_box below, an edge is only solved if it can win: |coordinate - edge| in the box frame is a
+// lower bound of the point's distance to that edge, its distance to the perimeter an upper bound of the winner's.
 VD v2 closest_point_box(const seg_t e[4], v2 p) {
+  const float c = e[2].c, s = e[2].s, hl = e[2].half, hw = e[0].half;
+  const float dx = p.x - (e[0].pos.x + e[1].pos.x) * 0.5f, dy = p.y - (e[0].pos.y + e[1].pos.y) * 0.5f;
+  const float px = dx * c + dy * s, py = dy * c - dx * s;
+  const float ax = fabsf(px) - hl, ay = fabsf(py) - hw;
+  const float ox = fmaxf(ax, 0.f), oy = fmaxf(ay, 0.f);
+  const float inside = (ax <= 0.f && ay <= 0.f) ? fminf(0.f - ax, 0.f - ay) : 0.f;
+  const float ub = sqrt_n(ox * ox + oy * oy) + inside;
+  const float thr = ub + 1e-4f * ub + 1e-5f * (1.f + hl + hw + fabsf(px) + fabsf(py));
+  const float lb[4] = {fabsf(px - hl), fabsf(px + hl), fabsf(py - hw), fabsf(py + hw)};
   v2 best = V(kInf, kInf);
   float dist = kInf;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    v2 q = closest_point_line<true>(e[i].pos, e[i].c, e[i].s, e[i].half, p);
-    float d = vnorm(p - q);
-    bool cl = d < dist;
-    best = cl ? q : best;
-    dist = cl ? d : dist;
+    if (__any(!(lb[i] > thr))) {
+      v2 q = closest_point_line<true>(e[i].pos, e[i].c, e[i].s, e[i].half, p);
+      float d = vnorm(p - q);
+      bool cl = d < dist;
+      best = cl ? q : best;
+      dist = cl ? d : dist;
+    }
   }
   return best;
 }
