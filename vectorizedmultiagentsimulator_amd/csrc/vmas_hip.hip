@@ -4,31 +4,37 @@
 // of 64 environments:
 //
 //   HBM (SoA planes, env fastest) --coalesced 256-B rows--> LDS tile [row][64 envs]
-//   once      : trig of every Line/Box entity, "non-finite environment" flag
+//   once      : trig of every Line/Box entity (which ones: masks in the kernel arguments; ONE barrier)
 //   per substep, out of LDS, no HBM traffic:
 //     B  gather : for every dynamic entity, its prologue force (action/friction/gravity)
-//                 plus the force of every incident joint/pair, accumulated IN THE
-//                 REFERENCE'S ORDER in registers, written to a partial-sum row
-//     C  integrate : semi-implicit Euler + clamps, new trig for the next substep
+//                 plus the force of every incident joint/pair whose OTHER side is static,
+//                 accumulated in the reference's order in registers -> a partial-sum row;
+//                 every joint/pair of TWO dynamic entities evaluated once -> its own rows
+//     C  integrate : partial rows + the entity's side of its shared pairs, in order, then
+//                 semi-implicit Euler + clamps, new trig for the next substep
 //   LDS tile --coalesced rows (dynamic planes only)--> HBM
 //
 // Work decomposition ("one wavefront lane per environment, W wavefronts per tile"):
 //   * lane l of every wave of a block is environment l of the block's 64-env tile, so
 //     EVERYTHING else - which entity, which pair, which shape code, every branch - is
-//     wave-uniform: descriptors live in SGPRs (scalar loads), there is no divergence,
-//     and LDS rows are read 64 consecutive floats at a time (conflict-free).
-//   * the W waves of a block split the tile's work by (entity, incident pair) ITEMS:
-//     each dynamic entity's item list (joints, SS, LS, LL, BS, BL, BB - the reference's
-//     accumulation order, core.py:2176-2189) is cut into segments, segments are dealt to
-//     waves by longest-processing-time-first with a per-type cost model.  A segment sums
-//     into its own LDS row, the entity's owner adds the rows in order: no atomics, bitwise
-//     deterministic, and with one segment per entity it IS the reference's sum order.
-//   * a pair of two dynamic entities is evaluated once per side ("owner computes"); that
-//     re-evaluation is cheaper than cross-wave atomics + the barrier they would need and
-//     keeps the accumulation order fixed.
+//     wave-uniform: there is no divergence, and LDS rows are read 64 consecutive floats
+//     at a time (conflict-free).  Descriptors come from one blob staged into LDS.
+//   * the W waves of a block split the tile's work by ITEMS: each dynamic entity's own item
+//     list (the reference's accumulation order, core.py:2176-2189) is cut into segments,
+//     the shared pairs into runs; both are sorted heaviest first, every wave starts with the
+//     one of its own index and pulls further ones from an LDS counter.  Results land in
+//     per-segment / per-pair rows, the entity's owner adds them in a fixed order: no
+//     atomics, bitwise deterministic whichever wave computed what.
 //   * per-environment conservative broad phase (bounding circle, or oriented-box distance
 //     for boxes) in front of every narrow phase; a wave skips an item when none of its 64
-//     environments needs it.
+//     environments needs it; the tests are NaN/inf-aware, so non-finite poses poison their
+//     pairs exactly as the reference's arithmetic does.
+//   * the kernel is compiled in code LEVELs (which pair types exist), ENV stages (action
+//     ingest prologue / scenario epilogue) and PLAIN specialisations (no optional inputs,
+//     padded planes, one substep, whole tiles): it is a dependent chain per wave at the
+//     benchmark sizes, and every scalar spill, uniform branch and predication block is on it.
+//   * waves per tile and which pairs are shared are chosen per world and batch by the
+//     number of waves the choice keeps running per CU (select_config).
 //
 // No MFMA: fp32 elementwise/transcendental work on 2-vectors; nothing is a contraction
 // (BASELINE.json north_star).  The roofline that bounds it is HBM (384 B per env-step for
