@@ -2,41 +2,92 @@
 """bench.py - BASELINE.json's metric on the MI355X-native hot path.
 
 metric : env-steps/sec (batch x substeps) on `balance`, 32768 envs per GPU, n_agents=4
-step   : ONE World.step() (core.py:1972-2015) over the whole batch = one fused kernel
-         launch; state and the pre-generated agent forces are resident in HBM before
-         the timed region starts.
-timing : W warm-up steps, then exactly K steps between barrier+synchronize pairs; MAX
-         over ranks; rank 0 prints one JSON line.  Multi-GPU: the batch is sharded by
-         environment (weak scaling: 32768 envs per GPU), no data-path collective.
-roofline: achieved = algorithmic bytes per launch (384 B/env x envs) /
-         average launch duration from HIP events recorded on the launch stream around
-         the timed region.
-cpu_baseline: the C oracle (a scalar port of the reference algorithm, kind "port") on
-         the host cores, same workload, bounded to ~10 s; rank 0, N=1 only.
+step   : ONE World.step() (core.py:1972-2015) over the whole batch = one fused kernel launch; state and the
+         pre-generated agent forces are resident in HBM before the timed region starts.  This is the north-star
+         hot path and what `value` reports.  The same line carries, as a peer field, `env_step`: the rate through
+         make_env('balance').step() (SURVEY.md 8d's definition: action ingest + World.step + reward / observation /
+         done, ONE launch) with its own roofline.
+timing : W warm-up steps, then exactly K steps between barrier+synchronize pairs; HIP events recorded on the launch
+         stream right inside the two fences bracket the same K launches.  `ms_per_step` and `value` come from the
+         events (MAX over ranks): with K = 20 the wall clock around a 0.2 ms region is mostly the cost of the fences
+         themselves; the wall-clock figures are kept beside them (`wall`).
+multi-GPU: `--gpus N` with no WORLD_SIZE in the environment re-executes itself under torch.distributed.run with N
+         ranks (one per GPU, backend nccl = RCCL); under a launcher it reads RANK/LOCAL_RANK/WORLD_SIZE.  The batch
+         is sharded by environment (weak scaling: 32768 envs per GPU), NO collective on the step path; the only
+         exchange of the pipeline - the end-of-rollout all-gather of obs/rew/done - is timed
+         separately (`rollout_gather`) and is not part of `value`.
+roofline: achieved = algorithmic bytes per launch (384 B/env x envs) / average launch duration from
+         the HIP events; achieved GFLOP/s beside it (1.7 kflop per env-step) and which bound binds.
+cpu_baseline: the REFERENCE itself (VMAS, `kind: "reference"`): its World.step (core.py:1972) and its
+         Environment.step (environment.py:325) on the host cores, device="cpu", torch threads = all cores, same
+         initial state and actions, bounded to ~10 s each; rank 0, N=1 only.  The reference is imported from
+         /root/reference when present, else from its byte-compiled build oracle/_ref (made by
+         __graft_entry__.build()).  `cpu_port` = the C oracle with OpenMP (a scalar port, the conservative baseline).
 
-Episodes are 100 steps long (actions ~ U(-1,1) * u_multiplier, reference law
-environment.py:536-548): every 100 steps the post-reset state is restored by a
-device-to-device copy inside the timed region (it costs one 6 MB copy per 100 launches).
+Episodes are 100 steps long (actions ~ U(-1,1) * u_multiplier, reference law environment.py:536-548): every 100
+steps the post-reset state is restored by a device-to-device copy inside the timed region.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 EPISODE = 100
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+FP32_PEAK_GFLOPS = 157286.4  # 256 CU x 4 SIMD x 32 lanes x 2 flop x 2.4 GHz (vector fp32, no MFMA)
+FLOP_PER_ENV_STEP = 1700.0   # balance n_agents=4, SURVEY.md section 8d
+POST_BYTES_PER_ENV = 273     # obs 4 x 16 x 4 + rew 4 x 4 + done 1 (SURVEY.md section 8d)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10000)
+    ap.add_argument("--warmup", type=int, default=500)
+    ap.add_argument("--num-envs", type=int, default=32768, help="environments PER GPU")
+    ap.add_argument("--n-agents", type=int, default=4)
+    ap.add_argument("--lanes", type=int, default=0, help="lanes per environment (0 = library default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fused", action="store_true", help="skip the secondary measurements (env_step, persistent rollout)")
+    ap.add_argument("--no-gather", action="store_true", help="skip the rollout all-gather timing (N > 1)")
+    ap.add_argument("--fused", action="store_true",
+                    help="time vmas_world_rollout (persistent launch, state resident in LDS) instead of one launch per step")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU plumbing check (tests): ranks, sharding and the rollout gather over gloo, NO physics, value = null")
+    return ap.parse_args()
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def maybe_spawn(args):
+    """`python bench.py --gpus N` without a launcher: become `python -m torch.distributed.run ... bench.py --gpus N`."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    if not args.dry_run:
+        import torch
+
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible: refusing to report an "
+                     f"n_gpus={args.gpus} line from fewer devices")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
 
 
 def build_world(num_envs, device, n_agents, lanes, seed):
+    import torch
     from vectorizedmultiagentsimulator_amd.scenarios.balance import Scenario
 
     torch.manual_seed(seed)
@@ -46,28 +97,36 @@ def build_world(num_envs, device, n_agents, lanes, seed):
     return sc, w
 
 
-def make_forces(w, n_steps, seed, device):
-    """[n_steps, A, 3, ld] packed agent forces: u ~ U(-u_range, u_range) * u_multiplier."""
+def make_actions(n_steps, n_agents, num_envs, seed):
+    """[n_steps, A, B, 2] ~ U(-1, 1) on the host (the reference's get_random_action law, u_range = 1)."""
+    import torch
+
     g = torch.Generator(device="cpu").manual_seed(seed)
-    A = len(w.agents)
+    return torch.rand(n_steps, n_agents, num_envs, 2, generator=g) * 2 - 1
+
+
+def pack_forces(w, actions, device):
+    """[n_steps, A, 3, ld] packed agent forces: u * u_multiplier (what Environment._set_action + Holonomic produce)."""
+    import torch
+
+    n_steps, A = actions.shape[0], len(w.agents)
     f = torch.zeros(n_steps, max(A, 1), 3, w._ld)
-    u = torch.rand(n_steps, A, 2, w.batch_dim, generator=g) * 2 - 1
     for i, a in enumerate(w.agents):
-        f[:, i, 0:2, : w.batch_dim] = u[:, i] * float(a.u_range) * float(a.u_multiplier)
+        f[:, i, 0:2, : w.batch_dim] = actions[:, i].transpose(1, 2) * float(a.u_range) * float(a.u_multiplier)
     return f.to(device)
 
 
-def cpu_baseline(w, forces_cpu, state0_cpu, budget_s=10.0):
-    """Oracle (scalar C port of the reference algorithm) on the host cores."""
+# ------------------------------------------------------------------------------------------------ CPU baselines
+def cpu_port(w, forces_cpu, state0_cpu, budget_s=6.0):
+    """C oracle (scalar port of the reference algorithm, OpenMP over environments) on the host cores."""
     from oracle.oracle import Oracle
 
     o = Oracle(w.spec)
     B = w.batch_dim
-    # pick the thread count that is actually fastest on this host (a 256-thread OpenMP team on
-    # 32768 x ~1 us of work is slower than 32 threads); 3 steps per candidate
-    best = (0.0, 1)
-    for th in sorted({1, 8, 16, 32, 64, 128, os.cpu_count() or 1}):
-        if th > (os.cpu_count() or 1):
+    ncpu = os.cpu_count() or 1
+    best = (0.0, 1)  # the thread count that is actually fastest on this host; 3 steps per candidate
+    for th in sorted({1, 8, 16, 32, 64, 128, ncpu}):
+        if th > ncpu:
             continue
         st = state0_cpu.copy()
         o.step(st, forces_cpu[0].copy(), batch=B, threads=th)
@@ -83,69 +142,192 @@ def cpu_baseline(w, forces_cpu, state0_cpu, budget_s=10.0):
     while True:
         if n % EPISODE == 0:
             st[...] = state0_cpu
-        ft = forces_cpu[n % forces_cpu.shape[0]].copy()
-        o.step(st, ft, batch=B, threads=threads)
+        o.step(st, forces_cpu[n % forces_cpu.shape[0]].copy(), batch=B, threads=threads)
         n += 1
         el = time.perf_counter() - t0
         if el > budget_s or n >= 2000:
             break
+    return {"value": B * n * w.substeps / el, "unit": "env-steps/s", "cores": threads, "kind": "port",
+            "sample": f"{n} World.step() of balance x {B} envs (same state/forces as the GPU run), {el:.1f} s, C oracle "
+                      f"with OpenMP over environments"}
+
+
+def cpu_reference(w, actions, state0_cpu, n_agents, budget_s=10.0):
+    """The reference's own World.step and Environment.step on the host cores (device="cpu")."""
+    import torch
+    from oracle import ref
+
+    B = w.batch_dim
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    env = ref.make_env("balance", num_envs=B, device="cpu", seed=0, continuous_actions=True, n_agents=n_agents)
+    world = env.world
+    assert [e.name for e in world.entities] == [e.name for e in w.entities], "entity order differs from the reference's"
+    st0 = torch.from_numpy(state0_cpu)
+
+    def restore():
+        for i, e in enumerate(world.entities):  # the GPU run's post-reset state, through the reference's own setters
+            e.set_pos(st0[i, 0:2, :B].T.clone(), batch_index=None)
+            e.set_vel(st0[i, 2:4, :B].T.clone(), batch_index=None)
+            e.set_rot(st0[i, 4:5, :B].T.clone(), batch_index=None)
+            e.set_ang_vel(st0[i, 5:6, :B].T.clone(), batch_index=None)
+
+    def world_step(k):
+        for i, a in enumerate(world.agents):  # what _set_action + Holonomic.process_action leave in the state
+            a.state.force = actions[k % EPISODE, i] * a.u_range * a.u_multiplier
+        world.step()
+
+    def env_step(k):
+        env.step([actions[k % EPISODE, i] * a.u_range for i, a in enumerate(env.agents)])
+
+    out = {}
+    with torch.no_grad():
+        for name, fn in (("world_step", world_step), ("env_step", env_step)):
+            restore()
+            for k in range(2):
+                fn(k)
+            restore()
+            n, t0 = 0, time.perf_counter()
+            while True:
+                fn(n)
+                n += 1
+                el = time.perf_counter() - t0
+                if el > budget_s or n >= EPISODE:
+                    break
+            out[name] = {"value": B * n * w.substeps / el, "ms_per_step": el / n * 1e3, "steps": n, "seconds": el}
     return {
-        "value": B * n * w.substeps / el,
-        "unit": "env-steps/s",
-        "cores": threads,
-        "kind": "port",
-        "sample": f"{n} World.step() of balance n_agents=4 x {B} envs (same state/forces as the GPU run), "
-                  f"{el:.1f} s, C oracle with OpenMP over environments",
+        "value": out["world_step"]["value"], "unit": "env-steps/s", "cores": threads, "kind": "reference",
+        "torch_threads": torch.get_num_threads(),
+        "sample": f"{out['world_step']['steps']} World.step() (vmas/simulator/core.py:1972) of the reference's balance "
+                  f"n_agents={n_agents} x {B} envs on device='cpu', same initial state and actions as the GPU run, "
+                  f"{out['world_step']['seconds']:.1f} s ({out['world_step']['ms_per_step']:.1f} ms/step); 2 warm-up steps",
+        "env_step": {**out["env_step"], "unit": "env-steps/s",
+                     "note": "the reference's Environment.step (environment.py:325): ingest + World.step + reward/obs/done"},
+        "reference_from": ref.root(),
     }
 
 
+# ------------------------------------------------------------------------------------------------ gather
+def time_rollout_gather(dist, shard_cls, gather_cls, rank, world_size, device, per_gpu_envs, t_steps=100,
+                        max_chunk_bytes=2 << 30, shrink=1):
+    """End-of-rollout all-gather, the ONLY collective of the pipeline: obs [T, b, A, D], rew [T, b, A],
+    done [T, b] of a T-step rollout, for the shapes of BASELINE configs 2 / 4 / 5, gathered in chunks of steps so
+    that the gathered chunk stays below ``max_chunk_bytes`` (config 5: 46 GB per 100-step rollout on 8 GPUs)."""
+    import torch
+
+    shapes = {  # name: (envs per GPU, agents, obs dim)
+        "balance_cfg2": (per_gpu_envs, 4, 16),
+        "navigation_cfg4": (max(65536 // world_size // shrink, 1), 8, 18),
+        "football_cfg5": (max(131072 // world_size // shrink, 1), 10, 88),
+    }
+    out = {}
+    for name, (b, A, D) in shapes.items():
+        shard = shard_cls(b * world_size, rank, world_size)
+        g = gather_cls(shard)
+        step_bytes = b * (A * D * 4 + A * 4 + 1) * world_size
+        tc = max(1, min(t_steps, max_chunk_bytes // step_bytes))
+        bufs = {"obs": torch.zeros(tc, b, A, D, device=device), "rew": torch.zeros(tc, b, A, device=device),
+                "done": torch.zeros(tc, b, device=device, dtype=torch.bool)}
+        g.gather(bufs, env_dim=1)  # warm-up (communicator set-up)
+        _sync(device)
+        dist.barrier()
+        t0 = time.perf_counter()
+        done = 0
+        while done < t_steps:
+            n = min(tc, t_steps - done)
+            res = g.gather({k: v[:n] for k, v in bufs.items()}, env_dim=1)
+            done += n
+        _sync(device)
+        el = time.perf_counter() - t0
+        assert res["obs"].shape[1] == b * world_size
+        del res
+        t = torch.tensor([el], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+        out[name] = {"ms_per_100_step_rollout": el * 1e3, "steps_per_chunk": tc, "envs_per_gpu": b,
+                     "gathered_GB": step_bytes * t_steps / 1e9,
+                     "GBps_received_per_gpu": step_bytes * t_steps * (world_size - 1) / world_size / el / 1e9}
+    return out
+
+
+def _sync(device):
+    import torch
+
+    if torch.device(device).type == "cuda":
+        torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------------------------------------------ main
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10000)
-    ap.add_argument("--warmup", type=int, default=500)
-    ap.add_argument("--num-envs", type=int, default=32768, help="environments PER GPU")
-    ap.add_argument("--n-agents", type=int, default=4)
-    ap.add_argument("--lanes", type=int, default=0, help="lanes per environment (0 = library default)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-fused", action="store_true", help="skip the secondary persistent-rollout measurement")
-    ap.add_argument("--fused", action="store_true",
-                    help="time vmas_world_rollout (persistent launch, state resident in LDS) instead of one launch per step")
-    args = ap.parse_args()
+    args = parse_args()
+    maybe_spawn(args)
+    import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_size != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world_size} ranks")
+    from vectorizedmultiagentsimulator_amd.shard import EnvShard, RolloutGather, max_over_ranks
+
     dist = None
+    if args.dry_run:
+        device = torch.device("cpu")
+    else:
+        if torch.cuda.device_count() <= local_rank:
+            sys.exit(f"bench.py: rank {rank} needs GPU {local_rank}, {torch.cuda.device_count()} visible")
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+    ranks_seen = 1
     if world_size > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world_size,
-                                device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+        if args.dry_run:
+            dist.init_process_group("gloo", rank=rank, world_size=world_size)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=device)
+        ranks_seen = dist.get_world_size()
+        t = torch.ones(1, device=device)
+        dist.all_reduce(t)  # every rank really is in the group
+        assert int(t.item()) == world_size == ranks_seen
 
-    from vectorizedmultiagentsimulator_amd.shard import EnvShard, max_over_ranks
-
-    # weak scaling: the global batch is world_size x num_envs, sharded by environment; every
-    # rank steps its own contiguous block, no collective on the step path
+    # weak scaling: the global batch is world_size x num_envs, sharded by environment; every rank steps its own
+    # contiguous block, no collective on the step path
     shard = EnvShard(world_size * args.num_envs, rank, world_size)
     assert shard.local_envs == args.num_envs
+
+    gather = None
+    if world_size > 1 and not args.no_gather:
+        gather = time_rollout_gather(dist, EnvShard, RolloutGather, rank, world_size, device,
+                                     args.num_envs if not args.dry_run else 64, t_steps=100 if not args.dry_run else 4,
+                                     shrink=512 if args.dry_run else 1)
+
+    if args.dry_run:
+        if rank == 0:
+            print(json.dumps({"metric": "env-steps/sec (batch x substeps) on 'balance'", "value": None, "dry_run": True,
+                              "n_gpus": world_size, "ranks_seen": ranks_seen, "backend": "gloo",
+                              "shard": [shard.lo, shard.hi], "rollout_gather": gather}), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     sc, w = build_world(shard.local_envs, device, args.n_agents, args.lanes, seed=shard.seed(0))
     be = w._get_backend()
     state0 = w._state.clone()
-    forces = make_forces(w, EPISODE, 1234 + rank, device)
+    actions = make_actions(EPISODE, args.n_agents, args.num_envs, 1234 + rank)
+    forces = pack_forces(w, actions, device)
     stream = torch.cuda.current_stream()
 
-    def run(n_steps, start=0):
+    def run(n_steps, start=0, fused=args.fused):
         done = 0
         while done < n_steps:
             k = (start + done) % EPISODE
             if k == 0:
                 w._state.copy_(state0)
             chunk = min(EPISODE - k, n_steps - done)
-            (be.rollout if args.fused else be.step_n)(chunk, forces[k : k + chunk])
+            (be.rollout if fused else be.step_n)(chunk, forces[k: k + chunk])
             done += chunk
 
     def fence():
@@ -154,55 +336,87 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(fn, n):
+        """K steps between fences: (HIP-event seconds, wall seconds), each MAX over ranks."""
+        fence()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        fn(n)
+        ev1.record(stream)
+        fence()
+        wall = time.perf_counter() - t0
+        return max_over_ranks(ev0.elapsed_time(ev1) * 1e-3, device), max_over_ranks(wall, device)
+
+    # ---- secondary legs first: they also bring the GPU to its steady clocks before the headline region
+    persistent = env_leg = None
+    if not args.no_fused and not args.fused:
+        run(EPISODE, fused=True)
+        ev_s, wall_s = timed(lambda n: run(n, fused=True), args.steps)
+        persistent = {
+            "value": world_size * args.num_envs * w.substeps * args.steps / ev_s, "unit": "env-steps/s",
+            "us_per_step": ev_s / args.steps * 1e6,
+            "note": "vmas_world_rollout: identical results bit for bit, state stays in LDS between steps (scripted / "
+                    "pre-computed forces only); NOT the headline value",
+        }
+        try:
+            from vectorizedmultiagentsimulator_amd.environment import make_env
+
+            env = make_env("balance", num_envs=args.num_envs, device=device, seed=0, validate_actions=False,
+                           n_agents=args.n_agents)
+            acts = [env.get_random_action(a) for a in env.agents]
+
+            def env_steps(n):
+                for _ in range(n):
+                    env.step(acts)
+
+            env_steps(400)  # (the first few hundred steps carry one-time costs)
+            n_env = max(min(args.steps, 2000), 200)
+            ev_s, wall_s = timed(env_steps, n_env)
+            per_env = be.step_bytes_per_env() + POST_BYTES_PER_ENV
+            env_leg = {
+                "value": world_size * args.num_envs * w.substeps * n_env / wall_s, "unit": "env-steps/s",
+                "us_per_step": wall_s / n_env * 1e6, "gpu_us_per_step": ev_s / n_env * 1e6, "steps": n_env,
+                "launches_per_step": 1 if env._one_launch else None,
+                "roofline": {"bound": "hbm", "achieved": per_env * args.num_envs / (ev_s / n_env) / 1e9,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": per_env * args.num_envs / (ev_s / n_env) / 1e9 / HBM_PEAK_GBS,
+                             "bytes_per_env": per_env},
+                "note": "make_env('balance').step() driven from Python, fresh output tensors every step: action ingest "
+                        "(prologue) + World.step + reward/observation/done/info (epilogue) in ONE kernel launch "
+                        "(vmas_world_step_env); value from the wall clock (host included), roofline from HIP events",
+            }
+            del env
+        except Exception as e:  # never let a secondary leg break the bench line
+            env_leg = {"error": repr(e)}
+
+    # ---- headline: W warm-up steps, then exactly K World.step launches
     run(args.warmup)
-    fence()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    run(args.steps, start=args.warmup)
-    ev1.record(stream)
-    fence()
-    t1 = time.perf_counter()
-    wall = t1 - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # avg launch-to-launch duration on the stream
-
-    wall = max_over_ranks(wall, device)
-
-    # secondary number (not `value`): the same K steps as ONE persistent launch per episode chunk
-    fused = None
-    if not args.fused and not args.no_fused:
-        def run_fused(n_steps):
-            done = 0
-            while done < n_steps:
-                k = done % EPISODE
-                if k == 0:
-                    w._state.copy_(state0)
-                chunk = min(EPISODE - k, n_steps - done)
-                be.rollout(chunk, forces[k : k + chunk])
-                done += chunk
-        run_fused(EPISODE)
-        fence()
-        tf0 = time.perf_counter()
-        run_fused(args.steps)
-        fence()
-        fused = max_over_ranks(time.perf_counter() - tf0, device)
+    ev_s, wall_s = timed(lambda n: run(n, start=args.warmup), args.steps)
+    kernel_s = ev_s / args.steps
 
     if rank == 0:
         bytes_per_env = be.step_bytes_per_env()
-        ach = bytes_per_env * args.num_envs / (kernel_ms * 1e-3) / 1e9
+        ach = bytes_per_env * args.num_envs / kernel_s / 1e9
+        gflops = FLOP_PER_ENV_STEP * args.num_envs / kernel_s / 1e9
         out = {
             "metric": "env-steps/sec (batch x substeps) on 'balance'",
-            "value": world_size * args.num_envs * w.substeps * args.steps / wall,
+            "value": world_size * args.num_envs * w.substeps * args.steps / ev_s,
             "unit": "env-steps/s",
             "n_gpus": world_size,
+            "ranks_seen": ranks_seen,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": wall / args.steps * 1e3,
+            "ms_per_step": kernel_s * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            "value_is": "World.step() physics (north-star hot path), timed with HIP events inside the fences; "
+                        "`env_step` = through Environment.step(); `wall` = the same K steps by the host clock",
+            "wall": {"ms_per_step": wall_s / args.steps * 1e3,
+                     "value": world_size * args.num_envs * w.substeps * args.steps / wall_s},
             "config": {
                 "workload": f"balance n_agents={args.n_agents}, {args.num_envs} envs/GPU, World.step() physics only, "
                             f"random actions, {EPISODE}-step episodes",
@@ -221,18 +435,21 @@ def main():
                 "frac": ach / HBM_PEAK_GBS,
                 "traffic": None,
                 "kernel": "step_kernel",
-                "kernel_us": kernel_ms * 1e3,
+                "kernel_us": kernel_s * 1e6,
                 "bytes_per_launch": bytes_per_env * args.num_envs,
+                "gflops": gflops,
+                "gflops_frac_of_fp32_vector_peak": gflops / FP32_PEAK_GFLOPS,
+                "binds": "neither roof at this batch: one launch moves 12.6 MB (1.6 us at 8 TB/s) and 56 Mflop "
+                         "(0.4 us at fp32 peak); the launch is a ~3 us launch floor plus one tile's dependent chain "
+                         "(profiles/r02_*_pmc_summary.txt: ~60 % of wave-cycles waiting). HBM is the nominal bound.",
             },
         }
-        if fused is not None:
-            out["persistent_rollout"] = {
-                "value": world_size * args.num_envs * w.substeps * args.steps / fused,
-                "unit": "env-steps/s",
-                "us_per_step": fused / args.steps * 1e6,
-                "note": "vmas_world_rollout: identical results bit for bit, state stays in LDS between steps "
-                        "(scripted / pre-computed forces only); NOT the headline value",
-            }
+        if env_leg is not None:
+            out["env_step"] = env_leg
+        if persistent is not None:
+            out["persistent_rollout"] = persistent
+        if gather is not None:
+            out["rollout_gather"] = gather
         tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
         if os.path.exists(tpath):  # HBM bytes per launch from rocprofv3 PMC passes (scripts/gpu_prof.sh)
             try:
@@ -242,33 +459,19 @@ def main():
                     out["roofline"]["traffic_note"] = tr["note"]
             except Exception:
                 pass
-        if world_size == 1 and not args.no_fused:  # informational: the full Environment.step of the same scenario
-            try:
-                from vectorizedmultiagentsimulator_amd.environment import make_env
-
-                env = make_env("balance", num_envs=args.num_envs, device=device, seed=0, validate_actions=False,
-                               n_agents=args.n_agents)
-                acts = [env.get_random_action(a) for a in env.agents]
-                for _ in range(400):  # (the first few hundred steps carry one-time costs)
-                    env.step(acts)
-                torch.cuda.synchronize()
-                te = time.perf_counter()
-                for _ in range(1000):
-                    env.step(acts)
-                torch.cuda.synchronize()
-                te = (time.perf_counter() - te) / 1000
-                out["end_to_end_env_step"] = {
-                    "value": args.num_envs / te, "unit": "env-steps/s", "us_per_step": te * 1e6,
-                    "launches_per_step": 1 if env._one_launch else None,
-                    "note": "make_env('balance').step() from Python with fresh output tensors every step: action "
-                            "ingest (prologue) + World.step + reward/observation/done/info (epilogue) in ONE kernel "
-                            "launch (vmas_world_step_env); NOT the headline value",
-                }
-            except Exception as e:  # never let the informational leg break the bench line
-                out["end_to_end_env_step"] = {"error": repr(e)}
         if world_size == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(w, forces.cpu().numpy(), state0.cpu().numpy())
+            st0, f_cpu = state0.cpu().numpy(), forces.cpu().numpy()
+            try:
+                out["cpu_baseline"] = cpu_reference(w, actions, st0, args.n_agents)
+            except Exception as e:  # the reference is not importable here: say so, keep the port
+                out["cpu_baseline_error"] = repr(e)
+            out["cpu_port"] = cpu_port(w, f_cpu, st0)
+            if "cpu_baseline" not in out:
+                out["cpu_baseline"] = dict(out["cpu_port"])
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            out["cpu_port"]["gpu_over_cpu"] = out["value"] / out["cpu_port"]["value"]
+            if env_leg and "value" in env_leg and "env_step" in out["cpu_baseline"]:
+                out["cpu_baseline"]["env_step"]["gpu_over_cpu"] = env_leg["value"] / out["cpu_baseline"]["env_step"]["value"]
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -1,0 +1,72 @@
+"""Summarise the rocprofv3 passes of scripts/gpu_counters.sh: per kernel of OUR library (step / lidar / post / mask
+kernels), mean counters per dispatch and per wave, achieved GB/s and GFLOP/s against the MI355X peaks, and which
+resource binds.  usage: pmc_summary.py WORKDIR KERNEL_STATS_CSV BYTES_PER_ENV FLOP_PER_ENV ENVS "cmd"
+
+Peaks (MI355X_MICROARCH.md): HBM 8.0 TB/s; fp32 vector 157.3 TFLOP/s (256 CU x 4 SIMD x 32 lanes x 2 flop x 2.4 GHz).
+FETCH_SIZE is doubled (gfx950 tallies 128-B requests at 64 B; calibrated in this library's own 4 B/lane row pattern,
+profiles/r01_traffic_calibration.txt), WRITE_SIZE taken as is.  SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* are quad-cycles.
+"""
+import collections
+import csv
+import glob
+import sys
+
+work, stats_csv, bpe, fpe, envs, cmd = sys.argv[1], sys.argv[2], float(sys.argv[3]), float(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
+OURS = ("step_kernel", "lidar_kernel", "post_kernel", "pair_mask_kernel", "ingest_kernel", "query_kernel", "reset_kernel",
+        "rollout")
+
+
+def short(name):
+    n = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    return n.split("(")[0]
+
+
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+meta = {}
+for d in ("p1", "p2", "p3", "p4"):
+    for f in glob.glob(f"{work}/{d}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            if not any(o in k for o in OURS):
+                continue
+            acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            meta[k] = (r["Grid_Size"], r["Workgroup_Size"], r["LDS_Block_Size"], r["VGPR_Count"], r["SGPR_Count"])
+dur = {}
+try:
+    for r in csv.DictReader(open(stats_csv)):
+        dur[short(r["Name"])] = (float(r["AverageNs"]), int(r["Calls"]), float(r["MinNs"]), float(r["MaxNs"]), float(r["StdDev"]))
+except Exception as e:  # noqa: BLE001
+    print("no kernel stats:", e)
+print(f"# {cmd}")
+print(f"# envs {envs}, algorithmic bytes/env-step {bpe:g}, flop/env-step {fpe:g} (SURVEY.md section 8d)")
+for k in sorted(acc, key=lambda k: -dur.get(k, (0,))[0]):
+    c = {n: sum(v) / len(v) for n, v in acc[k].items()}
+    g = meta[k]
+    print(f"\n== {k}\n   grid {g[0]} threads, block {g[1]}, LDS {g[2]} B, VGPR {g[3]}, SGPR {g[4]}")
+    if k in dur:
+        avg, calls, mn, mx, sd = dur[k]
+        print(f"   duration (kernel trace): avg {avg / 1e3:.2f} us over {calls} calls (min {mn / 1e3:.2f}, max {mx / 1e3:.2f}, sd {sd / 1e3:.2f})")
+    waves = c.get("SQ_WAVES", 0)
+    for n in sorted(c):
+        per_wave = f"  per wave {c[n] / waves:.1f}" if waves and n.startswith("SQ_") and n != "SQ_WAVES" else ""
+        print(f"   {n:22s} {c[n]:14.6g}{per_wave}")
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        traffic = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
+        print(f"   HBM traffic per launch  {traffic / 1e6:.2f} MB (FETCH x2 + WRITE)")
+    if k in dur and "step_kernel" in k or (k in dur and "lidar" in k):
+        t = dur[k][0] * 1e-9
+        gbs, gfs = bpe * envs / t / 1e9, fpe * envs / t / 1e9
+        print(f"   achieved (algorithmic)  {gbs:.0f} GB/s = {gbs / 8000:.3f} of HBM peak | {gfs:.0f} GFLOP/s = {gfs / 157300:.3f} of fp32 vector peak")
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            print(f"   traffic / algorithmic   {traffic / (bpe * envs):.3f}")
+    if waves and "SQ_WAVE_CYCLES" in c:
+        wc = c["SQ_WAVE_CYCLES"]
+        parts = []
+        for n in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_LDS"):
+            if n in c:
+                parts.append(f"{n[3:]} {c[n] / wc:.2f}")
+        print("   share of wave-cycles    " + ", ".join(parts))
+        if "SQ_BUSY_CYCLES" in c and "SQ_INSTS_VALU" in c:
+            # VALU issue pressure: a wave64 fp32 VALU instruction occupies a SIMD for 2 cycles (1 issue quad-cycle ~ 4 cyc);
+            # SQ_BUSY_CYCLES is summed over the XCDs' SQs (quad-cycles)
+            print(f"   VALU insts / SALU insts {c['SQ_INSTS_VALU'] / max(c.get('SQ_INSTS_SALU', 1), 1):.2f}")

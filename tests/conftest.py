@@ -10,12 +10,15 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    config.addinivalue_line("markers", "reference: needs /root/reference (build container only)")
+    config.addinivalue_line("markers", "reference: needs the reference (VMAS): /root/reference in the build container, "
+                            "its byte-compiled build oracle/_ref (made by __graft_entry__.build()) on the GPU box")
 
 
 def pytest_collection_modifyitems(config, items):
-    have_ref = os.path.isdir("/root/reference/vmas")
-    skip_ref = pytest.mark.skip(reason="/root/reference not present (GPU box)")
+    from oracle import ref
+
+    have_ref = ref.available()
+    skip_ref = pytest.mark.skip(reason="neither /root/reference nor oracle/_ref present")
     for item in items:
         if "reference" in item.keywords and not have_ref:
             item.add_marker(skip_ref)

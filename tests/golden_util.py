@@ -101,11 +101,20 @@ def ulp_sensitivity(step_fn, state: np.ndarray, ft: np.ndarray, n: int = 3, seed
     return sens
 
 
-def compare_state(got: np.ndarray, want: np.ndarray, name: str, atol=1e-5, rtol=1e-5, sens=None, sens_mult=8.0):
-    """|got - want| <= atol + rtol*|want| (+ sens_mult * 1-ulp conditioning if given)."""
+#: fixtures of the five BASELINE configs: parity must hold at the plain north-star tolerance, no allowance used
+BASELINE_FIXTURES = ("balance_n3", "balance_n4", "transport", "transport_2pkg", "navigation_n8", "football_5v5")
+
+
+def compare_state(got: np.ndarray, want: np.ndarray, name: str, atol=1e-5, rtol=1e-5, sens=None, sens_mult=8.0, stats=None):
+    """|got - want| <= atol + rtol*|want| (+ sens_mult * 1-ulp conditioning if given).  ``stats`` (a dict) counts in
+    ``stats["needed_sens"]`` how many values were only accepted thanks to the conditioning allowance and in
+    ``stats["values"]`` how many were compared."""
     with np.errstate(invalid="ignore"):
         err = np.abs(got - want)
     lim = atol + rtol * np.abs(want)
+    if stats is not None:
+        stats["values"] = stats.get("values", 0) + int(err.size)
+        stats["needed_sens"] = stats.get("needed_sens", 0) + int((err > lim).sum())
     if sens is not None:
         lim = lim + sens_mult * sens
     bad = err > lim

@@ -1,4 +1,4 @@
-"""attach() on the REFERENCE's own Environment (build container only: needs /root/reference).
+"""attach() on the REFERENCE's own Environment (the reference: /root/reference, or oracle/_ref on the GPU box).
 
 No GPU here, so the backend injected into the adapter is the CPU oracle (test
 infrastructure): what is under test is the drop-in plumbing - packing, the write-through
@@ -18,38 +18,13 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 @pytest.fixture(scope="module")
 def vmas():
-    sys.path[:0] = [os.path.join(ROOT, "oracle", "ref_shim"), "/root/reference"]
-    import vmas as _vmas
+    from oracle import ref  # /root/reference here, its byte-compiled build under oracle/_ref on the GPU box
 
-    return _vmas
+    ref.import_vmas()
+    return ref  # ref.make_env == vmas.make_env with scenario names resolved by import
 
 
-class OracleBackend:
-    """HipWorld look-alike driving the CPU oracle on the adapter's packed buffers."""
-
-    def __init__(self, spec, batch, device, state, agent_ft):
-        from oracle.oracle import Oracle
-
-        self.o, self.spec, self.batch = Oracle(spec), spec, batch
-        self.state, self.agent_ft = state, agent_ft
-
-    def _np(self, t):
-        return None if t is None else t.numpy()
-
-    def step(self, pair_mask=None, joint_fixed_rot=None, entity_gravity=None, first_substep=0, n_substeps=0):
-        self.o.step(self.state.numpy(), self.agent_ft.numpy()[: max(self.spec.n_agents, 0)] if self.spec.n_agents
-                    else np.zeros((0, 3, self.state.shape[-1]), np.float32), batch=self.batch,
-                    joint_fixed_rot=self._np(joint_fixed_rot), entity_gravity=self._np(entity_gravity))
-
-    def step_exact(self, joint_fixed_rot=None, entity_gravity=None):
-        self.o.step_exact(self.state.numpy(), self.agent_ft.numpy(), batch=self.batch,
-                          joint_fixed_rot=self._np(joint_fixed_rot), entity_gravity=self._np(entity_gravity))
-
-    def cast_rays(self):
-        return torch.from_numpy(self.o.cast_rays(self.state.numpy(), batch=self.batch))
-
-    def close(self):
-        pass
+from ref_backend import OracleBackend  # noqa: E402
 
 
 def _actions(env, g):

@@ -18,10 +18,10 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 @pytest.fixture(scope="module")
 def vmas():
-    sys.path[:0] = [os.path.join(ROOT, "oracle", "ref_shim"), "/root/reference"]
-    import vmas as _vmas
+    from oracle import ref  # /root/reference here, its byte-compiled build under oracle/_ref on the GPU box
 
-    return _vmas
+    ref.import_vmas()
+    return ref  # ref.make_env == vmas.make_env with scenario names resolved by import
 
 
 def _copy_state(ref_world, our_world):

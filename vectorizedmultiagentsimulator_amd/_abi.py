@@ -129,7 +129,9 @@ class VmasHipLibraryMissing(ImportError):
 
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "csrc", "libvmas_hip.so")
+# VMAS_HIP_LIB: another build of the SAME sources (profiling knobs compiled in, an experimental variant) for A/B
+# measurements; it must live beside the product library and export the same ABI version.
+LIB_PATH = os.path.join(_PKG_DIR, "csrc", os.path.basename(os.environ.get("VMAS_HIP_LIB", "libvmas_hip.so")))
 
 #: every symbol include/vmas_hip.h declares (checked by tests/test_abi_symbols.py)
 

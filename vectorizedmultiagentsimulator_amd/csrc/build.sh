@@ -7,5 +7,5 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared \
   -Wall -Wno-unused-function \
   ${VMAS_HIPCC_EXTRA:-} \
-  -o libvmas_hip.so vmas_hip.hip vmas_env.hip
-echo "built $(pwd)/libvmas_hip.so"
+  -o "${VMAS_LIB_OUT:-libvmas_hip.so}" vmas_hip.hip vmas_env.hip
+echo "built $(pwd)/${VMAS_LIB_OUT:-libvmas_hip.so}"
