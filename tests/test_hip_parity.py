@@ -7,11 +7,13 @@ Tolerance: north_star's 1e-5 (abs + rel), plus - only where the oracle MEASURES 
 1-ulp change of inputs/libm results moves an output by more than that (light jointed
 bodies, see golden_util.ulp_sensitivity) - 8x that measured sensitivity.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
 
-from golden_util import FIXTURES, compare_state, load, tolerances, ulp_sensitivity
+from golden_util import BASELINE_FIXTURES, FIXTURES, compare_state, load, tolerances, ulp_sensitivity
 
 pytestmark = pytest.mark.gpu
 
@@ -71,6 +73,19 @@ def make_batch(g, B, seed):
     return st, ft, jfr, eg
 
 
+def _record_allowance(name, what, stats, worst):
+    """One line per fixture in gpurun_out/parity_allowance.jsonl: how many values needed the 8 x sensitivity allowance."""
+    import json
+    out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.path.join(os.path.dirname(__file__), "..")), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_allowance.jsonl"), "a") as f:
+            f.write(json.dumps({"fixture": name, "check": what, "values": stats["values"],
+                                "needed_allowance": stats["needed_sens"], "max_abs_err": worst}) + "\n")
+    except OSError:
+        pass
+
+
 @pytest.mark.parametrize("name", FIXTURES)
 def test_hip_step_matches_reference_golden(name):
     """Teacher-forced, one substep at a time, with the reference's recorded broad-phase
@@ -80,7 +95,7 @@ def test_hip_step_matches_reference_golden(name):
     g = load(name)
     o = Oracle(g.spec)
     hw = _hip(g.spec, g.B)
-    worst = 0.0
+    worst, stats = 0.0, {}
     for t in range(g.T):
         ft = np.ascontiguousarray(g.ft_in[t]).copy()
         st = np.ascontiguousarray(g.state0[t]).copy()
@@ -98,9 +113,14 @@ def test_hip_step_matches_reference_golden(name):
             hw.step(pair_mask=mask, joint_fixed_rot=jfr, entity_gravity=eg, first_substep=s, n_substeps=1)
             st, ft = _down(hw, g.B, g.spec.n_agents)
             want = g.state1[t] if g.sub is None else g.sub[t, s + 1]
-            worst = max(worst, compare_state(st, want, f"{name}[t={t},s={s}] state", sens=sens, **tolerances(g.spec)))
+            worst = max(worst, compare_state(st, want, f"{name}[t={t},s={s}] state", sens=sens, stats=stats,
+                                             **tolerances(g.spec)))
         compare_state(ft, g.ft_out[t], f"{name}[t={t}] agent force/torque", atol=1e-6, rtol=1e-6)
-    print(f"{name}: HIP vs reference max abs err {worst:.3e}")
+    print(f"{name}: HIP vs reference max abs err {worst:.3e}; {stats['needed_sens']} of {stats['values']} values "
+          f"needed the conditioning allowance (beyond the plain 1e-5 + 1e-5*|x|)")
+    _record_allowance(name, "hip_vs_reference", stats, worst)
+    if name in BASELINE_FIXTURES:  # the five BASELINE configs hold at the plain north-star tolerance
+        assert stats["needed_sens"] == 0, f"{name}: {stats['needed_sens']} values beyond the plain tolerance"
 
 
 @pytest.mark.parametrize("name", FIXTURES)
@@ -272,6 +292,7 @@ FULL_SIZE = [  # BASELINE.json configs (per-GPU shard sizes for the 8-GPU ones)
     ("transport_2pkg", 16384),
     ("navigation_n8", 65536),
     ("football_5v5", 16384),
+    ("football_5v5", 131072),  # BASELINE config 5 at its full size
 ]
 
 
@@ -286,7 +307,7 @@ def test_hip_full_size_vs_oracle(name, B):
     o = Oracle(g.spec)
     st0, ft0, jfr_np, eg_np = make_batch(g, B, seed=11)
     want_s, want_f = st0.copy(), ft0.copy()
-    o.step(want_s, want_f, joint_fixed_rot=jfr_np, entity_gravity=eg_np, threads=8)
+    o.step(want_s, want_f, joint_fixed_rot=jfr_np, entity_gravity=eg_np, threads=min(os.cpu_count() or 8, 64))
     hw = _hip(g.spec, B)
     _up(hw, st0, ft0)
     hw.step()
@@ -352,6 +373,40 @@ def test_persistent_rollout_is_bitwise_equal_to_single_steps(name):
         outs.append((hw.state.clone(), full.clone()))
     assert torch.equal(outs[0][0].view(torch.int32), outs[1][0].view(torch.int32))
     assert torch.equal(outs[0][1].view(torch.int32), outs[1][1].view(torch.int32))
+
+
+@pytest.mark.parametrize("name,B", [("balance_n4", 32768), ("balance_n4", 1000), ("navigation_n8", 4096 + 17),
+                                    ("give_way", 130), ("football_5v5", 64)])
+def test_step_n_over_two_queues_is_bitwise_equal_to_one_queue(name, B):
+    """vmas_world_step_n with the batch cut in two halves on two HIP queues (vmas_world_set_queues): same kernels on
+    environment sub-ranges, so the state and the clamped forces written back must be those of one queue bit for bit -
+    whole-tile halves, a ragged last tile, a one-tile batch (never split), and work enqueued on the caller's stream
+    right after the call must see the joined result."""
+    g = load(name)
+    n = 12
+    st0, ft0, jfr_np, eg_np = make_batch(g, B, seed=31)
+    if jfr_np is not None or eg_np is not None:
+        pytest.skip("per-env joint/gravity inputs are single-step arguments")
+    rng = np.random.default_rng(9)
+    noise = (1 + 0.3 * rng.standard_normal((n,) + ft0.shape)).astype(np.float32)
+    outs = []
+    for queues in (1, 2, 0):
+        hw = _hip(g.spec, B)
+        hw.set_queues(queues)
+        assert hw.queues(n) == (1 if queues == 1 or B <= 64 else (2 if queues == 2 else hw.queues(n)))
+        _up(hw, st0, ft0)
+        full = torch.zeros(n, *hw.agent_ft.shape, device="cuda")
+        full[:, : ft0.shape[0], :, :B] = torch.from_numpy(ft0[None] * noise).cuda()
+        pad_before = hw.state[:, :, B:].clone()
+        hw.step_n(n, full)
+        after = hw.state.clone()  # enqueued on the caller's stream: ordered after the join
+        outs.append((after, full.clone(), hw.queues(n)))
+        assert torch.equal(hw.state[:, :, B:], pad_before), "padding columns were written"
+        hw.close()
+    assert outs[0][2] == 1 and outs[1][2] == (2 if B > 64 else 1)
+    for k in (1, 2):
+        assert torch.equal(outs[0][0].view(torch.int32), outs[k][0].view(torch.int32)), f"{name}: queues differ (state)"
+        assert torch.equal(outs[0][1].view(torch.int32), outs[k][1].view(torch.int32)), f"{name}: queues differ (forces)"
 
 
 @pytest.mark.parametrize("name", FIXTURES)

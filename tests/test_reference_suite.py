@@ -1,0 +1,188 @@
+"""The REFERENCE's own test-suite with every ``make_env`` put on the native step (the behavioural
+tests are the only thing the reference pins this path with).
+
+Every test function / method of the reference's ``tests/test_scenarios/*.py``, ``tests/test_lidar.py`` and the
+seeding / reset tests of ``tests/test_vmas.py`` is run UNMODIFIED (loaded from /root/reference, or from its
+byte-compiled build ``oracle/_ref`` on the GPU box - a sourceless tree pytest cannot collect, hence this small runner
+that expands the ``parametrize`` / ``skipif`` marks itself) with the module's ``make_env`` replaced by one that
+builds the reference environment and calls ``adapter.attach`` on it:
+
+* ``-m gpu``  : environment on ``cuda:0``, ``World.step`` / ``Lidar.measure`` = ``libvmas_hip.so`` (the real drop-in);
+                a thin proxy moves actions to the device and results back, because the reference's tests mix their
+                own CPU tensors with the environment's outputs;
+* otherwise   : environment on the CPU with the C oracle injected as the backend (plumbing check, no GPU here).
+"""
+import inspect
+import itertools
+import os
+import sys
+
+import pytest
+import torch
+
+from oracle import ref
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.dirname(__file__))
+
+FILES = [
+    "tests/test_scenarios/test_balance.py", "tests/test_scenarios/test_transport.py",
+    "tests/test_scenarios/test_football.py", "tests/test_scenarios/test_waterfall.py",
+    "tests/test_scenarios/test_passage.py", "tests/test_scenarios/test_wheel.py",
+    "tests/test_scenarios/test_reverse_transport.py", "tests/test_scenarios/test_navigation.py",
+    "tests/test_scenarios/test_give_way.py", "tests/test_scenarios/test_dropout.py",
+    "tests/test_scenarios/test_flocking.py", "tests/test_scenarios/test_dispersion.py",
+    "tests/test_scenarios/test_discovery.py", "tests/test_lidar.py",
+]
+VMAS_TESTS = ("test_seeding", "test_partial_reset", "test_global_reset")  # of tests/test_vmas.py (:249-323)
+
+
+def _to(x, device):
+    if isinstance(x, torch.Tensor):
+        return x.to(device)
+    if isinstance(x, (list, tuple)):
+        return type(x)(_to(v, device) for v in x)
+    if isinstance(x, dict):
+        return {k: _to(v, device) for k, v in x.items()}
+    return x
+
+
+class HostView:
+    """The reference's tests keep their own tensors on the CPU: actions go to the environment's device, whatever
+    ``step`` / ``reset`` / ``reset_at`` return comes back to the CPU.  Everything else is the environment itself."""
+
+    def __init__(self, env):
+        object.__setattr__(self, "_env", env)
+
+    def __getattr__(self, name):
+        return getattr(self._env, name)
+
+    def __setattr__(self, name, value):
+        setattr(self._env, name, value)
+
+    def step(self, actions):
+        return _to(self._env.step(_to(actions, self._env.device)), "cpu")
+
+    def reset(self, *a, **kw):
+        return _to(self._env.reset(*a, **kw), "cpu")
+
+    def reset_at(self, *a, **kw):
+        return _to(self._env.reset_at(*a, **kw), "cpu")
+
+    def get_random_actions(self):
+        return self._env.get_random_actions()
+
+
+ATTACHED = []
+
+
+def _attached_make_env(on_gpu):
+    from vectorizedmultiagentsimulator_amd.adapter import attach
+
+    def make_env(scenario, **kw):
+        kw = dict(kw)
+        if on_gpu:
+            kw["device"] = "cuda:0"
+            env = ref.make_env(scenario, **kw)
+            ATTACHED.append(attach(env, exact_broad_phase=True))
+            return HostView(env)
+        from ref_backend import OracleBackend
+
+        kw["device"] = "cpu"
+        env = ref.make_env(scenario, **kw)
+        ATTACHED.append(attach(env, backend_factory=OracleBackend, exact_broad_phase=True))
+        return env
+
+    return make_env
+
+
+def _expand(func):
+    """[(id, kwargs)] from the function's parametrize marks; None if a skipif / skip mark applies."""
+    marks = list(getattr(func, "pytestmark", []))
+    axes = []
+    for m in marks:
+        if m.name == "skip" or (m.name == "skipif" and m.args and m.args[0]):
+            return None
+        if m.name == "parametrize":
+            names, values = m.args[0], list(m.args[1])
+            names = [n.strip() for n in names.split(",")] if isinstance(names, str) else list(names)
+            axes.append([dict(zip(names, v if len(names) > 1 else (v,))) for v in values])
+    out = []
+    for combo in itertools.product(*axes) if axes else [()]:
+        kw = {}
+        for d in combo:
+            kw.update(d)
+        out.append(("-".join(str(v) for v in kw.values()) or "-", kw))
+    return out
+
+
+def _cases():
+    if not ref.available():
+        return []
+    cases = []
+    for rel in FILES + ["tests/test_vmas.py"]:
+        mod = ref.load_test_module(rel)
+        short = os.path.basename(rel)[:-3]
+        for name, obj in vars(mod).items():
+            if inspect.isclass(obj) and name.startswith("Test") and obj.__module__ == mod.__name__:
+                for mname, meth in vars(obj).items():
+                    if mname.startswith("test") and callable(meth):
+                        for pid, kw in _expand(meth) or []:
+                            cases.append((f"{short}::{name}::{mname}[{pid}]", rel, name, mname, kw))
+            elif inspect.isfunction(obj) and name.startswith("test") and obj.__module__ == mod.__name__:
+                if short == "test_vmas" and name not in VMAS_TESTS:
+                    continue
+                for pid, kw in _expand(obj) or []:
+                    cases.append((f"{short}::{name}[{pid}]", rel, None, name, kw))
+    return cases
+
+
+CASES = _cases()
+
+
+def _run(case, on_gpu):
+    _, rel, cls, fn, kw = case
+    if on_gpu and fn == "test_vectorized_lidar":
+        # the reference's scalar ray walk is thousands of tiny tensor ops per step (a minute on the CPU, several on a
+        # GPU): same test, 3 steps instead of its default 15 (the CPU variant runs the default)
+        kw = dict(kw, n_steps=3)
+    mod = ref.load_test_module(rel)
+    mod.make_env = _attached_make_env(on_gpu)
+    n0 = len(ATTACHED)
+    try:
+        if cls is None:
+            getattr(mod, fn)(**kw)
+        else:
+            getattr(getattr(mod, cls)(), fn)(**kw)
+        assert len(ATTACHED) > n0, "the reference test never called make_env: nothing ran on the native step"
+    except ModuleNotFoundError as e:  # a heuristic policy of the reference needs a package this image lacks (cvxpy)
+        if e.name in ("cvxpy", "cvxpylayers"):
+            pytest.skip(f"the reference's own test needs {e.name}, absent from this image")
+        raise
+    finally:
+        while len(ATTACHED) > n0:
+            ATTACHED.pop().detach()
+
+
+@pytest.mark.reference
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_reference_test_on_the_oracle_backend(case):
+    _run(case, on_gpu=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.reference
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_reference_test_on_the_hip_step(case):
+    from vectorizedmultiagentsimulator_amd import _abi
+
+    assert torch.cuda.is_available() and os.path.exists(_abi.LIB_PATH)
+    _run(case, on_gpu=True)
+
+
+def test_reference_suite_is_collected():
+    if not ref.available():
+        pytest.skip("neither /root/reference nor oracle/_ref present")
+    names = {c[0].split("::")[0] for c in CASES}
+    assert {os.path.basename(f)[:-3] for f in FILES} <= names and "test_vmas" in names
+    assert len(CASES) >= 100

@@ -68,3 +68,97 @@ def test_two_rank_rollout_gather(num_envs):
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res), res
     assert len({s for _, _, s in res}) == 2  # distinct per-shard seeds
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The whole N > 1 pipeline on two ranks: EnvShard -> a real sharded environment (native object model, per-shard seed,
+# scenario reset) -> rollout.collect -> rollout.gather_rollout.  No GPU here: the World.step of each shard runs on the
+# CPU oracle injected as the backend (test infrastructure; the product has no CPU path).
+def _sharded_env(shard):
+    from ref_backend import OracleBackend
+    from vectorizedmultiagentsimulator_amd.environment import make_env
+
+    env = make_env("balance", num_envs=shard.local_envs, device="cpu", seed=shard.seed(0), n_agents=3)
+    w = env.world
+    w._backend = OracleBackend(w.spec, shard.local_envs, "cpu", w._packed_state(), w._packed_agent_ft())
+    return env
+
+
+def _policy_for(shard, n_agents):
+    """Deterministic actions that depend on the GLOBAL environment index and the step."""
+    step = [0]
+
+    def policy(obs):
+        t = step[0]
+        step[0] += 1
+        genv = torch.arange(shard.lo, shard.hi, dtype=torch.float32)
+        return [torch.stack([torch.sin(0.37 * genv + 0.11 * t + a), torch.cos(0.23 * genv - 0.07 * t + a)], dim=1) * 0.9
+                for a in range(n_agents)]
+
+    return policy
+
+
+def _rollout_worker(rank, world, port, num_envs, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vectorizedmultiagentsimulator_amd.rollout import collect, gather_rollout
+
+        T = 5
+        sh = EnvShard.from_env(num_envs)
+        env = _sharded_env(sh)
+        local = collect(env, _policy_for(sh, 3), T)
+        assert local["obs"].shape == (T, sh.local_envs, 3, 16) and local["done"].dtype == torch.bool
+        full = gather_rollout(local, sh)
+        ok = full["obs"].shape == (T, num_envs, 3, 16) and full["rew"].shape == (T, num_envs, 3)
+        # global environment order: every rank finds its own block where its shard range says
+        for k in ("obs", "rew", "done"):
+            ok &= torch.equal(full[k][:, sh.lo:sh.hi], local[k])
+        # ... and the PEER's block is exactly what an environment of the peer's shard (its size, its seed, the same
+        # policy of the global index) produces: recomputed here, bit for bit (the CPU oracle is deterministic)
+        peer = EnvShard(num_envs, 1 - rank, world)
+        want = collect(_sharded_env(peer), _policy_for(peer, 3), T)
+        for k in ("obs", "rew", "done"):
+            ok &= torch.equal(full[k][:, peer.lo:peer.hi], want[k])
+        differs = not torch.equal(local["obs"][0, 0], want["obs"][0, 0])  # per-shard seeds: different reset states
+        q.put((rank, bool(ok), bool(differs), sh.seed(0)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("num_envs", [8, 9])  # equal and unequal shards
+def test_two_rank_sharded_environment_rollout_and_gather(num_envs):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rollout_worker, args=(r, 2, port, num_envs, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _, _ in res), res
+    assert all(d for _, _, d, _ in res), "both shards drew the same reset state: per-shard seeds are not applied"
+    assert len({s for _, _, _, s in res}) == 2
+
+
+def test_bench_dry_run_spawns_its_ranks():
+    """`python bench.py --gpus 2` with no launcher in the environment re-executes itself under torch.distributed.run;
+    --dry-run keeps it on the CPU (gloo, no physics): the line says n_gpus 2 and the group really had 2 ranks."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["dry_run"] is True
+    assert set(d["rollout_gather"]) == {"balance_cfg2", "navigation_cfg4", "football_cfg5"}

@@ -255,6 +255,8 @@ EXPORTED_SYMBOLS = (
     "vmas_world_run_queries",
     "vmas_world_set_lanes_per_env",
     "vmas_world_get_lanes_per_env",
+    "vmas_world_set_queues",
+    "vmas_world_get_queues",
     "vmas_world_step_bytes_per_env",
     "vmas_last_error",
     "vmas_abi_version",
@@ -308,6 +310,10 @@ def load_library() -> C.CDLL:
     lib.vmas_world_set_lanes_per_env.restype = C.c_int
     lib.vmas_world_get_lanes_per_env.argtypes = [vp]
     lib.vmas_world_get_lanes_per_env.restype = C.c_int
+    lib.vmas_world_set_queues.argtypes = [vp, i32]
+    lib.vmas_world_set_queues.restype = C.c_int
+    lib.vmas_world_get_queues.argtypes = [vp, i32]
+    lib.vmas_world_get_queues.restype = C.c_int
     lib.vmas_world_step_bytes_per_env.argtypes = [vp]
     lib.vmas_world_step_bytes_per_env.restype = i64
     lib.vmas_env_ingest_actions.argtypes = [C.POINTER(IngestArgs), i32, vp, vp, i64, vp, vp]

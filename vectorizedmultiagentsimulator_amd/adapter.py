@@ -174,7 +174,9 @@ class AttachedWorld:
                 orig = sensor.measure
                 self._orig_measures.append((sensor, orig))
 
-                def measure(vectorized: bool = True, _idx=idx, _n=n_rays, _sensor=sensor):
+                def measure(vectorized: bool = True, _idx=idx, _n=n_rays, _sensor=sensor, _orig=orig):
+                    if not vectorized:  # the reference's scalar walk (World.cast_ray, a debug mode) stays what it is
+                        return _orig(vectorized=False)
                     m = self.backend.cast_rays()[_idx, :_n, : self.batch].T
                     _sensor._last_measurement = m
                     return m

@@ -108,6 +108,15 @@ class HipWorld:
         if self.lib.vmas_world_set_lanes_per_env(self._h, int(lanes)) != 0:
             raise VmasHipError(A.last_error())
 
+    def set_queues(self, queues: int):
+        """``step_n`` over 0 (library's choice) / 1 / 2 HIP queues (include/vmas_hip.h, vmas_world_set_queues)."""
+        if self.lib.vmas_world_set_queues(self._h, int(queues)) != 0:
+            raise VmasHipError(A.last_error())
+
+    def queues(self, n_steps: int) -> int:
+        """How many queues a ``step_n`` of ``n_steps`` steps uses."""
+        return int(self.lib.vmas_world_get_queues(self._h, int(n_steps)))
+
     def reserve_epilogue(self, post_kind: int, n_packages: int = 0):
         """The steps of this world will be one-launch Environment.step calls with this post-step epilogue: let the
         library choose its kernel geometry with the epilogue's LDS included (include/vmas_env_hip.h)."""

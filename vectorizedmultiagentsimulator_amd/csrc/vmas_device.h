@@ -57,6 +57,10 @@ VD v2 rotate(v2 v, float c, float s) { return V(v.x * c - v.y * s, v.x * s + v.y
 // TorchUtils.clamp_with_norm utils.py:167-173
 VD v2 clamp_with_norm(v2 t, float max_norm) {
   float n = vnorm(t);
+#ifndef VMAS_X_CLAMP
+#define VMAS_X_CLAMP 1
+#endif
+  if (VMAS_X_CLAMP && !__any(n > max_norm)) return t;  // no lane of the wave is over the limit (a NaN norm keeps t in the reference too)
   const rcp_t rn = rcp_of(n);
   v2 nt = V((t.x / rn) * max_norm, (t.y / rn) * max_norm);
   return n > max_norm ? nt : t;

@@ -32,6 +32,8 @@
 
 #include <algorithm>
 #include <map>
+#include <mutex>
+#include <utility>
 
 #include "../../include/vmas_env_hip.h"
 #include "vmas_env_device.h"
@@ -339,8 +341,13 @@ template <class K>
 int ensure_lds(K kernel, size_t bytes, const char* what) {
   if (bytes <= 64 * 1024) return 0;
   if (bytes > 160 * 1024) return host_fail("observation too wide for one LDS tile");
-  static std::map<const void*, size_t> set_for;  // per kernel: the opt-in is sticky, ask once per size
-  size_t& have = set_for[(const void*)kernel];
+  // per (device, kernel): the opt-in is sticky on the device it was made on, ask once per size
+  static std::map<std::pair<int, const void*>, size_t> set_for;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return host_fail(what);
+  size_t& have = set_for[{dev, (const void*)kernel}];
   if (have >= bytes) return 0;
   if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
     return host_fail(what);

@@ -46,6 +46,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <map>
 #include <numeric>
 #include <vector>
@@ -63,6 +64,14 @@ constexpr int MAX_WAVES = 16;  // waves (workers) per tile (8 for the register-h
 constexpr int ITEMS_LDS_BUDGET = 48 * 1024;  // stage the item descriptors in LDS when they fit
 constexpr int TASK_JOINT = 6;  // item type next to VMAS_PAIR_*
 constexpr float kSkipSlack = 1e-3f;  // fp slack of the conservative broad-phase distances
+#ifndef VMAS_X_TIGHT_LS
+#define VMAS_X_TIGHT_LS 1
+#endif
+#ifndef VMAS_X_FIRED
+#define VMAS_X_FIRED 1
+#endif
+constexpr int FIRED_RECS = VMAS_X_FIRED ? 16 : 0;       // shared sphere-sphere records whose fired bits are published in LDS (two words per
+                                     // substep parity: 4 bits per record, 64 pairs)
 constexpr int TASK_SSQ = 7;    // up to four sphere-sphere partners of one entity in one record
 constexpr int TASK_LSQ = 8;    // up to four lines against one (owning) sphere in one record
 constexpr int TASK_SSP = 9;    // up to four SHARED sphere-sphere pairs (both spheres dynamic) in one record
@@ -146,6 +155,7 @@ struct DevWorld {
   int32_t b_ent, b_segs, b_owned, b_refs, b_items;
   int32_t n_segs, n_owned;
   int32_t items_in_lds;
+  int32_t fired_recs;    // shared sphere-sphere records (eval_ssp) that publish which of their pairs fired (<= 16)
   const DevItem* items;  // global copy, used when the item list is too big for LDS
 };
 
@@ -338,9 +348,20 @@ __device__ __forceinline__ void eval_lsq(const uint32_t* p, const DevWorld& W, c
   uint32_t needbits = 0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
+    // In the line's frame: the sphere's centre is farther than `m` from the segment's supporting line, or farther than
+    // `m` beyond one of its ends -> the closest point of the segment is farther than dist_min and the force is exactly 0
+    // (core.py:2836).  Football's walls span the pitch, their bounding circles never reject anything.  Only FINITE
+    // gaps skip: a NaN cos (non-finite rotation) or an infinite position makes both gaps NaN / inf.
     const float dx = pl[k].x - ps.x, dy = pl[k].y - ps.y;
-    const float m = half[k] + dist_min + kSkipSlack;  // bounding circles: beyond it the force is exactly 0
-    bool need = !far_apart(dx * dx + dy * dy, m * m) || cs[k] != cs[k];  // (cos of a non-finite rotation is NaN)
+#if VMAS_X_TIGHT_LS
+    const float m = dist_min + kSkipSlack;
+    const float along = fabsf(dx * cs[k] + dy * sn[k]) - half[k];
+    const float perp = fabsf(dy * cs[k] - dx * sn[k]);
+    bool need = !((along > m && along < kInf) || (perp > m && perp < kInf));
+#else
+    const float m = half[k] + dist_min + kSkipSlack;  // bounding circles
+    bool need = !far_apart(dx * dx + dy * dy, m * m) || cs[k] != cs[k];
+#endif
     bool on = k < n;
     if (args.pair_mask) on = on && ((args.pair_mask[sgpr(idx[k]) >> 5] >> (sgpr(idx[k]) & 31)) & 1u);
     needbits |= (on && __any(need)) ? (1u << k) : 0u;
@@ -360,9 +381,11 @@ __device__ __forceinline__ void eval_lsq(const uint32_t* p, const DevWorld& W, c
 // to the pair's two LDS rows, b's owner reads it with the sign flipped (cf(a,b) == -cf(b,a) bit for bit).
 //   w0: type, n, tile offset of the first pair's rows (pair k: + 2k rows), -
 //   w1: a offsets 0|1<<16, 2|3<<16, b offsets 0|1<<16, 2|3<<16   w2: r_sum 0..3   w3: pair index 0|1<<16, 2|3<<16
-__device__ __forceinline__ void eval_ssp(const uint32_t* p, const DevWorld& W, const DevStepArgs& args, float* tile) {
+__device__ __forceinline__ void eval_ssp(const uint32_t* p, const DevWorld& W, const DevStepArgs& args, float* tile,
+                                         uint32_t* fired) {
   const uint4 w0 = ((const uint4*)p)[0], w1 = ((const uint4*)p)[1], w2 = ((const uint4*)p)[2], w3 = ((const uint4*)p)[3];
   const int n = sgpr((int)w0.y);
+  const int rec = sgpr((int)w0.w);  // ordinal among the shared sphere-sphere records
   float* R = tile + (int)w0.z;
   const int oa[4] = {(int)(w1.x & 0xffffu), (int)(w1.x >> 16), (int)(w1.y & 0xffffu), (int)(w1.y >> 16)};
   const int ob[4] = {(int)(w1.z & 0xffffu), (int)(w1.z >> 16), (int)(w1.w & 0xffffu), (int)(w1.w >> 16)};
@@ -387,9 +410,15 @@ __device__ __forceinline__ void eval_ssp(const uint32_t* p, const DevWorld& W, c
     needbits |= (on && __any(need)) ? (1u << k) : 0u;
   }
   if (ABLATE(args) & 32) needbits = 0;
+  // Which pairs fired (some environment of the tile within reach) is published, four bits per record: the owners skip
+  // the rows of a pair that did not fire in phase C - its force is +0 on a, -0 on b in every environment, and
+  // F + (-0) == F, F + (+0) == F except for F == -0 (handled there) - so those rows are not even written.
+  const bool published = rec < FIRED_RECS;
+  if (published && needbits && (threadIdx.x & (TILE - 1)) == 0)
+    atomicOr(fired + (rec >> 3), needbits << ((rec & 7) * 4));  // (LDS atomic, no return value)
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    if (k < n) {
+    if (k < n && (!published || (needbits & (1u << k)))) {
       v2 f = V(0.f, 0.f);
       if (needbits & (1u << k)) f = contact_force(pa[k], pb[k], rs[k], W.c_coll, W.k);
       R[(2 * k) * ROWF] = f.x;
@@ -450,6 +479,11 @@ __device__ __forceinline__ void eval_item(const ItemV& K, const DevWorld& W, con
   {  // conservative per-environment broad phase: beyond it the force is exactly zero
     const float dx = pa.x - pb.x, dy = pa.y - pb.y;
     bool need = !far_apart(dx * dx + dy * dy, K.thr2);
+    if (VMAS_X_TIGHT_LS && K.type == VMAS_PAIR_LS) {  // a is a line: the sphere's gaps to the segment in the line's frame (see eval_lsq)
+      const float along = fabsf(dx * TA[0] + dy * TA[ROWF]) - K.p0;
+      const float perp = fabsf(dy * TA[0] - dx * TA[ROWF]);
+      need = need && !((along > K.reach && along < kInf) || (perp > K.reach && perp < kInf));
+    }
     if (K.type >= VMAS_PAIR_BS) {  // a is a box: test against the oriented box, much tighter
       if (K.type == VMAS_PAIR_BL) {
         const float gap = seg_obb_gap(pb, TB[0], TB[ROWF], K.p2, pa, TA[0], TA[ROWF], K.p0 * 0.5f, K.p1 * 0.5f);
@@ -574,6 +608,7 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
   float* tile = lds + lane;  // this lane's column: row r is tile[r * ROWF]
   uint32_t* blob = (uint32_t*)(lds + W.off_blob);
   int* ctr = (int*)(blob + W.blob_words);  // [4] work counters: (substep parity) x (gather, integrate)
+  uint32_t* fired_words = (uint32_t*)(ctr + 4);  // [2 parities][2] which shared sphere-sphere pairs fired (bit 4 * record + k)
   constexpr int EW = (int)(sizeof(DevEntity) / 4), SW = (int)(sizeof(DevSegment) / 4), OW = (int)(sizeof(DevOwned) / 4),
                 IW = (int)(sizeof(DevItem) / 4);
 
@@ -639,6 +674,7 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
   }
   const int first_dyn = (ABLATE(args) & 128) ? 0 : nw;  // 128: profiling toggle, fully dynamic
   if (threadIdx.x < 4) ctr[threadIdx.x] = first_dyn;  // the first unit of every wave is static (its own index)
+  if (threadIdx.x >= 4 && threadIdx.x < 8) ctr[threadIdx.x] = 0;  // fired bits: set by eval_ssp (atomic or)
 
   // ---- HBM -> LDS, one entity per wave at a time: six 256-byte row reads in flight, then the
   //      entity's trig straight from the registers
@@ -719,6 +755,8 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
     int* c_gather = ctr + 2 * (it & 1);
     int* c_integrate = c_gather + 1;
     if (threadIdx.x < 2) ctr[2 * ((it + 1) & 1) + threadIdx.x] = first_dyn;  // re-arm the other parity
+    if (threadIdx.x >= 2 && threadIdx.x < 4) fired_words[2 * ((it + 1) & 1) + threadIdx.x - 2] = 0u;
+    uint32_t* fired = fired_words + 2 * (it & 1);
     // ================= phase B: gather forces per (entity, segment)
 #ifdef VMAS_TRACE
     unsigned long long tg = TNOW();
@@ -733,7 +771,7 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
         for (int ii = i0; ii < i1u; ++ii) {
           const uint32_t* ip = blob + W.b_items + ii * IW;
           if (sgpr((int)ip[0]) == TASK_SSP) {
-            eval_ssp(ip, W, args, tile);
+            eval_ssp(ip, W, args, tile, fired);
             continue;
           }
           const ItemV K = load_item(ip);
@@ -855,6 +893,19 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
     // ================= phase C: _integrate_state core.py:2862-2908 (+ trig for the next substep,
     //                   or, after the last substep, the write-back of the entity's planes)
     const int n_own = (ABLATE(args) & 2) ? 0 : W.n_owned;
+    // this substep's fired bytes of the shared sphere-sphere records (one fetch per wave, off the per-entity chain)
+    uint32_t fw0 = ~0u, fw1 = ~0u;
+    if (W.fired_recs > 0) {
+      const uint2 fw = *(const uint2*)fired;
+      fw0 = (uint32_t)sgpr((int)fw.x); fw1 = (uint32_t)sgpr((int)fw.y);
+    }
+    // reference bits 19..25: 1 + index of the pair's fired bit (4 * record + k), 0 = not published (always read)
+    auto ref_fired = [&](uint32_t rf) -> bool {
+      const uint32_t b1 = (rf >> 19) & 0x7fu;
+      if (b1 == 0) return true;
+      const uint32_t b = b1 - 1u;
+      return (((b < 32u ? fw0 : fw1) >> (b & 31u)) & 1u) != 0u;
+    };
     for (int oi = first_dyn ? wv : grab(c_integrate); oi < n_own; oi = grab(c_integrate)) {
       const uint4* op = (const uint4*)(blob + W.b_owned + oi * OW);
       const uint4 o0 = op[0], o1 = op[1], o2 = op[2], o3 = op[3], q0 = op[4], q1 = op[5];
@@ -883,6 +934,7 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
         if (nr > 4 * c) {
 #pragma unroll
           for (int k = 4 * c; k < 4 * c + 4; ++k) {
+            if (!ref_fired(ref[k])) continue;  // (uniform) nobody wrote the rows of a pair that did not fire
             const float* R = tile + (ref[k] & 0xffffu) * ROWF;  // (padding repeats a valid row)
             const int td = (int)((ref[k] >> 17) & 3u);
             fx[k] = R[0];
@@ -900,9 +952,16 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
         if (fl & VMAS_F_MOVABLE) F = F + V(__uint_as_float(__float_as_uint(x) ^ flip), __uint_as_float(__float_as_uint(y) ^ flip));
         if (((rf >> 17) & 3u) && (fl & VMAS_F_ROTATABLE)) Tq = Tq + t;
       };
+      // a pair that did not fire contributes +0 (a's side) or -0 (b's side) in every environment: F + (-0) == F, and
+      // F + (+0) == F unless F == -0, so one +0 is added at the end if any a-side reference was skipped - the same bits
+      // as adding them one by one (once F is +0 only -0 terms could follow without changing it, and they do not)
+      bool skipped_a = false;
 #pragma unroll
       for (int k = 0; k < 8; ++k)
-        if (k < nr) add_ref(ref[k], fx[k], fy[k], tq[k]);
+        if (k < nr) {
+          if (ref_fired(ref[k])) add_ref(ref[k], fx[k], fy[k], tq[k]);
+          else if (!(ref[k] & 0x10000u)) skipped_a = true;
+        }
       for (int r = 8; r < nr; r += 4) {  // (more than eight: four references per fetch, their rows requested together)
         const uint4 q = *(const uint4*)(blob + W.b_refs + r0 + r);  // (ref_begin is a multiple of 4, the tail is padded)
         const uint32_t rf[4] = {(uint32_t)sgpr((int)q.x), (uint32_t)sgpr((int)q.y), (uint32_t)sgpr((int)q.z),
@@ -910,6 +969,7 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
         float gx[4], gy[4], gt[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
+          if (!ref_fired(rf[k])) continue;
           const float* R = tile + (rf[k] & 0xffffu) * ROWF;
           gx[k] = R[0];
           gy[k] = R[ROWF];
@@ -917,8 +977,12 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-          if (r + k < nr) add_ref(rf[k], gx[k], gy[k], gt[k]);
+          if (r + k < nr) {
+            if (ref_fired(rf[k])) add_ref(rf[k], gx[k], gy[k], gt[k]);
+            else if (!(rf[k] & 0x10000u)) skipped_a = true;
+          }
       }
+      if (skipped_a && (fl & VMAS_F_MOVABLE)) F = F + V(0.f, 0.f);
       float* dst = state + (long)e * 6 * ld + env;
       if (fl & VMAS_F_MOVABLE) {
         v2 vel = V(es[2], es[3]);
@@ -1235,6 +1299,7 @@ struct VmasWorld {
   // pairs/joints of two dynamic entities are evaluated ONCE ("shared"): their items follow the entities' own items,
   // their results live in LDS rows [row_shared, row_shared + n_shared_rows) that both owners read in phase C
   int unit_item_begin = 0, row_shared = 0, n_shared_rows = 0;
+  int fired_recs = 0;  // shared sphere-sphere records that publish their fired bits (build_items)
   std::vector<uint32_t> refs;       // per entity, reference order: row | side << 16 | torque row delta << 17
   std::vector<int> ent_ref_begin;   // [nE+1]
   std::vector<int> ent_ref_count;   // [nE]
@@ -1243,6 +1308,12 @@ struct VmasWorld {
   DevMaskPair* d_mpairs = nullptr;
   unsigned long long* d_trace = nullptr;
   std::map<int, Sched> scheds;
+  // vmas_world_step_n over two HIP queues (environments are independent: the launch gap of one half of the batch
+  // overlaps the compute of the other).  queues: 0 = library's choice, 1 = one queue, 2 = two
+  int queues = 0;
+  bool resident = false;  // every tile of the batch is on the chip at once (select_config): the latency regime
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // lidars
   DevLidar* d_lidars = nullptr;
   DevTarget* d_targets = nullptr;
@@ -1334,7 +1405,10 @@ static void build_items(VmasWorld* w, int share_mode) {
         m = t.p0 + 1e-4f;
         t.thr2 = m * m;
       } break;
-      case VMAS_PAIR_LS: t.p0 = A.length / 2.f; t.p1 = B.radius + kLineMinDist; break;
+      case VMAS_PAIR_LS:
+        t.p0 = A.length / 2.f; t.p1 = B.radius + kLineMinDist;
+        t.reach = B.radius + kLineMinDist + kSkipSlack;
+        break;
       case VMAS_PAIR_LL: t.p0 = A.length / 2.f; t.p1 = B.length / 2.f; break;
       case VMAS_PAIR_BS:
         t.p0 = A.length; t.p1 = A.width; t.p2 = B.radius + kLineMinDist;
@@ -1444,6 +1518,8 @@ static void build_items(VmasWorld* w, int share_mode) {
   // shared items behind the entities' own: consecutive sphere-sphere pairs packed four to a record
   w->unit_item_begin = (int)w->items.size();
   w->n_shared_rows = shared_rows;
+  int n_ssp_recs = 0;
+  std::map<int, int> fired_bit_of_row;  // first row of a shared sphere-sphere pair -> index of its fired bit
   for (size_t i = 0; i < units.size();) {
     if (units[i].type != VMAS_PAIR_SS) {
       w->items.push_back(units[i]);
@@ -1466,6 +1542,10 @@ static void build_items(VmasWorld* w, int share_mode) {
     }
     uint32_t wds[16] = {0};
     wds[0] = TASK_SSP; wds[1] = (uint32_t)n; wds[2] = (uint32_t)(units[i].side >> 2);
+    wds[3] = (uint32_t)n_ssp_recs;  // < FIRED_RECS: the record publishes which of its pairs fired
+    for (int k = 0; k < n && n_ssp_recs < FIRED_RECS; ++k)
+      fired_bit_of_row[(int)((units[i + k].side >> 2) / ROWF)] = 4 * n_ssp_recs + k;
+    ++n_ssp_recs;
     wds[4] = oa[0] | (oa[1] << 16); wds[5] = oa[2] | (oa[3] << 16);
     wds[6] = ob[0] | (ob[1] << 16); wds[7] = ob[2] | (ob[3] << 16);
     for (int k = 0; k < 4; ++k) wds[8 + k] = fbits(rs[k]);
@@ -1482,10 +1562,15 @@ static void build_items(VmasWorld* w, int share_mode) {
   for (int e = 0; e < nE; ++e) {  // fetched four at a time: every entity's run starts at a multiple of 4, padded with its last reference
     w->ent_ref_begin[e] = (int)w->refs.size();
     w->ent_ref_count[e] = (int)ent_refs[e].size();
+    for (uint32_t& rf : ent_refs[e]) {  // bits 19..25: 1 + fired-bit index of a published sphere-sphere pair
+      auto it = fired_bit_of_row.find((int)(rf & 0xffffu));
+      if (it != fired_bit_of_row.end()) rf |= (uint32_t)(it->second + 1) << 19;
+    }
     w->refs.insert(w->refs.end(), ent_refs[e].begin(), ent_refs[e].end());
     while (w->refs.size() % 4) w->refs.push_back(ent_refs[e].back());
   }
   w->ent_ref_begin[nE] = (int)w->refs.size();
+  w->fired_recs = std::min(n_ssp_recs, FIRED_RECS);
 }
 
 // Cut every dynamic entity's item list into segments of about total/nw cost and deal the
@@ -1595,7 +1680,8 @@ static int build_sched(VmasWorld* w, int nw, Sched& S) {
   S.dw.n_segs = (int)segs_sorted.size();
   S.dw.n_owned = (int)owned.size();
   S.dw.off_blob = row_bad * ROWF;  // (row_bad: the first row after the partial sums)
-  S.lds_bytes = ((size_t)row_bad * ROWF + S.dw.blob_words + 4) * sizeof(float);  // + work counters
+  S.dw.fired_recs = w->fired_recs;
+  S.lds_bytes = ((size_t)row_bad * ROWF + S.dw.blob_words + 4 + 4) * sizeof(float);  // + work counters, fired words (2 parities x 2)
   if (getenv("VMAS_DEBUG_SCHED")) fprintf(stderr, "[sched nw=%d] %d segments, LDS %zu B per tile\n", nw, (int)segs.size(), S.lds_bytes);
   return 0;
 }
@@ -1696,6 +1782,7 @@ static int select_config(VmasWorld* w) {
     build_items(w, best_mode);
   }
   w->lanes = best.nw;
+  w->resident = best.resident;
   return 0;
 }
 
@@ -1703,15 +1790,18 @@ static inline int blocks_of(int batch) { return (batch + TILE - 1) / TILE; }
 
 template <int LEVEL, int ENV, class EnvArgs>
 static int launch_level(VmasWorld* w, Sched* S, float* state, float* aft, long ld, const DevStepArgs& a,
-                        const EnvArgs& env, size_t extra_lds, hipStream_t s) {
+                        const EnvArgs& env, size_t extra_lds, hipStream_t s, int batch, long pad) {
+  // `batch` environments starting at `state` / `aft` (a sub-range of the world's batch when the step is split over two
+  // queues); `pad` = columns of the planes that exist from there on (ld minus the range's first environment)
   const size_t lds = S->lds_bytes + extra_lds;
   if (lds > 160 * 1024) return fail("vmas_world_step: %zu bytes of LDS per tile exceed the CU's 160 KB", lds);
   const bool plain = !a.pair_mask && !a.joint_fixed_rot && !a.entity_gravity && a.first_substep == 0 && a.n_substeps <= 0 &&
-                     ld >= (long)blocks_of(w->batch) * TILE && S->dw.items_in_lds;
-  const int mode = !plain ? 0 : ((S->dw.substeps == 1 && a.n_steps <= 1) ? (w->batch % TILE == 0 ? 3 : 2) : 1);
+                     pad >= (long)blocks_of(batch) * TILE && S->dw.items_in_lds;
+  const int mode = !plain ? 0 : ((S->dw.substeps == 1 && a.n_steps <= 1) ? (batch % TILE == 0 ? 3 : 2) : 1);
   if (lds > 64 * 1024) {
-    static thread_local size_t set_for = 0;
-    if (set_for < lds) {
+    static std::atomic<size_t> set_for_dev[64];  // the attribute is per DEVICE (function object of that device's module)
+    std::atomic<size_t>& set_for = set_for_dev[w->device & 63];
+    if (set_for.load() < lds) {
       HIP_TRY(hipFuncSetAttribute((const void*)step_kernel<LEVEL, ENV, EnvArgs, 0>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       HIP_TRY(hipFuncSetAttribute((const void*)step_kernel<LEVEL, ENV, EnvArgs, 1>,
@@ -1723,36 +1813,37 @@ static int launch_level(VmasWorld* w, Sched* S, float* state, float* aft, long l
       set_for = lds;
     }
   }
-  const int blocks = (w->batch + TILE - 1) / TILE;
+  const int blocks = (batch + TILE - 1) / TILE;
   if (mode == 3)
     hipLaunchKernelGGL((step_kernel<LEVEL, ENV, EnvArgs, 3>), dim3(blocks), dim3(TILE * S->nw), lds, s, S->dw, state, aft,
-                       ld, w->batch, a, env);
+                       ld, batch, a, env);
   else if (mode == 2)
     hipLaunchKernelGGL((step_kernel<LEVEL, ENV, EnvArgs, 2>), dim3(blocks), dim3(TILE * S->nw), lds, s, S->dw, state, aft,
-                       ld, w->batch, a, env);
+                       ld, batch, a, env);
   else if (mode == 1)
     hipLaunchKernelGGL((step_kernel<LEVEL, ENV, EnvArgs, 1>), dim3(blocks), dim3(TILE * S->nw), lds, s, S->dw, state, aft,
-                       ld, w->batch, a, env);
+                       ld, batch, a, env);
   else
     hipLaunchKernelGGL((step_kernel<LEVEL, ENV, EnvArgs, 0>), dim3(blocks), dim3(TILE * S->nw), lds, s, S->dw, state, aft,
-                       ld, w->batch, a, env);
+                       ld, batch, a, env);
   HIP_TRY(hipGetLastError());
   return 0;
 }
 
 template <int ENV, class EnvArgs>
 static int launch_any_level(VmasWorld* w, Sched* S, float* state, float* aft, long ld, const DevStepArgs& a,
-                            const EnvArgs& env, size_t extra_lds, hipStream_t s) {
+                            const EnvArgs& env, size_t extra_lds, hipStream_t s, int batch = -1, long pad = -1) {
+  if (batch < 0) { batch = w->batch; pad = ld; }
   switch (w->level) {
-    case 0: return launch_level<0, ENV>(w, S, state, aft, ld, a, env, extra_lds, s);
-    case 1: return launch_level<1, ENV>(w, S, state, aft, ld, a, env, extra_lds, s);
-    default: return launch_level<2, ENV>(w, S, state, aft, ld, a, env, extra_lds, s);
+    case 0: return launch_level<0, ENV>(w, S, state, aft, ld, a, env, extra_lds, s, batch, pad);
+    case 1: return launch_level<1, ENV>(w, S, state, aft, ld, a, env, extra_lds, s, batch, pad);
+    default: return launch_level<2, ENV>(w, S, state, aft, ld, a, env, extra_lds, s, batch, pad);
   }
 }
 
 static int step_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld, const VmasStepArgs* args, void* stream,
                      int n_steps, int64_t ft_stride, DevEnv* env = nullptr, int env_kind = ENV_NONE,
-                     size_t scratch_fixed = 0, size_t scratch_per_wave = 0);
+                     size_t scratch_fixed = 0, size_t scratch_per_wave = 0, int env_first = 0, int env_count = -1);
 
 extern "C" {
 
@@ -1854,6 +1945,9 @@ void vmas_world_destroy(VmasWorld* w) {
   if (!w) return;
   (void)hipSetDevice(w->device);
   for (auto& kv : w->scheds) kv.second.release();
+  if (w->side) { (void)hipStreamSynchronize(w->side); (void)hipStreamDestroy(w->side); }
+  if (w->ev_fork) (void)hipEventDestroy(w->ev_fork);
+  if (w->ev_join) (void)hipEventDestroy(w->ev_join);
   (void)hipFree(w->d_mpairs); (void)hipFree(w->d_trace);
   (void)hipFree(w->d_lidars); (void)hipFree(w->d_targets); (void)hipFree(w->d_angles); (void)hipFree(w->d_queries);
   delete w;
@@ -1900,6 +1994,18 @@ int vmas_world_reserve_epilogue(VmasWorld* w, int32_t post_kind, int32_t n_packa
 int64_t vmas_world_step_bytes_per_env(const VmasWorld* w) {
   if (!w) return -1;
   return 24LL * w->base.nE + 12LL * w->base.nA + 24LL * w->n_dyn;
+}
+
+int vmas_world_set_queues(VmasWorld* w, int32_t queues) {
+  if (!w) return fail("vmas_world_set_queues: null world");
+  if (queues < 0 || queues > 2) return fail("vmas_world_set_queues: queues must be 0 (library's choice), 1 or 2, got %d", queues);
+  w->queues = queues;
+  return 0;
+}
+int vmas_world_get_queues(const VmasWorld* w, int32_t n_steps) {
+  if (!w) return 0;
+  const bool two = blocks_of(w->batch) >= 2 && (w->queues == 2 || (w->queues == 0 && w->resident && n_steps >= 8));
+  return two ? 2 : 1;
 }
 
 int vmas_world_step(VmasWorld* w, float* state, float* agent_ft, int64_t ld, const VmasStepArgs* args, void* stream) {
@@ -1972,7 +2078,7 @@ int vmas_world_step_env(VmasWorld* w, float* state, float* agent_ft, int64_t ld,
 
 static int step_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld, const VmasStepArgs* args, void* stream,
                      int n_steps, int64_t ft_stride, DevEnv* env, int env_kind, size_t scratch_fixed,
-                     size_t scratch_per_wave) {
+                     size_t scratch_per_wave, int env_first, int env_count) {
   if (!w || !state) return fail("vmas_world_step: null argument");
   if (w->base.nA > 0 && !agent_ft) return fail("vmas_world_step: world has agents but agent_ft is null");
   if (ld < w->batch) return fail("vmas_world_step: ld (%lld) < batch (%d)", (long long)ld, w->batch);
@@ -2005,6 +2111,11 @@ static int step_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld, co
   Sched* S;
   if (get_sched(w, w->lanes, &S)) return -1;
   hipStream_t s = (hipStream_t)stream;
+  if (env_count >= 0) {  // a sub-range of the batch (vmas_world_step_n over two queues): plain physics, no optional inputs
+    if (env_kind != ENV_NONE || args) return fail("vmas_world_step: environment sub-ranges take no optional inputs");
+    return launch_any_level<ENV_NONE>(w, S, state + env_first, agent_ft ? agent_ft + env_first : nullptr, ld, a, NoEnv{}, 0,
+                                      s, env_count, (long)ld - env_first);
+  }
   if (env_kind == ENV_NONE) return launch_any_level<ENV_NONE>(w, S, state, agent_ft, ld, a, NoEnv{}, 0, s);
   if (S->nw < 2 && env_kind != ENV_INGEST)
     return fail("vmas_world_step_env: the fused epilogue needs at least 2 waves per tile");
@@ -2036,6 +2147,37 @@ int vmas_debug_softplus(const float* in, float* out, int32_t n, void* stream) {
 int vmas_world_step_n(VmasWorld* w, float* state, float* agent_ft, int64_t ld, int64_t ft_step_stride, int32_t n_steps,
                       const VmasStepArgs* args, void* stream) {
   if (n_steps < 0) return fail("vmas_world_step_n: n_steps %d < 0", n_steps);
+  if (!w) return fail("vmas_world_step_n: null world");
+  // Two queues: environments are independent, so the batch is cut at a tile boundary and the halves are stepped by
+  // two independent launch sequences - one on the caller's stream, one on a side stream forked from it and joined
+  // back at the end.  A dependent launch costs ~2.9 us of front-end time during which the chip idles; with two
+  // sequences the gap of one half is filled by the kernel of the other.  Same kernels, same results bit for bit.
+  // Library's choice: when the whole batch is on the chip at once (the latency regime) and the sequence is long
+  // enough to pay for the fork and the join.
+  const int tiles = blocks_of(w->batch);
+  const bool two = !args && tiles >= 2 && (w->queues == 2 || (w->queues == 0 && w->resident && n_steps >= 8));
+  if (two) {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != w->device) HIP_TRY(hipSetDevice(w->device));
+    if (!w->side) {
+      HIP_TRY(hipStreamCreateWithFlags(&w->side, hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&w->ev_join, hipEventDisableTiming));
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int first = (tiles / 2) * TILE;  // environments [0, first) on the caller's stream, [first, batch) on the side one
+    HIP_TRY(hipEventRecord(w->ev_fork, s));
+    HIP_TRY(hipStreamWaitEvent(w->side, w->ev_fork, 0));
+    int rc = 0;
+    for (int i = 0; i < n_steps && !rc; ++i) {
+      float* ft = agent_ft ? agent_ft + (int64_t)i * ft_step_stride : nullptr;
+      rc = step_impl(w, state, ft, ld, nullptr, (void*)s, 1, 0, nullptr, ENV_NONE, 0, 0, 0, first);
+      if (!rc) rc = step_impl(w, state, ft, ld, nullptr, (void*)w->side, 1, 0, nullptr, ENV_NONE, 0, 0, first, w->batch - first);
+    }
+    HIP_TRY(hipEventRecord(w->ev_join, w->side));  // (joined even after a failed launch: the caller's stream stays ordered)
+    HIP_TRY(hipStreamWaitEvent(s, w->ev_join, 0));
+    return rc;
+  }
   for (int i = 0; i < n_steps; ++i) {
     int rc = vmas_world_step(w, state, agent_ft ? agent_ft + (int64_t)i * ft_step_stride : nullptr, ld, args, stream);
     if (rc) return rc;
@@ -2053,8 +2195,9 @@ int vmas_world_pair_mask(VmasWorld* w, const float* state, int64_t ld, uint32_t*
   const size_t lds = (size_t)w->base.nE * 2 * T * sizeof(float);
   if (lds > 160 * 1024) return fail("vmas_world_pair_mask: %d entities do not fit in LDS", w->base.nE);
   if (lds > 64 * 1024) {
-    static thread_local size_t set_for = 0;
-    if (set_for < lds) {
+    static std::atomic<size_t> set_for_dev[64];
+    std::atomic<size_t>& set_for = set_for_dev[w->device & 63];
+    if (set_for.load() < lds) {
       HIP_TRY(hipFuncSetAttribute((const void*)pair_mask_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       set_for = lds;
     }

@@ -6,7 +6,8 @@ Differences that are deliberate:
 * one device-side RNG (``torch.Generator`` on the env device) instead of the process-global RNG
   swapping of ``local_seed`` (environment.py:31-47) - no hidden coupling between environments;
 * action validation (NaN / range asserts, environment.py:621,651-653) costs two host syncs per
-  agent per step in the reference; here it is on by default (same error behaviour) and can be
+  agent per step in the reference; here it is one small kernel + one sync in FRONT of the step launch
+  (same error behaviour: a bad action raises before the world is touched), on by default, and can be
   switched off with ``validate_actions=False`` for throughput runs;
 * ``World.step()`` is one kernel launch (core.World), Lidar sensors are cast by one launch for
   all agents right after the step and cached for ``observation()``.
@@ -52,6 +53,11 @@ class Environment:
         self.world: World = scenario.env_make_world(num_envs, self.device, **kwargs)
         self.agents: List[Agent] = self.world.policy_agents
         self.n_agents = len(self.agents)
+        if self.world.dim_c > 0 and any(not a.silent for a in self.agents):
+            # environment.py:718-749 (communication part of the action, one-hot mapping, c_noise) is not on the
+            # World.step path and is not mirrored here: refuse loudly instead of dropping state.c after the first step
+            raise NotImplementedError("communication actions (world.dim_c > 0 with non-silent policy agents) are not "
+                                      "supported by this Environment; attach() the reference's environment instead")
         self.steps = torch.zeros(num_envs, device=self.device)
         self._lidar_cache: Optional[Tensor] = None
         self.seed(seed)
@@ -263,9 +269,9 @@ class Environment:
         HIP-graph replay."""
         assert len(actions) == self.n_agents, f"Expecting actions for {self.n_agents}, got {len(actions)} actions"
         self._ingest.prepare(actions)
-        self._launch(0, None, None, self.validate_actions)
         if self.validate_actions:
-            self._ingest.check()
+            self._ingest.validate()  # raises before the world is touched, like the reference
+        self._launch(0, None, None, False)
         self.scenario.post_step()
         if self._graph is None:
             dev = self.device
@@ -288,17 +294,17 @@ class Environment:
         assert len(actions) == self.n_agents, f"Expecting actions for {self.n_agents}, got {len(actions)} actions"
         if self._one_launch:
             self._ingest.prepare(actions)
-            desc, buffers, result = self._post.prepare()
-            self._launch(self._post.kind, desc, buffers, self.validate_actions)
-            self._lidar_cache = None
             if self.validate_actions:
-                self._ingest.check()
+                self._ingest.validate()  # raises before the world is touched, like the reference
+            desc, buffers, result = self._post.prepare()
+            self._launch(self._post.kind, desc, buffers, False)
+            self._lidar_cache = None
             return result
         if self._ingest_in_step:
             self._ingest.prepare(actions)
-            self._launch(0, None, None, self.validate_actions)
             if self.validate_actions:
-                self._ingest.check()
+                self._ingest.validate()
+            self._launch(0, None, None, False)
         else:
             if self._ingest is not None:
                 self._ingest(actions, self.validate_actions)

@@ -56,6 +56,8 @@ class ActionIngest:
         for a in env.agents:
             if type(a.dynamics) not in (Holonomic, HolonomicWithRotation):
                 return f"dynamics {type(a.dynamics).__name__}"
+            if a.action_size != a.dynamics.needed_action_size:
+                return "action_size != dynamics.needed_action_size"  # (the kernel maps component k to force/torque row k)
             if a.action.u_noise not in (0, 0.0, None):
                 return "action noise"
             if not a.silent and env.world.dim_c > 0:
@@ -136,15 +138,26 @@ class ActionIngest:
             assert not (flags & A.ACTION_ERR_NAN), "actions contain NaN"
             raise AssertionError("Physical actions of an agent are out of its range")
 
-    def __call__(self, actions: List[Tensor], validate: bool):
+    def launch(self, validate: bool):
+        """The stand-alone ingest kernel on the prepared action tensors (+ the reference's asserts when ``validate``)."""
         env = self.env
-        self.prepare(actions)
         ft = env.world._packed_agent_ft()
         err = self.err.data_ptr() if validate else None
         _check(self.lib.vmas_env_ingest_actions(C.byref(self.args), env.num_envs, env.world._packed_state().data_ptr(),
                                                 ft.data_ptr(), ft.shape[-1], err, _stream(env.device)))
         if validate:
             self.check()
+
+    def validate(self):
+        """``validate_actions`` on a path whose ingest is the physics kernel's prologue: the reference asserts BEFORE it
+        touches the world (environment.py:621,651-653), so the actions are checked by the small stand-alone kernel (it
+        writes only ``agent.action.u`` and the agent-force rows, which the reference has also set by then) and the step is
+        launched only if that passed - a bad action never reaches the integrator."""
+        self.launch(True)
+
+    def __call__(self, actions: List[Tensor], validate: bool):
+        self.prepare(actions)
+        self.launch(validate)
 
 
 class StepLauncher:
