@@ -1,0 +1,27 @@
+/* vmas_debug_hip.h - TEST AND PROFILING HOOKS of libvmas_hip.so.  Not part of the drop-in boundary (include/vmas_hip.h,
+ * include/vmas_env_hip.h): nothing in the product path calls them.  They expose device-side primitives of the step
+ * kernel so that tests/test_hip_math.py can bound their accuracy, and the s_memtime stamps of profiling builds. */
+#ifndef VMAS_DEBUG_HIP_H
+#define VMAS_DEBUG_HIP_H
+#include <stdint.h>
+#include "vmas_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* out[i] = op(a[i], b[i]) with the device routines of csrc/vmas_device.h (device pointers; b may be NULL for unary ops) */
+#define VMAS_MATH_SOFTPLUS 0 /* softplus0(a)       = torch.logaddexp(0, a), core.py:2821 */
+#define VMAS_MATH_SQRT 1     /* sqrt_n(a)          the bare v_sqrt_f32 used for squared lengths */
+#define VMAS_MATH_DIV 2      /* a / rcp_of(b)      the division sequence without exponent scaling */
+#define VMAS_MATH_NORM 3     /* norm2(a, b)        = torch.linalg.vector_norm over a size-2 dim */
+#define VMAS_MATH_COS 4      /* cos(a) as write_trig computes it (sincosf) */
+#define VMAS_MATH_SIN 5      /* sin(a) as write_trig computes it (sincosf) */
+int vmas_debug_math(int32_t op, const float* a, const float* b, float* out, int32_t n, void* stream);
+
+/* VMAS_TRACE=1 in a -DVMAS_TRACE build: copy out the per-wave s_memtime stamps of the last launch */
+int vmas_debug_trace(VmasWorld* w, unsigned long long* host, int64_t n_words);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VMAS_DEBUG_HIP_H */

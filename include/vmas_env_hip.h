@@ -197,6 +197,20 @@ int vmas_world_step_env(VmasWorld* w, float* state, float* agent_ft, int64_t ld,
                         const VmasIngestArgs* ingest /* may be NULL */, uint32_t* err_flags /* may be NULL */,
                         int32_t post_kind, const void* post_desc, const void* post_buffers, void* stream);
 
+/* K consecutive Environment.step() calls in ONE launch: the same results, bit for bit, as
+ * `n_steps` vmas_world_step_env launches without resets in between, but the tile of 64 environments stays in LDS from
+ * step to step - per step only the actions are read from HBM and the outputs written; the state goes back once, at the
+ * end.  Step k reads rows [k * batch, (k + 1) * batch) of every slot's action tensor (`ingest->agents[i].action`:
+ * [n_steps * batch, action_size], or action_index [n_steps * batch]) and writes the k-th slab of every PER-STEP output
+ * of `post_buffers`, laid out as [n_steps][the single-step shape]: obs, rew, done (+ balance: pos_rew, ground_rew).
+ * Persistent terms (global_shaping, on_goal, on_the_ground, the step counter `limit.steps`, agent_ft, u_out) hold the
+ * values of the last step on return.  `err_flags` collects VMAS_ACTION_ERR_* over all steps; a flagged action has been
+ * integrated by then - validate beforehand (vmas_env_ingest_actions) where the reference's asserts are wanted.  No
+ * library-scripted agents (their scripts read the state in HBM).  post_kind as for vmas_world_step_env. */
+int vmas_world_rollout_env(VmasWorld* w, float* state, float* agent_ft, int64_t ld, const VmasStepArgs* args /* may be NULL */,
+                           const VmasIngestArgs* ingest, uint32_t* err_flags /* may be NULL */, int32_t post_kind,
+                           const void* post_desc, const void* post_buffers, int32_t n_steps, void* stream);
+
 /* Tells the library that this world's steps will be vmas_world_step_env launches with the `post_kind` epilogue
  * (`n_packages`: transport only), whose observation staging needs LDS beside the physics tile: the library's choice of
  * waves per tile and of shared pair rows (vmas_hip.h, "lanes per env") is re-made with that LDS included, instead of

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define VMAS_ABI_VERSION 1
+#define VMAS_ABI_VERSION 2
 
 #define VMAS_STATE_FIELDS 6
 #define VMAS_AGENT_FIELDS 3
@@ -143,6 +143,14 @@ typedef struct VmasStepArgs {
   const float* entity_gravity;
   int32_t first_substep; /* index of the first substep to run (drag is applied on 0) */
   int32_t n_substeps;    /* how many to run; <=0 => desc.substeps - first_substep */
+  /* != 0: the reference's broad phase exactly - at every substep a pair is evaluated (for all environments) iff the
+   * bounding circles of SOME environment of the batch overlap (World.collides, core.py:2797-2801).  Batches of at most
+   * 64 x CUs environments (16384 on MI355X) run it INSIDE the step launch: every tile ORs its hits into a mask with
+   * device-scope atomics and the tiles meet at a grid-wide barrier before the narrow phase (all tiles are resident, one
+   * per CU).  Larger batches run a mask launch + a one-substep launch per substep (no fused epilogue then).  Mutually
+   * exclusive with pair_mask.  0 = every static pair is evaluated per environment (see pair_mask above). */
+  int32_t exact_broad_phase;
+  int32_t reserved;
 } VmasStepArgs;
 
 /* LIDAR description for World.cast_rays (core.py:1662-1786): one entry per
@@ -182,6 +190,11 @@ int vmas_world_step_n(VmasWorld* w, float* state, float* agent_ft, int64_t ld, i
  * back once at the end.  For scripted / pre-computed forces (no policy in the loop). */
 int vmas_world_rollout(VmasWorld* w, float* state, float* agent_ft, int64_t ld, int64_t ft_step_stride,
                        int32_t n_steps, const VmasStepArgs* args /* may be NULL */, void* stream);
+
+/* After steps with exact_broad_phase: 0 if every in-kernel grid barrier completed, 1 if one gave up waiting (the
+ * grid was not co-resident; results of that step are those of exact_broad_phase = 0), < 0 on error.  Synchronises
+ * the device: a debugging / test aid. */
+int vmas_world_exact_status(VmasWorld* w);
 
 /* Batch-global broad phase of World.collides (core.py:2797-2801): mask[p/32] bit
  * p%32 = any_env(|pos_a - pos_b| <= R_a + R_b).  `mask` is zeroed on the stream

@@ -7,13 +7,13 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import torch
 from vectorizedmultiagentsimulator_amd import _abi
 lib = _abi.load_library()
-lib.vmas_debug_softplus.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
+lib.vmas_debug_math.argtypes = [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
 n = int(sys.argv[1])
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 x = torch.rand(n, device="cuda:0")
 y = torch.empty_like(x)
 torch.cuda.synchronize()
 for _ in range(reps):
-    assert lib.vmas_debug_softplus(x.data_ptr(), y.data_ptr(), n, None) == 0
+    assert lib.vmas_debug_math(0, x.data_ptr(), None, y.data_ptr(), n, None) == 0
 torch.cuda.synchronize()
 print("bytes_read_per_dispatch", 4 * n, "bytes_written_per_dispatch", 4 * n)

@@ -305,7 +305,55 @@ def rollout_soup(name, B, seed, rounds, steps_per_round, hollow, spread):
     rec.save(name)
 
 
+def rollout_band(name, B=4, seed=3):
+    """The thin band where the reference's batch-global broad phase (core.py:2797-2801) decides the result: a sphere
+    just beyond the END of a line, or just off the CORNER of a box - farther from the shape's centre than the sum of
+    the bounding circles (the pair is skipped for the whole batch unless SOME environment overlaps) yet within
+    `dist_min` of its surface (if the pair is evaluated, the penalty force is far from zero).  Even steps: every
+    environment sits in the band -> the reference applies NO force; odd steps: environment 0 is moved inside the
+    circles -> the pair is evaluated for ALL environments, the band ones included."""
+    torch.manual_seed(seed)
+    w = rcore.World(B, torch.device("cpu"), dt=0.1, substeps=2, drag=0.1, collision_force=400)
+    w.add_landmark(rcore.Landmark("wall", movable=False, rotatable=False, shape=rcore.Line(1.0)))
+    w.add_landmark(rcore.Landmark("block", movable=False, rotatable=False, shape=rcore.Box(0.4, 0.2)))
+    w.add_agent(rcore.Agent("a0", shape=rcore.Sphere(0.05), u_range=1.0))
+    w.add_agent(rcore.Agent("a1", shape=rcore.Sphere(0.04), u_range=1.0))
+    ents = {e.name: e for e in w.entities}
+    rec = StepRecorder(w, every=1)
+    g = torch.Generator().manual_seed(seed + 1)
+    LMD = 4.0 / 600.0
+    for t in range(8):
+        ents["wall"].set_pos(torch.tensor([[0.0, 0.6]]).repeat(B, 1), batch_index=None)
+        ents["wall"].set_rot(torch.full((B, 1), 0.3), batch_index=None)
+        ents["block"].set_pos(torch.tensor([[0.0, -0.5]]).repeat(B, 1), batch_index=None)
+        ents["block"].set_rot(torch.full((B, 1), -0.2), batch_index=None)
+        frac = 0.15 + 0.7 * torch.rand(B, 1, generator=g)  # how deep into the band, per environment
+        # a0 beyond the wall's end, on its axis: centre distance = L/2 + r + frac * LMD
+        ax = torch.tensor([[torch.cos(torch.tensor(0.3)), torch.sin(torch.tensor(0.3))]])
+        p0 = torch.tensor([[0.0, 0.6]]) + ax * (0.5 + 0.05 + frac * LMD)
+        # a1 off the block's corner, on the diagonal: centre distance = R_circ + r + frac * LMD
+        c, s_ = torch.cos(torch.tensor(-0.2)), torch.sin(torch.tensor(-0.2))
+        diag = torch.tensor([[0.2, 0.1]])
+        diag = diag / diag.norm()
+        diag = torch.stack([diag[:, 0] * c - diag[:, 1] * s_, diag[:, 0] * s_ + diag[:, 1] * c], dim=-1)
+        rc = (0.2 ** 2 + 0.1 ** 2) ** 0.5
+        p1 = torch.tensor([[0.0, -0.5]]) + diag * (rc + 0.04 + frac * LMD)
+        if t % 2 == 1:  # environment 0 inside the bounding circles: the pairs are evaluated for the whole batch
+            p0[0] = torch.tensor([0.0, 0.6]) + ax[0] * (0.5 + 0.04)
+            p1[0] = torch.tensor([0.0, -0.5]) + diag[0] * (rc + 0.03)
+        ents["a0"].set_pos(p0, batch_index=None)
+        ents["a1"].set_pos(p1, batch_index=None)
+        for a in w.agents:
+            a.set_vel((torch.rand(B, 2, generator=g) * 2 - 1) * 0.01, batch_index=None)
+            a.state.force = (torch.rand(B, 2, generator=g) * 2 - 1) * 0.05
+            a.state.torque = torch.zeros(B, 1)
+        w.step()
+    rec.save(name)
+
+
 FIXTURES = {
+    # the batch-global broad phase decides (exact-mode semantics pinned; fails without it) ---
+    "band_4env": lambda: rollout_band("band_4env"),
     # the five BASELINE.json configs (small batch versions) ------------------
     "balance_n3": lambda: rollout_env("balance_n3", "balance", 4, 100, 5, n_agents=3),
     "balance_n4": lambda: rollout_env("balance_n4", "balance", 8, 120, 6, n_agents=4),

@@ -28,7 +28,7 @@ from ref_backend import OracleBackend  # noqa: E402
 
 
 def _actions(env, g):
-    return [(torch.rand(env.num_envs, a.action_size, generator=g) * 2 - 1) * a.action.u_range_tensor for a in env.agents]
+    return [(torch.rand(env.num_envs, a.action_size, generator=g) * 2 - 1) * a.action.u_range_tensor.cpu() for a in env.agents]
 
 
 CASES = [("balance", dict(n_agents=3), 60), ("transport", {}, 40), ("navigation", dict(n_agents=4), 30),

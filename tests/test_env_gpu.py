@@ -30,8 +30,9 @@ def test_env_rollout_and_physics_vs_oracle(name, kw, obs_dim):
         if t % 10 == 0:  # the step the environment just made == oracle step from the same state/forces
             ft = env.world._agent_ft.cpu().numpy().copy()[:nA]
             want = st0.copy()
-            sens = ulp_sensitivity(lambda a, b: o.step(a, b, batch=B), st0, ft)
-            o.step(want, ft.copy(), batch=B)
+            assert env.world.exact_broad_phase  # (the default below 1024 environments: the reference's broad phase)
+            sens = ulp_sensitivity(lambda a, b: o.step_exact(a, b, batch=B), st0, ft)
+            o.step_exact(want, ft.copy(), batch=B)
             got = env.world._state.cpu().numpy()
             compare_state(got[:, :, :B], want[:, :, :B], f"{name} env.step physics t={t}", sens=sens[:, :, :B])
     env.reset_at(3)

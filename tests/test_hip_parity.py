@@ -241,6 +241,56 @@ def test_hip_pair_mask_matches_oracle(name):
         assert np.array_equal(m, o.pair_mask(st)), f"{name}[t={t}] vs oracle"
 
 
+def test_band_fixture_pins_the_batch_global_broad_phase_on_the_gpu():
+    """`band_4env` (see tests/test_oracle_golden.py): with exact_broad_phase the step kernel - mask and grid barrier
+    inside the ONE launch - lands on the reference's numbers on every step; the per-environment evaluation (the
+    large-batch default) is visibly off on the steps where no environment's bounding circles overlap; and the default
+    of the host model (core.World / attach) is exact at this batch size."""
+    from vectorizedmultiagentsimulator_amd.core import EXACT_AUTO_BELOW
+
+    g = load("band_4env")
+    assert g.B < EXACT_AUTO_BELOW
+    hw = _hip(g.spec, g.B)
+    differs = 0
+    for t in range(g.T):
+        st0, ft0 = np.ascontiguousarray(g.state0[t]).copy(), np.ascontiguousarray(g.ft_in[t]).copy()
+        _up(hw, st0, ft0)
+        hw.step_exact()
+        st, _ = _down(hw, g.B, g.spec.n_agents)
+        compare_state(st, g.state1[t], f"band_4env[t={t}] exact in-kernel", atol=1e-5, rtol=1e-5)
+        _up(hw, st0, ft0)
+        hw.step()
+        st2, _ = _down(hw, g.B, g.spec.n_agents)
+        if not g.masks[t].any():
+            assert np.abs(st2 - g.state1[t]).max() > 1e-2
+            differs += 1
+    assert differs == g.T // 2 and hw.exact_status() == 0
+
+
+@pytest.mark.parametrize("name,B", [("balance_n3", 4), ("balance_n4", 1000), ("navigation_n8", 333), ("football_5v5", 2048),
+                                    ("waterfall", 64), ("give_way", 700), ("soup_solid", 512), ("balance_n4", 16384),
+                                    ("balance_n4", 20000)])
+def test_exact_step_in_one_launch_equals_mask_and_substep_launches(name, B):
+    """exact_broad_phase inside the step launch (atomic mask + grid barrier per substep; <= 256 tiles) must be, bit for
+    bit, the explicit sequence pair_mask launch + one-substep launch with that mask; above 256 tiles the library runs
+    that sequence itself.  Several consecutive steps: the barrier sequence and the mask ring carry over launches."""
+    g = load(name)
+    st0, ft0, jfr_np, eg_np = make_batch(g, B, seed=41)
+    outs = []
+    for mode in ("launches", "exact"):
+        hw = _hip(g.spec, B)
+        _up(hw, st0, ft0)
+        jfr, eg = _dev(hw, jfr_np, B), _dev(hw, eg_np, B)
+        for _ in range(5):
+            (hw.step_exact_launches if mode == "launches" else hw.step_exact)(joint_fixed_rot=jfr, entity_gravity=eg)
+        outs.append((hw.state.clone(), hw.agent_ft.clone()))
+        if mode == "exact":
+            assert hw.exact_status() == 0
+        hw.close()
+    same = lambda a, b: torch.equal(a.view(torch.int32), b.view(torch.int32))  # noqa: E731
+    assert same(outs[0][0], outs[1][0]) and same(outs[0][1], outs[1][1]), f"{name} B={B}: exact forms differ"
+
+
 @pytest.mark.parametrize("name", ["balance_n3", "navigation_n8", "football_5v5", "waterfall", "reverse_transport"])
 def test_hip_step_exact_free_running(name):
     """step_exact (device broad phase + one substep per launch) over a whole step equals

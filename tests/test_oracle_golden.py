@@ -75,3 +75,25 @@ def test_oracle_queries_match_reference(name):
         flips += int((out[kinds][:, ok] != want[kinds][:, ok]).sum())
     # an overlap flag may flip only where the distance is within rounding of zero
     assert flips <= 2, f"{name}: {flips} overlap flags differ"
+
+
+def test_band_fixture_pins_the_batch_global_broad_phase():
+    """`band_4env` (made by the reference): every environment has a sphere just beyond the end of a line / the corner
+    of a box - outside the bounding circles, inside the contact distance.  Free-running with the batch-global broad
+    phase (step_exact) the oracle lands on the reference's numbers in every step; evaluating every pair per environment
+    instead (the large-batch default) gives a visibly different velocity on the steps where NO environment overlaps -
+    which is why small batches run exact by default (core.EXACT_AUTO_BELOW)."""
+    g = load("band_4env")
+    o = Oracle(g.spec)
+    differs = 0
+    for t in range(g.T):
+        st, ft = np.ascontiguousarray(g.state0[t]).copy(), np.ascontiguousarray(g.ft_in[t]).copy()
+        o.step_exact(st, ft)
+        compare_state(st, g.state1[t], f"band_4env[t={t}] exact free-running", atol=1e-5, rtol=1e-5)
+        st2, ft2 = np.ascontiguousarray(g.state0[t]).copy(), np.ascontiguousarray(g.ft_in[t]).copy()
+        o.step(st2, ft2)  # no mask: every static pair evaluated per environment
+        err = np.abs(st2 - g.state1[t]).max()
+        if not g.masks[t].any():
+            assert err > 1e-2, f"t={t}: per-environment evaluation should differ in the band, max err {err:.2e}"
+            differs += 1
+    assert differs == g.T // 2

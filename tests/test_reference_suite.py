@@ -147,6 +147,17 @@ def _run(case, on_gpu):
         # GPU): same test, 3 steps instead of its default 15 (the CPU variant runs the default)
         kw = dict(kw, n_steps=3)
     mod = ref.load_test_module(rel)
+    if on_gpu and fn == "test_seeding":
+        # The reference's seeding contract is a CPU-RNG contract: `local_seed` (environment.py:31-47) swaps the CPU
+        # generator's state only, so on a GPU device torch.manual_seed() between two resets changes the draw - for the
+        # UNTOUCHED reference too.  Shown here, then skipped (the CPU variant runs the test attached).
+        def plain(scenario, **kw):
+            return HostView(ref.make_env(scenario, **dict(kw, device="cuda:0")))
+
+        mod.make_env = plain
+        with pytest.raises(AssertionError):
+            getattr(mod, fn)(**kw)
+        pytest.skip("the reference's own test_seeding fails on a cuda device without attach(): CPU-RNG contract")
     mod.make_env = _attached_make_env(on_gpu)
     n0 = len(ATTACHED)
     try:

@@ -10,7 +10,7 @@ import ctypes as C
 import os
 from typing import Optional
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 STATE_FIELDS = 6
 AGENT_FIELDS = 3
 
@@ -103,6 +103,8 @@ class StepArgs(C.Structure):
         ("entity_gravity", C.c_void_p),
         ("first_substep", C.c_int32),
         ("n_substeps", C.c_int32),
+        ("exact_broad_phase", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 
@@ -255,6 +257,9 @@ EXPORTED_SYMBOLS = (
     "vmas_world_run_queries",
     "vmas_world_set_lanes_per_env",
     "vmas_world_get_lanes_per_env",
+    "vmas_debug_math",  # include/vmas_debug_hip.h: test / profiling hooks, never called by the product path
+    "vmas_debug_trace",
+    "vmas_world_exact_status",
     "vmas_world_set_queues",
     "vmas_world_get_queues",
     "vmas_world_step_bytes_per_env",
@@ -267,6 +272,7 @@ EXPORTED_SYMBOLS = (
     "vmas_navigation_post_step",
     "vmas_football_post_step",
     "vmas_world_step_env",
+    "vmas_world_rollout_env",
     "vmas_world_reserve_epilogue",
 )
 
@@ -310,6 +316,8 @@ def load_library() -> C.CDLL:
     lib.vmas_world_set_lanes_per_env.restype = C.c_int
     lib.vmas_world_get_lanes_per_env.argtypes = [vp]
     lib.vmas_world_get_lanes_per_env.restype = C.c_int
+    lib.vmas_world_exact_status.argtypes = [vp]
+    lib.vmas_world_exact_status.restype = C.c_int
     lib.vmas_world_set_queues.argtypes = [vp, i32]
     lib.vmas_world_set_queues.restype = C.c_int
     lib.vmas_world_get_queues.argtypes = [vp, i32]
@@ -326,6 +334,8 @@ def load_library() -> C.CDLL:
         fn.restype = C.c_int
     lib.vmas_world_step_env.argtypes = [vp, vp, vp, i64, C.POINTER(StepArgs), C.POINTER(IngestArgs), vp, i32, vp, vp, vp]
     lib.vmas_world_step_env.restype = C.c_int
+    lib.vmas_world_rollout_env.argtypes = [vp, vp, vp, i64, C.POINTER(StepArgs), C.POINTER(IngestArgs), vp, i32, vp, vp, i32, vp]
+    lib.vmas_world_rollout_env.restype = C.c_int
     lib.vmas_world_reserve_epilogue.argtypes = [vp, i32, i32]
     lib.vmas_world_reserve_epilogue.restype = C.c_int
     lib.vmas_last_error.argtypes = []

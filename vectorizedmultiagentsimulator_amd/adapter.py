@@ -69,9 +69,12 @@ def _patch_state_class(cls) -> None:
 class AttachedWorld:
     """Handle returned by ``attach``; ``detach()`` restores the reference behaviour."""
 
-    def __init__(self, world, backend_factory: Callable = _default_backend, exact_broad_phase: bool = False):
+    def __init__(self, world, backend_factory: Callable = _default_backend, exact_broad_phase: Optional[bool] = None):
+        from .core import EXACT_AUTO_BELOW
+
         self.world = world
-        self.exact_broad_phase = exact_broad_phase
+        # None: the reference's exact batch-global broad phase below EXACT_AUTO_BELOW environments (core.World)
+        self.exact_broad_phase = (int(world.batch_dim) < EXACT_AUTO_BELOW) if exact_broad_phase is None else bool(exact_broad_phase)
         self._factory = backend_factory
         self._orig_step = world.step
         self._orig_classes = {}
@@ -196,8 +199,11 @@ class AttachedWorld:
         self.backend.close()
 
 
-def attach(env_or_world, backend_factory: Callable = _default_backend, exact_broad_phase: bool = False) -> AttachedWorld:
-    """Put a reference ``Environment`` (or ``World``) on the MI355X-native physics step."""
+def attach(env_or_world, backend_factory: Callable = _default_backend,
+           exact_broad_phase: Optional[bool] = None) -> AttachedWorld:
+    """Put a reference ``Environment`` (or ``World``) on the MI355X-native physics step.  ``exact_broad_phase``: the
+    reference's batch-global ``.any()`` broad phase (core.py:2797-2801) exactly; None = below 1024 environments, where
+    it can matter (above, every pair that matters has SOME environment overlapping)."""
     world = getattr(env_or_world, "world", env_or_world)
     if getattr(env_or_world, "grad_enabled", False):
         raise NotImplementedError("grad_enabled=True needs the reference's autograd path; the HIP step has no backward")

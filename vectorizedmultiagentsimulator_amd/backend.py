@@ -166,9 +166,12 @@ class HipWorld:
         first_substep: int = 0,
         n_substeps: int = 0,
         stream=None,
+        exact: bool = False,
     ) -> None:
-        """World.step() for the whole batch, asynchronous on the (current) stream."""
+        """World.step() for the whole batch, asynchronous on the (current) stream.  ``exact``: the reference's
+        batch-global broad phase re-evaluated at every substep (include/vmas_hip.h, VmasStepArgs.exact_broad_phase)."""
         args = A.StepArgs()
+        args.exact_broad_phase = 1 if exact else 0
         args.pair_mask = self._dptr(pair_mask)
         if joint_fixed_rot is not None:
             assert joint_fixed_rot.shape == (len(self.spec.joints), self.ld) and joint_fixed_rot.is_contiguous()
@@ -185,14 +188,15 @@ class HipWorld:
 
     def step_env(self, ingest_args, err_flags: Optional[torch.Tensor], post_kind: int, post_desc, post_buffers,
                  joint_fixed_rot: Optional[torch.Tensor] = None, entity_gravity: Optional[torch.Tensor] = None,
-                 stream=None) -> None:
+                 stream=None, exact: bool = False) -> None:
         """World.step() with the action ingest as prologue and a scenario post-step as epilogue, ONE
         launch (``vmas_world_step_env``, include/vmas_env_hip.h)."""
         args = None
-        if joint_fixed_rot is not None or entity_gravity is not None:
+        if joint_fixed_rot is not None or entity_gravity is not None or exact:
             sa = A.StepArgs()
             sa.joint_fixed_rot = self._dptr(joint_fixed_rot)
             sa.entity_gravity = self._dptr(entity_gravity)
+            sa.exact_broad_phase = 1 if exact else 0
             args = C.byref(sa)
         rc = self.lib.vmas_world_step_env(
             self._h, self._dptr(self.state), self._dptr(self.agent_ft), self.ld, args,
@@ -242,11 +246,24 @@ class HipWorld:
         return self._mask
 
     def step_exact(self, joint_fixed_rot=None, entity_gravity=None, stream=None) -> None:
-        """World.step() with the reference's batch-global broad phase re-evaluated at
-        every substep (2 launches per substep; parity mode)."""
+        """World.step() with the reference's batch-global broad phase (core.py:2797-2801) re-evaluated at every
+        substep: ONE launch for batches of at most 64 x CUs environments (mask + grid barrier inside the step kernel),
+        a mask launch + a substep launch per substep beyond (the library decides)."""
+        self.step(None, joint_fixed_rot, entity_gravity, 0, 0, stream, exact=True)
+
+    def step_exact_launches(self, joint_fixed_rot=None, entity_gravity=None, stream=None) -> None:
+        """The same step as explicit launches (``vmas_world_pair_mask`` + a one-substep ``vmas_world_step`` with that
+        mask, per substep): what ``step_exact`` must equal bit for bit."""
         for s in range(self.spec.substeps):
             m = self.pair_mask(stream)
             self.step(m, joint_fixed_rot, entity_gravity, s, 1, stream)
+
+    def exact_status(self) -> int:
+        """0 = every in-kernel grid barrier of the exact steps so far completed (synchronises the device)."""
+        rc = int(self.lib.vmas_world_exact_status(self._h))
+        if rc < 0:
+            raise VmasHipError(A.last_error())
+        return rc
 
     def set_queries(self, queries) -> None:
         """Register (kind, a, b) geometric queries: kind "distance" | "overlap", entity indices."""

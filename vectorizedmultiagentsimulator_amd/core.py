@@ -602,6 +602,9 @@ class Joint:
 # ----------------------------------------------------------------------------------
 # world
 # ----------------------------------------------------------------------------------
+#: batches below this many environments use the reference's exact batch-global broad phase by default
+EXACT_AUTO_BELOW = 1024
+
 class World:
     """core.py:1088-1232 + step 1972-2015, re-homed on one packed buffer and one kernel."""
 
@@ -622,7 +625,7 @@ class World:
         torque_constraint_force: float = TORQUE_CONSTRAINT_FORCE,
         contact_margin: float = 1e-3,
         gravity: Tuple[float, float] = (0.0, 0.0),
-        exact_broad_phase: bool = False,
+        exact_broad_phase: Optional[bool] = None,
         lanes_per_env: int = 0,
     ):
         assert batch_dim > 0, f"Batch dim must be greater than 0, got {batch_dim}"
@@ -646,9 +649,11 @@ class World:
         self._agent_ft: Optional[Tensor] = None
         self._backend = None
         self._spec: Optional[WorldSpec] = None
-        #: True = reproduce the reference's batch-global ``.any()`` broad phase exactly
-        #: (2 launches per substep); False = every static pair evaluated per env
-        self.exact_broad_phase = exact_broad_phase
+        #: True = the reference's batch-global ``.any()`` broad phase exactly (core.py:2797-2801; inside the step launch
+        #: up to 64 x CUs environments); False = every static pair evaluated per environment - the same result whenever
+        #: SOME environment of the batch has the pair's bounding circles overlapping, i.e. practically always in a large
+        #: batch.  None = exact below EXACT_AUTO_BELOW environments, where that argument does not hold.
+        self.exact_broad_phase = (batch_dim < EXACT_AUTO_BELOW) if exact_broad_phase is None else bool(exact_broad_phase)
         self._lanes_per_env = lanes_per_env
         # geometric queries answered by ONE kernel launch per state version (GPU worlds)
         self._query_list: List[Tuple[str, int, int]] = []
@@ -827,11 +832,12 @@ class World:
     def step_env(self, ingest_args, err_flags, post_kind: int, post_desc, post_buffers):
         """``step()`` with the environment's action ingest and the scenario's post-step fused into the
         same launch (fused.py / ``vmas_world_step_env``)."""
-        assert not self.exact_broad_phase and self._dim_c == 0
+        assert self._dim_c == 0
         be = self._get_backend()
         self._query_cache = None
         jfr, eg = self._per_env_inputs()
-        be.step_env(ingest_args, err_flags, post_kind, post_desc, post_buffers, joint_fixed_rot=jfr, entity_gravity=eg)
+        be.step_env(ingest_args, err_flags, post_kind, post_desc, post_buffers, joint_fixed_rot=jfr, entity_gravity=eg,
+                    exact=self.exact_broad_phase)
 
     # ---- scenario-side geometric queries (core.py:1788-1969, 2788-2803): batched torch ops
     def collides(self, a: Entity, b: Entity) -> Tensor:

@@ -68,8 +68,8 @@ __global__ __launch_bounds__(512) void balance_post_kernel(const VmasBalanceDesc
   extern __shared__ float lds[];
   const TileCtx C(batch);
   stage_rows(C, lds, nE * 6, [&](int i) { return state[(long)i * ld + C.e]; });
-  const float prev_shaping = C.live ? o.global_shaping[C.env] : 0.f;
-  const float steps_in = C.wave == 0 ? load_steps(o.limit, C) : 0.f;
+  float prev_shaping = C.live ? o.global_shaping[C.env] : 0.f;
+  float steps_in = C.wave == 0 ? load_steps(o.limit, C) : 0.f;
   balance_build_table(C, lds + nE * 6 * 64);
   __syncthreads();
   balance_post_tile(C, d, o, batch, lds, lds + nE * 6 * 64, prev_shaping, steps_in);
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(512) void transport_post_kernel(const VmasTransport
   float* scratch = lds + nE * 6 * 64;
   stage_rows(C, lds, nE * 6, [&](int i) { return state[(long)i * ld + C.e]; });
   stage_rows(C, scratch, d.n_packages, [&](int p) { return C.live ? o.global_shaping[(long)p * batch + C.env] : 0.f; });
-  const float steps_in = C.wave == 0 ? load_steps(o.limit, C) : 0.f;
+  float steps_in = C.wave == 0 ? load_steps(o.limit, C) : 0.f;
   __syncthreads();
   transport_post_tile(C, d, o, batch, lds, scratch, steps_in);
 }

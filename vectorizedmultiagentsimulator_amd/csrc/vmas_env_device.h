@@ -148,7 +148,8 @@ VD void balance_build_table(const TileCtx& C, float* scratch) {
 __host__ __device__ inline size_t balance_scratch_floats(int nw) { return 2 * 64 + kBalanceObsDim * 64 + (size_t)nw * 64 * (kBalanceObsDim | 1); }
 
 VD void balance_post_tile(const TileCtx& C, const VmasBalanceDesc& d, const VmasBalanceBuffers& o, int batch,
-                          const float* rows, float* scratch, float prev_shaping, float steps_in, int ablate = 0,
+                          const float* rows, float* scratch, float& prev_shaping /* in: before, out: after this step */,
+                          float& steps_in /* wave 0: in/out Environment.steps */, int ablate = 0,
                           const float* floor_trig = nullptr /* this lane's cos, sin, cos2, sin2 rows (stride 64) */) {
   constexpr int D = kBalanceObsDim;
   float* flags = scratch;
@@ -238,6 +239,8 @@ VD void balance_post_tile(const TileCtx& C, const VmasBalanceDesc& d, const Vmas
   }
   if (C.live)
     for (int a = first; a < d.n_agents; a += C.nw) o.rew[(long)a * batch + C.env] = rew;
+  prev_shaping = shaping;  // (every wave computed it: the next step of a multi-step rollout starts from it)
+  if (o.limit.steps != nullptr) steps_in = steps_in + 1.f;
 }
 
 // ------------------------------------------------------------------------------------ transport
@@ -251,7 +254,7 @@ __host__ __device__ inline size_t transport_scratch_floats(int nw, int n_package
 }
 
 VD void transport_post_tile(const TileCtx& C, const VmasTransportDesc& d, const VmasTransportBuffers& o, int batch,
-                            const float* rows, float* scratch, float steps_in) {
+                            const float* rows, float* scratch, float& steps_in /* wave 0: in/out Environment.steps */) {
   const int P = d.n_packages, D = transport_obs_dim(P);
   float* term = scratch;
   float* on_goal_f = term + P * 64;
@@ -307,19 +310,21 @@ VD void transport_post_tile(const TileCtx& C, const VmasTransportDesc& d, const 
     T.flush(o.obs + ((long)a * batch + C.b0) * D, C.n_rows);
     if (C.live) o.rew[(long)a * batch + C.env] = rew;
   }
+  if (o.limit.steps != nullptr) steps_in = steps_in + 1.f;
 }
 
 // ------------------------------------------------------------------------------------ action ingest
 // Environment._set_action (environment.py:616-749, continuous branch) + Holonomic(.WithRotation)
 // .process_action for ONE agent slot and this lane's environment: returns the (up to 3) scaled
 // action components, stores agent_ft / u_out, and ORs VMAS_ACTION_ERR_* into `bad`.
+// `row0`: first row of this step's actions in the caller's [n_steps * batch, action_size] tensor (multi-step rollouts).
 VD void ingest_slot(const VmasActionSlot& S, int clamp, long env, bool live, float* __restrict__ agent_ft, long ld,
-                    float u_out[3], uint32_t& bad) {
+                    float u_out[3], uint32_t& bad, long row0 = 0) {
   u_out[0] = u_out[1] = u_out[2] = 0.f;
   if (!live) return;
   long flat = 0;
   if (S.action_index != nullptr) {  // flat index -> per-dimension index -> [-u_range, u_range] (environment.py:657-705)
-    flat = S.action_index[env];
+    flat = S.action_index[row0 + env];
     long total = 1;
     for (int k = 0; k < S.action_size; ++k) total *= S.nvec[k];
     if (flat < 0 || flat >= total) {
@@ -338,7 +343,7 @@ VD void ingest_slot(const VmasActionSlot& S, int clamp, long env, bool live, flo
       if (n & 1) a = a == 0 ? n / 2 : (a <= n / 2 ? a - 1 : a);  // odd count: index 0 is "stay"
       u = ((float)a / (float)(n - 1)) * (2.f * S.u_range[k]) - S.u_range[k];
     } else {
-      u = S.action[env * S.action_size + k];
+      u = S.action[(row0 + env) * S.action_size + k];
     }
     if (u != u) bad |= VMAS_ACTION_ERR_NAN;
     if (S.action_index != nullptr) {

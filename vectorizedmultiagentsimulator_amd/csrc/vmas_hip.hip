@@ -52,6 +52,7 @@
 #include <vector>
 
 #include "../../include/vmas_hip.h"
+#include "../../include/vmas_debug_hip.h"
 #include "vmas_env_device.h"
 
 using namespace vmas;
@@ -159,8 +160,17 @@ struct DevWorld {
   const DevItem* items;  // global copy, used when the item list is too big for LDS
 };
 
+struct DevMaskPair { int32_t a, b; float bound_sum; };
+
 struct DevStepArgs {
   const uint32_t* pair_mask;
+  // in-kernel exact broad phase (vmas_world_step with exact_broad_phase on a grid of at most one tile per CU): the
+  // batch-global `.any()` of World.collides (core.py:2797-2801) evaluated at the top of every substep by all tiles
+  // together - bits ORed into a ring of mask slots with device-scope atomics, then a grid-wide barrier on `sync[0]`
+  uint32_t* sync;              // [0] arrivals (monotonic), [1] gave-up flag, [4 + slot * mask_words ...] four mask slots
+  const DevMaskPair* mpairs;   // the world's static pairs with their bounding-circle sums
+  uint32_t seq0;               // barrier sequence number of this launch's first substep
+  int32_t n_mpairs, mask_words;
   const float* joint_fixed_rot;
   const float* entity_gravity;
   int32_t first_substep, n_substeps;
@@ -199,6 +209,11 @@ struct NoEnv {};
 #endif
 
 __device__ __forceinline__ int sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// One word of the pair mask.  A device-scope atomic load: the in-kernel exact broad phase fills the mask of the running
+// substep from every tile of the grid (atomic ORs), and its slots are re-used within one launch.
+__device__ __forceinline__ uint32_t mask_word(const uint32_t* mask, int w) {
+  return __hip_atomic_load(mask + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // A pair may be skipped only on a FINITE squared distance beyond its bound: a NaN or an infinite operand must reach the
 // narrow phase, where the reference's own arithmetic decides (inf * 0, cos(inf) ... = NaN poisons the pair however far
 // apart the shapes are).  Together with the NaN checks on the cos rows of Lines and Boxes this is why no separate
@@ -306,7 +321,7 @@ __device__ __forceinline__ void eval_ssq(const uint32_t* p, const DevWorld& W, c
     const float m = rs[k] + 1e-4f;  // the force is exactly 0 for dist > r_a + r_b (core.py:2836)
     bool need = !far_apart(dx * dx + dy * dy, m * m);
     bool on = k < n;
-    if (args.pair_mask) on = on && ((args.pair_mask[sgpr(idx[k]) >> 5] >> (sgpr(idx[k]) & 31)) & 1u);
+    if (args.pair_mask) on = on && ((mask_word(args.pair_mask, sgpr(idx[k]) >> 5) >> (sgpr(idx[k]) & 31)) & 1u);
     needbits |= (on && __any(need)) ? (1u << k) : 0u;
   }
   if (!needbits || (ABLATE(args) & 32)) return;
@@ -363,7 +378,7 @@ __device__ __forceinline__ void eval_lsq(const uint32_t* p, const DevWorld& W, c
     bool need = !far_apart(dx * dx + dy * dy, m * m) || cs[k] != cs[k];
 #endif
     bool on = k < n;
-    if (args.pair_mask) on = on && ((args.pair_mask[sgpr(idx[k]) >> 5] >> (sgpr(idx[k]) & 31)) & 1u);
+    if (args.pair_mask) on = on && ((mask_word(args.pair_mask, sgpr(idx[k]) >> 5) >> (sgpr(idx[k]) & 31)) & 1u);
     needbits |= (on && __any(need)) ? (1u << k) : 0u;
   }
   if (!needbits || (ABLATE(args) & 32)) return;
@@ -406,7 +421,7 @@ __device__ __forceinline__ void eval_ssp(const uint32_t* p, const DevWorld& W, c
     const float m = rs[k] + 1e-4f;  // the force is exactly 0 for dist > r_a + r_b (core.py:2836)
     bool need = !far_apart(dx * dx + dy * dy, m * m);
     bool on = k < n;
-    if (args.pair_mask) on = on && ((args.pair_mask[sgpr(idx[k]) >> 5] >> (sgpr(idx[k]) & 31)) & 1u);
+    if (args.pair_mask) on = on && ((mask_word(args.pair_mask, sgpr(idx[k]) >> 5) >> (sgpr(idx[k]) & 31)) & 1u);
     needbits |= (on && __any(need)) ? (1u << k) : 0u;
   }
   if (ABLATE(args) & 32) needbits = 0;
@@ -473,7 +488,7 @@ __device__ __forceinline__ void eval_item(const ItemV& K, const DevWorld& W, con
     f_out = own(fa);
     return;
   }
-  if (args.pair_mask && !((args.pair_mask[K.index >> 5] >> (K.index & 31)) & 1u)) return;
+  if (args.pair_mask && !((mask_word(args.pair_mask, K.index >> 5) >> (K.index & 31)) & 1u)) return;
   const float* TA = tile + K.tra;
   const float* TB = tile + K.trb;
   {  // conservative per-environment broad phase: beyond it the force is exactly zero
@@ -582,7 +597,7 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
   DevWorld W = W_in;
   if constexpr (PLAIN != 0) {
     args.pair_mask = nullptr; args.joint_fixed_rot = nullptr; args.entity_gravity = nullptr;
-    args.first_substep = 0; args.n_substeps = 0;
+    args.first_substep = 0; args.n_substeps = 0; args.sync = nullptr;
     W.items_in_lds = 1;
     if constexpr (PLAIN >= 2) { W.substeps = 1; args.n_steps = 1; args.ft_stride = 0; }  // (PLAIN == 1 also serves rollouts)
   }
@@ -622,6 +637,7 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
   }
   // Environment._set_action + process_action as the prologue: the agent's force rows are computed
   // from its action tensor (and stored to agent_ft, where scenario code reads agent.state.force)
+  long act_row0 = 0;  // multi-step rollouts (vmas_world_rollout_env): first row of the running step's actions
   auto load_agent_ft = [&](int a, float* f3) {
     const float* src = agent_ft + (long)a * 3 * ld + env;
     if constexpr (ENV != ENV_NONE) {
@@ -629,7 +645,7 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
       const VmasActionSlot& S = E.ingest.agents[a];
       if (on && (S.action != nullptr || S.action_index != nullptr)) {
         uint32_t bad = 0;
-        ingest_slot(S, E.ingest.clamp, env, live, agent_ft, ld, f3, bad);
+        ingest_slot(S, E.ingest.clamp, env, live, agent_ft, ld, f3, bad, act_row0);
         if (S.action_size < 3) f3[2] = lv ? src[2 * ld] : 0.f;  // Holonomic leaves the torque alone
         if (E.err_flags != nullptr && bad != 0) atomicOr(E.err_flags, bad);
         return;
@@ -740,13 +756,29 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
   int it = 0;  // running (step, substep) index: parity selects the live pair of work counters
   for (int stp = 0; stp < n_steps; ++stp) {
   float* aft = agent_ft + (long)stp * args.ft_stride;  // this step's agent forces
-  if (stp > 0) {  // persistent rollout: only the agent forces come from HBM, the state never left LDS
-    for (int a = wv; a < nA; a += nw) {
-      const float* src = aft + (long)a * 3 * ld + env;
-      float* dst = tile + W.off_af + a * 3 * ROWF;
+  if (stp > 0) {  // persistent rollout: only the agent forces (or the actions they are made of) come from HBM, the
+                  // state never left LDS
+    bool ingested = false;
+    if constexpr (ENV != ENV_NONE) {
+      if (E.has_ingest) {  // vmas_world_rollout_env: this step's rows of the action tensors through the ingest prologue
+        ingested = true;
+        act_row0 = (long)stp * batch;
+        for (int a = wv; a < nA; a += nw) {
+          float f3[3];
+          load_agent_ft(a, f3);
+          float* dst = tile + W.off_af + a * 3 * ROWF;
 #pragma unroll
-      for (int f = 0; f < 3; ++f) dst[f * ROWF] = lv ? src[f * ld] : 0.f;
+          for (int f = 0; f < 3; ++f) dst[f * ROWF] = f3[f];
+        }
+      }
     }
+    if (!ingested)
+      for (int a = wv; a < nA; a += nw) {
+        const float* src = aft + (long)a * 3 * ld + env;
+        float* dst = tile + W.off_af + a * 3 * ROWF;
+#pragma unroll
+        for (int f = 0; f < 3; ++f) dst[f * ROWF] = lv ? src[f * ld] : 0.f;
+      }
     __syncthreads();
   }
   for (int substep = s_begin; substep < s_end; ++substep, ++it) {
@@ -757,6 +789,43 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
     if (threadIdx.x < 2) ctr[2 * ((it + 1) & 1) + threadIdx.x] = first_dyn;  // re-arm the other parity
     if (threadIdx.x >= 2 && threadIdx.x < 4) fired_words[2 * ((it + 1) & 1) + threadIdx.x - 2] = 0u;
     uint32_t* fired = fired_words + 2 * (it & 1);
+    if constexpr (PLAIN == 0) {
+      if (args.sync != nullptr) {
+        // ---- World.collides' batch-global bounding-circle test (core.py:2797-2801) for THIS substep, by the whole grid:
+        // every tile ORs the pairs some environment of it overlaps into the substep's mask slot, all tiles meet at a
+        // grid-wide barrier (the grid is at most one tile per CU, so every tile is resident), then read the mask.
+        const uint32_t seq = args.seq0 + (uint32_t)it;
+        uint32_t* slot = args.sync + 4 + (seq & 3u) * (uint32_t)args.mask_words;
+        for (int p = wv; p < args.n_mpairs; p += nw) {
+          const DevMaskPair P = args.mpairs[p];
+          const float* A = tile + sgpr(P.a) * 6 * ROWF;
+          const float* B = tile + sgpr(P.b) * 6 * ROWF;
+          const bool hit = live && norm2(A[0] - B[0], A[ROWF] - B[ROWF]) <= P.bound_sum;
+          if (__any(hit) && lane == 0)
+            __hip_atomic_fetch_or(slot + (p >> 5), 1u << (p & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();  // (waits for this tile's atomics to be issued and returned: vmcnt(0) + barrier)
+        if (threadIdx.x == 0) {
+          const uint32_t target = (seq + 1u) * gridDim.x;  // arrivals are never reset: every launch of this world has this grid
+          __hip_atomic_fetch_add(args.sync, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+          int spins = 0;
+          while ((int32_t)(__hip_atomic_load(args.sync, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1 << 18)) {  // the grid is not co-resident (it should be): flag it and go on, never hang
+              __hip_atomic_fetch_or(args.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              break;
+            }
+          }
+          if (blockIdx.x == 0) {  // every tile is past substep seq-1: the slot used two substeps ago is free, clear it for seq+2
+            uint32_t* nxt = args.sync + 4 + ((seq + 2u) & 3u) * (uint32_t)args.mask_words;
+            for (int w_ = 0; w_ < args.mask_words; ++w_)
+              __hip_atomic_store(nxt + w_, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        __syncthreads();
+        args.pair_mask = slot;
+      }
+    }
     // ================= phase B: gather forces per (entity, segment)
 #ifdef VMAS_TRACE
     unsigned long long tg = TNOW();
@@ -1018,11 +1087,11 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
     }
     if (!last) __syncthreads();
   }
-  }
-  STAMP(5);
-  // ---- epilogue: the scenario's reward / observation / done on the tile that is still in LDS
-  if constexpr (ENV != ENV_NONE) {
-    __syncthreads();
+  // ---- epilogue of this step: the scenario's reward / observation / done on the tile that is still in LDS.  In a
+  //      multi-step rollout (vmas_world_rollout_env) step k writes the k-th slab of every per-step output; the
+  //      persistent terms (shaping, step counter) are carried in registers / re-read by the thread that wrote them.
+  if constexpr (ENV == ENV_BALANCE || ENV == ENV_TRANSPORT) {
+    if (stp + 1 == n_steps) __syncthreads();  // (earlier steps: the substep loop ended with a barrier)
     const TileCtx C(batch);
     if constexpr (ENV == ENV_BALANCE)
       if (!(ABLATE(E) & 4))  // profiling (VMAS_ENV_ABLATE): 1 queries off, 2 observations off, 4 epilogue off, 8 prologue off
@@ -1030,18 +1099,40 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
         // the floor's cos/sin rows of the tile are current if it cannot rotate (they are not refreshed after the last substep)
         const uint32_t ffl = (uint32_t)sgpr((int)blob[W.b_ent + E.balance.d.floor * EW]);
         const int tr_off = sgpr((int)blob[W.b_ent + E.balance.d.floor * EW + 3]);
-        balance_post_tile(C, E.balance.d, E.balance.o, batch, lds, lds + E.scratch_off, post_prev, post_steps, ABLATE(E),
+        VmasBalanceBuffers o = E.balance.o;
+        if (stp > 0) {
+          const long nb = (long)E.balance.d.n_agents * batch;
+          o.obs += (long)stp * nb * kBalanceObsDim; o.rew += (long)stp * nb;
+          o.pos_rew += (long)stp * batch; o.ground_rew += (long)stp * batch; o.done += (long)stp * batch;
+        }
+        balance_post_tile(C, E.balance.d, o, batch, lds, lds + E.scratch_off, post_prev, post_steps, ABLATE(E),
                           (tr_off >= 0 && !(ffl & VMAS_F_ROTATABLE)) ? tile + tr_off : nullptr);
       }
-    if constexpr (ENV == ENV_TRANSPORT)
-      transport_post_tile(C, E.transport.d, E.transport.o, batch, lds, lds + E.scratch_off, post_steps);
+    if constexpr (ENV == ENV_TRANSPORT) {
+      VmasTransportBuffers o = E.transport.o;
+      if (stp > 0) {
+        const long nb = (long)E.transport.d.n_agents * batch;
+        o.obs += (long)stp * nb * transport_obs_dim(E.transport.d.n_packages); o.rew += (long)stp * nb;
+        o.done += (long)stp * batch;
+      }
+      transport_post_tile(C, E.transport.d, o, batch, lds, lds + E.scratch_off, post_steps);
+    }
+    if (stp + 1 < n_steps) {
+      __syncthreads();  // the next step's prologue rewrites the agent-force rows and the epilogue's scratch
+      if constexpr (ENV == ENV_TRANSPORT) {  // previous shaping of every package: by the wave that just stored it
+        float* term = lds + E.scratch_off + lane;
+        for (int p = wv; p < E.transport.d.n_packages; p += nw)
+          term[p * 64] = live ? E.transport.o.global_shaping[(long)p * batch + env] : 0.f;
+      }
+    }
   }
+  }
+  STAMP(5);
 }
 
 // ------------------------------------------------------------------------------------
 // batch-global broad phase (World.collides core.py:2797-2801)
 // ------------------------------------------------------------------------------------
-struct DevMaskPair { int32_t a, b; float bound_sum; };
 
 __global__ __launch_bounds__(256) void pair_mask_kernel(const DevMaskPair* __restrict__ pairs, int nP, int nE,
                                                         const float* __restrict__ state, long ld, int batch,
@@ -1226,10 +1317,22 @@ __global__ __launch_bounds__(256) void query_kernel(const DevQuery* __restrict__
   out[(long)blockIdx.y * ld + env] = r;
 }
 
-// test hook (not part of the ABI): the device softplus on an array, for the accuracy test
-__global__ void softplus_kernel(const float* __restrict__ in, float* __restrict__ out, int n) {
+// test hook (include/vmas_debug_hip.h, not part of the drop-in ABI): device primitives on arrays, for the accuracy tests
+__global__ void math_kernel(int op, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = softplus0(in[i]);
+  if (i >= n) return;
+  const float x = a[i], y = b ? b[i] : 0.f;
+  float r = 0.f, sn, cs;
+  switch (op) {
+    case VMAS_MATH_SOFTPLUS: r = softplus0(x); break;
+    case VMAS_MATH_SQRT: r = sqrt_n(x); break;
+    case VMAS_MATH_DIV: r = x / rcp_of(y); break;
+    case VMAS_MATH_NORM: r = norm2(x, y); break;
+    case VMAS_MATH_COS: sincosf(x, &sn, &cs); r = cs; break;
+    case VMAS_MATH_SIN: sincosf(x, &sn, &cs); r = sn; break;
+    default: break;
+  }
+  out[i] = r;
 }
 
 // ------------------------------------------------------------------------------------
@@ -1314,6 +1417,11 @@ struct VmasWorld {
   bool resident = false;  // every tile of the batch is on the chip at once (select_config): the latency regime
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // exact broad phase (VmasStepArgs.exact_broad_phase): grid barrier word + ring of mask slots for the in-kernel form,
+  // one mask for the launch-per-substep form used when the grid is larger than the chip
+  uint32_t* d_sync = nullptr;
+  uint32_t sync_seq = 0;
+  uint32_t* d_exact_mask = nullptr;
   // lidars
   DevLidar* d_lidars = nullptr;
   DevTarget* d_targets = nullptr;
@@ -1795,7 +1903,7 @@ static int launch_level(VmasWorld* w, Sched* S, float* state, float* aft, long l
   // queues); `pad` = columns of the planes that exist from there on (ld minus the range's first environment)
   const size_t lds = S->lds_bytes + extra_lds;
   if (lds > 160 * 1024) return fail("vmas_world_step: %zu bytes of LDS per tile exceed the CU's 160 KB", lds);
-  const bool plain = !a.pair_mask && !a.joint_fixed_rot && !a.entity_gravity && a.first_substep == 0 && a.n_substeps <= 0 &&
+  const bool plain = !a.pair_mask && !a.sync && !a.joint_fixed_rot && !a.entity_gravity && a.first_substep == 0 && a.n_substeps <= 0 &&
                      pad >= (long)blocks_of(batch) * TILE && S->dw.items_in_lds;
   const int mode = !plain ? 0 : ((S->dw.substeps == 1 && a.n_steps <= 1) ? (batch % TILE == 0 ? 3 : 2) : 1);
   if (lds > 64 * 1024) {
@@ -1926,6 +2034,12 @@ int vmas_world_create(const VmasWorldDesc* d, int32_t batch, int32_t device_id, 
   for (int p = 0; p < d->n_pairs; ++p) mp[p] = {d->pairs[p].a, d->pairs[p].b, d->pairs[p].bound_sum};
   w->dev_ents = ents;
   HIP_TRY(upload(&w->d_mpairs, mp));
+  {  // exact broad phase: barrier word + four mask slots (in-kernel form), one mask (launch-per-substep form)
+    const size_t mw = (size_t)(d->n_pairs + 31) / 32;
+    HIP_TRY(hipMalloc((void**)&w->d_sync, (4 + 4 * mw) * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(w->d_sync, 0, (4 + 4 * mw) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&w->d_exact_mask, (mw ? mw : 1) * sizeof(uint32_t)));
+  }
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) w->n_cu = prop.multiProcessorCount;
@@ -1948,6 +2062,7 @@ void vmas_world_destroy(VmasWorld* w) {
   if (w->side) { (void)hipStreamSynchronize(w->side); (void)hipStreamDestroy(w->side); }
   if (w->ev_fork) (void)hipEventDestroy(w->ev_fork);
   if (w->ev_join) (void)hipEventDestroy(w->ev_join);
+  (void)hipFree(w->d_sync); (void)hipFree(w->d_exact_mask);
   (void)hipFree(w->d_mpairs); (void)hipFree(w->d_trace);
   (void)hipFree(w->d_lidars); (void)hipFree(w->d_targets); (void)hipFree(w->d_angles); (void)hipFree(w->d_queries);
   delete w;
@@ -1996,6 +2111,16 @@ int64_t vmas_world_step_bytes_per_env(const VmasWorld* w) {
   return 24LL * w->base.nE + 12LL * w->base.nA + 24LL * w->n_dyn;
 }
 
+int vmas_world_exact_status(VmasWorld* w) {
+  if (!w) return fail("vmas_world_exact_status: null world");
+  if (!w->d_sync) return 0;
+  uint32_t flag = 0;
+  HIP_TRY(hipSetDevice(w->device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(&flag, w->d_sync + 1, sizeof(flag), hipMemcpyDeviceToHost));
+  return (int)flag;
+}
+
 int vmas_world_set_queues(VmasWorld* w, int32_t queues) {
   if (!w) return fail("vmas_world_set_queues: null world");
   if (queues < 0 || queues > 2) return fail("vmas_world_set_queues: queues must be 0 (library's choice), 1 or 2, got %d", queues);
@@ -2020,9 +2145,29 @@ int vmas_world_rollout(VmasWorld* w, float* state, float* agent_ft, int64_t ld, 
   return step_impl(w, state, agent_ft, ld, args, stream, n_steps, ft_step_stride);
 }
 
+static int step_env_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld, const VmasStepArgs* args,
+                         const VmasIngestArgs* ingest, uint32_t* err_flags, int32_t post_kind, const void* post_desc,
+                         const void* post_buffers, int32_t n_steps, void* stream);
+
 int vmas_world_step_env(VmasWorld* w, float* state, float* agent_ft, int64_t ld, const VmasStepArgs* args,
                         const VmasIngestArgs* ingest, uint32_t* err_flags, int32_t post_kind, const void* post_desc,
                         const void* post_buffers, void* stream) {
+  return step_env_impl(w, state, agent_ft, ld, args, ingest, err_flags, post_kind, post_desc, post_buffers, 1, stream);
+}
+
+int vmas_world_rollout_env(VmasWorld* w, float* state, float* agent_ft, int64_t ld, const VmasStepArgs* args,
+                           const VmasIngestArgs* ingest, uint32_t* err_flags, int32_t post_kind, const void* post_desc,
+                           const void* post_buffers, int32_t n_steps, void* stream) {
+  if (n_steps <= 0) return fail("vmas_world_rollout_env: n_steps must be > 0, got %d", n_steps);
+  if (!ingest) return fail("vmas_world_rollout_env: the steps' actions come through `ingest`");
+  if (ingest->n_scripts > 0 && n_steps > 1)
+    return fail("vmas_world_rollout_env: scripted agents read the state in HBM, which a multi-step launch does not refresh");
+  return step_env_impl(w, state, agent_ft, ld, args, ingest, err_flags, post_kind, post_desc, post_buffers, n_steps, stream);
+}
+
+static int step_env_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld, const VmasStepArgs* args,
+                         const VmasIngestArgs* ingest, uint32_t* err_flags, int32_t post_kind, const void* post_desc,
+                         const void* post_buffers, int32_t n_steps, void* stream) {
   if (!w) return fail("vmas_world_step_env: null world");
   if (args && (args->first_substep != 0 || args->n_substeps > 0))
     return fail("vmas_world_step_env: partial substep ranges cannot carry an epilogue");
@@ -2059,7 +2204,7 @@ int vmas_world_step_env(VmasWorld* w, float* state, float* agent_ft, int64_t ld,
     if (vmas::check_balance_args(d, o, w->batch, state, ld, w->base.nE)) return -1;
     env.balance.d = *d;
     env.balance.o = *o;
-    return step_impl(w, state, agent_ft, ld, args, stream, 1, 0, &env, ENV_BALANCE, balance_scratch_floats(0),
+    return step_impl(w, state, agent_ft, ld, args, stream, n_steps, 0, &env, ENV_BALANCE, balance_scratch_floats(0),
                      balance_scratch_floats(1) - balance_scratch_floats(0));
   }
   if (post_kind == VMAS_POST_TRANSPORT) {
@@ -2068,11 +2213,11 @@ int vmas_world_step_env(VmasWorld* w, float* state, float* agent_ft, int64_t ld,
     if (vmas::check_transport_args(d, o, w->batch, state, ld, w->base.nE)) return -1;
     env.transport.d = *d;
     env.transport.o = *o;
-    return step_impl(w, state, agent_ft, ld, args, stream, 1, 0, &env, ENV_TRANSPORT,
+    return step_impl(w, state, agent_ft, ld, args, stream, n_steps, 0, &env, ENV_TRANSPORT,
                      transport_scratch_floats(0, d->n_packages),
                      transport_scratch_floats(1, d->n_packages) - transport_scratch_floats(0, d->n_packages));
   }
-  if (post_kind == VMAS_POST_NONE) return step_impl(w, state, agent_ft, ld, args, stream, 1, 0, &env, ENV_INGEST, 0, 0);
+  if (post_kind == VMAS_POST_NONE) return step_impl(w, state, agent_ft, ld, args, stream, n_steps, 0, &env, ENV_INGEST, 0, 0);
   return fail("vmas_world_step_env: post_kind %d has no fused epilogue", post_kind);
 }
 
@@ -2111,6 +2256,35 @@ static int step_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld, co
   Sched* S;
   if (get_sched(w, w->lanes, &S)) return -1;
   hipStream_t s = (hipStream_t)stream;
+  if (args && args->exact_broad_phase && w->n_pairs > 0) {
+    // The reference's broad phase: a pair is processed - for ALL environments - iff SOME environment of the batch has the
+    // pair's bounding circles overlapping (core.py:2797-2801), re-evaluated at every substep.
+    if (args->pair_mask) return fail("vmas_world_step: exact_broad_phase and a recorded pair_mask are mutually exclusive");
+    const int mask_words = (w->n_pairs + 31) / 32;
+    const int run = a.n_substeps > 0 ? a.n_substeps : w->base.substeps - a.first_substep;
+    // (a launch captured into a HIP graph would replay the barrier sequence number baked into its arguments: under
+    // capture the launch-per-substep form is used, which keeps no state on the host)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
+    if (blocks_of(w->batch) <= w->n_cu && cap == hipStreamCaptureStatusNone) {  // every tile resident at once: mask +
+                                                                                // grid barrier inside the step kernel
+      a.sync = w->d_sync; a.mpairs = w->d_mpairs; a.n_mpairs = w->n_pairs; a.mask_words = mask_words;
+      a.seq0 = w->sync_seq;
+      w->sync_seq += (uint32_t)(run * (n_steps > 1 ? n_steps : 1));
+    } else {  // more tiles than the chip holds: a mask launch + a one-substep launch per substep
+      if (env_kind != ENV_NONE || n_steps > 1)
+        return fail("vmas_world_step: exact_broad_phase on %d tiles (> %d CUs) runs one launch per substep: no fused "
+                    "epilogue, no rollout", blocks_of(w->batch), w->n_cu);
+      for (int sub = a.first_substep; sub < a.first_substep + run; ++sub) {
+        HIP_TRY(hipMemsetAsync(w->d_exact_mask, 0, (size_t)mask_words * sizeof(uint32_t), s));
+        if (vmas_world_pair_mask(w, state, ld, w->d_exact_mask, stream)) return -1;
+        DevStepArgs b = a;
+        b.pair_mask = w->d_exact_mask; b.first_substep = sub; b.n_substeps = 1;
+        if (launch_any_level<ENV_NONE>(w, S, state, agent_ft, ld, b, NoEnv{}, 0, s)) return -1;
+      }
+      return 0;
+    }
+  }
   if (env_count >= 0) {  // a sub-range of the batch (vmas_world_step_n over two queues): plain physics, no optional inputs
     if (env_kind != ENV_NONE || args) return fail("vmas_world_step: environment sub-ranges take no optional inputs");
     return launch_any_level<ENV_NONE>(w, S, state + env_first, agent_ft ? agent_ft + env_first : nullptr, ld, a, NoEnv{}, 0,
@@ -2138,8 +2312,11 @@ int vmas_debug_trace(VmasWorld* w, unsigned long long* host, int64_t n_words) {
   return 0;
 }
 
-int vmas_debug_softplus(const float* in, float* out, int32_t n, void* stream) {
-  hipLaunchKernelGGL(softplus_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, in, out, n);
+int vmas_debug_math(int32_t op, const float* a, const float* b, float* out, int32_t n, void* stream) {
+  if (!a || !out || n < 0 || op < 0 || op > VMAS_MATH_SIN) return fail("vmas_debug_math: bad argument");
+  if ((op == VMAS_MATH_DIV || op == VMAS_MATH_NORM) && !b) return fail("vmas_debug_math: op %d needs two operands", op);
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(math_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, op, a, b, out, n);
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -88,9 +88,12 @@ class Environment:
         # the whole step as ONE launch (vmas_world_step_env): ingest = prologue, post-step = epilogue of
         # the physics kernel.  Needs the hooks between the stages to be the base class no-ops.
         w = self.world
+        # (the exact broad phase runs inside the step launch while every 64-environment tile has a CU of its own)
+        exact_in_launch = (not w.exact_broad_phase or
+                           (self.num_envs + 63) // 64 <= torch.cuda.get_device_properties(self.device).multi_processor_count)
         self._ingest_in_step = (  # action ingest as the physics kernel's prologue
             self._ingest is not None and type(self.scenario).pre_step is BaseScenario.pre_step
-            and not w.exact_broad_phase and w.dim_c == 0
+            and w.dim_c == 0 and exact_in_launch
         )
         self._one_launch = (
             self._ingest_in_step and self._post is not None and self._post.kind is not None
@@ -289,6 +292,24 @@ class Environment:
                 self._static_out = self._post()
         self._graph.replay()
         return self._static_out
+
+    def rollout(self, actions: List[Tensor]) -> Dict[str, Tensor]:
+        """K consecutive ``step()`` calls with given actions in ONE kernel launch.
+
+        ``actions[i]`` = agent i's actions for all K steps, ``[K, num_envs, action_size]``.  Returns
+        ``{"obs": [K, n_agents, num_envs, obs_dim], "rew": [K, n_agents, num_envs], "done": [K, num_envs]}`` (+ the
+        scenario's per-step info terms): entry k is what the k-th ``step()`` would have returned, bit for bit.  No
+        resets in between (like K plain ``step()`` calls: ``done`` environments keep running until the caller
+        resets them); the 64 environments of a tile stay in LDS for the whole rollout.  For the scenarios whose step
+        is one launch (balance, transport); others: loop over ``step()``."""
+        assert self._one_launch, "rollout() needs a scenario whose Environment.step is one launch (balance, transport)"
+        assert len(actions) == self.n_agents, f"Expecting actions for {self.n_agents}, got {len(actions)} actions"
+        K = int(actions[0].shape[0])
+        self._ingest.prepare_rollout(actions, K, self.validate_actions)
+        desc, buffers, out = self._post.prepare_rollout(K)
+        self._launch.rollout(self._post.kind, desc, buffers, K)
+        self._lidar_cache = None
+        return out
 
     def _step_eager(self, actions):
         assert len(actions) == self.n_agents, f"Expecting actions for {self.n_agents}, got {len(actions)} actions"

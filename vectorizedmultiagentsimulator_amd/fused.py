@@ -130,6 +130,38 @@ class ActionIngest:
                 self.args.agents[i].action_index = act.data_ptr()
         self._keep = held  # the launch is asynchronous: keep the inputs alive until the next call
 
+    def prepare_rollout(self, actions: List[Tensor], n_steps: int, validate: bool):
+        """Point the slots at K-step action tensors ([K, B, action_size] per agent, continuous; [K, B] or [K, B, 1]
+        flat indices, discrete).  ``validate``: the reference's asserts (environment.py:621,651-653) on the whole
+        tensors up front - one host sync - because a multi-step launch cannot stop at a bad action."""
+        env = self.env
+        held, bad_nan, bad_range = [], None, None
+        for i, (agent, act) in enumerate(zip(env.agents, actions)):
+            want = env.get_agent_action_size(agent)
+            if act.dim() == 2:
+                act = act.unsqueeze(-1)
+            assert act.shape == (n_steps, env.num_envs, want), (
+                f"Agent {agent.name}: rollout actions must be [{n_steps}, {env.num_envs}, {want}], got {tuple(act.shape)}")
+            dtype = torch.float32 if env.continuous_actions else torch.int64
+            if act.dtype != dtype or act.device != env.device or not act.is_contiguous():
+                act = act.detach().to(device=env.device, dtype=dtype).contiguous()
+            held.append(act)
+            if env.continuous_actions:
+                self.args.agents[i].action = act.data_ptr()
+                if validate:
+                    rng = torch.tensor(_per_dim(agent.action.u_range, want), device=env.device)
+                    n = (act != act).any()
+                    r = (act.abs() > rng).any() if not env.clamp_action else torch.zeros((), dtype=torch.bool, device=env.device)
+                    bad_nan = n if bad_nan is None else bad_nan | n
+                    bad_range = r if bad_range is None else bad_range | r
+            else:
+                self.args.agents[i].action_index = act.data_ptr()
+        if validate and bad_nan is not None:
+            flags = torch.stack([bad_nan, bad_range]).cpu()
+            assert not bool(flags[0]), "actions contain NaN"
+            assert not bool(flags[1]), "Physical actions of an agent are out of its range"
+        self._keep = held
+
     def check(self):
         """The reference asserts on the host (environment.py:621,651-653): one sync, not 2 per agent."""
         flags = int(self.err.item())
@@ -177,6 +209,7 @@ class StepLauncher:
         self._st, self._ft, self._ld = C.c_void_p(be.state.data_ptr()), C.c_void_p(be.agent_ft.data_ptr()), be.ld
         spec = w.spec
         self._per_env = any(j.per_env_fixed_rotation for j in spec.joints) or any(e.per_env_gravity for e in spec.entities)
+        self._exact = bool(w.exact_broad_phase)
         self._ing = C.byref(self.ingest.args)
         self._err = C.c_void_p(self.ingest.err.data_ptr())
         self._dev = self.env.device
@@ -187,15 +220,38 @@ class StepLauncher:
             self._bind()
         w._query_cache = None
         args = None
-        if self._per_env:
-            jfr, eg = w._per_env_inputs()
+        if self._per_env or self._exact:
+            jfr, eg = w._per_env_inputs() if self._per_env else (None, None)
             sa = A.StepArgs()
             sa.joint_fixed_rot = jfr.data_ptr() if jfr is not None else None
             sa.entity_gravity = eg.data_ptr() if eg is not None else None
+            sa.exact_broad_phase = 1 if self._exact else 0
             args = C.byref(sa)
         rc = self.fn(self._h, self._st, self._ft, self._ld, args, self._ing, self._err if validate else None, kind,
                      C.byref(desc) if desc is not None else None, C.byref(buffers) if buffers is not None else None,
                      torch.cuda.current_stream(self._dev).cuda_stream)
+        if rc != 0:
+            raise VmasHipError(A.last_error())
+
+
+    def rollout(self, kind: int, desc, buffers, n_steps: int):
+        """``vmas_world_rollout_env``: n_steps Environment.step() calls in one launch."""
+        w = self.env.world
+        if self._be is None or w._backend is not self._be:
+            self._bind()
+        w._query_cache = None
+        args = None
+        if self._per_env or self._exact:
+            jfr, eg = w._per_env_inputs() if self._per_env else (None, None)
+            sa = A.StepArgs()
+            sa.joint_fixed_rot = jfr.data_ptr() if jfr is not None else None
+            sa.entity_gravity = eg.data_ptr() if eg is not None else None
+            sa.exact_broad_phase = 1 if self._exact else 0
+            args = C.byref(sa)
+        rc = A.load_library().vmas_world_rollout_env(
+            self._h, self._st, self._ft, self._ld, args, self._ing, None, kind,
+            C.byref(desc) if desc is not None else None, C.byref(buffers) if buffers is not None else None, int(n_steps),
+            torch.cuda.current_stream(self._dev).cuda_stream)
         if rc != 0:
             raise VmasHipError(A.last_error())
 
@@ -245,6 +301,12 @@ class _Post:
         st = self.env.world._packed_state()
         return st.data_ptr(), st.shape[-1]
 
+    def prepare_rollout(self, n_steps: int):
+        """(descriptor, buffers, outputs) for ``vmas_world_rollout_env``: every per-step output gets a leading
+        ``n_steps`` axis ([K, n_agents, B, D] observations, [K, n_agents, B] rewards, [K, B] dones ...), the buffer
+        struct points at step 0."""
+        raise NotImplementedError
+
 
 class BalancePost(_Post):
     def __init__(self, env):
@@ -279,6 +341,23 @@ class BalancePost(_Post):
         b.pos_rew, b.ground_rew, b.on_the_ground = (t.data_ptr() for t in self._info)
         infos = [{"pos_rew": sc.pos_rew, "ground_rew": sc.ground_rew} for _ in range(self.n)]
         return self.desc, b, (list(obs.unbind(0)), list(rew.unbind(0)), done, infos)
+
+    def prepare_rollout(self, n_steps: int):
+        sc, K = self.env.scenario, int(n_steps)
+        out = {
+            "obs": torch.empty(K, self.n, self.B, 16, device=self.dev), "rew": torch.empty(K, self.n, self.B, device=self.dev),
+            "done": torch.empty(K, self.B, device=self.dev, dtype=torch.bool),
+            "pos_rew": torch.empty(K, self.B, device=self.dev), "ground_rew": torch.empty(K, self.B, device=self.dev),
+        }
+        sc.on_the_ground = torch.empty(self.B, device=self.dev, dtype=torch.bool)
+        sc.pos_rew, sc.ground_rew = out["pos_rew"][-1], out["ground_rew"][-1]  # scenario attributes: the last step's
+        b = A.BalanceBuffers()
+        b.limit = self._limit()
+        b.global_shaping = sc.global_shaping.data_ptr()
+        b.obs, b.rew, b.done = out["obs"].data_ptr(), out["rew"].data_ptr(), out["done"].data_ptr()
+        b.pos_rew, b.ground_rew = out["pos_rew"].data_ptr(), out["ground_rew"].data_ptr()
+        b.on_the_ground = sc.on_the_ground.data_ptr()
+        return self.desc, b, out
 
     def __call__(self):
         desc, b, result = self.prepare()
@@ -332,6 +411,20 @@ class TransportPost(_Post):
         b.obs, b.rew, b.done = obs.data_ptr(), rew.data_ptr(), done.data_ptr()
         sc.rew = rew[0]
         return self.desc, b, (list(obs.unbind(0)), list(rew.unbind(0)), done, [{} for _ in range(self.n)])
+
+    def prepare_rollout(self, n_steps: int):
+        K, D = int(n_steps), 4 + 7 * self.P
+        self.prepare()  # (re-binds the packages' persistent terms)
+        out = {
+            "obs": torch.empty(K, self.n, self.B, D, device=self.dev), "rew": torch.empty(K, self.n, self.B, device=self.dev),
+            "done": torch.empty(K, self.B, device=self.dev, dtype=torch.bool),
+        }
+        self.env.scenario.rew = out["rew"][-1, 0]
+        b = A.TransportBuffers()
+        b.limit = self._limit()
+        b.global_shaping, b.on_goal = self.global_shaping.data_ptr(), self.on_goal.data_ptr()
+        b.obs, b.rew, b.done = out["obs"].data_ptr(), out["rew"].data_ptr(), out["done"].data_ptr()
+        return self.desc, b, out
 
     def __call__(self):
         desc, b, result = self.prepare()
