@@ -1,0 +1,35 @@
+"""Environment.step() one launch per step vs Environment.rollout() (K steps in one launch, vmas_world_rollout_env):
+python scripts/bench_rollout_env.py balance 32768 [K]"""
+import json, os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+from vectorizedmultiagentsimulator_amd.environment import make_env
+name = sys.argv[1] if len(sys.argv) > 1 else "balance"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 32768
+K = int(sys.argv[3]) if len(sys.argv) > 3 else 100
+kw = {"balance": dict(n_agents=4), "transport": {}}[name]
+env = make_env(name, num_envs=B, device="cuda:0", seed=0, validate_actions=False, **kw)
+g = torch.Generator(device="cuda:0").manual_seed(1)
+acts = [(torch.rand(K, B, 2, device="cuda:0", generator=g) * 2 - 1) for _ in env.agents]
+for _ in range(3):
+    env.rollout(acts)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+reps = 20
+t0 = time.perf_counter(); e0.record()
+for _ in range(reps):
+    out = env.rollout(acts)
+e1.record(); torch.cuda.synchronize()
+wall = (time.perf_counter() - t0) / (reps * K)
+gpu = e0.elapsed_time(e1) * 1e-3 / (reps * K)
+for k in range(50):
+    env.step([u[k % K] for u in acts])
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for k in range(reps * K // 4):
+    env.step([u[k % K] for u in acts])
+torch.cuda.synchronize()
+step = (time.perf_counter() - t0) / (reps * K // 4)
+print(json.dumps({"scenario": name, "num_envs": B, "K": K, "rollout_us_per_step_gpu": round(gpu * 1e6, 2),
+                  "rollout_us_per_step_wall": round(wall * 1e6, 2), "rollout_env_steps_per_s": round(B / wall),
+                  "step_us_per_step_wall": round(step * 1e6, 2), "step_env_steps_per_s": round(B / step)}))
