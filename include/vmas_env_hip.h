@@ -181,6 +181,48 @@ typedef struct VmasFootballBuffers {
 int vmas_football_post_step(const VmasFootballDesc* desc, const VmasFootballBuffers* buf, int32_t batch,
                             const float* state, int64_t ld, void* stream);
 
+/* ---------------------------------------------------------------- masked reset
+ * Environment.reset_at(i) for EVERY environment whose mask byte is set, in one launch and without a host sync: the
+ * reference resets one environment per Python call (environment.py:204-252 -> World.reset, core.py:1184-1192, then the
+ * scenario's reset_world_at).  For a masked environment the kernel zeroes the whole entity state and the agent forces
+ * (World.reset), then runs the scenario's spawn program - the placement law of its reset_world_at restated as a list
+ * of operations - on a counter-based generator (Philox4x32-10 keyed by `seed`, counter = environment index, that
+ * environment's episode number, operation, try), so a reset draws nothing from a shared stream and unmasked
+ * environments are not touched at all (their bits stay).  Finally the scenario's cached terms are re-initialised.
+ *
+ * UNIFORM restates ScenarioUtils.spawn_entities_randomly / find_random_pos_for_entity (utils.py:241-319): the position is
+ * uniform in the box and re-drawn while it is closer than `min_dist` to any entity placed by operations
+ * [avoid_from, this one) - per environment the same rejection law as the reference's batch loop. */
+#define VMAS_RESET_MAX_OPS 48
+#define VMAS_RESET_MAX_TERMS 36
+#define VMAS_SPAWN_UNIFORM 1 /* pos ~ U([x_lo,x_hi) x [y_lo,y_hi)), rejected within min_dist of ops [avoid_from, i) */
+#define VMAS_SPAWN_OFFSET 2  /* pos = pos(base) + (U([x_lo,x_hi)) , y_lo): x_lo == x_hi = a constant offset, no draw */
+#define VMAS_SPAWN_FIXED 3   /* pos = (x_lo, y_lo) */
+typedef struct VmasSpawnOp {
+  int32_t kind;       /* VMAS_SPAWN_* */
+  int32_t entity;     /* entity placed */
+  int32_t base;       /* OFFSET: entity it is placed relative to (placed by an earlier operation) */
+  int32_t avoid_from; /* UNIFORM: first operation whose entity must be kept at min_dist */
+  float x_lo, x_hi, y_lo, y_hi;
+  float min_dist;
+} VmasSpawnOp;
+typedef struct VmasResetTerm { /* out[env] = |pos(a) - pos(b)| * factor (shaping caches); a < 0: out[env] = factor */
+  int32_t a, b;
+  float factor;
+  float* out; /* [batch] */
+} VmasResetTerm;
+typedef struct VmasResetArgs {
+  int32_t n_ops, n_terms, n_flags;
+  VmasSpawnOp ops[VMAS_RESET_MAX_OPS];
+  VmasResetTerm terms[VMAS_RESET_MAX_TERMS];
+  uint8_t* flags[8];  /* [batch] bool tensors cleared for a reset environment (on_goal, on_the_ground, ...) */
+  float* steps;       /* [batch] Environment.steps, zeroed; may be NULL */
+  uint32_t* episode;  /* [batch] in/out: resets this environment has had (part of the generator's counter) */
+  uint64_t seed;
+} VmasResetArgs;
+int vmas_env_reset_where(const VmasResetArgs* args, int32_t batch, int32_t n_entities, int32_t n_agents,
+                         const uint8_t* mask /* [batch] bool */, float* state, float* agent_ft, int64_t ld, void* stream);
+
 /* ---------------------------------------------------------------- the whole step in one launch
  * World.step() with the action ingest as its prologue and one scenario's post-step as its
  * epilogue: the tile of 64 environments a block integrates is still in LDS when the physics is

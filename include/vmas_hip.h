@@ -226,13 +226,13 @@ int vmas_world_run_queries(VmasWorld* w, const float* state, int64_t ld, float* 
 int vmas_world_set_lanes_per_env(VmasWorld* w, int32_t lanes);
 int vmas_world_get_lanes_per_env(const VmasWorld* w);
 
-/* vmas_world_step_n over two HIP queues.  Environments are independent, so a sequence of steps can be enqueued as two
- * independent launch sequences over the two halves of the batch (cut at a 64-environment tile boundary): one on the
- * caller's stream, one on a library-owned side stream that is forked from the caller's stream (event) at the start of
- * the call and joined back into it at the end, so the call stays stream-ordered for the caller.  The ~2.9 us launch gap
- * between two dependent kernels of one half is filled by the kernel of the other half; results are bit for bit those of
- * one queue.  queues: 0 = the library's choice (two when every tile of the batch is on the chip at once and n_steps >= 8),
- * 1 = always one queue, 2 = always two.  Only launches without optional per-call inputs (args == NULL) are split.
+/* vmas_world_step_n over several HIP queues.  Environments are independent, so a sequence of steps can be enqueued as
+ * independent launch sequences over parts of the batch (cut at 64-environment tile boundaries): one on the caller's
+ * stream, the others on library-owned side streams that are forked from the caller's stream (event) at the start of the
+ * call and joined back into it at the end, so the call stays stream-ordered for the caller.  The ~2.9 us launch gap
+ * between two dependent kernels of one part is filled by the kernels of the others; results are bit for bit those of
+ * one queue.  queues: 0 = the library's choice (two when each half keeps at least one tile per CU and n_steps >= 8),
+ * 1..4 = that many.  Only launches without optional per-call inputs (args == NULL) are split.
  * vmas_world_get_queues returns how many queues a vmas_world_step_n of `n_steps` steps would use. */
 int vmas_world_set_queues(VmasWorld* w, int32_t queues);
 int vmas_world_get_queues(const VmasWorld* w, int32_t n_steps);

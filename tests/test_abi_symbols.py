@@ -58,7 +58,7 @@ def test_struct_sizes_match_the_c_header(tmp_path):
 
 def test_env_struct_sizes_match_the_c_header(tmp_path):
     """Same for include/vmas_env_hip.h (structs passed by pointer AND copied into kernel arguments)."""
-    names = ["VmasAgentScript", "VmasFootballDesc", "VmasFootballBuffers", "VmasActionSlot", "VmasIngestArgs", "VmasStepLimit", "VmasBalanceDesc", "VmasBalanceBuffers",
+    names = ["VmasSpawnOp", "VmasResetTerm", "VmasResetArgs", "VmasAgentScript", "VmasFootballDesc", "VmasFootballBuffers", "VmasActionSlot", "VmasIngestArgs", "VmasStepLimit", "VmasBalanceDesc", "VmasBalanceBuffers",
              "VmasTransportDesc", "VmasTransportBuffers", "VmasNavigationDesc", "VmasNavigationBuffers"]
     prog = tmp_path / "sz.c"
     prog.write_text(
@@ -70,7 +70,7 @@ def test_env_struct_sizes_match_the_c_header(tmp_path):
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(prog)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
-    py = [_abi.AgentScript, _abi.FootballDesc, _abi.FootballBuffers, _abi.ActionSlot, _abi.IngestArgs, _abi.StepLimit, _abi.BalanceDesc, _abi.BalanceBuffers, _abi.TransportDesc,
+    py = [_abi.SpawnOp, _abi.ResetTerm, _abi.ResetArgs, _abi.AgentScript, _abi.FootballDesc, _abi.FootballBuffers, _abi.ActionSlot, _abi.IngestArgs, _abi.StepLimit, _abi.BalanceDesc, _abi.BalanceBuffers, _abi.TransportDesc,
           _abi.TransportBuffers, _abi.NavigationDesc, _abi.NavigationBuffers]
     want = [ctypes.sizeof(t) for t in py] + [_abi.NavigationBuffers.limit.offset, _abi.NavigationDesc.agent_radius.offset,
                                              _abi.IngestArgs.agents.offset]

@@ -123,7 +123,12 @@ def test_hip_step_matches_reference_golden(name):
         assert stats["needed_sens"] == 0, f"{name}: {stats['needed_sens']} values beyond the plain tolerance"
 
 
-@pytest.mark.parametrize("name", FIXTURES)
+# `band_4env` sits ON the discontinuity of the penalty force (dist == dist_min) by construction: it is for the exact
+# broad-phase tests; a noisy batch drawn from it flips contact decisions on last-bit differences of a distance
+NOISY = [n for n in FIXTURES if n != "band_4env"]
+
+
+@pytest.mark.parametrize("name", NOISY)
 def test_hip_matches_oracle_every_lane_count(name):
     """Full World.step (all substeps fused in one launch, no mask) on a 1000-env seeded
     batch, for every lanes-per-env geometry, against the oracle."""
@@ -163,7 +168,7 @@ def test_hip_matches_oracle_every_lane_count(name):
         hw.close()
 
 
-@pytest.mark.parametrize("name", FIXTURES)
+@pytest.mark.parametrize("name", NOISY)
 def test_hip_plain_kernels_match_oracle(name):
     """Whole-tile batches without optional per-environment inputs run on the PLAIN specialisations of the step
     kernel (no lane predication, no mask / joint-rotation / gravity pointers; one-substep worlds on their own
@@ -427,7 +432,7 @@ def test_persistent_rollout_is_bitwise_equal_to_single_steps(name):
 
 @pytest.mark.parametrize("name,B", [("balance_n4", 32768), ("balance_n4", 1000), ("navigation_n8", 4096 + 17),
                                     ("give_way", 130), ("football_5v5", 64)])
-def test_step_n_over_two_queues_is_bitwise_equal_to_one_queue(name, B):
+def test_step_n_over_several_queues_is_bitwise_equal_to_one_queue(name, B):
     """vmas_world_step_n with the batch cut in two halves on two HIP queues (vmas_world_set_queues): same kernels on
     environment sub-ranges, so the state and the clamped forces written back must be those of one queue bit for bit -
     whole-tile halves, a ragged last tile, a one-tile batch (never split), and work enqueued on the caller's stream
@@ -440,10 +445,11 @@ def test_step_n_over_two_queues_is_bitwise_equal_to_one_queue(name, B):
     rng = np.random.default_rng(9)
     noise = (1 + 0.3 * rng.standard_normal((n,) + ft0.shape)).astype(np.float32)
     outs = []
-    for queues in (1, 2, 0):
+    tiles = (B + 63) // 64
+    for queues in (1, 2, 0, 4):
         hw = _hip(g.spec, B)
         hw.set_queues(queues)
-        assert hw.queues(n) == (1 if queues == 1 or B <= 64 else (2 if queues == 2 else hw.queues(n)))
+        assert hw.queues(n) == (min(queues, tiles) if queues else hw.queues(n))
         _up(hw, st0, ft0)
         full = torch.zeros(n, *hw.agent_ft.shape, device="cuda")
         full[:, : ft0.shape[0], :, :B] = torch.from_numpy(ft0[None] * noise).cuda()
@@ -453,8 +459,8 @@ def test_step_n_over_two_queues_is_bitwise_equal_to_one_queue(name, B):
         outs.append((after, full.clone(), hw.queues(n)))
         assert torch.equal(hw.state[:, :, B:], pad_before), "padding columns were written"
         hw.close()
-    assert outs[0][2] == 1 and outs[1][2] == (2 if B > 64 else 1)
-    for k in (1, 2):
+    assert outs[0][2] == 1 and outs[1][2] == min(2, tiles) and outs[3][2] == min(4, tiles)
+    for k in (1, 2, 3):
         assert torch.equal(outs[0][0].view(torch.int32), outs[k][0].view(torch.int32)), f"{name}: queues differ (state)"
         assert torch.equal(outs[0][1].view(torch.int32), outs[k][1].view(torch.int32)), f"{name}: queues differ (forces)"
 

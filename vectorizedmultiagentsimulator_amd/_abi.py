@@ -171,6 +171,25 @@ class IngestArgs(C.Structure):
                 ("n_scripts", C.c_int32), ("scripts", AgentScript * ENV_MAX_SCRIPTS)]
 
 
+RESET_MAX_OPS, RESET_MAX_TERMS = 48, 36
+SPAWN_UNIFORM, SPAWN_OFFSET, SPAWN_FIXED = 1, 2, 3
+
+
+class SpawnOp(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("entity", C.c_int32), ("base", C.c_int32), ("avoid_from", C.c_int32),
+                ("x_lo", C.c_float), ("x_hi", C.c_float), ("y_lo", C.c_float), ("y_hi", C.c_float), ("min_dist", C.c_float)]
+
+
+class ResetTerm(C.Structure):
+    _fields_ = [("a", C.c_int32), ("b", C.c_int32), ("factor", C.c_float), ("out", C.c_void_p)]
+
+
+class ResetArgs(C.Structure):
+    _fields_ = [("n_ops", C.c_int32), ("n_terms", C.c_int32), ("n_flags", C.c_int32),
+                ("ops", SpawnOp * RESET_MAX_OPS), ("terms", ResetTerm * RESET_MAX_TERMS), ("flags", C.c_void_p * 8),
+                ("steps", C.c_void_p), ("episode", C.c_void_p), ("seed", C.c_uint64)]
+
+
 class StepLimit(C.Structure):
     _fields_ = [("steps", C.c_void_p), ("max_steps", C.c_float)]
 
@@ -271,6 +290,7 @@ EXPORTED_SYMBOLS = (
     "vmas_transport_post_step",
     "vmas_navigation_post_step",
     "vmas_football_post_step",
+    "vmas_env_reset_where",
     "vmas_world_step_env",
     "vmas_world_rollout_env",
     "vmas_world_reserve_epilogue",
@@ -334,6 +354,8 @@ def load_library() -> C.CDLL:
         fn.restype = C.c_int
     lib.vmas_world_step_env.argtypes = [vp, vp, vp, i64, C.POINTER(StepArgs), C.POINTER(IngestArgs), vp, i32, vp, vp, vp]
     lib.vmas_world_step_env.restype = C.c_int
+    lib.vmas_env_reset_where.argtypes = [C.POINTER(ResetArgs), i32, i32, i32, vp, vp, vp, i64, vp]
+    lib.vmas_env_reset_where.restype = C.c_int
     lib.vmas_world_rollout_env.argtypes = [vp, vp, vp, i64, C.POINTER(StepArgs), C.POINTER(IngestArgs), vp, i32, vp, vp, i32, vp]
     lib.vmas_world_rollout_env.restype = C.c_int
     lib.vmas_world_reserve_epilogue.argtypes = [vp, i32, i32]

@@ -437,6 +437,99 @@ int vmas_env_ingest_actions(const VmasIngestArgs* args, int32_t batch, const flo
   return check_launch("vmas_env_ingest_actions");
 }
 
+// ------------------------------------------------------------------------------------ masked reset
+// Philox4x32-10 (Salmon et al., SC'11): counter-based, so a reset needs no shared stream state.
+__device__ __forceinline__ void philox4x32(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+    const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+    c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+// torch's uniform_ law: lo + (hi - lo) * u, u = 24 random bits / 2^24 in [0, 1)
+__device__ __forceinline__ float uniform_in(uint32_t bits, float lo, float hi) {
+  return lo + (hi - lo) * ((float)(bits >> 8) * (1.0f / 16777216.0f));
+}
+
+__global__ __launch_bounds__(256) void reset_kernel(const VmasResetArgs A, int batch, int nE, int nA,
+                                                    const uint8_t* __restrict__ mask, float* __restrict__ state,
+                                                    float* __restrict__ agent_ft, long ld) {
+  const long env = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= batch || !mask[env]) return;  // unmasked environments are not touched
+  const uint32_t episode = A.episode[env] + 1u;
+  A.episode[env] = episode;
+  for (int i = 0; i < nE * 6; ++i) state[(long)i * ld + env] = 0.f;  // World.reset core.py:1184-1192
+  for (int i = 0; i < nA * 3; ++i) agent_ft[(long)i * ld + env] = 0.f;
+  auto px = [&](int e) -> float& { return state[((long)e * 6 + 0) * ld + env]; };
+  auto py = [&](int e) -> float& { return state[((long)e * 6 + 1) * ld + env]; };
+  const uint32_t k0 = (uint32_t)A.seed, k1 = (uint32_t)(A.seed >> 32);
+  for (int i = 0; i < A.n_ops; ++i) {
+    const VmasSpawnOp& op = A.ops[i];
+    float x = op.x_lo, y = op.y_lo;
+    if (op.kind == VMAS_SPAWN_UNIFORM) {
+      for (uint32_t tries = 0;; ++tries) {  // find_random_pos_for_entity utils.py:276-319, this environment's own loop
+        uint32_t c[4] = {(uint32_t)env, episode, ((uint32_t)i << 20) | tries, (uint32_t)((unsigned long)env >> 32)};
+        philox4x32(c, k0, k1);
+        x = uniform_in(c[0], op.x_lo, op.x_hi);
+        y = uniform_in(c[1], op.y_lo, op.y_hi);
+        bool overlaps = false;
+        for (int j = op.avoid_from; j < i; ++j) {
+          const int o = A.ops[j].entity;
+          overlaps = overlaps || norm2(px(o) - x, py(o) - y) < op.min_dist;  // torch.cdist(...) < min_dist
+        }
+        if (!overlaps || tries >= 4096u) break;  // (an infeasible placement ends after 4096 tries instead of hanging)
+      }
+    } else if (op.kind == VMAS_SPAWN_OFFSET) {
+      float dx = op.x_lo;
+      if (op.x_hi != op.x_lo) {
+        uint32_t c[4] = {(uint32_t)env, episode, (uint32_t)i << 20, (uint32_t)((unsigned long)env >> 32)};
+        philox4x32(c, k0, k1);
+        dx = uniform_in(c[0], op.x_lo, op.x_hi);
+      }
+      x = px(op.base) + dx;
+      y = py(op.base) + op.y_lo;
+    }
+    px(op.entity) = x;
+    py(op.entity) = y;
+  }
+  for (int t = 0; t < A.n_terms; ++t) {
+    const VmasResetTerm& T = A.terms[t];
+    T.out[env] = T.a < 0 ? T.factor : norm2(px(T.a) - px(T.b), py(T.a) - py(T.b)) * T.factor;
+  }
+  for (int f = 0; f < A.n_flags; ++f) A.flags[f][env] = 0;
+  if (A.steps != nullptr) A.steps[env] = 0.f;
+}
+
+int vmas_env_reset_where(const VmasResetArgs* a, int32_t batch, int32_t n_entities, int32_t n_agents, const uint8_t* mask,
+                         float* state, float* agent_ft, int64_t ld, void* stream) {
+  if (!a || !mask || !state || !a->episode) return host_fail("vmas_env_reset_where: null argument");
+  if (n_agents > 0 && !agent_ft) return host_fail("vmas_env_reset_where: world has agents but agent_ft is null");
+  if (batch <= 0 || ld < batch || n_entities <= 0) return host_fail("vmas_env_reset_where: bad batch / ld / n_entities");
+  if (a->n_ops < 0 || a->n_ops > VMAS_RESET_MAX_OPS || a->n_terms < 0 || a->n_terms > VMAS_RESET_MAX_TERMS ||
+      a->n_flags < 0 || a->n_flags > 8)
+    return host_fail("vmas_env_reset_where: too many operations / terms / flags");
+  for (int i = 0; i < a->n_ops; ++i) {
+    const VmasSpawnOp& op = a->ops[i];
+    if (op.kind < VMAS_SPAWN_UNIFORM || op.kind > VMAS_SPAWN_FIXED || op.entity < 0 || op.entity >= n_entities)
+      return host_fail("vmas_env_reset_where: malformed spawn operation");
+    if (op.kind == VMAS_SPAWN_OFFSET && (op.base < 0 || op.base >= n_entities))
+      return host_fail("vmas_env_reset_where: OFFSET operation without a base entity");
+    if (op.kind == VMAS_SPAWN_UNIFORM && (op.avoid_from < 0 || op.avoid_from > i))
+      return host_fail("vmas_env_reset_where: avoid_from must name an earlier operation");
+  }
+  for (int t = 0; t < a->n_terms; ++t)
+    if (!a->terms[t].out || a->terms[t].a >= n_entities || (a->terms[t].a >= 0 && (a->terms[t].b < 0 || a->terms[t].b >= n_entities)))
+      return host_fail("vmas_env_reset_where: malformed shaping term");
+  for (int f = 0; f < a->n_flags; ++f)
+    if (!a->flags[f]) return host_fail("vmas_env_reset_where: null flag tensor");
+  hipLaunchKernelGGL(reset_kernel, dim3((batch + 255) / 256), dim3(256), 0, (hipStream_t)stream, *a, batch, n_entities,
+                     n_agents, mask, state, agent_ft, (long)ld);
+  return check_launch("vmas_env_reset_where");
+}
+
 int vmas_balance_post_step(const VmasBalanceDesc* d, const VmasBalanceBuffers* o, int32_t batch, const float* state,
                            int64_t ld, void* stream) {
   if (check_balance_args(d, o, batch, state, ld, -1)) return -1;

@@ -1411,12 +1411,12 @@ struct VmasWorld {
   DevMaskPair* d_mpairs = nullptr;
   unsigned long long* d_trace = nullptr;
   std::map<int, Sched> scheds;
-  // vmas_world_step_n over two HIP queues (environments are independent: the launch gap of one half of the batch
-  // overlaps the compute of the other).  queues: 0 = library's choice, 1 = one queue, 2 = two
+  // vmas_world_step_n over several HIP queues (environments are independent: the launch gap of one part of the batch
+  // overlaps the compute of the others).  queues: 0 = library's choice, 1..MAX_QUEUES = that many
   int queues = 0;
-  bool resident = false;  // every tile of the batch is on the chip at once (select_config): the latency regime
-  hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  static constexpr int MAX_QUEUES = 4;
+  hipStream_t side[MAX_QUEUES - 1] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[MAX_QUEUES - 1] = {nullptr, nullptr, nullptr};
   // exact broad phase (VmasStepArgs.exact_broad_phase): grid barrier word + ring of mask slots for the in-kernel form,
   // one mask for the launch-per-substep form used when the grid is larger than the chip
   uint32_t* d_sync = nullptr;
@@ -1890,7 +1890,6 @@ static int select_config(VmasWorld* w) {
     build_items(w, best_mode);
   }
   w->lanes = best.nw;
-  w->resident = best.resident;
   return 0;
 }
 
@@ -2059,9 +2058,11 @@ void vmas_world_destroy(VmasWorld* w) {
   if (!w) return;
   (void)hipSetDevice(w->device);
   for (auto& kv : w->scheds) kv.second.release();
-  if (w->side) { (void)hipStreamSynchronize(w->side); (void)hipStreamDestroy(w->side); }
+  for (int q = 0; q < VmasWorld::MAX_QUEUES - 1; ++q) {
+    if (w->side[q]) { (void)hipStreamSynchronize(w->side[q]); (void)hipStreamDestroy(w->side[q]); }
+    if (w->ev_join[q]) (void)hipEventDestroy(w->ev_join[q]);
+  }
   if (w->ev_fork) (void)hipEventDestroy(w->ev_fork);
-  if (w->ev_join) (void)hipEventDestroy(w->ev_join);
   (void)hipFree(w->d_sync); (void)hipFree(w->d_exact_mask);
   (void)hipFree(w->d_mpairs); (void)hipFree(w->d_trace);
   (void)hipFree(w->d_lidars); (void)hipFree(w->d_targets); (void)hipFree(w->d_angles); (void)hipFree(w->d_queries);
@@ -2121,17 +2122,23 @@ int vmas_world_exact_status(VmasWorld* w) {
   return (int)flag;
 }
 
+// how many HIP queues a vmas_world_step_n of n_steps steps is spread over (see vmas_world_step_n)
+static int queues_for(const VmasWorld* w, int n_steps) {
+  const int tiles = blocks_of(w->batch);
+  int nq = w->queues;
+  if (nq == 0) nq = (tiles >= 2 * w->n_cu && n_steps >= 8) ? 2 : 1;  // the library's choice
+  while (nq > 1 && tiles < nq) --nq;  // at least one tile per queue
+  return nq;
+}
+
 int vmas_world_set_queues(VmasWorld* w, int32_t queues) {
   if (!w) return fail("vmas_world_set_queues: null world");
-  if (queues < 0 || queues > 2) return fail("vmas_world_set_queues: queues must be 0 (library's choice), 1 or 2, got %d", queues);
+  if (queues < 0 || queues > VmasWorld::MAX_QUEUES)
+    return fail("vmas_world_set_queues: queues must be 0 (library's choice) .. %d, got %d", VmasWorld::MAX_QUEUES, queues);
   w->queues = queues;
   return 0;
 }
-int vmas_world_get_queues(const VmasWorld* w, int32_t n_steps) {
-  if (!w) return 0;
-  const bool two = blocks_of(w->batch) >= 2 && (w->queues == 2 || (w->queues == 0 && w->resident && n_steps >= 8));
-  return two ? 2 : 1;
-}
+int vmas_world_get_queues(const VmasWorld* w, int32_t n_steps) { return w ? queues_for(w, n_steps) : 0; }
 
 int vmas_world_step(VmasWorld* w, float* state, float* agent_ft, int64_t ld, const VmasStepArgs* args, void* stream) {
   return step_impl(w, state, agent_ft, ld, args, stream, 1, 0);
@@ -2325,34 +2332,44 @@ int vmas_world_step_n(VmasWorld* w, float* state, float* agent_ft, int64_t ld, i
                       const VmasStepArgs* args, void* stream) {
   if (n_steps < 0) return fail("vmas_world_step_n: n_steps %d < 0", n_steps);
   if (!w) return fail("vmas_world_step_n: null world");
-  // Two queues: environments are independent, so the batch is cut at a tile boundary and the halves are stepped by
-  // two independent launch sequences - one on the caller's stream, one on a side stream forked from it and joined
+  // Several queues: environments are independent, so the batch is cut at tile boundaries and the parts are stepped by
+  // independent launch sequences - one on the caller's stream, the others on side streams forked from it and joined
   // back at the end.  A dependent launch costs ~2.9 us of front-end time during which the chip idles; with two
-  // sequences the gap of one half is filled by the kernel of the other.  Same kernels, same results bit for bit.
-  // Library's choice: when the whole batch is on the chip at once (the latency regime) and the sequence is long
-  // enough to pay for the fork and the join.
-  const int tiles = blocks_of(w->batch);
-  const bool two = !args && tiles >= 2 && (w->queues == 2 || (w->queues == 0 && w->resident && n_steps >= 8));
-  if (two) {
+  // sequences the gap of one part is filled by the kernel of the other, and the load / compute / store phases of the
+  // parts' tiles fall out of step and overlap.  Same kernels, same results bit for bit.
+  // Library's choice: when each half still has a tile for every CU (measured, profiles/r02_two_queues.txt: balance
+  // 32768 envs -15 %, 131072 -12 %, 1 M -4 %, football 131072 -8.5 %, navigation 65536 -15 %; transport 16384 = one tile
+  // per CU in total: +11 %, not split) and the sequence is long enough to pay for the fork and the join.
+  const int nq = !args ? queues_for(w, n_steps) : 1;
+  if (nq > 1) {
     int cur = -1;
     if (hipGetDevice(&cur) != hipSuccess || cur != w->device) HIP_TRY(hipSetDevice(w->device));
-    if (!w->side) {
-      HIP_TRY(hipStreamCreateWithFlags(&w->side, hipStreamNonBlocking));
-      HIP_TRY(hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming));
-      HIP_TRY(hipEventCreateWithFlags(&w->ev_join, hipEventDisableTiming));
-    }
+    if (!w->ev_fork) HIP_TRY(hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming));
+    for (int q = 0; q < nq - 1; ++q)
+      if (!w->side[q]) {
+        HIP_TRY(hipStreamCreateWithFlags(&w->side[q], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&w->ev_join[q], hipEventDisableTiming));
+      }
     hipStream_t s = (hipStream_t)stream;
-    const int first = (tiles / 2) * TILE;  // environments [0, first) on the caller's stream, [first, batch) on the side one
+    const int tiles = blocks_of(w->batch);
+    // queue q steps the tiles [q * tiles / nq, (q + 1) * tiles / nq): queue 0 = the caller's stream, the others are side
+    // streams forked from it here and joined back at the end
+    auto first_env = [&](int q) { return (int)((long)tiles * q / nq) * TILE; };
     HIP_TRY(hipEventRecord(w->ev_fork, s));
-    HIP_TRY(hipStreamWaitEvent(w->side, w->ev_fork, 0));
+    for (int q = 0; q < nq - 1; ++q) HIP_TRY(hipStreamWaitEvent(w->side[q], w->ev_fork, 0));
     int rc = 0;
     for (int i = 0; i < n_steps && !rc; ++i) {
       float* ft = agent_ft ? agent_ft + (int64_t)i * ft_step_stride : nullptr;
-      rc = step_impl(w, state, ft, ld, nullptr, (void*)s, 1, 0, nullptr, ENV_NONE, 0, 0, 0, first);
-      if (!rc) rc = step_impl(w, state, ft, ld, nullptr, (void*)w->side, 1, 0, nullptr, ENV_NONE, 0, 0, first, w->batch - first);
+      for (int q = 0; q < nq && !rc; ++q) {
+        const int lo = first_env(q), hi = q + 1 == nq ? w->batch : first_env(q + 1);
+        rc = step_impl(w, state, ft, ld, nullptr, q == 0 ? (void*)s : (void*)w->side[q - 1], 1, 0, nullptr, ENV_NONE, 0, 0,
+                       lo, hi - lo);
+      }
     }
-    HIP_TRY(hipEventRecord(w->ev_join, w->side));  // (joined even after a failed launch: the caller's stream stays ordered)
-    HIP_TRY(hipStreamWaitEvent(s, w->ev_join, 0));
+    for (int q = 0; q < nq - 1; ++q) {  // (joined even after a failed launch: the caller's stream stays ordered)
+      HIP_TRY(hipEventRecord(w->ev_join[q], w->side[q]));
+      HIP_TRY(hipStreamWaitEvent(s, w->ev_join[q], 0));
+    }
     return rc;
   }
   for (int i = 0; i < n_steps; ++i) {

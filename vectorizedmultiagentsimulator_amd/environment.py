@@ -21,6 +21,7 @@ from typing import Callable, Dict, List, Optional, Union
 import torch
 from torch import Tensor
 
+from ._abi import RESET_MAX_OPS as A_RESET_MAX_OPS, RESET_MAX_TERMS as A_RESET_MAX_TERMS
 from .core import Agent, World
 from .scenario import BaseScenario
 
@@ -62,7 +63,7 @@ class Environment:
         self._lidar_cache: Optional[Tensor] = None
         self.seed(seed)
         self.reset(return_observations=False)
-        self._ingest = self._post = None
+        self._ingest = self._post = self._masked_reset = None
         self._one_launch = self._ingest_in_step = False
         self._setup_fused()
 
@@ -101,6 +102,11 @@ class Environment:
         )
         if self._ingest_in_step:
             self._launch = F.StepLauncher(self, self._ingest)
+        # reset_where as one kernel over the masked environments (scenarios that state their reset as a spawn program)
+        prog = getattr(self.scenario, "fused_reset_program", None)
+        prog = prog() if prog is not None and type(self.scenario).env_reset_world_at is BaseScenario.env_reset_world_at else None
+        if prog is not None and len(prog["ops"]) <= A_RESET_MAX_OPS and len(prog.get("terms", [])) <= A_RESET_MAX_TERMS:
+            self._masked_reset = F.MaskedReset(self, prog, self._seed)
 
     batch_dim = property(lambda self: self.num_envs)
 
@@ -108,6 +114,9 @@ class Environment:
     def seed(self, seed: Optional[int] = None):
         if seed is None:
             seed = 0
+        self._seed = int(seed)
+        if getattr(self, "_masked_reset", None) is not None:
+            self._masked_reset.args.seed = self._seed & 0xFFFFFFFFFFFFFFFF
         torch.manual_seed(seed)
         if self.device.type == "cuda":
             torch.cuda.manual_seed(seed)
@@ -133,10 +142,21 @@ class Environment:
         device, without a host sync.  (The reference only has ``reset_at(i)``, one Python call per
         environment - SURVEY.md section 8f-4; a rollout over 32 768 environments resets hundreds per step.)
 
-        A fresh initial state is drawn for every environment by the scenario's own vectorised reset and
-        blended in where the mask is set: the packed world state, the agent forces, the step counter and the
-        scenario's in-place tensors (``scenario.keep``).  Unmasked environments keep their bits."""
-        mask = mask.to(self.device).reshape(self.num_envs).bool()
+        Scenarios that state their reset as a spawn program (``fused_reset_program``: balance, transport, navigation)
+        run ONE kernel that draws only the masked environments - ``World.reset`` + the placement law of
+        ``reset_world_at`` with the reference's minimum-distance rejection (utils.py:241-319) on a counter-based
+        generator keyed by (seed, environment, that environment's episode number) + the scenario's cached terms -
+        and touches nothing else.  Otherwise a fresh initial state is drawn for every environment by the scenario's
+        own vectorised reset and blended in where the mask is set (packed state, agent forces, step counter, the
+        scenario's in-place tensors).  Either way unmasked environments keep their bits."""
+        mask = mask.to(self.device).reshape(self.num_envs).bool().contiguous()
+        if self._masked_reset is not None:
+            # ONE launch over the masked environments (vmas_env_reset_where): World.reset + the scenario's spawn program on
+            # a counter-based generator + its cached terms; unmasked environments are not touched
+            self._masked_reset(mask)
+            self.world.invalidate_queries()
+            self._lidar_cache = None
+            return self._observations() if return_observations else None
         persistent = self._persistent_tensors()
         saved = [t.clone() for t in persistent]
         self.scenario.env_reset_world_at(env_index=None)

@@ -192,6 +192,63 @@ class ActionIngest:
         self.launch(validate)
 
 
+class MaskedReset:
+    """``vmas_env_reset_where``: Environment.reset_at for every masked environment in one launch.
+
+    The scenario describes its ``reset_world_at`` as a spawn program (``scenario.fused_reset_program()``):
+    ``ops``   - ("uniform", entity, (x_lo, x_hi), (y_lo, y_hi), min_dist, avoid_from_op) |
+                ("offset", entity, base_entity, (dx_lo, dx_hi), dy) | ("fixed", entity, x, y), in placement order;
+    ``terms`` - (tensor [B], entity_a, entity_b, factor): tensor[env] = |pos(a) - pos(b)| * factor, or
+                (tensor [B], None, None, value): tensor[env] = value;
+    ``flags`` - bool tensors [B] cleared for a reset environment."""
+
+    def __init__(self, env, program: dict, seed: int):
+        self.env, self.lib = env, A.load_library()
+        w = env.world
+        args = A.ResetArgs()
+        ops, terms, flags = program["ops"], program.get("terms", []), program.get("flags", [])
+        assert len(ops) <= A.RESET_MAX_OPS and len(terms) <= A.RESET_MAX_TERMS and len(flags) <= 8
+        args.n_ops, args.n_terms, args.n_flags = len(ops), len(terms), len(flags)
+        for i, op in enumerate(ops):
+            o = args.ops[i]
+            if op[0] == "uniform":
+                _, ent, xb, yb, min_dist, avoid_from = op
+                o.kind, o.entity, o.avoid_from = A.SPAWN_UNIFORM, ent._index, int(avoid_from)
+                o.x_lo, o.x_hi, o.y_lo, o.y_hi, o.min_dist = float(xb[0]), float(xb[1]), float(yb[0]), float(yb[1]), float(min_dist)
+            elif op[0] == "offset":
+                _, ent, base, dxb, dy = op
+                o.kind, o.entity, o.base = A.SPAWN_OFFSET, ent._index, base._index
+                o.x_lo, o.x_hi, o.y_lo = float(dxb[0]), float(dxb[1]), float(dy)
+            else:
+                _, ent, x, y = op
+                o.kind, o.entity, o.x_lo, o.y_lo = A.SPAWN_FIXED, ent._index, float(x), float(y)
+        self._terms = terms
+        for i, (t, a, b, f) in enumerate(terms):
+            T = args.terms[i]
+            T.a, T.b, T.factor = (a._index, b._index, float(f)) if a is not None else (-1, -1, float(f))
+        self._flags = flags
+        self.episode = torch.zeros(env.num_envs, dtype=torch.int32, device=env.device)
+        args.episode = self.episode.data_ptr()
+        args.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.args = args
+        self.nE, self.nA = len(w.entities), len(w.agents)
+
+    def __call__(self, mask: Tensor):
+        env, w, a = self.env, self.env.world, self.args
+        for i, (t, *_rest) in enumerate(self._terms):  # (the scenario may have rebound its tensors since the last call)
+            t = t() if callable(t) else t
+            assert t.shape == (env.num_envs,) and t.dtype == torch.float32 and t.is_contiguous()
+            a.terms[i].out = t.data_ptr()
+        for i, t in enumerate(self._flags):
+            t = t() if callable(t) else t
+            assert t.shape == (env.num_envs,) and t.dtype == torch.bool and t.is_contiguous()
+            a.flags[i] = t.data_ptr()
+        a.steps = env.steps.data_ptr()
+        st, ft = w._packed_state(), w._packed_agent_ft()
+        _check(self.lib.vmas_env_reset_where(C.byref(a), env.num_envs, self.nE, self.nA, mask.data_ptr(), st.data_ptr(),
+                                             ft.data_ptr(), st.shape[-1], _stream(env.device)))
+
+
 class StepLauncher:
     """``vmas_world_step_env`` with every argument that does not change between steps marshalled once
     (world handle, buffer pointers, the ingest struct): the Python side of a one-launch step is then

@@ -116,6 +116,23 @@ class Scenario(BaseScenario):
     def info(self, agent):
         return {"pos_rew": self.pos_rew, "ground_rew": self.ground_rew}
 
+    def fused_reset_program(self):
+        """``reset_world_at`` (balance.py:86-216) as a spawn program for the masked-reset kernel (fused.MaskedReset)."""
+        w = self.world
+        half, r_pkg, r = self.line_length / 2, self.package.shape.radius, self.agent_radius
+        line_y = -w.y_semidim + r * 2
+        spread = (half - r_pkg) if self.random_package_pos_on_line else 0.0
+        span = self.line_length - r
+        ops = [("uniform", self.goal, (-1.0, 1.0), (0.0, w.y_semidim), 0.0, 0),
+               ("uniform", self.line, (-1.0 + half, 1.0 - half), (line_y, line_y), 0.0, 1),
+               ("offset", self.package, self.line, (-spread, spread), r_pkg)]
+        for i, agent in enumerate(w.agents):
+            dx = -span / 2 + i * span / (self.n_agents - 1)
+            ops.append(("offset", agent, self.line, (dx, dx), -r * 2))
+        ops.append(("fixed", self.floor, 0.0, -w.y_semidim - self.floor.shape.width / 2 - r))
+        return {"ops": ops, "terms": [(lambda: self.global_shaping, self.package, self.goal, self.shaping_factor)],
+                "flags": [lambda: self.on_the_ground]}
+
     def make_fused_post(self, env):
         """reward + observation + done + info of every agent as one kernel (fused.BalancePost)."""
         from ..fused import BalancePost

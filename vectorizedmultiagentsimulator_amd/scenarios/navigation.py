@@ -142,6 +142,17 @@ class Scenario(BaseScenario):
         return {"pos_rew": self.pos_rew if self.shared_rew else agent.pos_rew, "final_rew": self.final_rew,
                 "agent_collisions": agent.agent_collision_rew}
 
+    def fused_reset_program(self):
+        """``reset_world_at`` (navigation.py:137-198) as a spawn program: agents, then one goal per agent, all at the
+        minimum distance from everything placed before.  Shared goals are a post-processing of the draws: tensor path."""
+        if self.agents_with_same_goal > 1 or self.split_goals:
+            return None
+        w = self.world
+        xb, yb = (-self.world_spawning_x, self.world_spawning_x), (-self.world_spawning_y, self.world_spawning_y)
+        ops = [("uniform", e, xb, yb, self.min_distance_between_entities, 0) for e in list(w.agents) + [a.goal for a in w.agents]]
+        terms = [(lambda a=a: a.pos_shaping, a, a.goal, self.pos_shaping_factor) for a in w.agents]
+        return {"ops": ops, "terms": terms, "flags": []}
+
     def make_fused_post(self, env):
         """reward + observation (LIDAR included) + done + info as one kernel (fused.NavigationPost)."""
         from ..fused import NavigationPost

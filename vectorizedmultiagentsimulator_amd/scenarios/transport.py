@@ -76,6 +76,17 @@ class Scenario(BaseScenario):
     def done(self):
         return torch.stack([p.on_goal for p in self.packages], dim=1).all(dim=-1)
 
+    def fused_reset_program(self):
+        """``reset_world_at`` (transport.py:86-129) as a spawn program: the agents, then the goal and the packages, each
+        kept at its call's minimum distance from everything placed before (ScenarioUtils.spawn_entities_randomly)."""
+        w = self.world
+        b = (-self.world_semidim, self.world_semidim)
+        ops = [("uniform", a, b, b, self.agent_radius * 2, 0) for a in w.agents]
+        min_dist = max(p.shape.circumscribed_radius() + self.goal.shape.radius + 0.01 for p in self.packages)
+        ops += [("uniform", e, b, b, min_dist, 0) for e in [self.goal] + self.packages]
+        terms = [(lambda p=p: p.global_shaping, p, p.goal, self.shaping_factor) for p in self.packages]
+        return {"ops": ops, "terms": terms, "flags": [(lambda p=p: p.on_goal) for p in self.packages]}
+
     def make_fused_post(self, env):
         """reward + observation + done of every agent as one kernel (fused.TransportPost)."""
         from .. import _abi
