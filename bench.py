@@ -54,6 +54,7 @@ def parse_args():
     ap.add_argument("--num-envs", type=int, default=32768, help="environments PER GPU")
     ap.add_argument("--n-agents", type=int, default=4)
     ap.add_argument("--lanes", type=int, default=0, help="lanes per environment (0 = library default)")
+    ap.add_argument("--queues", type=int, default=0, help="HIP queues of vmas_world_step_n (0 = library's choice, 1..4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused", action="store_true", help="skip the secondary measurements (env_step, persistent rollout)")
     ap.add_argument("--no-gather", action="store_true", help="skip the rollout all-gather timing (N > 1)")
@@ -158,8 +159,7 @@ def cpu_reference(w, actions, state0_cpu, n_agents, budget_s=10.0):
     from oracle import ref
 
     B = w.batch_dim
-    threads = os.cpu_count() or 1
-    torch.set_num_threads(threads)
+    ncpu = os.cpu_count() or 1
     env = ref.make_env("balance", num_envs=B, device="cpu", seed=0, continuous_actions=True, n_agents=n_agents)
     world = env.world
     assert [e.name for e in world.entities] == [e.name for e in w.entities], "entity order differs from the reference's"
@@ -180,6 +180,27 @@ def cpu_reference(w, actions, state0_cpu, n_agents, budget_s=10.0):
     def env_step(k):
         env.step([actions[k % EPISODE, i] * a.u_range for i, a in enumerate(env.agents)])
 
+    # torch's intra-op thread count that is actually fastest on this host: World.step is ~2800 small aten calls per step,
+    # and os.cpu_count() threads (the survey's plan) can be pathological - 256 threads measured 58 s per step on a pool
+    # box against 50 ms with 8.  Probed in ascending order on World.step, stopping once a count is clearly slower.
+    probed, best = {}, (float("inf"), 1)
+    with torch.no_grad():
+        for th in sorted({4, 8, 16, 32, 64, min(ncpu, 128), ncpu}):
+            if th > ncpu:
+                continue
+            torch.set_num_threads(th)
+            restore()
+            world_step(0)
+            t0 = time.perf_counter()
+            world_step(1)
+            dt = time.perf_counter() - t0
+            probed[th] = round(dt * 1e3, 2)
+            if dt < best[0]:
+                best = (dt, th)
+            elif dt > 1.3 * best[0]:
+                break
+    threads = best[1]
+    torch.set_num_threads(threads)
     out = {}
     with torch.no_grad():
         for name, fn in (("world_step", world_step), ("env_step", env_step)):
@@ -197,7 +218,8 @@ def cpu_reference(w, actions, state0_cpu, n_agents, budget_s=10.0):
             out[name] = {"value": B * n * w.substeps / el, "ms_per_step": el / n * 1e3, "steps": n, "seconds": el}
     return {
         "value": out["world_step"]["value"], "unit": "env-steps/s", "cores": threads, "kind": "reference",
-        "torch_threads": torch.get_num_threads(),
+        "torch_threads": torch.get_num_threads(), "host_cpus": ncpu,
+        "ms_per_world_step_by_threads": probed,
         "sample": f"{out['world_step']['steps']} World.step() (vmas/simulator/core.py:1972) of the reference's balance "
                   f"n_agents={n_agents} x {B} envs on device='cpu', same initial state and actions as the GPU run, "
                   f"{out['world_step']['seconds']:.1f} s ({out['world_step']['ms_per_step']:.1f} ms/step); 2 warm-up steps",
@@ -315,6 +337,7 @@ def main():
 
     sc, w = build_world(shard.local_envs, device, args.n_agents, args.lanes, seed=shard.seed(0))
     be = w._get_backend()
+    be.set_queues(args.queues)
     state0 = w._state.clone()
     actions = make_actions(EPISODE, args.n_agents, args.num_envs, 1234 + rank)
     forces = pack_forces(w, actions, device)
@@ -390,10 +413,22 @@ def main():
         except Exception as e:  # never let a secondary leg break the bench line
             env_leg = {"error": repr(e)}
 
+    # ---- the same K launches on ONE queue (what rocprofv3's per-kernel durations describe); then the headline
+    single = None
+    if not args.fused:
+        be.set_queues(1)
+        run(args.warmup)
+        ev_1, wall_1 = timed(lambda n: run(n, start=args.warmup), args.steps)
+        single = {"value": world_size * args.num_envs * w.substeps * args.steps / ev_1, "unit": "env-steps/s",
+                  "us_per_step": ev_1 / args.steps * 1e6,
+                  "note": "vmas_world_set_queues(1): one launch per step on one HIP queue; its time per step is the "
+                          "kernel's launch-to-launch time and agrees with rocprofv3's per-kernel duration + launch gap"}
+        be.set_queues(args.queues)
     # ---- headline: W warm-up steps, then exactly K World.step launches
     run(args.warmup)
     ev_s, wall_s = timed(lambda n: run(n, start=args.warmup), args.steps)
     kernel_s = ev_s / args.steps
+    n_queues = 1 if args.fused else be.queues(min(EPISODE, args.steps))
 
     if rank == 0:
         bytes_per_env = be.step_bytes_per_env()
@@ -424,7 +459,11 @@ def main():
                 "global_envs": world_size * args.num_envs,
                 "substeps": w.substeps,
                 "lanes_per_env": be.lanes_per_env,
-                "launch": "persistent rollout (vmas_world_rollout)" if args.fused else "one launch per step",
+                "launch": "persistent rollout (vmas_world_rollout)" if args.fused else (
+                    "one launch per step" if n_queues == 1 else
+                    f"one launch per step and per part of the batch: {n_queues} HIP queues, {n_queues} launches per "
+                    f"World.step of the whole batch (vmas_world_step_n, environments are independent)"),
+                "queues": n_queues,
                 "parallelism": f"env-sharded x{world_size}",
             },
             "roofline": {
@@ -436,7 +475,11 @@ def main():
                 "traffic": None,
                 "kernel": "step_kernel",
                 "kernel_us": kernel_s * 1e6,
-                "bytes_per_launch": bytes_per_env * args.num_envs,
+                "kernel_us_is": "time per World.step of the whole batch from the HIP events (region / K)" + (
+                    "" if n_queues == 1 else f"; {n_queues} launches of {args.num_envs // n_queues} environments each "
+                    "overlap in it - rocprofv3's per-launch durations add up to more than this, see `single_queue`"),
+                "bytes_per_launch": bytes_per_env * args.num_envs // n_queues,
+                "launches_per_step": n_queues,
                 "gflops": gflops,
                 "gflops_frac_of_fp32_vector_peak": gflops / FP32_PEAK_GFLOPS,
                 "binds": "neither roof at this batch: one launch moves 12.6 MB (1.6 us at 8 TB/s) and 56 Mflop "
@@ -444,6 +487,9 @@ def main():
                          "(profiles/r02_*_pmc_summary.txt: ~60 % of wave-cycles waiting). HBM is the nominal bound.",
             },
         }
+        if single is not None:
+            single["roofline_frac"] = bytes_per_env * args.num_envs / (single["us_per_step"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+            out["single_queue"] = single
         if env_leg is not None:
             out["env_step"] = env_leg
         if persistent is not None:

@@ -9,7 +9,7 @@ for n in 1572864 134217728; do   # 6.3 MB (cache resident between dispatches, li
 import csv, glob, sys
 n, c = int(sys.argv[1]), sys.argv[2]
 f = glob.glob('/tmp/cal/**/*counter_collection.csv', recursive=True)[0]
-v = [float(r['Counter_Value']) for r in csv.DictReader(open(f)) if 'softplus' in r['Kernel_Name'] and r['Counter_Name'] == c]
+v = [float(r['Counter_Value']) for r in csv.DictReader(open(f)) if 'math_kernel' in r['Kernel_Name'] and r['Counter_Name'] == c]
 v = v[2:]  # first dispatches: cold
 m = sum(v) / len(v)
 print(f"n={n} ({4*n/2**20:.1f} MiB each way) {c}: {m:.1f} KiB per dispatch = {m*1024/(4*n):.4f} of the known bytes")

@@ -3,7 +3,7 @@
 # writes gpurun_out/r02/TAG_kernel_stats.csv and gpurun_out/r02/TAG_pmc_summary.txt (copy to profiles/ to keep).
 TAG=$1; BPE=$2; FPE=$3; ENVS=$4; shift 5
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/r02; mkdir -p $OUT
+OUT=$R/gpurun_out/${EVIDENCE_DIR:-r02}; mkdir -p $OUT
 W=/tmp/cnt_$TAG; rm -rf $W; mkdir -p $W
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $W/trace -o t -- "$@" > $W/trace.log 2>&1

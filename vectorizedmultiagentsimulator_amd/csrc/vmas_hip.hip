@@ -1338,6 +1338,17 @@ __global__ void math_kernel(int op, const float* __restrict__ a, const float* __
 // ------------------------------------------------------------------------------------
 // host side: the C ABI
 // ------------------------------------------------------------------------------------
+// A/B and profiling knobs (VMAS_ABLATE, VMAS_TRACE, VMAS_SHARE, VMAS_NO_SSQ ...) are read from the environment only
+// in -DVMAS_PROFILE builds (libvmas_hip_profile.so, scripts/gpu_*.sh); the product library has none.
+static inline const char* knob(const char* name) {
+#ifdef VMAS_PROFILE
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
+
 static thread_local char g_err[512] = "";
 static int fail(const char* fmt, ...) {
   va_list ap;
@@ -1462,7 +1473,7 @@ static void build_items(VmasWorld* w, int share_mode) {
   // sphere-sphere partners of one entity are consecutive (type-major order): pack them four to
   // a record when the item list will live in LDS (the packed form is read from the blob only)
   const bool pack_ss = (size_t)(2 * n_pairs + 2 * n_joints) * sizeof(DevItem) <= (size_t)ITEMS_LDS_BUDGET &&
-                       n_pairs < 65536 && !getenv("VMAS_NO_SSQ");
+                       n_pairs < 65536 && !knob("VMAS_NO_SSQ");
   // ... and a pair/joint of TWO dynamic entities is evaluated once for both (same condition: blob records only)
   const bool share = share_mode > 0 && pack_ss && nE * 6 * ROWF < 65536;
   std::vector<DevItem> units;
@@ -1578,7 +1589,7 @@ static void build_items(VmasWorld* w, int share_mode) {
         if (t.type == VMAS_PAIR_LL || t.type == VMAS_PAIR_BL || t.type == VMAS_PAIR_BB || t.type == TASK_JOINT) level0 = false;
     for (const DevItem& t : units)
       if (t.type == VMAS_PAIR_LL || t.type == VMAS_PAIR_BL || t.type == VMAS_PAIR_BB || t.type == TASK_JOINT) level0 = false;
-    for (int e = 0; e < nE && level0 && !getenv("VMAS_NO_LSQ"); ++e) {
+    for (int e = 0; e < nE && level0 && !knob("VMAS_NO_LSQ"); ++e) {
       std::vector<DevItem> packed;
       size_t i = 0;
       auto packable = [](const DevItem& it) {
@@ -1742,7 +1753,7 @@ static int build_sched(VmasWorld* w, int nw, Sched& S) {
   std::vector<DevSegment> segs_sorted;
   for (int si : order) segs_sorted.push_back(segs[si]);
   std::vector<DevOwned> owned = owned_all;
-  if (getenv("VMAS_DEBUG_SCHED")) {
+  if (knob("VMAS_DEBUG_SCHED")) {
     fprintf(stderr, "[sched nw=%d] %d own + %d shared items, %d shared rows, %zu refs\n", nw, w->unit_item_begin,
             (int)w->items.size() - w->unit_item_begin, w->n_shared_rows, w->refs.size());
     for (int si : order) {
@@ -1790,7 +1801,7 @@ static int build_sched(VmasWorld* w, int nw, Sched& S) {
   S.dw.off_blob = row_bad * ROWF;  // (row_bad: the first row after the partial sums)
   S.dw.fired_recs = w->fired_recs;
   S.lds_bytes = ((size_t)row_bad * ROWF + S.dw.blob_words + 4 + 4) * sizeof(float);  // + work counters, fired words (2 parities x 2)
-  if (getenv("VMAS_DEBUG_SCHED")) fprintf(stderr, "[sched nw=%d] %d segments, LDS %zu B per tile\n", nw, (int)segs.size(), S.lds_bytes);
+  if (knob("VMAS_DEBUG_SCHED")) fprintf(stderr, "[sched nw=%d] %d segments, LDS %zu B per tile\n", nw, (int)segs.size(), S.lds_bytes);
   return 0;
 }
 
@@ -1860,7 +1871,7 @@ static int choose_lanes(VmasWorld* w, int n_cu, LaneChoice* out) {
 // waves per tile, else fewer; then the higher mode.  (Measured, DESIGN.md: football at 16384 envs 31.1 -> 28.8 us with
 // everything shared, at 131072 envs - two resident tiles per CU without the rows, one with - 224 -> 351 us.)
 static int select_config(VmasWorld* w) {
-  static const int share_env = getenv("VMAS_SHARE") ? atoi(getenv("VMAS_SHARE")) : -1;  // (A/B measurements)
+  static const int share_env = knob("VMAS_SHARE") ? atoi(knob("VMAS_SHARE")) : -1;  // (A/B measurements)
   int best_mode = -1;
   LaneChoice best;
   for (int mode = 2; mode >= 0; --mode) {
@@ -2182,7 +2193,7 @@ static int step_env_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld
     return fail("vmas_world_step_env: null post-step descriptor");
   if (post_kind == VMAS_POST_NONE && !ingest) return fail("vmas_world_step_env: neither actions nor a post-step given");
   DevEnv env{};
-  static const int env_ablate = getenv("VMAS_ENV_ABLATE") ? atoi(getenv("VMAS_ENV_ABLATE")) : 0;
+  static const int env_ablate = knob("VMAS_ENV_ABLATE") ? atoi(knob("VMAS_ENV_ABLATE")) : 0;
   env.ablate = env_ablate;
   env.err_flags = err_flags;
   for (int a = 0; a < VMAS_ENV_MAX_AGENTS; ++a) env.script_of_agent[a] = -1;
@@ -2244,8 +2255,8 @@ static int step_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld, co
       return fail("vmas_world_step: first_substep %d outside [0,%d)", a.first_substep, w->base.substeps);
   }
   {
-    static const int ablate = getenv("VMAS_ABLATE") ? atoi(getenv("VMAS_ABLATE")) : 0;
-    static const int trace = getenv("VMAS_TRACE") ? atoi(getenv("VMAS_TRACE")) : 0;
+    static const int ablate = knob("VMAS_ABLATE") ? atoi(knob("VMAS_ABLATE")) : 0;
+    static const int trace = knob("VMAS_TRACE") ? atoi(knob("VMAS_TRACE")) : 0;
     a.ablate = ablate;
     if (trace) {
       const size_t n = (size_t)((w->batch + TILE - 1) / TILE) * 16 * 16;
@@ -2470,7 +2481,7 @@ int vmas_world_cast_rays(VmasWorld* w, const float* state, int64_t ld, float* ou
   if (w->n_lidars <= 0) return fail("vmas_world_cast_rays: no sensors registered (vmas_world_set_lidars)");
   // rays per thread: few when the batch alone cannot fill the chip (latency-bound), more when it
   // can (each thread then reads its targets once for several rays); VMAS_LIDAR_RPT overrides
-  static const int force_rpt = getenv("VMAS_LIDAR_RPT") ? atoi(getenv("VMAS_LIDAR_RPT")) : 0;
+  static const int force_rpt = knob("VMAS_LIDAR_RPT") ? atoi(knob("VMAS_LIDAR_RPT")) : 0;
   const long threads = (long)w->batch * w->n_lidars;
   int rpt = force_rpt ? force_rpt : (threads >= (1L << 19) ? 4 : 2);  // measured: navigation 8x12 rays, B = 8192 / 65536
   const dim3 block(256);
