@@ -102,6 +102,8 @@ struct DevSegment {
   int32_t item_begin, item_end;
   int32_t first;     // 1: this segment starts from the entity's prologue force
   int32_t part_off;  // tile offset of its 3 partial-sum rows (fx, fy, torque)
+  uint32_t eflags;   // the entity's VMAS_F_* flags (saves the dependent fetch of its descriptor)
+  int32_t pad;       // (32 bytes: the record is two ds_read_b128)
 };
 
 struct DevOwned {  // phase C work unit: everything the integration of one entity needs, ONE LDS round trip (6 x 16 bytes)
@@ -261,20 +263,21 @@ struct ItemV {
   int32_t oa, ob, tra, trb;
   float thr2, reach, p0, p1, p2, p3, q0, q1;
 };
-__device__ __forceinline__ ItemV load_item(const uint32_t* p) {
-  const uint4 w0 = ((const uint4*)p)[0], w1 = ((const uint4*)p)[1], w2 = ((const uint4*)p)[2], w3 = ((const uint4*)p)[3];
+// The 16 words of one item record, as fetched (uniform address: broadcast read).  The gather loops fetch record i + 1
+// while record i is evaluated: the record's LDS round trip is off the wave's dependent chain.
+struct ItemW { uint4 w0, w1, w2, w3; };
+__device__ __forceinline__ ItemW fetch_words(const uint32_t* p) {
+  ItemW r;
+  r.w0 = ((const uint4*)p)[0]; r.w1 = ((const uint4*)p)[1]; r.w2 = ((const uint4*)p)[2]; r.w3 = ((const uint4*)p)[3];
+  return r;
+}
+__device__ __forceinline__ ItemV load_item(const ItemW& I) {
+  const uint4 w0 = I.w0, w1 = I.w1, w2 = I.w2, w3 = I.w3;
   ItemV K;
   K.type = sgpr((int)w0.x); K.side = sgpr((int)w0.y); K.flags = (uint32_t)sgpr((int)w0.z); K.index = sgpr((int)w0.w);
   K.oa = (int)w1.x; K.ob = (int)w1.y; K.tra = (int)w1.z; K.trb = (int)w1.w;
   K.thr2 = __uint_as_float(w2.x); K.reach = __uint_as_float(w2.y); K.p0 = __uint_as_float(w2.z); K.p1 = __uint_as_float(w2.w);
   K.p2 = __uint_as_float(w3.x); K.p3 = __uint_as_float(w3.y); K.q0 = __uint_as_float(w3.z); K.q1 = __uint_as_float(w3.w);
-  return K;
-}
-__device__ __forceinline__ ItemV item_from_global(const DevItem& D) {
-  ItemV K;
-  K.type = D.type; K.side = D.side; K.flags = D.flags; K.index = D.index;
-  K.oa = D.oa; K.ob = D.ob; K.tra = D.tra; K.trb = D.trb;
-  K.thr2 = D.thr2; K.reach = D.reach; K.p0 = D.p0; K.p1 = D.p1; K.p2 = D.p2; K.p3 = D.p3; K.q0 = D.q0; K.q1 = D.q1;
   return K;
 }
 struct EntV {
@@ -299,9 +302,9 @@ static_assert(sizeof(DevItem) == 64 && sizeof(DevEntity) == 68, "descriptor layo
 // One descriptor fetch and eight position reads in flight instead of four dependent round
 // trips; the forces are added to F one by one, in the reference's order.  Both sides of a
 // sphere pair see force(own, other): cf(a,b) == -cf(b,a) bit for bit, so no sign flip is needed.
-__device__ __forceinline__ void eval_ssq(const uint32_t* p, const DevWorld& W, const DevStepArgs& args,
+__device__ __forceinline__ void eval_ssq(const ItemW& I, const DevWorld& W, const DevStepArgs& args,
                                          const float* tile, bool movable, v2& F) {
-  const uint4 w0 = ((const uint4*)p)[0], w1 = ((const uint4*)p)[1], w2 = ((const uint4*)p)[2], w3 = ((const uint4*)p)[3];
+  const uint4 w0 = I.w0, w1 = I.w1, w2 = I.w2, w3 = I.w3;
   const int n = sgpr((int)w0.y);
   const float* E = tile + (int)w1.x;
   const v2 pe = V(E[0], E[ROWF]);
@@ -339,9 +342,9 @@ __device__ __forceinline__ void eval_ssq(const uint32_t* p, const DevWorld& W, c
 //   w2: half lengths 0..3   w3: pair index 0|1<<16, 2|3<<16
 // Same arithmetic as the unpacked item (own(-cf(sphere, cp)) with the b-side sign flip == cf(sphere, cp) bit for
 // bit), one descriptor fetch and sixteen operand reads in flight instead of four dependent round trips.
-__device__ __forceinline__ void eval_lsq(const uint32_t* p, const DevWorld& W, const DevStepArgs& args,
+__device__ __forceinline__ void eval_lsq(const ItemW& I, const DevWorld& W, const DevStepArgs& args,
                                          const float* tile, bool movable, v2& F) {
-  const uint4 w0 = ((const uint4*)p)[0], w1 = ((const uint4*)p)[1], w2 = ((const uint4*)p)[2], w3 = ((const uint4*)p)[3];
+  const uint4 w0 = I.w0, w1 = I.w1, w2 = I.w2, w3 = I.w3;
   const int n = sgpr((int)w0.y);
   const float* E = tile + (int)w0.z;
   const float dist_min = __uint_as_float(w0.w);
@@ -396,9 +399,9 @@ __device__ __forceinline__ void eval_lsq(const uint32_t* p, const DevWorld& W, c
 // to the pair's two LDS rows, b's owner reads it with the sign flipped (cf(a,b) == -cf(b,a) bit for bit).
 //   w0: type, n, tile offset of the first pair's rows (pair k: + 2k rows), -
 //   w1: a offsets 0|1<<16, 2|3<<16, b offsets 0|1<<16, 2|3<<16   w2: r_sum 0..3   w3: pair index 0|1<<16, 2|3<<16
-__device__ __forceinline__ void eval_ssp(const uint32_t* p, const DevWorld& W, const DevStepArgs& args, float* tile,
+__device__ __forceinline__ void eval_ssp(const ItemW& I, const DevWorld& W, const DevStepArgs& args, float* tile,
                                          uint32_t* fired) {
-  const uint4 w0 = ((const uint4*)p)[0], w1 = ((const uint4*)p)[1], w2 = ((const uint4*)p)[2], w3 = ((const uint4*)p)[3];
+  const uint4 w0 = I.w0, w1 = I.w1, w2 = I.w2, w3 = I.w3;
   const int n = sgpr((int)w0.y);
   const int rec = sgpr((int)w0.w);  // ordinal among the shared sphere-sphere records
   float* R = tile + (int)w0.z;
@@ -831,19 +834,30 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
     unsigned long long tg = TNOW();
 #endif
     for (int si = first_dyn ? wv : grab(c_gather); si < W.n_segs; si = grab(c_gather)) {
-      const uint32_t* sp = blob + W.b_segs + si * SW;
-      const int e = sgpr((int)sp[0]);
-      const float* Es = tile + (int)sp[1];
-      const int i0 = sgpr((int)sp[2]), i1s = sgpr((int)sp[3]), first = sgpr((int)sp[4]);
+      const uint4 s0 = ((const uint4*)(blob + W.b_segs + si * SW))[0], s1 = ((const uint4*)(blob + W.b_segs + si * SW))[1];
+      const int e = sgpr((int)s0.x);
+      const float* Es = tile + (int)s0.y;
+      const int i0 = sgpr((int)s0.z), i1s = sgpr((int)s0.w), first = sgpr((int)s1.x);
+      // item records: record i + 1 is fetched while record i is evaluated (LDS copy; the global copy of worlds whose item
+      // list does not fit the LDS budget holds the same 16 words per item)
+      auto item_words = [&](int ii) {
+        return W.items_in_lds ? fetch_words(blob + W.b_items + ii * IW) : fetch_words((const uint32_t*)(W.items + ii));
+      };
+      const int i1 = (ABLATE(args) & 1) ? i0 : i1s;
+      // (only the lean kernels have the 16 registers to spare: the general and multi-substep variants sit at the 128-VGPR
+      // limit of 1024-thread blocks, the box-box level at three waves per SIMD)
+      constexpr bool PREFETCH = PLAIN >= 2 && LEVEL < 2;
+      ItemW cur;
+      if (PREFETCH && i0 < i1) cur = item_words(i0);
       if (e < 0) {  // a run of SHARED pairs/joints (both entities dynamic): evaluated once, both owners read the rows in phase C
-        const int i1u = (ABLATE(args) & 1) ? i0 : i1s;
-        for (int ii = i0; ii < i1u; ++ii) {
-          const uint32_t* ip = blob + W.b_items + ii * IW;
-          if (sgpr((int)ip[0]) == TASK_SSP) {
-            eval_ssp(ip, W, args, tile, fired);
+        for (int ii = i0; ii < i1; ++ii) {
+          const ItemW I = PREFETCH ? cur : item_words(ii);
+          if (PREFETCH && ii + 1 < i1) cur = item_words(ii + 1);
+          if (sgpr((int)I.w0.x) == TASK_SSP) {
+            eval_ssp(I, W, args, tile, fired);
             continue;
           }
-          const ItemV K = load_item(ip);
+          const ItemV K = load_item(I);
           v2 f = V(0.f, 0.f);
           float ta = 0.f, tb = 0.f;
           if (!(ABLATE(args) & 16)) eval_item<LEVEL>(K, W, args, tile, env, live, ld, f, ta, tb);
@@ -856,8 +870,8 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
 #endif
         continue;
       }
-      float* P = tile + (int)sp[5];
-      const uint32_t efl = (uint32_t)sgpr((int)blob[W.b_ent + e * EW]);
+      float* P = tile + (int)s1.y;
+      const uint32_t efl = (uint32_t)sgpr((int)s1.z);
       v2 F = V(0.f, 0.f);
       float Tq = 0.f;
 #ifdef VMAS_TRACE
@@ -916,19 +930,20 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
 #ifdef VMAS_TRACE
       { unsigned long long t1 = TNOW(); acc_pro += t1 - tg; tg = t1; }
 #endif
-      const int i1 = (ABLATE(args) & 1) ? i0 : i1s;
       for (int ii = i0; ii < i1; ++ii) {
-        const int packed_type = W.items_in_lds ? sgpr((int)blob[W.b_items + ii * IW]) : 0;
-        if (packed_type >= TASK_SSQ) {  // packed records exist only in the LDS copy of the item list
+        const ItemW I = PREFETCH ? cur : item_words(ii);
+        if (PREFETCH && ii + 1 < i1) cur = item_words(ii + 1);
+        const int packed_type = sgpr((int)I.w0.x);
+        if (packed_type >= TASK_SSQ) {  // (packed records exist only in the LDS copy of the item list)
           if (!(ABLATE(args) & 16)) {
             if (LEVEL > 0 || packed_type == TASK_SSQ)  // (line-sphere records are only built for level-0 worlds)
-              eval_ssq(blob + W.b_items + ii * IW, W, args, tile, efl & VMAS_F_MOVABLE, F);
+              eval_ssq(I, W, args, tile, efl & VMAS_F_MOVABLE, F);
             else
-              eval_lsq(blob + W.b_items + ii * IW, W, args, tile, efl & VMAS_F_MOVABLE, F);
+              eval_lsq(I, W, args, tile, efl & VMAS_F_MOVABLE, F);
           }
           continue;
         }
-        const ItemV K = W.items_in_lds ? load_item(blob + W.b_items + ii * IW) : item_from_global(W.items[ii]);
+        const ItemV K = load_item(I);
         v2 f = V(0.f, 0.f);
         float t = 0.f, t_unused = 0.f;
         if (!(ABLATE(args) & 16)) eval_item<LEVEL>(K, W, args, tile, env, live, ld, f, t, t_unused);
@@ -1729,7 +1744,7 @@ static int build_sched(VmasWorld* w, int nw, Sched& S) {
       float c = first ? 60.f : 0.f;
       int j = i;
       while (j < n && (j == i || c + w->item_cost[j] <= target)) c += w->item_cost[j++];
-      segs.push_back({e, e * 6 * ROWF, i, j, first ? 1 : 0, 3 * (int)segs.size()});
+      segs.push_back({e, e * 6 * ROWF, i, j, first ? 1 : 0, 3 * (int)segs.size(), w->dev_ents[e].flags, 0});
       seg_cost.push_back(c);
       O.n_parts++;
       first = false;
@@ -1742,7 +1757,7 @@ static int build_sched(VmasWorld* w, int nw, Sched& S) {
     float c = 0.f;
     int j = i;
     while (j < n && (j == i || c + w->item_cost[j] <= target)) c += w->item_cost[j++];
-    segs.push_back({-1, 0, i, j, 0, 0});
+    segs.push_back({-1, 0, i, j, 0, 0, 0u, 0});
     seg_cost.push_back(c);
     i = j;
   }
@@ -1782,6 +1797,7 @@ static int build_sched(VmasWorld* w, int nw, Sched& S) {
     return at;
   };
   S.dw.b_ent = append(w->dev_ents.data(), w->dev_ents.size() * sizeof(DevEntity));
+  while (blob.size() % 4) blob.push_back(0);  // (ds_read_b128 of the segment records)
   S.dw.b_segs = append(segs_sorted.data(), segs_sorted.size() * sizeof(DevSegment));
   while (blob.size() % 4) blob.push_back(0);  // (ds_read_b128 of the owned records)
   S.dw.b_owned = append(owned.data(), owned.size() * sizeof(DevOwned));
@@ -1963,6 +1979,32 @@ static int step_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld, co
                      int n_steps, int64_t ft_stride, DevEnv* env = nullptr, int env_kind = ENV_NONE,
                      size_t scratch_fixed = 0, size_t scratch_per_wave = 0, int env_first = 0, int env_count = -1);
 
+// The side streams of vmas_world_step_n and their fork / join events.  Created - and the streams' hardware queues
+// brought up by a first operation - when the world is created or the knob is set, never inside a caller's timed loop
+// (stream creation and a stream's first submission cost milliseconds).
+static int ensure_queues(VmasWorld* w, int nq) {
+  if (nq <= 1) return 0;
+  if (!w->ev_fork) HIP_TRY(hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming));
+  for (int q = 0; q < nq - 1 && q < VmasWorld::MAX_QUEUES - 1; ++q)
+    if (!w->side[q]) {
+      HIP_TRY(hipStreamCreateWithFlags(&w->side[q], hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&w->ev_join[q], hipEventDisableTiming));
+      HIP_TRY(hipMemsetAsync(w->d_exact_mask, 0, sizeof(uint32_t), w->side[q]));  // (first submission: queue set-up)
+      HIP_TRY(hipEventRecord(w->ev_join[q], w->side[q]));
+      HIP_TRY(hipStreamSynchronize(w->side[q]));
+    }
+  return 0;
+}
+
+// how many HIP queues a vmas_world_step_n of n_steps steps is spread over (see vmas_world_step_n)
+static int queues_for(const VmasWorld* w, int n_steps) {
+  const int tiles = blocks_of(w->batch);
+  int nq = w->queues;
+  if (nq == 0) nq = (tiles >= 2 * w->n_cu && n_steps >= 8) ? 2 : 1;  // the library's choice
+  while (nq > 1 && tiles < nq) --nq;  // at least one tile per queue
+  return nq;
+}
+
 extern "C" {
 
 int vmas_abi_version(void) { return VMAS_ABI_VERSION; }
@@ -2060,6 +2102,7 @@ int vmas_world_create(const VmasWorldDesc* d, int32_t batch, int32_t device_id, 
   if (S->lds_bytes > 160 * 1024) {
     return fail("vmas_world_create: a 64-environment tile of this world needs %zu B of LDS (> 160 KiB)", S->lds_bytes);
   }
+  if (ensure_queues(w, queues_for(w, 1 << 20))) return -1;  // the side queue of vmas_world_step_n, if this batch gets one
   guard.w = nullptr;
   *out = w;
   return 0;
@@ -2133,21 +2176,13 @@ int vmas_world_exact_status(VmasWorld* w) {
   return (int)flag;
 }
 
-// how many HIP queues a vmas_world_step_n of n_steps steps is spread over (see vmas_world_step_n)
-static int queues_for(const VmasWorld* w, int n_steps) {
-  const int tiles = blocks_of(w->batch);
-  int nq = w->queues;
-  if (nq == 0) nq = (tiles >= 2 * w->n_cu && n_steps >= 8) ? 2 : 1;  // the library's choice
-  while (nq > 1 && tiles < nq) --nq;  // at least one tile per queue
-  return nq;
-}
-
 int vmas_world_set_queues(VmasWorld* w, int32_t queues) {
   if (!w) return fail("vmas_world_set_queues: null world");
   if (queues < 0 || queues > VmasWorld::MAX_QUEUES)
     return fail("vmas_world_set_queues: queues must be 0 (library's choice) .. %d, got %d", VmasWorld::MAX_QUEUES, queues);
   w->queues = queues;
-  return 0;
+  HIP_TRY(hipSetDevice(w->device));
+  return ensure_queues(w, queues_for(w, 1 << 20));
 }
 int vmas_world_get_queues(const VmasWorld* w, int32_t n_steps) { return w ? queues_for(w, n_steps) : 0; }
 
@@ -2355,12 +2390,7 @@ int vmas_world_step_n(VmasWorld* w, float* state, float* agent_ft, int64_t ld, i
   if (nq > 1) {
     int cur = -1;
     if (hipGetDevice(&cur) != hipSuccess || cur != w->device) HIP_TRY(hipSetDevice(w->device));
-    if (!w->ev_fork) HIP_TRY(hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming));
-    for (int q = 0; q < nq - 1; ++q)
-      if (!w->side[q]) {
-        HIP_TRY(hipStreamCreateWithFlags(&w->side[q], hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&w->ev_join[q], hipEventDisableTiming));
-      }
+    if (ensure_queues(w, nq)) return -1;
     hipStream_t s = (hipStream_t)stream;
     const int tiles = blocks_of(w->batch);
     // queue q steps the tiles [q * tiles / nq, (q + 1) * tiles / nq): queue 0 = the caller's stream, the others are side
