@@ -844,9 +844,10 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
         return W.items_in_lds ? fetch_words(blob + W.b_items + ii * IW) : fetch_words((const uint32_t*)(W.items + ii));
       };
       const int i1 = (ABLATE(args) & 1) ? i0 : i1s;
-      // (only the lean kernels have the 16 registers to spare: the general and multi-substep variants sit at the 128-VGPR
-      // limit of 1024-thread blocks, the box-box level at three waves per SIMD)
-      constexpr bool PREFETCH = PLAIN >= 2 && LEVEL < 2;
+      // MEASURED AND SWITCHED OFF (profiles/r02_item_prefetch.txt): fetching record i + 1 during record i costs 26 VGPRs
+      // (90 -> 116 in the lean kernels: 5 -> 4 waves per SIMD); balance 32768 envs 10.1 -> 10.4 us on one queue and
+      // 8.5 -> 10.0 us on two (the second queue's tiles no longer fit beside the first's), 1 M envs 226 -> 234 us.
+      constexpr bool PREFETCH = false;
       ItemW cur;
       if (PREFETCH && i0 < i1) cur = item_words(i0);
       if (e < 0) {  // a run of SHARED pairs/joints (both entities dynamic): evaluated once, both owners read the rows in phase C
@@ -1989,7 +1990,10 @@ static int ensure_queues(VmasWorld* w, int nq) {
     if (!w->side[q]) {
       HIP_TRY(hipStreamCreateWithFlags(&w->side[q], hipStreamNonBlocking));
       HIP_TRY(hipEventCreateWithFlags(&w->ev_join[q], hipEventDisableTiming));
-      HIP_TRY(hipMemsetAsync(w->d_exact_mask, 0, sizeof(uint32_t), w->side[q]));  // (first submission: queue set-up)
+      // first submissions (a copy-engine operation and a kernel dispatch): the queue's set-up cost is paid here
+      HIP_TRY(hipMemsetAsync(w->d_exact_mask, 0, sizeof(uint32_t), w->side[q]));
+      hipLaunchKernelGGL(math_kernel, dim3(1), dim3(64), 0, w->side[q], VMAS_MATH_SQRT, (const float*)w->d_exact_mask,
+                         (const float*)nullptr, (float*)w->d_exact_mask, 1);
       HIP_TRY(hipEventRecord(w->ev_join[q], w->side[q]));
       HIP_TRY(hipStreamSynchronize(w->side[q]));
     }
