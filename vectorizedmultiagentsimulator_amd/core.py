@@ -862,6 +862,8 @@ class World:
         d = self._query("distance", entity_a, entity_b)
         if d is None:
             d = geometry.get_distance(entity_a, entity_b)
+        else:
+            d = d.clone()  # (the query kernel's output buffer is re-used by the next launch: the reference returns fresh tensors)
         return d if env_index is None else d[env_index]
 
     def is_overlapping(self, entity_a: Entity, entity_b: Entity, env_index: int = None) -> Tensor:

@@ -686,7 +686,7 @@ class FootballPost(_Post):
         ball.pos_rew_agent_blue, ball.pos_rew_agent_red = t["pos_rew_agent_blue"], t["pos_rew_agent_red"]
         sc.min_agent_dist_to_ball_blue, sc.min_agent_dist_to_ball_red = (
             t["min_agent_dist_to_ball_blue"], t["min_agent_dist_to_ball_red"])
-        ball_pos = ball.state.pos
+        ball_pos = ball.state.pos if self.static_outputs else ball.state.pos.clone()  # (not a live view of the state)
         sparse_red = None
         infos = []
         for a in env.agents:

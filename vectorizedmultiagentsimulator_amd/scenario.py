@@ -68,12 +68,14 @@ class BaseScenario:
 def keep(obj, name: str, value: Tensor) -> Tensor:
     """Persistent per-scenario tensor (shaping caches ...): created once, then updated IN PLACE, so a
     HIP graph captured over ``Environment.step`` keeps reading and writing the same memory."""
+    # (registered on BOTH paths: a tensor created elsewhere - football's `_done` in make_world - and only ever updated
+    # in place is persistent state too; Environment snapshots / blends these around graph warm-ups and masked resets)
+    obj.__dict__.setdefault("_kept_names", set()).add(name)
     cur = getattr(obj, name, None)
     if isinstance(cur, Tensor) and cur.shape == value.shape and cur.dtype == value.dtype and cur.device == value.device:
         cur.copy_(value)
         return cur
     setattr(obj, name, value.clone())
-    obj.__dict__.setdefault("_kept_names", set()).add(name)  # Environment snapshots these around a graph warm-up
     return getattr(obj, name)
 
 

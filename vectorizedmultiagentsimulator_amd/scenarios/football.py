@@ -310,7 +310,7 @@ class Scenario(BaseScenario):
             "sparse_reward": self._sparse_reward_blue if blue else self._sparse_reward_red,
             "ball_goal_pos_rew": getattr(ball, f"pos_rew_{side}"),
             "all_agent_ball_pos_rew": getattr(ball, f"pos_rew_agent_{side}"),
-            "ball_pos": ball.state.pos,
+            "ball_pos": ball.state.pos.clone(),  # (a state VIEW would change under the caller at the next step)
             "dist_ball_to_goal": getattr(ball, f"pos_shaping_{side}") / self.pos_shaping_factor_ball_goal,
             "min_agent_dist_to_ball": min_dist,
             "touching_ball": min_dist <= self.agent_size + self.ball_size + 1e-2,
