@@ -21,13 +21,16 @@ from vectorizedmultiagentsimulator_amd.spec import WorldSpec
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(_DIR, "vmas_oracle.c")
-LIB = os.path.join(_DIR, "libvmas_oracle.so")
+# VMAS_ORACLE_LIB: another build of the same source (tests/test_oracle_sanitizers.py runs an ASan + UBSan build)
+LIB = os.environ.get("VMAS_ORACLE_LIB") or os.path.join(_DIR, "libvmas_oracle.so")
 _lib = None
 
 
 def build(force: bool = False) -> str:
     """gcc the restatement (no FMA contraction; OpenMP only parallelises over envs)."""
     hdr = os.path.join(_DIR, "..", "include", "vmas_hip.h")
+    if os.environ.get("VMAS_ORACLE_LIB"):
+        return LIB  # (built by whoever set it)
     if (
         not force
         and os.path.exists(LIB)

@@ -130,6 +130,19 @@ class HipWorld:
     def step_bytes_per_env(self) -> int:
         return int(self.lib.vmas_world_step_bytes_per_env(self._h))
 
+    # ------------------------------------------------------------------ snapshots
+    def get_state(self):
+        """(state [E, 6, batch], agent_ft [A, 3, batch]) - copies of the packed buffers without their padding columns."""
+        return self.state[:, :, : self.batch].clone(), self.agent_ft[:, :, : self.batch].clone()
+
+    def set_state(self, state: torch.Tensor, agent_ft: Optional[torch.Tensor] = None) -> None:
+        """Write a snapshot taken with ``get_state`` (same shapes) back into the packed buffers."""
+        assert tuple(state.shape) == (self.state.shape[0], A.STATE_FIELDS, self.batch), tuple(state.shape)
+        self.state[:, :, : self.batch].copy_(state)
+        if agent_ft is not None:
+            assert tuple(agent_ft.shape) == (self.agent_ft.shape[0], A.AGENT_FIELDS, self.batch), tuple(agent_ft.shape)
+            self.agent_ft[:, :, : self.batch].copy_(agent_ft)
+
     # ------------------------------------------------------------------ views
     def pos(self, e: int) -> torch.Tensor:  # [B, 2] view
         return self.state[e, 0:2, : self.batch].T

@@ -278,6 +278,27 @@ class Environment:
         self._graph.replay()
         return self._static_out
 
+    def get_state(self) -> List[Tensor]:
+        """Snapshot of everything a step reads and writes (checkpoint / resume; the reference has no counterpart - its state
+        is spread over per-entity attributes): the packed world state, the agent forces, the step counter, the scenario's
+        persistent terms and the masked-reset episode counters.  ``set_state`` of the snapshot followed by the same
+        actions reproduces the same steps bit for bit."""
+        ts = [t.clone() for t in self._persistent_tensors()]
+        if self._masked_reset is not None:
+            ts.append(self._masked_reset.episode.clone())
+        return ts
+
+    def set_state(self, snapshot: List[Tensor]) -> None:
+        cur = self._persistent_tensors()
+        if self._masked_reset is not None:
+            cur = cur + [self._masked_reset.episode]
+        assert len(cur) == len(snapshot), f"snapshot has {len(snapshot)} tensors, this environment {len(cur)}"
+        for t, s_ in zip(cur, snapshot):
+            assert t.shape == s_.shape and t.dtype == s_.dtype, (tuple(t.shape), tuple(s_.shape))
+            t.copy_(s_)
+        self.world.invalidate_queries()
+        self._lidar_cache = None
+
     def _persistent_tensors(self):
         """Everything a step reads and writes: the packed world state, the step counter and the scenario's
         in-place tensors (``scenario.keep``)."""
