@@ -2,6 +2,7 @@
 0 start | 1 loads issued+landed | 2 after load barrier | 3 end of gather | 4 after barrier | 5 end"""
 import os, sys, ctypes
 os.environ["VMAS_TRACE"] = "1"
+os.environ.setdefault("VMAS_HIP_LIB", "libvmas_hip_trace.so")  # -DVMAS_PROFILE -DVMAS_TRACE build of the same sources
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import numpy as np, torch
 import bench
@@ -9,7 +10,8 @@ lanes = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32768
 sc, w = bench.build_world(B, torch.device("cuda", 0), 4, lanes, 0)
 be = w._get_backend()
-forces = bench.make_forces(w, 100, 1234, torch.device("cuda", 0))
+be.set_queues(1)
+forces = bench.pack_forces(w, bench.make_actions(100, 4, B, 1234), torch.device("cuda", 0))
 be.step_n(60, forces[:60]); torch.cuda.synchronize()
 be.step_n(1, forces[60:61]); torch.cuda.synchronize()
 tiles = (B + 63) // 64
@@ -21,7 +23,13 @@ full = buf.reshape(tiles, 16, 16).astype(np.int64)[:, :lanes]
 t = full[:, :, :6]
 t0 = t[:, :, 0].min()
 print("lanes", lanes, "tiles", tiles, "kernel span (cycles, s_memtime @100MHz?)", t[:, :, 5].max() - t0)
-for b in (tiles // 2,):
+span = (t[:, :, 5].max(axis=1) - t[:, :, 0].min(axis=1))
+print("per-tile span: mean %.0f min %d max %d" % (span.mean(), span.min(), span.max()))
+gat = t[:, :, 3] - t[:, :, 2]
+print("gather per wave: mean %.0f; slowest wave of a tile: mean %.0f (imbalance %.2fx)" % (gat.mean(), gat.max(axis=1).mean(), gat.max(axis=1).mean() / gat.mean()))
+integ = t[:, :, 5] - t[:, :, 4]
+print("integrate per wave: mean %.0f; slowest wave of a tile: mean %.0f" % (integ.mean(), integ.max(axis=1).mean()))
+for b in (tiles // 2, 3):
     print("tile", b)
     for wv in range(lanes):
         r = t[b, wv] - t0
