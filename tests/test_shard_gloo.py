@@ -162,3 +162,20 @@ def test_bench_dry_run_spawns_its_ranks():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["dry_run"] is True
     assert set(d["rollout_gather"]) == {"balance_cfg2", "navigation_cfg4", "football_cfg5"}
+
+
+def test_bench_refuses_to_claim_more_gpus_than_it_sees():
+    """`python bench.py --gpus 2` where fewer than two devices are visible (here: none) must fail loudly instead of
+    printing an n_gpus=2 line."""
+    import subprocess
+    import sys
+
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("two devices visible: the real run is the driver's")
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0
+    assert "--gpus 2 but only" in (out.stderr + out.stdout)
+    assert not any(l.startswith("{") for l in out.stdout.splitlines())
