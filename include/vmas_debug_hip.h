@@ -18,6 +18,15 @@ extern "C" {
 #define VMAS_MATH_SIN 5      /* sin(a) as write_trig computes it (sincosf) */
 int vmas_debug_math(int32_t op, const float* a, const float* b, float* out, int32_t n, void* stream);
 
+/* The schedule the library planned for a world (waves per tile, shared rows, segments, items): the descriptor blob as it
+ * is staged into LDS (`words`, may be NULL to query the size) and meta[24] = {waves per tile, share mode, kernel level,
+ * blob words, b_ent, b_segs, b_owned, b_refs, b_items, n_segs, n_owned, tile rows, fired records, items in LDS, nE, nA,
+ * off_af, row_tr, trig_mask lo/hi, box_mask lo/hi, trig_in_args, specialisation id (-1: none)}.  Works on PLANNING worlds
+ * too: vmas_world_create(desc, batch, device_id = -1, &w) builds the schedules on the host without touching a GPU (such a
+ * world cannot be stepped).  scripts/gen_spec.py generates csrc/vmas_spec_gen.h - the tables of the world-specialised
+ * kernel - from it. */
+int vmas_debug_schedule(VmasWorld* w, uint32_t* words, int64_t capacity, int32_t* meta /* [24] */);
+
 /* VMAS_TRACE=1 in a -DVMAS_TRACE build: copy out the per-wave s_memtime stamps of the last launch */
 int vmas_debug_trace(VmasWorld* w, unsigned long long* host, int64_t n_words);
 

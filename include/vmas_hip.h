@@ -237,6 +237,15 @@ int vmas_world_get_lanes_per_env(const VmasWorld* w);
 int vmas_world_set_queues(VmasWorld* w, int32_t queues);
 int vmas_world_get_queues(const VmasWorld* w, int32_t n_steps);
 
+/* World-specialised kernels.  For the worlds and geometries the library was built with tables for
+ * (csrc/vmas_spec_gen.h: balance n_agents=4 at two tiles per CU, BASELINE config 2), a plain vmas_world_step / _step_n
+ * launch (one-substep world, no optional inputs) runs a form of the step kernel whose schedule - segments, items,
+ * owners - is compile-time constants instead of records interpreted from LDS; it is used only when the schedule planned
+ * at run time is word for word the generated one, and its results are bit for bit the interpreter's.
+ * vmas_world_set_specialized(w, 0) keeps the interpreter (A/B measurements); _get_ tells which one a launch would run. */
+int vmas_world_set_specialized(VmasWorld* w, int32_t on);
+int vmas_world_get_specialized(VmasWorld* w);
+
 /* Algorithmic HBM bytes one vmas_world_step moves per environment
  * (24*E read + 12*A read + 24*E_dyn written). */
 int64_t vmas_world_step_bytes_per_env(const VmasWorld* w);

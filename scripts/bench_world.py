@@ -16,6 +16,8 @@ for _ in range(30):  # a few real steps so that the state is a typical mid-episo
 be = env.world._get_backend()
 if lanes:
     be.set_lanes_per_env(lanes)
+if os.environ.get("SPEC"):
+    be.set_specialized(os.environ["SPEC"] != "0")
 if os.environ.get("QUEUES"):
     be.set_queues(int(os.environ["QUEUES"]))
 be.step_n(50)
@@ -24,6 +26,6 @@ t0 = time.perf_counter()
 be.step_n(steps)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
-print(json.dumps({"scenario": name, "num_envs": B, "lanes": be.lanes_per_env, "queues": be.queues(steps),
+print(json.dumps({"scenario": name, "num_envs": B, "lanes": be.lanes_per_env, "queues": be.queues(steps), "specialized": be.specialized,
                   "lib": os.environ.get("VMAS_HIP_LIB", "libvmas_hip.so"), "ablate": os.environ.get("VMAS_ABLATE", "0"),
                   "world_step_us": round(dt * 1e6, 2), "env_steps_per_s": round(B / dt)}))

@@ -540,3 +540,34 @@ def test_degenerate_worlds_and_batch_sizes(kind, B):
     got = w._state.cpu().numpy()
     compare_state(got[:, :, :B], st[:, :, :B], f"{kind} B={B}", atol=1e-5, rtol=1e-5)
     assert np.array_equal(got[:, :, B:], np.zeros_like(got[:, :, B:])), "padding columns were written"
+
+
+@pytest.mark.parametrize("B", [32768, 32700, 20480])
+def test_specialised_kernel_is_bitwise_the_generic_one(B):
+    """The world-specialised step kernel (csrc/vmas_spec_kernel.h: balance n_agents=4 at BASELINE config 2's geometry,
+    schedule tables generated from the library's own planner) must give, bit for bit, what the interpreter gives - state
+    and the clamped forces written back - over a sequence of steps with contacts, on whole-tile and ragged batches, on one
+    and on two queues; and it must really be the kernel that runs at that geometry."""
+    from vectorizedmultiagentsimulator_amd.scenarios.balance import Scenario
+
+    outs = []
+    for on in (True, False):
+        torch.manual_seed(5)
+        torch.cuda.manual_seed(5)
+        sc = Scenario()
+        w = sc.env_make_world(B, "cuda:0", n_agents=4)
+        sc.env_reset_world_at(None)
+        be = w._get_backend()
+        be.set_specialized(on)
+        assert be.specialized == on, "the generated tables do not match the schedule planned at run time"
+        g = torch.Generator(device="cuda:0").manual_seed(9)
+        forces = torch.zeros(24, *be.agent_ft.shape, device="cuda:0")
+        forces[:, :4, 0:2, :B] = (torch.rand(24, 4, 2, B, device="cuda:0", generator=g) * 2 - 1) * 0.7
+        for q in (1, 2):
+            be.set_queues(q)
+            be.step_n(12, forces[12 * (q - 1): 12 * q])
+        be.step()
+        outs.append((be.state.clone(), be.agent_ft.clone()))
+    same = lambda a, b: torch.equal(a.view(torch.int32), b.view(torch.int32))  # noqa: E731
+    assert same(outs[0][0], outs[1][0]) and same(outs[0][1], outs[1][1])
+    assert torch.isfinite(outs[0][0]).all()

@@ -1,5 +1,6 @@
 """Host-side object model (core.py) and scenarios - runs on CPU tensors, no GPU."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -97,3 +98,41 @@ def test_joint_builds_link_landmark_and_constraints():
     assert torch.allclose(j.landmark.state.pos, torch.tensor([[0.1, 0.0]] * 3))
     with pytest.raises(AssertionError):  # joints need substeps > 1 (core.py:1167)
         core.World(3, "cpu").add_joint(core.Joint(core.Agent("x"), core.Agent("y")))
+
+
+def test_generated_specialisation_is_current():
+    """csrc/vmas_spec_gen.h (the world-specialised kernel's tables) is what scripts/gen_spec.py generates from the current
+    planner and scenario: a change to either must be followed by re-running the script (the library would otherwise -
+    correctly, but silently - fall back to the interpreter)."""
+    import subprocess
+    import sys
+
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    rc = subprocess.run([sys.executable, os.path.join(root, "scripts", "gen_spec.py"), "--check"], capture_output=True, text=True)
+    assert rc.returncode == 0, "csrc/vmas_spec_gen.h is stale: run python scripts/gen_spec.py and rebuild\n" + rc.stderr[-2000:]
+
+
+def test_planning_world_matches_the_generated_tables():
+    """A planning world (device -1: no GPU touched) of balance n_agents=4 at 32768 environments reports the specialisation
+    as matching its schedule, and cannot be stepped."""
+    import ctypes as C
+
+    from vectorizedmultiagentsimulator_amd import _abi as A
+    from vectorizedmultiagentsimulator_amd.scenarios.balance import Scenario
+
+    w = Scenario().env_make_world(32768, "cpu", n_agents=4)
+    cd = w.spec.to_ctypes()
+    lib = A.load_library()
+    lib.vmas_debug_schedule.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    h = C.c_void_p()
+    assert lib.vmas_world_create(C.byref(cd.world), 32768, -1, C.byref(h)) == 0, A.last_error()
+    try:
+        assert lib.vmas_world_reserve_epilogue(h, *w.epilogue_hint) == 0
+        meta = (C.c_int32 * 24)()
+        assert lib.vmas_debug_schedule(h, None, 0, meta) == 0
+        assert meta[0] == 8 and meta[23] == 0, list(meta)  # 8 waves per tile, specialisation 0 (SpecBalance4)
+        assert lib.vmas_world_get_specialized(h) == 1
+        assert lib.vmas_world_step(h, C.c_void_p(64), C.c_void_p(64), 32768, None, None) != 0
+        assert b"planning world" in lib.vmas_last_error()
+    finally:
+        lib.vmas_world_destroy(h)

@@ -278,7 +278,10 @@ EXPORTED_SYMBOLS = (
     "vmas_world_get_lanes_per_env",
     "vmas_debug_math",  # include/vmas_debug_hip.h: test / profiling hooks, never called by the product path
     "vmas_debug_trace",
+    "vmas_debug_schedule",
     "vmas_world_exact_status",
+    "vmas_world_set_specialized",
+    "vmas_world_get_specialized",
     "vmas_world_set_queues",
     "vmas_world_get_queues",
     "vmas_world_step_bytes_per_env",
@@ -336,6 +339,10 @@ def load_library() -> C.CDLL:
     lib.vmas_world_set_lanes_per_env.restype = C.c_int
     lib.vmas_world_get_lanes_per_env.argtypes = [vp]
     lib.vmas_world_get_lanes_per_env.restype = C.c_int
+    lib.vmas_world_set_specialized.argtypes = [vp, i32]
+    lib.vmas_world_set_specialized.restype = C.c_int
+    lib.vmas_world_get_specialized.argtypes = [vp]
+    lib.vmas_world_get_specialized.restype = C.c_int
     lib.vmas_world_exact_status.argtypes = [vp]
     lib.vmas_world_exact_status.restype = C.c_int
     lib.vmas_world_set_queues.argtypes = [vp, i32]

@@ -117,6 +117,15 @@ class HipWorld:
         """How many queues a ``step_n`` of ``n_steps`` steps uses."""
         return int(self.lib.vmas_world_get_queues(self._h, int(n_steps)))
 
+    def set_specialized(self, on: bool):
+        """Allow / forbid the world-specialised kernel for plain World.step launches (include/vmas_hip.h)."""
+        if self.lib.vmas_world_set_specialized(self._h, 1 if on else 0) != 0:
+            raise VmasHipError(A.last_error())
+
+    @property
+    def specialized(self) -> bool:
+        return bool(self.lib.vmas_world_get_specialized(self._h))
+
     def reserve_epilogue(self, post_kind: int, n_packages: int = 0):
         """The steps of this world will be one-launch Environment.step calls with this post-step epilogue: let the
         library choose its kernel geometry with the epilogue's LDS included (include/vmas_env_hip.h)."""

@@ -1147,6 +1147,12 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
 }
 
 // ------------------------------------------------------------------------------------
+// world-specialised form of the same kernel (compile-time schedule tables)
+// ------------------------------------------------------------------------------------
+#include "vmas_spec_gen.h"
+#include "vmas_spec_kernel.h"
+
+// ------------------------------------------------------------------------------------
 // batch-global broad phase (World.collides core.py:2797-2801)
 // ------------------------------------------------------------------------------------
 
@@ -1400,6 +1406,9 @@ struct Sched {
   int nw = 0;
   DevWorld dw{};
   size_t lds_bytes = 0;
+  int rows = 0;                  // LDS rows of the tile in front of the blob (state | agent forces | trig | shared | partial)
+  std::vector<uint32_t> h_blob;  // host copy of the descriptor blob (planning worlds; the world-specialised kernel's match)
+  int spec_id = -1;              // >= 0: this schedule is word for word the one a generated specialisation was built from
   uint32_t* d_blob = nullptr;
   void release() {
     (void)hipFree(d_blob);
@@ -1441,6 +1450,8 @@ struct VmasWorld {
   // vmas_world_step_n over several HIP queues (environments are independent: the launch gap of one part of the batch
   // overlaps the compute of the others).  queues: 0 = library's choice, 1..MAX_QUEUES = that many
   int queues = 0;
+  bool host_only = false;  // a PLANNING world (device_id -1): schedules are built on the host, nothing is uploaded or launched
+  bool use_spec = true;    // launch the world-specialised kernel when the schedule matches one (vmas_world_set_specialized)
   static constexpr int MAX_QUEUES = 4;
   hipStream_t side[MAX_QUEUES - 1] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[MAX_QUEUES - 1] = {nullptr, nullptr, nullptr};
@@ -1810,7 +1821,21 @@ static int build_sched(VmasWorld* w, int nw, Sched& S) {
   S.dw.b_items = (int)blob.size();
   S.dw.blob_words = (int)blob.size() + (S.dw.items_in_lds ? (int)(item_bytes / 4) : 0);  // (a multiple of 4: 16-byte staging)
   append(w->items.data(), item_bytes);
-  HIP_TRY(upload(&S.d_blob, blob));
+  S.h_blob = blob;
+  S.rows = row_bad;
+  // A generated specialisation serves this schedule iff it was generated from the very same words (and geometry).
+  S.spec_id = -1;
+  {
+    using G = SpecBalance4;
+    if (nw == G::NW && w->level == G::LEVEL && (int)blob.size() == G::BLOB_WORDS && S.dw.items_in_lds && w->base.trig_in_args &&
+        row_bad == G::ROWS && w->base.nE == G::NE && w->base.nA == G::NA && w->base.off_af == G::OFF_AF &&
+        w->base.row_tr == G::ROW_TR && w->base.trig_mask == G::TRIG_MASK && w->base.box_mask == G::BOX_MASK &&
+        S.dw.b_ent == G::B_ENT && S.dw.b_segs == G::B_SEGS && S.dw.b_owned == G::B_OWNED && S.dw.b_refs == G::B_REFS &&
+        S.dw.b_items == G::B_ITEMS && (int)segs_sorted.size() == G::N_SEGS && (int)owned.size() == G::N_OWNED &&
+        w->fired_recs == G::FIRED_RECS && memcmp(blob.data(), G::blob, sizeof(uint32_t) * G::BLOB_WORDS) == 0)
+      S.spec_id = G::ID;
+  }
+  if (!w->host_only) HIP_TRY(upload(&S.d_blob, blob));
   S.dw.blob = S.d_blob;
   S.dw.items = (const DevItem*)(S.d_blob + S.dw.b_items);
   S.dw.n_segs = (int)segs_sorted.size();
@@ -1949,6 +1974,20 @@ static int launch_level(VmasWorld* w, Sched* S, float* state, float* aft, long l
     }
   }
   const int blocks = (batch + TILE - 1) / TILE;
+  if constexpr (ENV == ENV_NONE && LEVEL == SpecBalance4::LEVEL) {
+    // the world-specialised kernel (csrc/vmas_spec_kernel.h): same results bit for bit, the schedule as compile-time tables
+    if (mode >= 2 && S->spec_id == SpecBalance4::ID && w->use_spec && !ABLATE(a) && !a.trace) {
+      const size_t lds_spec = ((size_t)SpecBalance4::ROWS * ROWF + 8) * sizeof(float);
+      if (mode == 3)
+        hipLaunchKernelGGL((step_kernel_spec<SpecBalance4, 0>), dim3(blocks), dim3(TILE * SpecBalance4::NW), lds_spec, s, S->dw,
+                           state, aft, ld, batch);
+      else
+        hipLaunchKernelGGL((step_kernel_spec<SpecBalance4, 1>), dim3(blocks), dim3(TILE * SpecBalance4::NW), lds_spec, s, S->dw,
+                           state, aft, ld, batch);
+      HIP_TRY(hipGetLastError());
+      return 0;
+    }
+  }
   if (mode == 3)
     hipLaunchKernelGGL((step_kernel<LEVEL, ENV, EnvArgs, 3>), dim3(blocks), dim3(TILE * S->nw), lds, s, S->dw, state, aft,
                        ld, batch, a, env);
@@ -2027,10 +2066,13 @@ int vmas_world_create(const VmasWorldDesc* d, int32_t batch, int32_t device_id, 
   for (int j = 0; j < d->n_joints; ++j)
     if (d->joints[j].a < 0 || d->joints[j].a >= d->n_entities || d->joints[j].b < 0 || d->joints[j].b >= d->n_entities)
       return fail("vmas_world_create: joint %d is malformed", j);
-  int ndev = 0;
-  HIP_TRY(hipGetDeviceCount(&ndev));
-  if (device_id < 0 || device_id >= ndev) return fail("vmas_world_create: device %d of %d", device_id, ndev);
-  HIP_TRY(hipSetDevice(device_id));
+  const bool host_only = device_id == -1;  // planning world (include/vmas_debug_hip.h): no device is touched
+  if (!host_only) {
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device_id < 0 || device_id >= ndev) return fail("vmas_world_create: device %d of %d", device_id, ndev);
+    HIP_TRY(hipSetDevice(device_id));
+  }
 
   VmasWorld* w = new VmasWorld();
   struct Guard {  // destroys the half-built world on every early return below
@@ -2038,6 +2080,7 @@ int vmas_world_create(const VmasWorldDesc* d, int32_t batch, int32_t device_id, 
     ~Guard() { if (w) vmas_world_destroy(w); }
   } guard{w};
   w->device = device_id;
+  w->host_only = host_only;
   w->batch = batch;
   w->ents.assign(d->entities, d->entities + d->n_entities);
   w->pairs.assign(d->pairs, d->pairs + d->n_pairs);
@@ -2089,14 +2132,14 @@ int vmas_world_create(const VmasWorldDesc* d, int32_t batch, int32_t device_id, 
   std::vector<DevMaskPair> mp(d->n_pairs);
   for (int p = 0; p < d->n_pairs; ++p) mp[p] = {d->pairs[p].a, d->pairs[p].b, d->pairs[p].bound_sum};
   w->dev_ents = ents;
-  HIP_TRY(upload(&w->d_mpairs, mp));
-  {  // exact broad phase: barrier word + four mask slots (in-kernel form), one mask (launch-per-substep form)
+  if (!host_only) HIP_TRY(upload(&w->d_mpairs, mp));
+  if (!host_only) {  // exact broad phase: barrier word + four mask slots (in-kernel form), one mask (launch-per-substep form)
     const size_t mw = (size_t)(d->n_pairs + 31) / 32;
     HIP_TRY(hipMalloc((void**)&w->d_sync, (4 + 4 * mw) * sizeof(uint32_t)));
     HIP_TRY(hipMemset(w->d_sync, 0, (4 + 4 * mw) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void**)&w->d_exact_mask, (mw ? mw : 1) * sizeof(uint32_t)));
   }
-  {
+  if (!host_only) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) w->n_cu = prop.multiProcessorCount;
   }
@@ -2106,7 +2149,7 @@ int vmas_world_create(const VmasWorldDesc* d, int32_t batch, int32_t device_id, 
   if (S->lds_bytes > 160 * 1024) {
     return fail("vmas_world_create: a 64-environment tile of this world needs %zu B of LDS (> 160 KiB)", S->lds_bytes);
   }
-  if (ensure_queues(w, queues_for(w, 1 << 20))) return -1;  // the side queue of vmas_world_step_n, if this batch gets one
+  if (!host_only && ensure_queues(w, queues_for(w, 1 << 20))) return -1;  // the side queue of vmas_world_step_n
   guard.w = nullptr;
   *out = w;
   return 0;
@@ -2114,6 +2157,7 @@ int vmas_world_create(const VmasWorldDesc* d, int32_t batch, int32_t device_id, 
 
 void vmas_world_destroy(VmasWorld* w) {
   if (!w) return;
+  if (w->host_only) { delete w; return; }
   (void)hipSetDevice(w->device);
   for (auto& kv : w->scheds) kv.second.release();
   for (int q = 0; q < VmasWorld::MAX_QUEUES - 1; ++q) {
@@ -2137,7 +2181,7 @@ int vmas_world_set_lanes_per_env(VmasWorld* w, int32_t lanes) {
   }
   const int max_w = w->level >= 2 ? 8 : MAX_WAVES;
   if (lanes < 1 || lanes > max_w) return fail("lanes_per_env must be in 1..%d for this world, got %d", max_w, lanes);
-  HIP_TRY(hipSetDevice(w->device));
+  if (!w->host_only) HIP_TRY(hipSetDevice(w->device));
   Sched* S;
   if (get_sched(w, lanes, &S)) return -1;
   if (S->lds_bytes > 160 * 1024 && w->n_shared_rows > 0 && (unshare(w) || get_sched(w, lanes, &S))) return -1;
@@ -2159,7 +2203,7 @@ int vmas_world_reserve_epilogue(VmasWorld* w, int32_t post_kind, int32_t n_packa
   } else if (post_kind != VMAS_POST_NONE) {
     return fail("vmas_world_reserve_epilogue: post_kind %d has no fused epilogue", post_kind);
   }
-  HIP_TRY(hipSetDevice(w->device));
+  if (!w->host_only) HIP_TRY(hipSetDevice(w->device));
   w->reserve_fixed = f0 * sizeof(float);
   w->reserve_per_wave = (f1 - f0) * sizeof(float);
   return select_config(w);
@@ -2168,6 +2212,18 @@ int vmas_world_reserve_epilogue(VmasWorld* w, int32_t post_kind, int32_t n_packa
 int64_t vmas_world_step_bytes_per_env(const VmasWorld* w) {
   if (!w) return -1;
   return 24LL * w->base.nE + 12LL * w->base.nA + 24LL * w->n_dyn;
+}
+
+int vmas_world_set_specialized(VmasWorld* w, int32_t on) {
+  if (!w) return fail("vmas_world_set_specialized: null world");
+  w->use_spec = on != 0;
+  return 0;
+}
+int vmas_world_get_specialized(VmasWorld* w) {  // 1: plain World.step launches of this world run a generated specialisation
+  if (!w) return 0;
+  Sched* S;
+  if (get_sched(w, w->lanes, &S)) return 0;
+  return (w->use_spec && S->spec_id >= 0) ? 1 : 0;
 }
 
 int vmas_world_exact_status(VmasWorld* w) {
@@ -2185,6 +2241,7 @@ int vmas_world_set_queues(VmasWorld* w, int32_t queues) {
   if (queues < 0 || queues > VmasWorld::MAX_QUEUES)
     return fail("vmas_world_set_queues: queues must be 0 (library's choice) .. %d, got %d", VmasWorld::MAX_QUEUES, queues);
   w->queues = queues;
+  if (w->host_only) return 0;
   HIP_TRY(hipSetDevice(w->device));
   return ensure_queues(w, queues_for(w, 1 << 20));
 }
@@ -2282,6 +2339,7 @@ static int step_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld, co
                      int n_steps, int64_t ft_stride, DevEnv* env, int env_kind, size_t scratch_fixed,
                      size_t scratch_per_wave, int env_first, int env_count) {
   if (!w || !state) return fail("vmas_world_step: null argument");
+  if (w->host_only) return fail("vmas_world_step: a planning world (device -1) cannot be stepped");
   if (w->base.nA > 0 && !agent_ft) return fail("vmas_world_step: world has agents but agent_ft is null");
   if (ld < w->batch) return fail("vmas_world_step: ld (%lld) < batch (%d)", (long long)ld, w->batch);
   DevStepArgs a{};
@@ -2369,6 +2427,23 @@ int vmas_debug_trace(VmasWorld* w, unsigned long long* host, int64_t n_words) {
   return 0;
 }
 
+int vmas_debug_schedule(VmasWorld* w, uint32_t* words, int64_t capacity, int32_t* meta) {
+  if (!w || !meta) return fail("vmas_debug_schedule: null argument");
+  Sched* S;
+  if (get_sched(w, w->lanes, &S)) return -1;
+  const DevWorld& D = S->dw;
+  const int32_t m[24] = {S->nw, w->share_mode, w->level, (int32_t)S->h_blob.size(), D.b_ent, D.b_segs, D.b_owned, D.b_refs,
+                         D.b_items, D.n_segs, D.n_owned, S->rows, D.fired_recs, D.items_in_lds, D.nE, D.nA, D.off_af, D.row_tr,
+                         (int32_t)(D.trig_mask & 0xffffffffu), (int32_t)(D.trig_mask >> 32), (int32_t)(D.box_mask & 0xffffffffu),
+                         (int32_t)(D.box_mask >> 32), D.trig_in_args, S->spec_id};
+  memcpy(meta, m, sizeof(m));
+  if (words) {
+    if (capacity < (int64_t)S->h_blob.size()) return fail("vmas_debug_schedule: %zu words do not fit", S->h_blob.size());
+    memcpy(words, S->h_blob.data(), S->h_blob.size() * sizeof(uint32_t));
+  }
+  return 0;
+}
+
 int vmas_debug_math(int32_t op, const float* a, const float* b, float* out, int32_t n, void* stream) {
   if (!a || !out || n < 0 || op < 0 || op > VMAS_MATH_SIN) return fail("vmas_debug_math: bad argument");
   if ((op == VMAS_MATH_DIV || op == VMAS_MATH_NORM) && !b) return fail("vmas_debug_math: op %d needs two operands", op);
@@ -2425,6 +2500,7 @@ int vmas_world_step_n(VmasWorld* w, float* state, float* agent_ft, int64_t ld, i
 }
 
 int vmas_world_pair_mask(VmasWorld* w, const float* state, int64_t ld, uint32_t* mask, void* stream) {
+  if (w && w->host_only) return fail("vmas_world_pair_mask: a planning world (device -1) has no device side");
   if (!w || !state || !mask) return fail("vmas_world_pair_mask: null argument");
   hipStream_t s = (hipStream_t)stream;
   const int words = (w->n_pairs + 31) / 32;
@@ -2448,6 +2524,7 @@ int vmas_world_pair_mask(VmasWorld* w, const float* state, int64_t ld, uint32_t*
 }
 
 int vmas_world_set_lidars(VmasWorld* w, const VmasLidarDesc* lidars, int32_t n) {
+  if (w && w->host_only) return fail("vmas_world_set_lidars: a planning world (device -1) has no device side");
   if (!w || (n > 0 && !lidars)) return fail("vmas_world_set_lidars: null argument");
   HIP_TRY(hipSetDevice(w->device));
   (void)hipFree(w->d_lidars); (void)hipFree(w->d_targets); (void)hipFree(w->d_angles);
@@ -2479,6 +2556,7 @@ int vmas_world_set_lidars(VmasWorld* w, const VmasLidarDesc* lidars, int32_t n) 
 }
 
 int vmas_world_set_queries(VmasWorld* w, const VmasQuery* queries, int32_t n) {
+  if (w && w->host_only) return fail("vmas_world_set_queries: a planning world (device -1) has no device side");
   if (!w || (n > 0 && !queries)) return fail("vmas_world_set_queries: null argument");
   HIP_TRY(hipSetDevice(w->device));
   (void)hipFree(w->d_queries);
@@ -2502,6 +2580,7 @@ int vmas_world_set_queries(VmasWorld* w, const VmasQuery* queries, int32_t n) {
 }
 
 int vmas_world_run_queries(VmasWorld* w, const float* state, int64_t ld, float* out, void* stream) {
+  if (w && w->host_only) return fail("vmas_world_run_queries: a planning world (device -1) has no device side");
   if (!w || !state || !out) return fail("vmas_world_run_queries: null argument");
   if (w->n_queries <= 0) return fail("vmas_world_run_queries: no queries registered (vmas_world_set_queries)");
   hipLaunchKernelGGL(query_kernel, dim3((w->batch + 255) / 256, w->n_queries), dim3(256), 0, (hipStream_t)stream,
@@ -2511,6 +2590,7 @@ int vmas_world_run_queries(VmasWorld* w, const float* state, int64_t ld, float* 
 }
 
 int vmas_world_cast_rays(VmasWorld* w, const float* state, int64_t ld, float* out, void* stream) {
+  if (w && w->host_only) return fail("vmas_world_cast_rays: a planning world (device -1) has no device side");
   if (!w || !state || !out) return fail("vmas_world_cast_rays: null argument");
   if (w->n_lidars <= 0) return fail("vmas_world_cast_rays: no sensors registered (vmas_world_set_lidars)");
   // rays per thread: few when the batch alone cannot fill the chip (latency-bound), more when it
