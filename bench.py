@@ -415,7 +415,7 @@ def main():
 
     # ---- the same K launches on ONE queue (what rocprofv3's per-kernel durations describe); then the headline
     single = None
-    if not args.fused:
+    if not args.fused and be.queues(min(EPISODE, args.steps)) > 1:
         be.set_queues(1)
         run(args.warmup)
         ev_1, wall_1 = timed(lambda n: run(n, start=args.warmup), args.steps)
@@ -464,6 +464,9 @@ def main():
                     f"one launch per step and per part of the batch: {n_queues} HIP queues, {n_queues} launches per "
                     f"World.step of the whole batch (vmas_world_step_n, environments are independent)"),
                 "queues": n_queues,
+                "kernel": ("step_kernel_spec<SpecBalance4>: the world-specialised form of the step kernel (schedule as "
+                           "compile-time tables, generated from the library's planner; bitwise the interpreter's results)")
+                if be.specialized else "step_kernel (interpreter of the schedule)",
                 "parallelism": f"env-sharded x{world_size}",
             },
             "roofline": {
@@ -473,7 +476,7 @@ def main():
                 "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS,
                 "traffic": None,
-                "kernel": "step_kernel",
+                "kernel": "step_kernel_spec" if be.specialized else "step_kernel",
                 "kernel_us": kernel_s * 1e6,
                 "kernel_us_is": "time per World.step of the whole batch from the HIP events (region / K)" + (
                     "" if n_queues == 1 else f"; {n_queues} launches of {args.num_envs // n_queues} environments each "

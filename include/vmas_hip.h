@@ -231,7 +231,8 @@ int vmas_world_get_lanes_per_env(const VmasWorld* w);
  * stream, the others on library-owned side streams that are forked from the caller's stream (event) at the start of the
  * call and joined back into it at the end, so the call stays stream-ordered for the caller.  The ~2.9 us launch gap
  * between two dependent kernels of one part is filled by the kernels of the others; results are bit for bit those of
- * one queue.  queues: 0 = the library's choice (two when each half keeps at least one tile per CU and n_steps >= 8),
+ * one queue.  queues: 0 = the library's choice (two when each half keeps at least one tile per CU, a launch is long
+ * against the host's enqueue cost and n_steps >= 8),
  * 1..4 = that many.  Only launches without optional per-call inputs (args == NULL) are split.
  * vmas_world_get_queues returns how many queues a vmas_world_step_n of `n_steps` steps would use. */
 int vmas_world_set_queues(VmasWorld* w, int32_t queues);

@@ -2043,7 +2043,14 @@ static int ensure_queues(VmasWorld* w, int nq) {
 static int queues_for(const VmasWorld* w, int n_steps) {
   const int tiles = blocks_of(w->batch);
   int nq = w->queues;
-  if (nq == 0) nq = (tiles >= 2 * w->n_cu && n_steps >= 8) ? 2 : 1;  // the library's choice
+  if (nq == 0) {  // the library's choice: the second queue pays when a launch is long against the 2.9 us the host needs to
+                  // enqueue one - four tiles per CU, or two of a world that runs the interpreter (balance 32768 envs:
+                  // interpreter 10.0 -> 8.5 us with two queues, specialised kernel 6.7 us on one, 8.5 on two)
+    bool spec = false;
+    auto it = w->scheds.find(w->lanes);
+    if (it != w->scheds.end()) spec = w->use_spec && it->second.spec_id >= 0 && w->base.substeps == 1;
+    nq = (n_steps >= 8 && (tiles >= 4 * w->n_cu || (tiles >= 2 * w->n_cu && !spec))) ? 2 : 1;
+  }
   while (nq > 1 && tiles < nq) --nq;  // at least one tile per queue
   return nq;
 }
@@ -2462,9 +2469,10 @@ int vmas_world_step_n(VmasWorld* w, float* state, float* agent_ft, int64_t ld, i
   // back at the end.  A dependent launch costs ~2.9 us of front-end time during which the chip idles; with two
   // sequences the gap of one part is filled by the kernel of the other, and the load / compute / store phases of the
   // parts' tiles fall out of step and overlap.  Same kernels, same results bit for bit.
-  // Library's choice: when each half still has a tile for every CU (measured, profiles/r02_two_queues.txt: balance
-  // 32768 envs -15 %, 131072 -12 %, 1 M -4 %, football 131072 -8.5 %, navigation 65536 -15 %; transport 16384 = one tile
-  // per CU in total: +11 %, not split) and the sequence is long enough to pay for the fork and the join.
+  // Library's choice (queues_for): when each half still has a tile for every CU and a launch is long against the host's
+  // 2.9 us per enqueue (measured, profiles/r02_queues_sweep.jsonl: interpreter balance 32768 envs -15 %, 131072 -12 %,
+  // 1 M -4 %, football 131072 -8.5 %, navigation 65536 -15 %; transport 16384 = one tile per CU in total: +11 %, not
+  // split; the specialised balance kernel at 32768 envs is faster on one queue) and the call has >= 8 steps.
   const int nq = !args ? queues_for(w, n_steps) : 1;
   if (nq > 1) {
     int cur = -1;
