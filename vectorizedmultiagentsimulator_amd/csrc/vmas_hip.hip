@@ -1974,18 +1974,34 @@ static int launch_level(VmasWorld* w, Sched* S, float* state, float* aft, long l
     }
   }
   const int blocks = (batch + TILE - 1) / TILE;
-  if constexpr (ENV == ENV_NONE && LEVEL == SpecBalance4::LEVEL) {
-    // the world-specialised kernel (csrc/vmas_spec_kernel.h): same results bit for bit, the schedule as compile-time tables
-    if (mode >= 2 && S->spec_id == SpecBalance4::ID && w->use_spec && !ABLATE(a) && !a.trace) {
-      const size_t lds_spec = ((size_t)SpecBalance4::ROWS * ROWF + 8) * sizeof(float);
-      if (mode == 3)
-        hipLaunchKernelGGL((step_kernel_spec<SpecBalance4, 0>), dim3(blocks), dim3(TILE * SpecBalance4::NW), lds_spec, s, S->dw,
-                           state, aft, ld, batch);
-      else
-        hipLaunchKernelGGL((step_kernel_spec<SpecBalance4, 1>), dim3(blocks), dim3(TILE * SpecBalance4::NW), lds_spec, s, S->dw,
-                           state, aft, ld, batch);
-      HIP_TRY(hipGetLastError());
-      return 0;
+  if constexpr ((ENV == ENV_NONE || ENV == ENV_BALANCE) && LEVEL == SpecBalance4::LEVEL) {
+    // the world-specialised kernel (csrc/vmas_spec_kernel.h): same results bit for bit, the schedule as compile-time
+    // tables - the single World.step(), and the multi-step / fused-environment forms of a one-substep world
+    using G = SpecBalance4;
+    bool ok = plain && S->spec_id == G::ID && w->use_spec && S->dw.substeps == 1 && !ABLATE(a) && !a.trace;
+    if constexpr (ENV == ENV_BALANCE) ok = ok && env.ingest.n_scripts == 0 && !ABLATE(env);
+    if (ok) {
+      const size_t lds_spec = ((size_t)G::ROWS * ROWF + 8) * sizeof(float) + extra_lds;
+      const bool tail = batch % TILE != 0;
+      const int n = a.n_steps > 1 ? a.n_steps : 1;
+      const dim3 grid(blocks), block(TILE * G::NW);
+      if constexpr (ENV == ENV_NONE) {
+        if (n == 1) {
+          if (tail) hipLaunchKernelGGL((step_kernel_spec<G, 1>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch);
+          else hipLaunchKernelGGL((step_kernel_spec<G, 0>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch);
+        } else {
+          if (tail) hipLaunchKernelGGL((step_kernel_spec_multi<G, 1, ENV_NONE, NoEnv>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch, n, (long)a.ft_stride, env);
+          else hipLaunchKernelGGL((step_kernel_spec_multi<G, 0, ENV_NONE, NoEnv>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch, n, (long)a.ft_stride, env);
+        }
+      } else {
+        if (lds_spec > 64 * 1024) ok = false;  // (never for this world; the interpreter path sets the attribute)
+        else if (tail) hipLaunchKernelGGL((step_kernel_spec_multi<G, 1, ENV_BALANCE, EnvArgs>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch, n, (long)a.ft_stride, env);
+        else hipLaunchKernelGGL((step_kernel_spec_multi<G, 0, ENV_BALANCE, EnvArgs>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch, n, (long)a.ft_stride, env);
+      }
+      if (ok) {
+        HIP_TRY(hipGetLastError());
+        return 0;
+      }
     }
   }
   if (mode == 3)
