@@ -1994,8 +1994,18 @@ static int launch_level(VmasWorld* w, Sched* S, float* state, float* aft, long l
           else hipLaunchKernelGGL((step_kernel_spec_multi<G, 0, ENV_NONE, NoEnv>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch, n, (long)a.ft_stride, env);
         }
       } else {
-        if (lds_spec > 64 * 1024) ok = false;  // (never for this world; the interpreter path sets the attribute)
-        else if (tail) hipLaunchKernelGGL((step_kernel_spec_multi<G, 1, ENV_BALANCE, EnvArgs>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch, n, (long)a.ft_stride, env);
+        if (lds_spec > 64 * 1024) {  // (the epilogue's observation staging: opt in to the large LDS once per device)
+          static std::atomic<size_t> spec_set_for[64];
+          std::atomic<size_t>& set_for = spec_set_for[w->device & 63];
+          if (set_for.load() < lds_spec) {
+            HIP_TRY(hipFuncSetAttribute((const void*)step_kernel_spec_multi<G, 0, ENV_BALANCE, EnvArgs>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_spec));
+            HIP_TRY(hipFuncSetAttribute((const void*)step_kernel_spec_multi<G, 1, ENV_BALANCE, EnvArgs>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_spec));
+            set_for = lds_spec;
+          }
+        }
+        if (tail) hipLaunchKernelGGL((step_kernel_spec_multi<G, 1, ENV_BALANCE, EnvArgs>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch, n, (long)a.ft_stride, env);
         else hipLaunchKernelGGL((step_kernel_spec_multi<G, 0, ENV_BALANCE, EnvArgs>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch, n, (long)a.ft_stride, env);
       }
       if (ok) {
