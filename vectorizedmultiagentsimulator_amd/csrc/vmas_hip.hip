@@ -1990,23 +1990,32 @@ static int launch_level(VmasWorld* w, Sched* S, float* state, float* aft, long l
           if (tail) hipLaunchKernelGGL((step_kernel_spec<G, 1>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch);
           else hipLaunchKernelGGL((step_kernel_spec<G, 0>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch);
         } else {
-          if (tail) hipLaunchKernelGGL((step_kernel_spec_multi<G, 1, ENV_NONE, NoEnv>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch, n, (long)a.ft_stride, env);
-          else hipLaunchKernelGGL((step_kernel_spec_multi<G, 0, ENV_NONE, NoEnv>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch, n, (long)a.ft_stride, env);
+          if (tail) hipLaunchKernelGGL((step_kernel_spec_multi<G, 1, ENV_NONE, NoEnv, false>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch, n, (long)a.ft_stride, env);
+          else hipLaunchKernelGGL((step_kernel_spec_multi<G, 0, ENV_NONE, NoEnv, false>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch, n, (long)a.ft_stride, env);
         }
       } else {
         if (lds_spec > 64 * 1024) {  // (the epilogue's observation staging: opt in to the large LDS once per device)
           static std::atomic<size_t> spec_set_for[64];
           std::atomic<size_t>& set_for = spec_set_for[w->device & 63];
           if (set_for.load() < lds_spec) {
-            HIP_TRY(hipFuncSetAttribute((const void*)step_kernel_spec_multi<G, 0, ENV_BALANCE, EnvArgs>,
+            HIP_TRY(hipFuncSetAttribute((const void*)step_kernel_spec_multi<G, 0, ENV_BALANCE, EnvArgs, false>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_spec));
-            HIP_TRY(hipFuncSetAttribute((const void*)step_kernel_spec_multi<G, 1, ENV_BALANCE, EnvArgs>,
+            HIP_TRY(hipFuncSetAttribute((const void*)step_kernel_spec_multi<G, 1, ENV_BALANCE, EnvArgs, false>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_spec));
+            HIP_TRY(hipFuncSetAttribute((const void*)step_kernel_spec_multi<G, 0, ENV_BALANCE, EnvArgs, true>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_spec));
+            HIP_TRY(hipFuncSetAttribute((const void*)step_kernel_spec_multi<G, 1, ENV_BALANCE, EnvArgs, true>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_spec));
             set_for = lds_spec;
           }
         }
-        if (tail) hipLaunchKernelGGL((step_kernel_spec_multi<G, 1, ENV_BALANCE, EnvArgs>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch, n, (long)a.ft_stride, env);
-        else hipLaunchKernelGGL((step_kernel_spec_multi<G, 0, ENV_BALANCE, EnvArgs>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch, n, (long)a.ft_stride, env);
+        if (n == 1) {
+          if (tail) hipLaunchKernelGGL((step_kernel_spec_multi<G, 1, ENV_BALANCE, EnvArgs, true>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch, 1, 0l, env);
+          else hipLaunchKernelGGL((step_kernel_spec_multi<G, 0, ENV_BALANCE, EnvArgs, true>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch, 1, 0l, env);
+        } else {
+          if (tail) hipLaunchKernelGGL((step_kernel_spec_multi<G, 1, ENV_BALANCE, EnvArgs, false>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch, n, (long)a.ft_stride, env);
+          else hipLaunchKernelGGL((step_kernel_spec_multi<G, 0, ENV_BALANCE, EnvArgs, false>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch, n, (long)a.ft_stride, env);
+        }
       }
       if (ok) {
         HIP_TRY(hipGetLastError());
