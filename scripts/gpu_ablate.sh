@@ -5,7 +5,7 @@
 #   0 full | 1 no items | 16 descriptors only | 32 broad phase only | 2 no integrate | 3 neither | 8 no trig
 W=${1:-football}; B=${2:-131072}; N=${3:-200}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-export VMAS_HIP_LIB=libvmas_hip_profile.so QUEUES=1
+export VMAS_HIP_LIB=libvmas_hip_profile.so QUEUES=1 SPEC=0   # (the phases of the INTERPRETER: step_kernel)
 cd /tmp && export TMPDIR=/tmp
 for A in 0 1 16 32 2 3; do
   T=$(VMAS_ABLATE=$A python $R/scripts/bench_world.py $W $B $N 2>/dev/null | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['world_step_us'])")
