@@ -571,3 +571,39 @@ def test_specialised_kernel_is_bitwise_the_generic_one(B):
     same = lambda a, b: torch.equal(a.view(torch.int32), b.view(torch.int32))  # noqa: E731
     assert same(outs[0][0], outs[1][0]) and same(outs[0][1], outs[1][1])
     assert torch.isfinite(outs[0][0]).all()
+
+
+@pytest.mark.parametrize("scenario,kw,B,n_sub", [("transport", {}, 16384, 1), ("transport", {}, 16300, 1),
+                                                 ("navigation", dict(n_agents=8), 65536, 2),
+                                                 ("navigation", dict(n_agents=8), 65500, 2)])
+def test_other_specialised_worlds_are_bitwise_the_interpreter(scenario, kw, B, n_sub):
+    """The generated specialisations of BASELINE configs 3 and 4 (transport at 16 waves per tile; navigation n_agents=8 at 4
+    waves per tile, TWO substeps per step: the multi-pass form) against the interpreter: single steps, a step_n sequence and
+    a persistent rollout, bit for bit."""
+    import importlib
+
+    mod = importlib.import_module(f"vectorizedmultiagentsimulator_amd.scenarios.{scenario}")
+    outs = []
+    for on in (True, False):
+        torch.manual_seed(7)
+        torch.cuda.manual_seed(7)
+        sc = mod.Scenario()
+        w = sc.env_make_world(B, "cuda:0", **kw)
+        sc.env_reset_world_at(None)
+        assert w.substeps == n_sub
+        be = w._get_backend()
+        be.set_specialized(on)
+        assert be.specialized == on, "the generated tables do not match the schedule planned at run time"
+        nA = len(w.agents)
+        g = torch.Generator(device="cuda:0").manual_seed(11)
+        forces = torch.zeros(14, *be.agent_ft.shape, device="cuda:0")
+        forces[:, :nA, 0:2, :B] = (torch.rand(14, nA, 2, B, device="cuda:0", generator=g) * 2 - 1) * 0.8
+        be.set_queues(1)
+        be.step_n(8, forces[:8])
+        be.rollout(5, forces[8:13])
+        be.agent_ft.copy_(forces[13])
+        be.step()
+        outs.append((be.state.clone(), be.agent_ft.clone(), forces.clone()))
+    same = lambda a, b: torch.equal(a.view(torch.int32), b.view(torch.int32))  # noqa: E731
+    assert all(same(x, y) for x, y in zip(outs[0], outs[1]))
+    assert torch.isfinite(outs[0][0]).all()

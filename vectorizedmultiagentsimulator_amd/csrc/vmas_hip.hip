@@ -1825,16 +1825,17 @@ static int build_sched(VmasWorld* w, int nw, Sched& S) {
   S.rows = row_bad;
   // A generated specialisation serves this schedule iff it was generated from the very same words (and geometry).
   S.spec_id = -1;
-  {
-    using G = SpecBalance4;
-    if (nw == G::NW && w->level == G::LEVEL && (int)blob.size() == G::BLOB_WORDS && S.dw.items_in_lds && w->base.trig_in_args &&
-        row_bad == G::ROWS && w->base.nE == G::NE && w->base.nA == G::NA && w->base.off_af == G::OFF_AF &&
-        w->base.row_tr == G::ROW_TR && w->base.trig_mask == G::TRIG_MASK && w->base.box_mask == G::BOX_MASK &&
-        S.dw.b_ent == G::B_ENT && S.dw.b_segs == G::B_SEGS && S.dw.b_owned == G::B_OWNED && S.dw.b_refs == G::B_REFS &&
-        S.dw.b_items == G::B_ITEMS && (int)segs_sorted.size() == G::N_SEGS && (int)owned.size() == G::N_OWNED &&
-        w->fired_recs == G::FIRED_RECS && memcmp(blob.data(), G::blob, sizeof(uint32_t) * G::BLOB_WORDS) == 0)
-      S.spec_id = G::ID;
-  }
+#define VMAS_MATCH_SPEC(G)                                                                                               \
+  if (S.spec_id < 0 && nw == G::NW && w->level == G::LEVEL && (int)blob.size() == G::BLOB_WORDS && S.dw.items_in_lds &&  \
+      w->base.trig_in_args && row_bad == G::ROWS && w->base.nE == G::NE && w->base.nA == G::NA &&                        \
+      w->base.substeps == G::SUBSTEPS && w->base.off_af == G::OFF_AF && w->base.row_tr == G::ROW_TR &&                   \
+      w->base.trig_mask == G::TRIG_MASK && w->base.box_mask == G::BOX_MASK && S.dw.b_ent == G::B_ENT &&                  \
+      S.dw.b_segs == G::B_SEGS && S.dw.b_owned == G::B_OWNED && S.dw.b_refs == G::B_REFS && S.dw.b_items == G::B_ITEMS && \
+      (int)segs_sorted.size() == G::N_SEGS && (int)owned.size() == G::N_OWNED && w->fired_recs == G::FIRED_RECS &&       \
+      memcmp(blob.data(), G::blob, sizeof(uint32_t) * G::BLOB_WORDS) == 0)                                               \
+    S.spec_id = G::ID;
+  VMAS_SPEC_LIST(VMAS_MATCH_SPEC)
+#undef VMAS_MATCH_SPEC
   if (!w->host_only) HIP_TRY(upload(&S.d_blob, blob));
   S.dw.blob = S.d_blob;
   S.dw.items = (const DevItem*)(S.d_blob + S.dw.b_items);
@@ -1948,6 +1949,49 @@ static int select_config(VmasWorld* w) {
 
 static inline int blocks_of(int batch) { return (batch + TILE - 1) / TILE; }
 
+// Launch of a generated specialisation G (its schedule is word for word S's): the lean single World.step, the multi-step
+// form (several steps and / or substeps per launch) or the fused-environment forms.  0 ok, -1 error.
+template <class G, int ENV, class EnvArgs>
+static int launch_spec(VmasWorld* w, Sched* S, float* state, float* aft, long ld, const DevStepArgs& a, const EnvArgs& env,
+                       size_t extra_lds, hipStream_t s, int batch) {
+  const size_t lds_spec = ((size_t)G::ROWS * ROWF + 8) * sizeof(float) + extra_lds;
+  const bool tail = batch % TILE != 0;
+  const int n = a.n_steps > 1 ? a.n_steps : 1;
+  const dim3 grid((batch + TILE - 1) / TILE), block(TILE * G::NW);
+  if (lds_spec > 64 * 1024) {  // (a fused epilogue's observation staging: opt in to the large LDS once per device)
+    static std::atomic<size_t> spec_set_for[64];
+    std::atomic<size_t>& set_for = spec_set_for[w->device & 63];
+    if (set_for.load() < lds_spec) {
+      HIP_TRY(hipFuncSetAttribute((const void*)step_kernel_spec_multi<G, 0, ENV, EnvArgs, false>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_spec));
+      HIP_TRY(hipFuncSetAttribute((const void*)step_kernel_spec_multi<G, 1, ENV, EnvArgs, false>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_spec));
+      HIP_TRY(hipFuncSetAttribute((const void*)step_kernel_spec_multi<G, 0, ENV, EnvArgs, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_spec));
+      HIP_TRY(hipFuncSetAttribute((const void*)step_kernel_spec_multi<G, 1, ENV, EnvArgs, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_spec));
+      set_for = lds_spec;
+    }
+  }
+  if constexpr (ENV == ENV_NONE && G::SUBSTEPS == 1) {
+    if (n == 1) {  // the lean form
+      if (tail) hipLaunchKernelGGL((step_kernel_spec<G, 1>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch);
+      else hipLaunchKernelGGL((step_kernel_spec<G, 0>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch);
+      HIP_TRY(hipGetLastError());
+      return 0;
+    }
+  }
+  if (n == 1) {
+    if (tail) hipLaunchKernelGGL((step_kernel_spec_multi<G, 1, ENV, EnvArgs, true>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch, 1, 0l, env);
+    else hipLaunchKernelGGL((step_kernel_spec_multi<G, 0, ENV, EnvArgs, true>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch, 1, 0l, env);
+  } else {
+    if (tail) hipLaunchKernelGGL((step_kernel_spec_multi<G, 1, ENV, EnvArgs, false>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch, n, (long)a.ft_stride, env);
+    else hipLaunchKernelGGL((step_kernel_spec_multi<G, 0, ENV, EnvArgs, false>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch, n, (long)a.ft_stride, env);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 template <int LEVEL, int ENV, class EnvArgs>
 static int launch_level(VmasWorld* w, Sched* S, float* state, float* aft, long ld, const DevStepArgs& a,
                         const EnvArgs& env, size_t extra_lds, hipStream_t s, int batch, long pad) {
@@ -1974,53 +2018,19 @@ static int launch_level(VmasWorld* w, Sched* S, float* state, float* aft, long l
     }
   }
   const int blocks = (batch + TILE - 1) / TILE;
-  if constexpr ((ENV == ENV_NONE || ENV == ENV_BALANCE) && LEVEL == SpecBalance4::LEVEL) {
-    // the world-specialised kernel (csrc/vmas_spec_kernel.h): same results bit for bit, the schedule as compile-time
-    // tables - the single World.step(), and the multi-step / fused-environment forms of a one-substep world
-    using G = SpecBalance4;
-    bool ok = plain && S->spec_id == G::ID && w->use_spec && S->dw.substeps == 1 && !ABLATE(a) && !a.trace;
-    if constexpr (ENV == ENV_BALANCE) ok = ok && env.ingest.n_scripts == 0 && !ABLATE(env);
-    if (ok) {
-      const size_t lds_spec = ((size_t)G::ROWS * ROWF + 8) * sizeof(float) + extra_lds;
-      const bool tail = batch % TILE != 0;
-      const int n = a.n_steps > 1 ? a.n_steps : 1;
-      const dim3 grid(blocks), block(TILE * G::NW);
-      if constexpr (ENV == ENV_NONE) {
-        if (n == 1) {
-          if (tail) hipLaunchKernelGGL((step_kernel_spec<G, 1>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch);
-          else hipLaunchKernelGGL((step_kernel_spec<G, 0>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch);
-        } else {
-          if (tail) hipLaunchKernelGGL((step_kernel_spec_multi<G, 1, ENV_NONE, NoEnv, false>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch, n, (long)a.ft_stride, env);
-          else hipLaunchKernelGGL((step_kernel_spec_multi<G, 0, ENV_NONE, NoEnv, false>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch, n, (long)a.ft_stride, env);
-        }
-      } else {
-        if (lds_spec > 64 * 1024) {  // (the epilogue's observation staging: opt in to the large LDS once per device)
-          static std::atomic<size_t> spec_set_for[64];
-          std::atomic<size_t>& set_for = spec_set_for[w->device & 63];
-          if (set_for.load() < lds_spec) {
-            HIP_TRY(hipFuncSetAttribute((const void*)step_kernel_spec_multi<G, 0, ENV_BALANCE, EnvArgs, false>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_spec));
-            HIP_TRY(hipFuncSetAttribute((const void*)step_kernel_spec_multi<G, 1, ENV_BALANCE, EnvArgs, false>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_spec));
-            HIP_TRY(hipFuncSetAttribute((const void*)step_kernel_spec_multi<G, 0, ENV_BALANCE, EnvArgs, true>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_spec));
-            HIP_TRY(hipFuncSetAttribute((const void*)step_kernel_spec_multi<G, 1, ENV_BALANCE, EnvArgs, true>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_spec));
-            set_for = lds_spec;
-          }
-        }
-        if (n == 1) {
-          if (tail) hipLaunchKernelGGL((step_kernel_spec_multi<G, 1, ENV_BALANCE, EnvArgs, true>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch, 1, 0l, env);
-          else hipLaunchKernelGGL((step_kernel_spec_multi<G, 0, ENV_BALANCE, EnvArgs, true>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch, 1, 0l, env);
-        } else {
-          if (tail) hipLaunchKernelGGL((step_kernel_spec_multi<G, 1, ENV_BALANCE, EnvArgs, false>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch, n, (long)a.ft_stride, env);
-          else hipLaunchKernelGGL((step_kernel_spec_multi<G, 0, ENV_BALANCE, EnvArgs, false>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch, n, (long)a.ft_stride, env);
-        }
-      }
-      if (ok) {
-        HIP_TRY(hipGetLastError());
-        return 0;
-      }
+  // the world-specialised kernels (csrc/vmas_spec_kernel.h): same results bit for bit, the schedule as compile-time tables
+  if (plain && S->spec_id >= 0 && w->use_spec && !ABLATE(a) && !a.trace) {
+    bool spec_ok = true;
+    if constexpr (ENV != ENV_NONE) spec_ok = env.ingest.n_scripts == 0 && !ABLATE(env);
+    if (spec_ok) {
+      int rc = 1;  // 1: no specialisation serves this launch
+#define VMAS_LAUNCH_SPEC(G)                                                                                              \
+      if constexpr (LEVEL == G::LEVEL && (ENV == ENV_NONE || (ENV == ENV_BALANCE && G::POST == 1)))                       \
+        if (rc == 1 && S->spec_id == G::ID)                                                                              \
+          rc = launch_spec<G, ENV, EnvArgs>(w, S, state, aft, ld, a, env, extra_lds, s, batch);
+      VMAS_SPEC_LIST(VMAS_LAUNCH_SPEC)
+#undef VMAS_LAUNCH_SPEC
+      if (rc <= 0) return rc;
     }
   }
   if (mode == 3)
