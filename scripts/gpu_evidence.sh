@@ -28,6 +28,7 @@ S=$R/scripts
 export QUEUES=1 EVIDENCE_DIR=$TAG
 bash scripts/gpu_counters.sh ${TAG}_football131072_physics 948 11900 131072 -- python $S/bench_world.py football 131072 200 > /dev/null 2>&1
 bash scripts/gpu_counters.sh ${TAG}_navigation65536_physics 672 1800 65536 -- python $S/bench_world.py navigation 65536 200 > /dev/null 2>&1
+bash scripts/gpu_counters.sh ${TAG}_transport16384_physics 312 800 16384 -- python $S/bench_world.py transport 16384 300 > /dev/null 2>&1
 bash scripts/gpu_counters.sh ${TAG}_balance1048576_physics 384 1700 1048576 -- python $S/bench_world.py balance 1048576 100 > /dev/null 2>&1
 bash scripts/gpu_counters.sh ${TAG}_balance32768_physics 384 1700 32768 -- python $S/bench_world.py balance 32768 300 > /dev/null 2>&1
 SPEC=0 bash scripts/gpu_counters.sh ${TAG}_balance32768_physics_interpreter 384 1700 32768 -- python $S/bench_world.py balance 32768 300 > /dev/null 2>&1
@@ -39,7 +40,7 @@ unset QUEUES
 for W in "balance 32768" "transport 16384" "navigation 65536" "navigation 8192" "football 131072" "football 16384" "balance 1048576"; do
   for Q in 1 2; do QUEUES=$Q python scripts/bench_world.py $W 500; done
 done
-for W in "balance 32768" "balance 131072" "balance 1048576"; do   # specialised kernel vs interpreter, one queue
+for W in "balance 32768" "balance 131072" "balance 1048576" "transport 16384" "navigation 65536" "navigation 8192"; do   # specialised kernel vs interpreter, one queue
   for SP in 1 0; do SPEC=$SP QUEUES=1 python scripts/bench_world.py $W 1000; done
 done
 } 2>&1 | grep "^{" > $OUT/${TAG}_world_step_rates.jsonl

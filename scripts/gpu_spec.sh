@@ -1,7 +1,7 @@
 mkdir -p gpurun_out/quick
-timeout 600 python -m pytest tests/test_hip_parity.py tests/test_env_fused_gpu.py tests/test_env_gpu.py -m gpu -q -k "specialised or rollout or one_launch or golden or several_queues or checkpoint" -p no:cacheprovider 2>&1 | tail -12
 {
+for W in "football 131072" "football 16384" "navigation 8192"; do
+  for SP in 1 0; do SPEC=$SP python scripts/bench_world.py $W 1000; done
+done
 python scripts/bench_rollout_env.py balance 32768 100
-ONLY=fused-eager python scripts/bench_env.py balance 32768; ONLY=fused-graph python scripts/bench_env.py balance 32768
-python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline
-} 2>&1 | grep "^{" | cut -c1-1500 | tee gpurun_out/quick/spec_rates.jsonl
+} 2>&1 | grep "^{" | cut -c1-300 | tee gpurun_out/quick/spec_rates2.jsonl

@@ -575,10 +575,12 @@ def test_specialised_kernel_is_bitwise_the_generic_one(B):
 
 @pytest.mark.parametrize("scenario,kw,B,n_sub", [("transport", {}, 16384, 1), ("transport", {}, 16300, 1),
                                                  ("navigation", dict(n_agents=8), 65536, 2),
-                                                 ("navigation", dict(n_agents=8), 65500, 2)])
+                                                 ("navigation", dict(n_agents=8), 65500, 2),
+                                                 ("navigation", dict(n_agents=8), 8192, 2)])
 def test_other_specialised_worlds_are_bitwise_the_interpreter(scenario, kw, B, n_sub):
     """The generated specialisations of BASELINE configs 3 and 4 (transport at 16 waves per tile; navigation n_agents=8 at 4
-    waves per tile, TWO substeps per step: the multi-pass form) against the interpreter: single steps, a step_n sequence and
+    waves per tile and, the per-GPU shard of 8192 environments, at 16 - TWO substeps per step: the multi-pass form) against
+    the interpreter: single steps, a step_n sequence and
     a persistent rollout, bit for bit."""
     import importlib
 
