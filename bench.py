@@ -487,7 +487,7 @@ def main():
                 "gflops_frac_of_fp32_vector_peak": gflops / FP32_PEAK_GFLOPS,
                 "binds": "neither roof at this batch: one launch moves 12.6 MB (1.6 us at 8 TB/s) and 56 Mflop "
                          "(0.4 us at fp32 peak); the launch is a ~3 us launch floor plus one tile's dependent chain "
-                         "(profiles/r02d_balance32768_physics_pmc_summary.txt, r02_balance32768_phase_trace.txt). At "
+                         "(profiles/r02e_balance32768_physics_pmc_summary.txt, r02_balance32768_phase_trace.txt). At "
                          "1 M environments the same kernel reaches 50 % of the HBM roof. HBM is the nominal bound.",
             },
         }
