@@ -14,6 +14,8 @@ for fused in (False, True):
         if only and only != f"{'fused' if fused else 'plain'}-{'graph' if graph else 'eager'}":
             continue
         env = make_env(name, num_envs=B, device="cuda:0", seed=0, validate_actions=False, graph=graph, fused=fused, **kw)
+        if os.environ.get("SPEC") == "0":  # A/B: the interpreter instead of the world-specialised kernel
+            env.world._get_backend().set_specialized(False)
         acts = [env.get_random_action(a) for a in env.agents]
         for _ in range(300 if (graph or fused) else 5):  # (the first few hundred steps carry one-time costs)
             env.step(acts)
@@ -24,5 +26,5 @@ for fused in (False, True):
             env.step(acts)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
-        print(json.dumps({"scenario": name, "num_envs": B, "fused": fused, "graph": graph, "env_step_us": round(dt * 1e6, 2),
+        print(json.dumps({"scenario": name, "num_envs": B, "specialized": env.world._get_backend().specialized, "fused": fused, "graph": graph, "env_step_us": round(dt * 1e6, 2),
                           "env_steps_per_s": round(B / dt)}), flush=True)

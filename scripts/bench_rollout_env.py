@@ -9,6 +9,8 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 32768
 K = int(sys.argv[3]) if len(sys.argv) > 3 else 100
 kw = {"balance": dict(n_agents=4), "transport": {}}[name]
 env = make_env(name, num_envs=B, device="cuda:0", seed=0, validate_actions=False, **kw)
+if os.environ.get("SPEC") == "0":  # A/B: the interpreter instead of the world-specialised kernel
+    env.world._get_backend().set_specialized(False)
 g = torch.Generator(device="cuda:0").manual_seed(1)
 acts = [(torch.rand(K, B, 2, device="cuda:0", generator=g) * 2 - 1) for _ in env.agents]
 for _ in range(3):
@@ -30,6 +32,6 @@ for k in range(reps * K // 4):
     env.step([u[k % K] for u in acts])
 torch.cuda.synchronize()
 step = (time.perf_counter() - t0) / (reps * K // 4)
-print(json.dumps({"scenario": name, "num_envs": B, "K": K, "rollout_us_per_step_gpu": round(gpu * 1e6, 2),
+print(json.dumps({"scenario": name, "num_envs": B, "K": K, "specialized": env.world._get_backend().specialized, "rollout_us_per_step_gpu": round(gpu * 1e6, 2),
                   "rollout_us_per_step_wall": round(wall * 1e6, 2), "rollout_env_steps_per_s": round(B / wall),
                   "step_us_per_step_wall": round(step * 1e6, 2), "step_env_steps_per_s": round(B / step)}))

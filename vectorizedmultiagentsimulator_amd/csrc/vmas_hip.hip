@@ -2025,7 +2025,8 @@ static int launch_level(VmasWorld* w, Sched* S, float* state, float* aft, long l
     if (spec_ok) {
       int rc = 1;  // 1: no specialisation serves this launch
 #define VMAS_LAUNCH_SPEC(G)                                                                                              \
-      if constexpr (LEVEL == G::LEVEL && (ENV == ENV_NONE || (ENV == ENV_BALANCE && G::POST == 1)))                       \
+      if constexpr (LEVEL == G::LEVEL && (ENV == ENV_NONE || ENV == ENV_INGEST || (ENV == ENV_BALANCE && G::POST == 1) ||  \
+                                          (ENV == ENV_TRANSPORT && G::POST == 2)))                                       \
         if (rc == 1 && S->spec_id == G::ID)                                                                              \
           rc = launch_spec<G, ENV, EnvArgs>(w, S, state, aft, ld, a, env, extra_lds, s, batch);
       VMAS_SPEC_LIST(VMAS_LAUNCH_SPEC)
