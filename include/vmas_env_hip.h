@@ -235,6 +235,11 @@ int vmas_env_reset_where(const VmasResetArgs* args, int32_t batch, int32_t n_ent
 #define VMAS_POST_NONE 0 /* prologue only (post_desc / post_buffers NULL): actions -> forces -> World.step() */
 #define VMAS_POST_BALANCE 1
 #define VMAS_POST_TRANSPORT 2
+#define VMAS_POST_NAVIGATION 3 /* VmasNavigationDesc / VmasNavigationBuffers (lidar, lidar_max_rays, pair_any unused: the
+                                * epilogue casts the world's registered sensors - sensor a = agent a's - on the tile, and
+                                * World.collides' reduction over the batch is made in the launch itself; the collision
+                                * penalties are added by a second small kernel behind the step kernel, same stream).  One
+                                * step per call (no vmas_world_rollout_env). */
 int vmas_world_step_env(VmasWorld* w, float* state, float* agent_ft, int64_t ld, const VmasStepArgs* args /* may be NULL */,
                         const VmasIngestArgs* ingest /* may be NULL */, uint32_t* err_flags /* may be NULL */,
                         int32_t post_kind, const void* post_desc, const void* post_buffers, void* stream);
@@ -259,6 +264,13 @@ int vmas_world_rollout_env(VmasWorld* w, float* state, float* agent_ft, int64_t 
  * falling back at the first launch that does not fit.  Optional; call it before the first step.  The reference has no
  * counterpart (kernel geometry). */
 int vmas_world_reserve_epilogue(VmasWorld* w, int32_t post_kind, int32_t n_packages);
+
+/* 0 if vmas_world_step_env(post_kind = VMAS_POST_NAVIGATION, post_desc) can run on this world as it is planned now: the
+ * world's registered sensors are what the epilogue casts (sensor a on agent a, `n_rays` rays of `lidar_range`, its targets
+ * the other agents in order), and the tile plus the epilogue's scratch fit the CU's LDS (shared pair rows are given up
+ * for it if that is what it takes).  -1 with vmas_last_error() otherwise: the caller keeps the separate launches
+ * (vmas_world_cast_rays, vmas_world_pair_mask, vmas_navigation_post_step). */
+int vmas_world_step_env_check(VmasWorld* w, int32_t post_kind, const void* post_desc);
 
 #ifdef __cplusplus
 }

@@ -141,7 +141,7 @@ LIB_PATH = os.path.join(_PKG_DIR, "csrc", os.path.basename(os.environ.get("VMAS_
 ENV_MAX_AGENTS = 32
 ENV_MAX_PACKAGES = 8
 ACTION_ERR_NAN, ACTION_ERR_OUT_OF_RANGE = 1, 2
-POST_BALANCE, POST_TRANSPORT = 1, 2
+POST_BALANCE, POST_TRANSPORT, POST_NAVIGATION = 1, 2, 3
 
 
 class ActionSlot(C.Structure):
@@ -297,6 +297,7 @@ EXPORTED_SYMBOLS = (
     "vmas_world_step_env",
     "vmas_world_rollout_env",
     "vmas_world_reserve_epilogue",
+    "vmas_world_step_env_check",
 )
 
 _lib: Optional[C.CDLL] = None
@@ -367,6 +368,8 @@ def load_library() -> C.CDLL:
     lib.vmas_world_rollout_env.restype = C.c_int
     lib.vmas_world_reserve_epilogue.argtypes = [vp, i32, i32]
     lib.vmas_world_reserve_epilogue.restype = C.c_int
+    lib.vmas_world_step_env_check.argtypes = [vp, i32, vp]
+    lib.vmas_world_step_env_check.restype = C.c_int
     lib.vmas_last_error.argtypes = []
     lib.vmas_last_error.restype = C.c_char_p
     lib.vmas_abi_version.argtypes = []

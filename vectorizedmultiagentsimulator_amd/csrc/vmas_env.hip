@@ -45,7 +45,6 @@ using namespace vmas;
 
 namespace {
 
-constexpr int kMaxOwn = VMAS_ENV_MAX_AGENTS / 4;  // agents one wave can own (blocks have >= 4 waves)
 
 // ------------------------------------------------------------------------------------ ingest
 __global__ __launch_bounds__(256) void ingest_kernel(const VmasIngestArgs args, int batch, const float* __restrict__ state,
@@ -130,44 +129,54 @@ __global__ __launch_bounds__(512) void navigation_post_kernel(const VmasNavigati
   auto vel = [&](int a) { return V(rows[(a * 6 + 2) * 64 + C.lane], rows[(a * 6 + 3) * 64 + C.lane]); };
   auto goal = [&](int a) { return V(rows[(a * 6 + 4) * 64 + C.lane], rows[(a * 6 + 5) * 64 + C.lane]); };
 
-  // agent_reward of every agent (navigation.py:232-242, 206-216), recomputed by every wave: the shared
-  // terms need all of them; the wave that owns agent a stores a's terms
-  float pos_rew = 0.f, my_pos_rew[kMaxOwn];  // (launched with nw >= 4)
-  bool all_reached = true, all_done = true;
-  for (int a = 0; a < A; ++a) {
-    const float dist = vnorm(pos(a) - goal(a));
-    all_reached = all_reached && (dist < d.goal_radius);
-    all_done = all_done && (dist < d.agent_radius);  // done(): compared with the AGENT's radius
-    const float shaping = dist * d.pos_shaping_factor;
-    const float r = per_agent[a * 64 + C.lane] - shaping;
-    if (a % C.nw == C.wave) {
-      my_pos_rew[a / C.nw] = r;
-      if (C.live) {
-        o.pos_shaping[(long)a * batch + C.env] = shaping;
-        o.agent_pos_rew[(long)a * batch + C.env] = r;
-      }
-    }
-    pos_rew = pos_rew + r;
-  }
-  const float final_rew = all_reached ? d.final_reward : 0.f;
-  if (C.wave == 0) {
-    const bool done = apply_step_limit(o.limit, C, steps_in, all_done);
-    if (C.live) {
-      o.pos_rew[C.env] = pos_rew;
-      o.final_rew[C.env] = final_rew;
-      o.done[C.env] = done ? 1 : 0;
-    }
-  }
+  auto rays = [&](int a, int s) {
+    if (s > 0)  // (the wave's first agent had its rays put in the opening burst)
+      burst<16>(n_rays, [&](int r) { return o.lidar[((long)a * n_rays + r) * ld + C.e]; },
+                [&](int r, float v) { T.put(4 + 2 * n_goal + r, d.lidar_range - v); });
+  };
+  navigation_post_body<false>(C, d, o, batch, per_agent, collide_with, T, steps_in, pos, vel, goal, rays);
+}
 
-#pragma unroll
-  for (int s = 0; s < kMaxOwn; ++s) {
-    const int a = C.wave + s * C.nw;
-    if (a >= A) break;
-    const v2 p = pos(a);
-    // pairwise penalties navigation.py:218-229: a pair counts only if World.collides(a, b) holds
+// The collision penalties of a one-launch navigation step (vmas_world_step_env with VMAS_POST_NAVIGATION): the step
+// kernel's epilogue stored every agent's reward without them and ORed World.collides' per-tile pair bits into `mask`;
+// this kernel - behind it on the same stream, so the reduction over the whole batch is complete - adds
+// navigation.py:218-229 and zeroes the mask for the next step (by the block that reads it last).
+__global__ __launch_bounds__(256) void navigation_collision_kernel(const VmasNavigationDesc d, float* __restrict__ rew,
+                                                                  float* __restrict__ collision_rew,
+                                                                  const int32_t* __restrict__ pair_index, int batch,
+                                                                  const float* __restrict__ state, long ld,
+                                                                  uint32_t* __restrict__ mask, int mask_words) {
+  __shared__ uint32_t collide_with[VMAS_ENV_MAX_AGENTS];
+  const int A = d.n_agents;
+  if ((int)threadIdx.x < A) {
+    uint32_t m = 0;
+    for (int j = 0; j < A; ++j) {
+      const int pi = pair_index[threadIdx.x * A + j];
+      if (j != (int)threadIdx.x && pi >= 0 && ((__builtin_nontemporal_load(&mask[pi >> 5]) >> (pi & 31)) & 1u)) m |= 1u << j;
+    }
+    collide_with[threadIdx.x] = m;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && atomicAdd(&mask[mask_words], 1u) == gridDim.x - 1) {  // every block has read the mask
+    for (int k = 0; k <= mask_words; ++k) mask[k] = 0u;
+  }
+  const long env = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long e = env < batch ? env : (long)batch - 1;
+  // every position and reward of this environment in one burst of independent loads (a load per use would chain a
+  // dozen L2 round trips: 12 us for this kernel at 8192 environments)
+  extern __shared__ float sh[];  // xy[2 * A][256] | rw[A][256]
+  float* xy = sh + threadIdx.x;
+  float* rw = xy + 2 * A * 256;
+  burst<16>(2 * A, [&](int i) { return state[((long)(d.agent0 + (i >> 1)) * 6 + (i & 1)) * ld + e]; },
+            [&](int i, float v) { xy[i * 256] = v; });
+  burst<16>(A, [&](int a) { return rew[(long)a * batch + e]; }, [&](int a, float v) { rw[a * 256] = v; });
+  if (env >= batch) return;
+  auto pos = [&](int a) { return V(xy[2 * a * 256], xy[(2 * a + 1) * 256]); };
+  for (int a = 0; a < A; ++a) {
     float col = 0.f;
-    if (d.collisions) {
-      uint32_t m = __builtin_amdgcn_readfirstlane(collide_with[a]);
+    uint32_t m = collide_with[a];
+    if (m) {
+      const v2 p = pos(a);
       while (m) {
         const int j = __builtin_ctz(m);
         m &= m - 1;
@@ -175,21 +184,8 @@ __global__ __launch_bounds__(512) void navigation_post_kernel(const VmasNavigati
         if (distance <= d.min_collision_distance) col += d.agent_collision_penalty;
       }
     }
-    if (C.live) {
-      o.collision_rew[(long)a * batch + C.env] = col;
-      o.rew[(long)a * batch + C.env] = ((d.shared_rew ? pos_rew : my_pos_rew[s]) + final_rew) + col;
-    }
-    // observation navigation.py:244-263
-    T.put(0, p); T.put(2, vel(a));
-    if (d.observe_all_goals) {
-      for (int g = 0; g < A; ++g) T.put(4 + 2 * g, p - goal(g));
-    } else {
-      T.put(4, p - goal(a));
-    }
-    if (s > 0)  // (the wave's first agent had its rays put in the opening burst)
-      burst<16>(n_rays, [&](int r) { return o.lidar[((long)a * n_rays + r) * ld + C.e]; },
-                [&](int r, float v) { T.put(4 + 2 * n_goal + r, d.lidar_range - v); });
-    T.flush(o.obs + ((long)a * batch + C.b0) * D, C.n_rows);
+    collision_rew[(long)a * batch + env] = col;
+    rew[(long)a * batch + env] = rw[a * 256] + col;
   }
 }
 
@@ -369,6 +365,37 @@ int waves_for(int n_agents) { return n_agents > 4 ? 8 : 4; }
 
 // ---- argument validation, shared with vmas_world_step_env (vmas_hip.hip) ----
 namespace vmas {
+
+// fused != 0: as the epilogue of the step kernel (LIDAR cast and World.collides' reduction made in the launch itself)
+int check_navigation_args(const VmasNavigationDesc* d, const VmasNavigationBuffers* o, int32_t batch, const float* state,
+                          int64_t ld, int fused) {
+  if (!d || !o || !state) return host_fail("vmas_navigation_post_step: null argument");
+  if (batch <= 0 || ld < batch) return host_fail("vmas_navigation_post_step: bad batch / ld");
+  if (d->n_agents < 1 || d->n_agents > VMAS_ENV_MAX_AGENTS)
+    return host_fail("vmas_navigation_post_step: n_agents out of range");
+  if (!o->pos_shaping || !o->obs || !o->rew || !o->agent_pos_rew || !o->pos_rew || !o->final_rew || !o->collision_rew ||
+      !o->done)
+    return host_fail("vmas_navigation_post_step: null buffer");
+  if (d->collisions && (!o->pair_index || d->n_rays < 0))
+    return host_fail("vmas_navigation_post_step: collisions need pair_index and n_rays >= 0");
+  if (!fused) {
+    if (d->collisions && (!o->lidar || !o->pair_any))
+      return host_fail("vmas_navigation_post_step: collisions need lidar, pair_any and pair_index");
+    if (d->collisions && o->lidar_max_rays != d->n_rays)
+      return host_fail("vmas_navigation_post_step: every registered sensor must have n_rays rays (lidar_max_rays != n_rays)");
+  }
+  return 0;
+}
+
+// behind a step kernel with the navigation epilogue, same stream (navigation_collision_kernel)
+int launch_navigation_collisions(const VmasNavigationDesc* d, const VmasNavigationBuffers* o, int32_t batch,
+                                 const float* state, int64_t ld, uint32_t* mask, int mask_words, void* stream) {
+  const size_t lds = (size_t)3 * d->n_agents * 256 * sizeof(float);
+  if (ensure_lds(navigation_collision_kernel, lds, "vmas_world_step_env: hipFuncSetAttribute failed")) return -1;
+  hipLaunchKernelGGL(navigation_collision_kernel, dim3((batch + 255) / 256), dim3(256), lds, (hipStream_t)stream, *d, o->rew,
+                     o->collision_rew, o->pair_index, batch, state, (long)ld, mask, mask_words);
+  return check_launch("vmas_world_step_env: navigation collision penalties");
+}
 
 int check_ingest_args(const VmasIngestArgs* args, int32_t batch, const float* agent_ft, int64_t ld) {
   if (!args || !agent_ft) return host_fail("action ingest: null argument");
@@ -550,25 +577,14 @@ int vmas_transport_post_step(const VmasTransportDesc* d, const VmasTransportBuff
 
 int vmas_navigation_post_step(const VmasNavigationDesc* d, const VmasNavigationBuffers* o, int32_t batch,
                               const float* state, int64_t ld, void* stream) {
-  if (!d || !o || !state) return host_fail("vmas_navigation_post_step: null argument");
-  if (batch <= 0 || ld < batch) return host_fail("vmas_navigation_post_step: bad batch / ld");
-  if (d->n_agents < 1 || d->n_agents > VMAS_ENV_MAX_AGENTS)
-    return host_fail("vmas_navigation_post_step: n_agents out of range");
-  if (!o->pos_shaping || !o->obs || !o->rew || !o->agent_pos_rew || !o->pos_rew || !o->final_rew || !o->collision_rew ||
-      !o->done)
-    return host_fail("vmas_navigation_post_step: null buffer");
-  if (d->collisions && (!o->lidar || !o->pair_any || !o->pair_index || d->n_rays < 0))
-    return host_fail("vmas_navigation_post_step: collisions need lidar, pair_any and pair_index");
-  if (d->collisions && o->lidar_max_rays != d->n_rays)
-    return host_fail("vmas_navigation_post_step: every registered sensor must have n_rays rays (lidar_max_rays != n_rays)");
+  if (check_navigation_args(d, o, batch, state, ld, 0)) return -1;
   const int D = 4 + 2 * (d->observe_all_goals ? d->n_agents : 1) + (d->collisions ? d->n_rays : 0);
   // waves per tile: one agent per wave (8) only if four tiles still fit a CU's LDS together - all tiles of
   // a 65536-environment batch resident at once beat shorter chains in two rounds (33 -> 24 us measured)
   auto lds_for = [&](int nw) {
     return ((size_t)d->n_agents * (6 + 1) * 64 + VMAS_ENV_MAX_AGENTS + D * 64 + (size_t)nw * 64 * (D | 1)) * sizeof(float);
   };
-  static const int nw_env = getenv("VMAS_NAV_NW") ? atoi(getenv("VMAS_NAV_NW")) : 0;  // tuning knob
-  const int nw = nw_env ? nw_env : (d->n_agents > 4 && lds_for(8) <= 40 * 1024 ? 8 : 4);
+  const int nw = d->n_agents > 4 && lds_for(8) <= 40 * 1024 ? 8 : 4;
   const size_t lds = lds_for(nw);
   LAUNCH_POST(navigation_post_kernel, nw, lds, "vmas_navigation_post_step", *d, *o, batch, state, (long)ld);
 }

@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/vmas_env_hip.h"
 #include "vmas_device.h"
 
@@ -310,6 +312,397 @@ VD void transport_post_tile(const TileCtx& C, const VmasTransportDesc& d, const 
     T.flush(o.obs + ((long)a * batch + C.b0) * D, C.n_rows);
     if (C.live) o.rew[(long)a * batch + C.env] = rew;
   }
+  if (o.limit.steps != nullptr) steps_in = steps_in + 1.f;
+}
+
+// ------------------------------------------------------------------------------------ LIDAR
+// World.cast_rays (core.py:1662-1786) for RAY_CHUNK rays r0 .. of one sensor in one environment.  `col` is that
+// environment's column of the packed state - entity e, field f at col[(e * 6 + f) * ld] - in HBM (lidar_kernel: ld = the
+// planes' leading dimension) or in the step kernel's LDS tile (the navigation epilogue: ld = 64); `o`, `arot` the
+// sensor's own position and rotation.  Wave-level: all lanes of the wave call it together (__any).
+struct DevMaskPair { int32_t a, b; float bound_sum; };
+struct DevLidar {
+  int32_t entity, n_rays, n_targets, target_off, angle_off;
+  float max_range, half_range;
+};
+struct DevTarget { int32_t entity, shape; float length, width, radius; };
+
+// `angles_cs`: cos, sin of (angle + 0.f) for every registered ray, made on the device by lidar_table_kernel with the very
+// sincosf below - so when no lane of the wave has its sensor rotated (arot == 0: every agent of `navigation`, any
+// non-rotatable carrier) the directions are two uniform loads instead of a ~100-instruction sincosf per ray, same bits.
+// `target(ti)`: descriptor of the sensor's ti-th target (from the world's registered list, or implied by the scenario).
+template <int RAY_CHUNK, class TargetFn>
+VD void lidar_cast_chunk(const DevLidar& L, TargetFn target, const float* __restrict__ angles,
+                         const float2* __restrict__ angles_cs, const float* col, long ld, v2 o, float arot, int r0,
+                         float (&best)[RAY_CHUNK]) {
+  const float R = L.max_range;
+  float c[RAY_CHUNK], s[RAY_CHUNK];
+  if (angles_cs != nullptr && __all(arot == 0.f)) {
+#pragma unroll
+    for (int i = 0; i < RAY_CHUNK; ++i) {
+      const int r = r0 + i < L.n_rays ? r0 + i : L.n_rays - 1;
+      const float2 cs = angles_cs[L.angle_off + r];
+      c[i] = cs.x; s[i] = cs.y;
+      best[i] = R;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < RAY_CHUNK; ++i) {
+      const int r = r0 + i < L.n_rays ? r0 + i : L.n_rays - 1;
+      const float th = angles[L.angle_off + r] + arot;  // sensors.py:118
+      sincosf(th, &s[i], &c[i]);  // one range reduction for both
+      best[i] = R;  // core.py:1672-1674
+    }
+  }
+  // ---- sphere targets: only the ones a ray of this environment can reach.  A sphere whose
+  //      centre is farther than max_range + r can only produce distances > max_range, which
+  //      never lower the running minimum (core.py:1672-1674, 1785), so it is skipped exactly.
+  //      Each lane keeps a bit mask of ITS near spheres and the wave walks the masks together:
+  //      the loop runs max-popcount times (~3 of 7 in `navigation`) instead of n_targets times.
+  unsigned long long near = 0ull;
+  const int n_mask = L.n_targets < 64 ? L.n_targets : 64;
+  for (int ti = 0; ti < n_mask; ++ti) {
+    const DevTarget Tg = target(ti);
+    if (Tg.shape != VMAS_SHAPE_SPHERE) continue;
+    const float* tp = col + (long)Tg.entity * 6 * ld;
+    const float dx = tp[0] - o.x, dy = tp[ld] - o.y;
+    const float lim = R + Tg.radius + 1e-4f;
+    if (!(dx * dx + dy * dy > lim * lim)) near |= 1ull << ti;  // NaN counts as near
+  }
+  while (__any(near != 0ull)) {
+    if (near != 0ull) {
+      const int ti = __ffsll((long long)near) - 1;
+      near &= near - 1ull;
+      const DevTarget Tg = target(ti);  // per-lane target
+      const float* tp = col + (long)Tg.entity * 6 * ld;
+      const v2 tpos = V(tp[0], tp[ld]);
+      const v2 u = tpos - o;  // _cast_rays_to_sphere core.py:1414-1490
+#pragma unroll
+      for (int i = 0; i < RAY_CHUNK; ++i) {
+        const v2 dir = V(c[i], s[i]);
+        const v2 lp = V(o.x + dir.x * L.half_range, o.y + dir.y * L.half_range);
+        const v2 cp = closest_point_line<false>(lp, c[i], s[i], 0.f, tpos);
+        const float dn = vnorm(tpos - cp);
+        const bool ok = (dn < Tg.radius) && (vdot(u, dir) > 0.f);
+        const float a = Tg.radius * Tg.radius - dn * dn;
+        const float m = sqrt_n(a > 0.f ? a : 1e-8f);
+        float dist = vnorm(cp - o) - m;
+        dist = ok ? dist : R;
+        best[i] = min_t(best[i], dist);
+      }
+    }
+  }
+  for (int ti = 0; ti < L.n_targets; ++ti) {
+    const DevTarget Tg = target(ti);
+    if (Tg.shape == VMAS_SHAPE_SPHERE && ti < 64) continue;  // handled above
+    const float* tp = col + (long)Tg.entity * 6 * ld;
+    const v2 tpos = V(tp[0], tp[ld]);
+    if (Tg.shape == VMAS_SHAPE_SPHERE) {  // (more than 64 targets: plain loop)
+      const v2 u = tpos - o;
+#pragma unroll
+      for (int i = 0; i < RAY_CHUNK; ++i) {
+        const v2 dir = V(c[i], s[i]);
+        const v2 lp = V(o.x + dir.x * L.half_range, o.y + dir.y * L.half_range);
+        const v2 cp = closest_point_line<false>(lp, c[i], s[i], 0.f, tpos);
+        const float dn = vnorm(tpos - cp);
+        const bool ok = (dn < Tg.radius) && (vdot(u, dir) > 0.f);
+        const float a = Tg.radius * Tg.radius - dn * dn;
+        const float m = sqrt_n(a > 0.f ? a : 1e-8f);
+        float dist = vnorm(cp - o) - m;
+        dist = ok ? dist : R;
+        best[i] = min_t(best[i], dist);
+      }
+    } else if (Tg.shape == VMAS_SHAPE_BOX) {  // _cast_rays_to_box core.py:1281-1372
+      const float trot = tp[4 * ld];
+      const float cn = cosf(-trot), sn = sinf(-trot), cp_ = cosf(trot), sp_ = sinf(trot);
+      const v2 p = rotate(o - tpos, cn, sn);
+#pragma unroll
+      for (int i = 0; i < RAY_CHUNK; ++i) {
+        const v2 q = rotate(V(c[i], s[i]), cn, sn);
+        const float tx1 = (-Tg.length / 2.f - p.x) / q.x, tx2 = (Tg.length / 2.f - p.x) / q.x;
+        const float ty1 = (-Tg.width / 2.f - p.y) / q.y, ty2 = (Tg.width / 2.f - p.y) / q.y;
+        const float t0 = max_t(min_t(tx1, tx2), min_t(ty1, ty2));
+        const float t1 = min_t(max_t(tx1, tx2), max_t(ty1, ty2));
+        const v2 ia = V(t0 * q.x + p.x, t0 * q.y + p.y);
+        const v2 iw = rotate(ia, cp_, sp_) + tpos;
+        float dist = vnorm(o - iw);
+        dist = ((t1 >= t0) && (t0 > 0.f)) ? dist : R;
+        best[i] = min_t(best[i], dist);
+      }
+    } else {  // _cast_rays_to_line core.py:1544-1626
+      const float trot = tp[4 * ld];
+      const v2 rr = V(cosf(trot) * Tg.length, sinf(trot) * Tg.length);
+      const v2 qo = o - tpos;
+#pragma unroll
+      for (int i = 0; i < RAY_CHUNK; ++i) {
+        const v2 dir = V(c[i], s[i]);
+        const float rxs = vcross(rr, dir);
+        const float tt = vcross(qo, V(dir.x / rxs, dir.y / rxs));
+        const float uu = vcross(qo, V(rr.x / rxs, rr.y / rxs));
+        float dist = norm2(uu * dir.x, uu * dir.y);
+        dist = (rxs == 0.f || tt > 0.5f || tt < -0.5f || uu < 0.f) ? R : dist;
+        best[i] = min_t(best[i], dist);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ navigation
+// navigation.py:200-285.  One body for the stand-alone kernel (vmas_env.hip: rows staged from HBM, LIDAR read from a
+// vmas_world_cast_rays output, World.collides' batch-global reduction read from a vmas_world_pair_mask output) and for
+// the epilogue of the physics step kernel (FUSED: rows = the kernel's own tile, LIDAR cast in place on the tile; the
+// pairwise collision penalties need the reduction over ALL tiles of the post-step state, so the epilogue only
+// contributes this tile's pair bits and stores the reward without them - navigation_collision_kernel, launched behind
+// the step kernel, adds them).
+constexpr int kNavMaxOwn = VMAS_ENV_MAX_AGENTS / 4;  // agents one wave can own: ceil(n_agents / nw) (host-checked)
+__host__ __device__ inline int navigation_obs_dim(const VmasNavigationDesc& d) {
+  return 4 + 2 * (d.observe_all_goals ? d.n_agents : 1) + (d.collisions ? d.n_rays : 0);
+}
+// scratch of the fused epilogue: per_agent[A][64] (agent.pos_shaping in) | misc[2 * MAX_AGENTS] (work counter, this tile's
+// pair bits, collide_with[MAX_AGENTS]) | tab[D][64] | tiles[min(nw, A)][64][D|1] | rays[A * n_rays][64] (LIDAR
+// measurements of the tile)
+// | staged descriptors: cos, sin[R] | angles[R] | pairs[n_pairs] | pair_index[A * A] (R = A * n_rays)
+__host__ __device__ inline size_t navigation_scratch_floats(int nw, int n_agents, int D, int n_rays_total = 0, int n_pairs = 0) {
+  return (size_t)n_agents * 64 + 2 * VMAS_ENV_MAX_AGENTS + (size_t)D * 64 + (size_t)nw * 64 * (D | 1) + (size_t)n_rays_total * 64 +
+         (size_t)n_rays_total * 3 + (size_t)n_pairs * 3 + (n_rays_total > 0 ? (size_t)n_agents * n_agents : 0);
+}
+
+template <bool FUSED, class Pos, class Vel, class Goal, class Rays>
+VD void navigation_post_body(const TileCtx& C, const VmasNavigationDesc& d, const VmasNavigationBuffers& o, int batch,
+                             const float* per_agent, const uint32_t* collide_with, const ObsTile& T, float steps_in,
+                             Pos pos, Vel vel, Goal goal, Rays rays /* (agent, slot): its LIDAR part into T */) {
+  const int A = d.n_agents;
+  // agent_reward of every agent (navigation.py:232-242, 206-216), recomputed by every wave: the shared
+  // terms need all of them; the wave that owns agent a stores a's terms
+  float pos_rew = 0.f, my_pos_rew[kNavMaxOwn];
+  bool all_reached = true, all_done = true;
+  for (int a = 0; a < A; ++a) {
+    const float dist = vnorm(pos(a) - goal(a));
+    all_reached = all_reached && (dist < d.goal_radius);
+    all_done = all_done && (dist < d.agent_radius);  // done(): compared with the AGENT's radius
+    const float shaping = dist * d.pos_shaping_factor;
+    const float r = per_agent[a * 64 + C.lane] - shaping;
+    if (a % C.nw == C.wave) {
+      my_pos_rew[a / C.nw] = r;
+      if (C.live) {
+        o.pos_shaping[(long)a * batch + C.env] = shaping;
+        o.agent_pos_rew[(long)a * batch + C.env] = r;
+      }
+    }
+    pos_rew = pos_rew + r;
+  }
+  const float final_rew = all_reached ? d.final_reward : 0.f;
+  if (C.wave == 0) {
+    const bool done = apply_step_limit(o.limit, C, steps_in, all_done);
+    if (C.live) {
+      o.pos_rew[C.env] = pos_rew;
+      o.final_rew[C.env] = final_rew;
+      o.done[C.env] = done ? 1 : 0;
+    }
+  }
+
+#pragma unroll
+  for (int s = 0; s < kNavMaxOwn; ++s) {
+    const int a = C.wave + s * C.nw;
+    if (a >= A) break;
+    const v2 p = pos(a);
+    // pairwise penalties navigation.py:218-229: a pair counts only if World.collides(a, b) holds
+    float col = 0.f;
+    if (!FUSED && d.collisions) {
+      uint32_t m = __builtin_amdgcn_readfirstlane(collide_with[a]);
+      while (m) {
+        const int j = __builtin_ctz(m);
+        m &= m - 1;
+        const float distance = (vnorm(p - pos(j)) - d.agent_radius) - d.agent_radius;
+        if (distance <= d.min_collision_distance) col += d.agent_collision_penalty;
+      }
+    }
+    if (C.live) {
+      const float partial = (d.shared_rew ? pos_rew : my_pos_rew[s]) + final_rew;
+      if (!FUSED || !d.collisions) {
+        o.collision_rew[(long)a * batch + C.env] = col;
+        o.rew[(long)a * batch + C.env] = partial + col;
+      } else {
+        o.rew[(long)a * batch + C.env] = partial;  // + its collision penalties: navigation_collision_kernel
+      }
+    }
+    // observation navigation.py:244-263
+    T.put(0, p); T.put(2, vel(a));
+    if (d.observe_all_goals) {
+      for (int g = 0; g < A; ++g) T.put(4 + 2 * g, p - goal(g));
+    } else {
+      T.put(4, p - goal(a));
+    }
+    rays(a, s);
+    T.flush(o.obs + ((long)a * batch + C.b0) * T.dim, C.n_rows);
+  }
+}
+
+// What the fused epilogue needs from the world besides the tile: its registered sensors (sensor a = agent a) and its
+// static pair list with the mask words the tiles OR their bits into.
+struct NavWorld {
+  const float* angles;         // [n_agents * n_rays] sensor a = agent a's, its targets = the other agents in order (host-checked)
+  const float2* angles_cs;
+  const DevMaskPair* pairs;
+  uint32_t* mask;  // [(n_pairs + 31) / 32] words, then the collision kernel's block counter
+  uint32_t* sync;  // grid-barrier form (NULL: off): arrivals | timeout flag | two mask slots (launch parity)
+  uint32_t seq;    // this launch's barrier number
+  int32_t n_pairs;
+};
+
+// before the physics (the loads fly behind it): agent.pos_shaping of this lane and the observation flush table
+VD void navigation_prologue_tile(const TileCtx& C, const VmasNavigationDesc& d, const VmasNavigationBuffers& o,
+                                 const NavWorld& nav, int batch, float* scratch) {
+  const int A = d.n_agents;
+  float* per_agent = scratch;
+  int* misc = (int*)(per_agent + A * 64);  // [0] the LIDAR units' work counter, [1..] this tile's pair bits
+  int* tab = misc + 2 * VMAS_ENV_MAX_AGENTS;
+  for (int a = C.wave; a < A; a += C.nw)
+    per_agent[a * 64 + C.lane] = C.live ? o.pos_shaping[(long)a * batch + C.env] : 0.f;
+  if (threadIdx.x < 2 * VMAS_ENV_MAX_AGENTS) misc[threadIdx.x] = threadIdx.x == 0 ? C.nw : 0;
+  const int D = navigation_obs_dim(d);
+  build_flush_table(C, tab, D, D | 1);
+  if (d.collisions) {  // the epilogue's descriptors: a dependent global load per use would chain microseconds behind the physics
+    const int R = A * d.n_rays;
+    float* stage = (float*)(tab + D * 64) + (size_t)(C.nw < A ? C.nw : A) * 64 * (D | 1) + (size_t)R * 64;
+    for (int i = threadIdx.x; i < R; i += blockDim.x) {
+      const float2 cs = nav.angles_cs[i];  // (cos, sin first: 8-byte aligned whatever R is)
+      stage[2 * i] = cs.x; stage[2 * i + 1] = cs.y;
+      stage[2 * R + i] = nav.angles[i];
+    }
+    const float* pw = (const float*)nav.pairs;
+    for (int i = threadIdx.x; i < nav.n_pairs * 3; i += blockDim.x) stage[3 * R + i] = pw[i];
+    int* pidx = (int*)(stage + 3 * R + 3 * nav.n_pairs);
+    for (int i = threadIdx.x; i < A * A; i += blockDim.x) pidx[i] = o.pair_index[i];
+  }
+}
+
+// after the last substep: `rows` = the tile with the new state, every wave past the barrier behind the integration
+VD void navigation_post_tile(const TileCtx& C, const VmasNavigationDesc& d, const VmasNavigationBuffers& o,
+                             const NavWorld& nav, int batch, const float* rows, float* scratch, float& steps_in,
+                             unsigned long long* tr = nullptr /* profiling build: s_memtime stamps of this wave */) {
+  auto stamp = [&](int k) { if (tr != nullptr && (threadIdx.x & 63) == 0) tr[k] = __builtin_amdgcn_s_memtime(); };
+  stamp(6);
+  const int A = d.n_agents, D = navigation_obs_dim(d), n_goal = d.observe_all_goals ? A : 1;
+  const float* per_agent = scratch;
+  int* misc = (int*)(scratch + A * 64);
+  const int* tab = misc + 2 * VMAS_ENV_MAX_AGENTS;
+  uint32_t* collide_with = (uint32_t*)(misc + VMAS_ENV_MAX_AGENTS);
+  const ObsTile T = obs_tile(C, (float*)(tab + D * 64), tab, D);
+  const float* col = rows + C.lane;
+  const int words = (nav.n_pairs + 31) >> 5;
+  // World.collides' reduction over the batch, two ways.  nav.sync != NULL (every tile of the grid resident at once, at
+  // most one per CU): the tiles OR their bits into this launch's mask slot, meet at a grid-wide barrier - its latency
+  // behind the LIDAR units - and apply the collision penalties themselves.  Otherwise the bits go to nav.mask, the reward
+  // is stored without the penalties and navigation_collision_kernel, launched behind this kernel, adds them.
+  const bool grid_sync = nav.sync != nullptr;
+  uint32_t* slot = grid_sync ? nav.sync + 2 + (nav.seq & 1u) * (uint32_t)words : nav.mask;
+  const int R = d.collisions ? A * d.n_rays : 0;
+  float* ray_rows0 = (float*)(tab + D * 64) + (size_t)(C.nw < A ? C.nw : A) * 64 * (D | 1);
+  const float* stage = ray_rows0 + (size_t)R * 64;  // staged by navigation_prologue_tile
+  const float2* st_cs = (const float2*)stage;
+  const float* st_angles = stage + 2 * R;
+  const DevMaskPair* st_pairs = (const DevMaskPair*)(stage + 3 * R);
+  const int* st_pair_index = (const int*)(stage + 3 * R + 3 * nav.n_pairs);
+  if (d.collisions) {  // World.collides' reduction over the batch (core.py:2797-2801), this tile's share: into LDS words
+                       // now, into the world's mask by one lane of the tile behind the LIDAR barrier
+    for (int k = C.wave; k < nav.n_pairs; k += C.nw) {
+      const DevMaskPair P = st_pairs[k];
+      const float* sa = col + P.a * 6 * 64;
+      const float* sb = col + P.b * 6 * 64;
+      const bool hit = C.live && norm2(sa[0] - sb[0], sa[64] - sb[64]) <= P.bound_sum;
+      if (__any(hit) && C.lane == 0) atomicOr((uint32_t*)&misc[1 + (k >> 5)], 1u << (k & 31));
+    }
+    if (grid_sync) {  // publish and arrive now, wait behind the LIDAR units
+      __syncthreads();
+      if ((int)threadIdx.x < words) {
+        const uint32_t b = (uint32_t)misc[1 + threadIdx.x];
+        if (b != 0u) __hip_atomic_fetch_or(slot + threadIdx.x, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();  // (vmcnt(0) + barrier: the tile's atomics have returned)
+      if (threadIdx.x == 0) __hip_atomic_fetch_add(nav.sync, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  stamp(7);
+  auto pos = [&](int a) { const float* e = col + (d.agent0 + a) * 6 * 64; return V(e[0], e[64]); };
+  auto vel = [&](int a) { const float* e = col + (d.agent0 + a) * 6 * 64; return V(e[2 * 64], e[3 * 64]); };
+  auto goal = [&](int a) { const float* e = col + d.goal_of[a] * 6 * 64; return V(e[0], e[64]); };
+  // LIDAR: units of CH rays of one sensor, dealt round-robin to ALL waves of the tile (a wave per agent would leave half
+  // of a 16-wave tile idle behind 12-ray chains); measurements through LDS to the wave that assembles the observation
+  float* ray_rows = ray_rows0 + C.lane;
+  if (d.collisions && d.n_rays > 0) {
+    auto cast_units = [&](auto ch_tag) {
+      constexpr int CH = decltype(ch_tag)::value;
+      const int per = (d.n_rays + CH - 1) / CH;
+      auto grab = [&]() {  // units differ (targets within reach): the first is static, the rest are pulled
+        int v = 0;
+        if (C.lane == 0) v = atomicAdd(&misc[0], 1);
+        return __builtin_amdgcn_readfirstlane(v);
+      };
+      for (int u = C.wave; u < A * per; u = grab()) {
+        const int a = u / per, r0 = (u - a * per) * CH;
+        // sensor a: on agent a, its targets the other agents in order - spheres of the agents' radius (host-checked
+        // against the world's registered sensors, whose descriptors the stand-alone lidar_kernel reads)
+        const DevLidar L = {d.agent0 + a, d.n_rays, A - 1, 0, a * d.n_rays, d.lidar_range, d.lidar_range * 0.5f};
+        auto target = [&](int ti) {
+          return DevTarget{d.agent0 + (ti < a ? ti : ti + 1), VMAS_SHAPE_SPHERE, 0.f, 0.f, d.agent_radius};
+        };
+        const float* sp = col + L.entity * 6 * 64;
+        float best[CH];
+        lidar_cast_chunk<CH>(L, target, st_angles, st_cs, col, 64, V(sp[0], sp[64]), sp[4 * 64], r0, best);
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+          if (r0 + i < d.n_rays) ray_rows[(a * d.n_rays + r0 + i) * 64] = best[i];
+      }
+    };
+    if (A * ((d.n_rays + 3) / 4) < 2 * C.nw) cast_units(std::integral_constant<int, 2>{});
+    else cast_units(std::integral_constant<int, 4>{});
+    stamp(8);
+    if (grid_sync) {
+      if (threadIdx.x == 0) {
+        const uint32_t target = (nav.seq + 1u) * gridDim.x;  // arrivals are never reset: every launch of this world has this grid
+        int spins = 0;
+        while ((int32_t)(__hip_atomic_load(nav.sync, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+          __builtin_amdgcn_s_sleep(8);
+          if (++spins > (1 << 18)) {  // the grid is not co-resident (it should be): flag it and go on, never hang
+            __hip_atomic_fetch_or(nav.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+        if (blockIdx.x == 0)  // every tile is past this launch's barrier, the previous launch is over: its slot is free
+          for (int w_ = 0; w_ < words; ++w_)
+            __hip_atomic_store(nav.sync + 2 + ((nav.seq + 1u) & 1u) * (uint32_t)words + w_, 0u, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+      if ((int)threadIdx.x < A) {  // bit j of collide_with[a]: World.collides(agent a, agent j)
+        uint32_t m = 0;
+        for (int j = 0; j < A; ++j) {
+          const int pi = st_pair_index[threadIdx.x * A + j];
+          if (j != (int)threadIdx.x && pi >= 0 &&
+              ((__hip_atomic_load(slot + (pi >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (pi & 31)) & 1u))
+            m |= 1u << j;
+        }
+        collide_with[threadIdx.x] = m;
+      }
+      __syncthreads();
+    } else {
+      __syncthreads();
+      // (the mask only grows during a step: a stale read is harmless - and a thousand tiles hammering one word is not)
+      if ((int)threadIdx.x < words) {
+        const uint32_t b = (uint32_t)misc[1 + threadIdx.x];
+        if (b != 0u && (b & ~__builtin_nontemporal_load(&nav.mask[threadIdx.x])) != 0u) atomicOr(&nav.mask[threadIdx.x], b);
+      }
+    }
+  }
+  stamp(9);
+  auto rays = [&](int a, int) {
+    if (!d.collisions) return;
+    for (int r = 0; r < d.n_rays; ++r) T.put(4 + 2 * n_goal + r, d.lidar_range - ray_rows[(a * d.n_rays + r) * 64]);
+  };
+  if (grid_sync && d.collisions) navigation_post_body<false>(C, d, o, batch, per_agent, collide_with, T, steps_in, pos, vel, goal, rays);
+  else navigation_post_body<true>(C, d, o, batch, per_agent, nullptr, T, steps_in, pos, vel, goal, rays);
+  stamp(10);
   if (o.limit.steps != nullptr) steps_in = steps_in + 1.f;
 }
 

@@ -162,7 +162,7 @@ struct DevWorld {
   const DevItem* items;  // global copy, used when the item list is too big for LDS
 };
 
-struct DevMaskPair { int32_t a, b; float bound_sum; };
+// (DevMaskPair, DevLidar, DevTarget: vmas_env_device.h - the navigation epilogue uses them too)
 
 struct DevStepArgs {
   const uint32_t* pair_mask;
@@ -184,7 +184,7 @@ struct DevStepArgs {
 
 // The Environment.step() stages fused around the physics (vmas_world_step_env): action ingest as the
 // kernel's prologue, one scenario's reward / observation / done as its epilogue on the LDS tile.
-enum { ENV_NONE = 0, ENV_BALANCE = 1, ENV_TRANSPORT = 2, ENV_INGEST = 3 };  // 3: prologue only
+enum { ENV_NONE = 0, ENV_BALANCE = 1, ENV_TRANSPORT = 2, ENV_INGEST = 3, ENV_NAVIGATION = 4 };  // 3: prologue only
 struct DevEnv {
   int32_t has_ingest;
   int32_t ablate;       // profiling only (env VMAS_ENV_ABLATE)
@@ -197,6 +197,7 @@ struct DevEnv {
   union {
     struct { VmasBalanceDesc d; VmasBalanceBuffers o; } balance;
     struct { VmasTransportDesc d; VmasTransportBuffers o; } transport;
+    struct { VmasNavigationDesc d; VmasNavigationBuffers o; NavWorld w; } navigation;
   };
 };
 struct NoEnv {};
@@ -676,6 +677,11 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
       term[p * 64] = live ? E.transport.o.global_shaping[(long)p * batch + env] : 0.f;
     if (wv == 0) post_steps = (E.transport.o.limit.steps != nullptr && live) ? E.transport.o.limit.steps[env] : 0.f;
   }
+  if constexpr (ENV == ENV_NAVIGATION) {
+    const TileCtx C(batch);
+    navigation_prologue_tile(C, E.navigation.d, E.navigation.o, E.navigation.w, batch, lds + E.scratch_off);  // (published by the load barrier)
+    if (wv == 0) post_steps = load_steps(E.navigation.o.limit, C);
+  }
   {  // the descriptor blob, 16 bytes per thread and up to four requests in flight before the first LDS write (a plain
      // copy loop waits for every load before it issues the next: one full HBM latency per iteration)
     const uint4* src = (const uint4*)W.blob;
@@ -1106,6 +1112,17 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
   // ---- epilogue of this step: the scenario's reward / observation / done on the tile that is still in LDS.  In a
   //      multi-step rollout (vmas_world_rollout_env) step k writes the k-th slab of every per-step output; the
   //      persistent terms (shaping, step counter) are carried in registers / re-read by the thread that wrote them.
+  if constexpr (ENV == ENV_NAVIGATION) {  // (single step: the collision penalties need a reduction over all tiles, made
+                                          //  by a kernel behind this one - see navigation_post_tile)
+    __syncthreads();
+#ifdef VMAS_TRACE
+    unsigned long long* nav_tr = args.trace ? args.trace + ((long)blockIdx.x * 16 + wv) * 16 : nullptr;
+#else
+    unsigned long long* nav_tr = nullptr;
+#endif
+    navigation_post_tile(TileCtx(batch), E.navigation.d, E.navigation.o, E.navigation.w, batch, lds, lds + E.scratch_off,
+                         post_steps, nav_tr);
+  }
   if constexpr (ENV == ENV_BALANCE || ENV == ENV_TRANSPORT) {
     if (stp + 1 == n_steps) __syncthreads();  // (earlier steps: the substep loop ended with a barrier)
     const TileCtx C(batch);
@@ -1196,17 +1213,20 @@ __global__ __launch_bounds__(256) void pair_mask_kernel(const DevMaskPair* __res
 // ------------------------------------------------------------------------------------
 // LIDAR (World.cast_rays core.py:1662-1786): one thread per (environment, sensor)
 // ------------------------------------------------------------------------------------
-struct DevLidar {
-  int32_t entity, n_rays, n_targets, target_off, angle_off;
-  float max_range, half_range;
-};
-struct DevTarget { int32_t entity, shape; float length, width, radius; };
-
+// directions of the unrotated rays (see lidar_cast_chunk): the same sincosf on the same input as the general path
+__global__ void lidar_table_kernel(const float* __restrict__ angles, int n, float2* __restrict__ cs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s, c;
+  sincosf(angles[i] + 0.f, &s, &c);
+  cs[i] = make_float2(c, s);
+}
 
 template <int RAY_CHUNK>  // rays per thread; blockIdx.z selects the chunk of the sensor's fan
 __global__ __launch_bounds__(256) void lidar_kernel(const DevLidar* __restrict__ lidars,
                                                     const DevTarget* __restrict__ targets,
-                                                    const float* __restrict__ angles, int max_rays,
+                                                    const float* __restrict__ angles,
+                                                    const float2* __restrict__ angles_cs, int max_rays,
                                                     const float* __restrict__ state, long ld, int batch,
                                                     float* __restrict__ out) {
   const long env = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1216,107 +1236,10 @@ __global__ __launch_bounds__(256) void lidar_kernel(const DevLidar* __restrict__
   const float* sp = state + (long)L.entity * 6 * ld + env;
   const v2 o = V(sp[0], sp[ld]);
   const float arot = sp[4 * ld];
-  const float R = L.max_range;
   for (int r0 = blockIdx.z * RAY_CHUNK; r0 < L.n_rays; r0 += gridDim.z * RAY_CHUNK) {
-    float best[RAY_CHUNK], c[RAY_CHUNK], s[RAY_CHUNK];
-#pragma unroll
-    for (int i = 0; i < RAY_CHUNK; ++i) {
-      const int r = r0 + i < L.n_rays ? r0 + i : L.n_rays - 1;
-      const float th = angles[L.angle_off + r] + arot;  // sensors.py:118
-      sincosf(th, &s[i], &c[i]);  // one range reduction for both
-      best[i] = R;  // core.py:1672-1674
-    }
-    // ---- sphere targets: only the ones a ray of this environment can reach.  A sphere whose
-    //      centre is farther than max_range + r can only produce distances > max_range, which
-    //      never lower the running minimum (core.py:1672-1674, 1785), so it is skipped exactly.
-    //      Each lane keeps a bit mask of ITS near spheres and the wave walks the masks together:
-    //      the loop runs max-popcount times (~3 of 7 in `navigation`) instead of n_targets times.
-    unsigned long long near = 0ull;
-    const int n_mask = L.n_targets < 64 ? L.n_targets : 64;
-    for (int ti = 0; ti < n_mask; ++ti) {
-      const DevTarget Tg = targets[L.target_off + ti];
-      if (Tg.shape != VMAS_SHAPE_SPHERE) continue;
-      const float* tp = state + (long)Tg.entity * 6 * ld + env;
-      const float dx = tp[0] - o.x, dy = tp[ld] - o.y;
-      const float lim = R + Tg.radius + 1e-4f;
-      if (!(dx * dx + dy * dy > lim * lim)) near |= 1ull << ti;  // NaN counts as near
-    }
-    while (__any(near != 0ull)) {
-      if (near != 0ull) {
-        const int ti = __ffsll((long long)near) - 1;
-        near &= near - 1ull;
-        const DevTarget Tg = targets[L.target_off + ti];  // per-lane target
-        const float* tp = state + (long)Tg.entity * 6 * ld + env;
-        const v2 tpos = V(tp[0], tp[ld]);
-        const v2 u = tpos - o;  // _cast_rays_to_sphere core.py:1414-1490
-#pragma unroll
-        for (int i = 0; i < RAY_CHUNK; ++i) {
-          const v2 dir = V(c[i], s[i]);
-          const v2 lp = V(o.x + dir.x * L.half_range, o.y + dir.y * L.half_range);
-          const v2 cp = closest_point_line<false>(lp, c[i], s[i], 0.f, tpos);
-          const float dn = vnorm(tpos - cp);
-          const bool ok = (dn < Tg.radius) && (vdot(u, dir) > 0.f);
-          const float a = Tg.radius * Tg.radius - dn * dn;
-          const float m = sqrt_n(a > 0.f ? a : 1e-8f);
-          float dist = vnorm(cp - o) - m;
-          dist = ok ? dist : R;
-          best[i] = min_t(best[i], dist);
-        }
-      }
-    }
-    for (int ti = 0; ti < L.n_targets; ++ti) {
-      const DevTarget Tg = targets[L.target_off + ti];
-      if (Tg.shape == VMAS_SHAPE_SPHERE && ti < 64) continue;  // handled above
-      const float* tp = state + (long)Tg.entity * 6 * ld + env;
-      const v2 tpos = V(tp[0], tp[ld]);
-      if (Tg.shape == VMAS_SHAPE_SPHERE) {  // (more than 64 targets: plain loop)
-        const v2 u = tpos - o;
-#pragma unroll
-        for (int i = 0; i < RAY_CHUNK; ++i) {
-          const v2 dir = V(c[i], s[i]);
-          const v2 lp = V(o.x + dir.x * L.half_range, o.y + dir.y * L.half_range);
-          const v2 cp = closest_point_line<false>(lp, c[i], s[i], 0.f, tpos);
-          const float dn = vnorm(tpos - cp);
-          const bool ok = (dn < Tg.radius) && (vdot(u, dir) > 0.f);
-          const float a = Tg.radius * Tg.radius - dn * dn;
-          const float m = sqrt_n(a > 0.f ? a : 1e-8f);
-          float dist = vnorm(cp - o) - m;
-          dist = ok ? dist : R;
-          best[i] = min_t(best[i], dist);
-        }
-      } else if (Tg.shape == VMAS_SHAPE_BOX) {  // _cast_rays_to_box core.py:1281-1372
-        const float trot = tp[4 * ld];
-        const float cn = cosf(-trot), sn = sinf(-trot), cp_ = cosf(trot), sp_ = sinf(trot);
-        const v2 p = rotate(o - tpos, cn, sn);
-#pragma unroll
-        for (int i = 0; i < RAY_CHUNK; ++i) {
-          const v2 q = rotate(V(c[i], s[i]), cn, sn);
-          const float tx1 = (-Tg.length / 2.f - p.x) / q.x, tx2 = (Tg.length / 2.f - p.x) / q.x;
-          const float ty1 = (-Tg.width / 2.f - p.y) / q.y, ty2 = (Tg.width / 2.f - p.y) / q.y;
-          const float t0 = max_t(min_t(tx1, tx2), min_t(ty1, ty2));
-          const float t1 = min_t(max_t(tx1, tx2), max_t(ty1, ty2));
-          const v2 ia = V(t0 * q.x + p.x, t0 * q.y + p.y);
-          const v2 iw = rotate(ia, cp_, sp_) + tpos;
-          float dist = vnorm(o - iw);
-          dist = ((t1 >= t0) && (t0 > 0.f)) ? dist : R;
-          best[i] = min_t(best[i], dist);
-        }
-      } else {  // _cast_rays_to_line core.py:1544-1626
-        const float trot = tp[4 * ld];
-        const v2 rr = V(cosf(trot) * Tg.length, sinf(trot) * Tg.length);
-        const v2 qo = o - tpos;
-#pragma unroll
-        for (int i = 0; i < RAY_CHUNK; ++i) {
-          const v2 dir = V(c[i], s[i]);
-          const float rxs = vcross(rr, dir);
-          const float tt = vcross(qo, V(dir.x / rxs, dir.y / rxs));
-          const float uu = vcross(qo, V(rr.x / rxs, rr.y / rxs));
-          float dist = norm2(uu * dir.x, uu * dir.y);
-          dist = (rxs == 0.f || tt > 0.5f || tt < -0.5f || uu < 0.f) ? R : dist;
-          best[i] = min_t(best[i], dist);
-        }
-      }
-    }
+    float best[RAY_CHUNK];
+    lidar_cast_chunk<RAY_CHUNK>(L, [&](int ti) { return targets[L.target_off + ti]; }, angles, angles_cs, state + env, ld, o,
+                                arot, r0, best);
 #pragma unroll
     for (int i = 0; i < RAY_CHUNK; ++i)
       if (r0 + i < L.n_rays) out[((long)l * max_rays + r0 + i) * ld + env] = best[i];
@@ -1385,6 +1308,10 @@ int host_fail(const char* msg) { return fail("%s", msg); }  // for vmas_env.hip
 int check_ingest_args(const VmasIngestArgs* args, int32_t batch, const float* agent_ft, int64_t ld);
 int check_balance_args(const VmasBalanceDesc* d, const VmasBalanceBuffers* o, int32_t batch, const float* state, int64_t ld,
                        int n_entities);
+int check_navigation_args(const VmasNavigationDesc* d, const VmasNavigationBuffers* o, int32_t batch, const float* state,
+                          int64_t ld, int fused);
+int launch_navigation_collisions(const VmasNavigationDesc* d, const VmasNavigationBuffers* o, int32_t batch,
+                                 const float* state, int64_t ld, uint32_t* mask, int mask_words, void* stream);
 int check_transport_args(const VmasTransportDesc* d, const VmasTransportBuffers* o, int32_t batch, const float* state,
                          int64_t ld, int n_entities);
 }
@@ -1460,10 +1387,16 @@ struct VmasWorld {
   uint32_t* d_sync = nullptr;
   uint32_t sync_seq = 0;
   uint32_t* d_exact_mask = nullptr;
+  uint32_t* d_nav_mask = nullptr;  // navigation epilogue: World.collides' pair bits of the post-step state + a block counter
+  uint32_t* d_nav_sync = nullptr;  // its grid-barrier form: arrivals | timeout flag | two mask slots
+  uint32_t nav_seq = 0;
+  std::vector<DevLidar> h_lidars;  // host copy of the registered sensors (argument checks of the navigation epilogue)
+  std::vector<DevTarget> h_targets;
   // lidars
   DevLidar* d_lidars = nullptr;
   DevTarget* d_targets = nullptr;
   float* d_angles = nullptr;
+  float2* d_angles_cs = nullptr;  // cos, sin of every registered ray at rotation 0 (lidar_table_kernel)
   int n_lidars = 0, max_rays = 0;
   // queries
   DevQuery* d_queries = nullptr;
@@ -2026,7 +1959,8 @@ static int launch_level(VmasWorld* w, Sched* S, float* state, float* aft, long l
       int rc = 1;  // 1: no specialisation serves this launch
 #define VMAS_LAUNCH_SPEC(G)                                                                                              \
       if constexpr (LEVEL == G::LEVEL && (ENV == ENV_NONE || ENV == ENV_INGEST || (ENV == ENV_BALANCE && G::POST == 1) ||  \
-                                          (ENV == ENV_TRANSPORT && G::POST == 2)))                                       \
+                                          (ENV == ENV_TRANSPORT && G::POST == 2) ||                                      \
+                                          (ENV == ENV_NAVIGATION && G::POST == 3)))                                      \
         if (rc == 1 && S->spec_id == G::ID)                                                                              \
           rc = launch_spec<G, ENV, EnvArgs>(w, S, state, aft, ld, a, env, extra_lds, s, batch);
       VMAS_SPEC_LIST(VMAS_LAUNCH_SPEC)
@@ -2063,7 +1997,8 @@ static int launch_any_level(VmasWorld* w, Sched* S, float* state, float* aft, lo
 
 static int step_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld, const VmasStepArgs* args, void* stream,
                      int n_steps, int64_t ft_stride, DevEnv* env = nullptr, int env_kind = ENV_NONE,
-                     size_t scratch_fixed = 0, size_t scratch_per_wave = 0, int env_first = 0, int env_count = -1);
+                     size_t scratch_fixed = 0, size_t scratch_per_wave = 0, int env_first = 0, int env_count = -1,
+                     int scratch_wave_cap = 1 << 20);
 
 // The side streams of vmas_world_step_n and their fork / join events.  Created - and the streams' hardware queues
 // brought up by a first operation - when the world is created or the knob is set, never inside a caller's timed loop
@@ -2191,6 +2126,10 @@ int vmas_world_create(const VmasWorldDesc* d, int32_t batch, int32_t device_id, 
     HIP_TRY(hipMalloc((void**)&w->d_sync, (4 + 4 * mw) * sizeof(uint32_t)));
     HIP_TRY(hipMemset(w->d_sync, 0, (4 + 4 * mw) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void**)&w->d_exact_mask, (mw ? mw : 1) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&w->d_nav_mask, (mw + 1) * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(w->d_nav_mask, 0, (mw + 1) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&w->d_nav_sync, (2 + 2 * mw) * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(w->d_nav_sync, 0, (2 + 2 * mw) * sizeof(uint32_t)));
   }
   if (!host_only) {
     hipDeviceProp_t prop;
@@ -2218,9 +2157,10 @@ void vmas_world_destroy(VmasWorld* w) {
     if (w->ev_join[q]) (void)hipEventDestroy(w->ev_join[q]);
   }
   if (w->ev_fork) (void)hipEventDestroy(w->ev_fork);
-  (void)hipFree(w->d_sync); (void)hipFree(w->d_exact_mask);
+  (void)hipFree(w->d_sync); (void)hipFree(w->d_exact_mask); (void)hipFree(w->d_nav_mask); (void)hipFree(w->d_nav_sync);
   (void)hipFree(w->d_mpairs); (void)hipFree(w->d_trace);
   (void)hipFree(w->d_lidars); (void)hipFree(w->d_targets); (void)hipFree(w->d_angles); (void)hipFree(w->d_queries);
+  (void)hipFree(w->d_angles_cs);
   delete w;
 }
 
@@ -2286,7 +2226,9 @@ int vmas_world_exact_status(VmasWorld* w) {
   HIP_TRY(hipSetDevice(w->device));
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(&flag, w->d_sync + 1, sizeof(flag), hipMemcpyDeviceToHost));
-  return (int)flag;
+  uint32_t nav_flag = 0;  // (the navigation epilogue's barrier: same rule, same report)
+  if (w->d_nav_sync) HIP_TRY(hipMemcpy(&nav_flag, w->d_nav_sync + 1, sizeof(nav_flag), hipMemcpyDeviceToHost));
+  return (int)(flag | nav_flag);
 }
 
 int vmas_world_set_queues(VmasWorld* w, int32_t queues) {
@@ -2315,6 +2257,67 @@ int vmas_world_rollout(VmasWorld* w, float* state, float* agent_ft, int64_t ld, 
 static int step_env_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld, const VmasStepArgs* args,
                          const VmasIngestArgs* ingest, uint32_t* err_flags, int32_t post_kind, const void* post_desc,
                          const void* post_buffers, int32_t n_steps, void* stream);
+
+// LDS (bytes) a fused epilogue needs behind the tile: `fixed` + `per_wave` floats for each of min(waves per tile, cap)
+// waves.  If the tile plus that does not fit the CU, the shared pair rows are given up once (the schedule is rebuilt).
+static int env_extra_lds(VmasWorld* w, Sched** S, size_t fixed, size_t per_wave, int cap, size_t* extra) {
+  auto need = [&]() { return (fixed + per_wave * (size_t)std::min((*S)->nw, cap)) * sizeof(float); };
+  *extra = need();
+  if ((*S)->lds_bytes + *extra > 160 * 1024 && w->n_shared_rows > 0) {
+    if (unshare(w) || get_sched(w, w->lanes, S)) return -1;
+    *extra = need();
+  }
+  if ((*S)->lds_bytes + *extra > 160 * 1024)
+    return fail("vmas_world_step_env: %zu bytes of LDS per tile with this epilogue exceed the CU's 160 KB",
+                (*S)->lds_bytes + *extra);
+  return 0;
+}
+
+// navigation as an epilogue: argument checks against the world and its registered sensors, LDS need
+static int nav_epilogue_plan(VmasWorld* w, const VmasNavigationDesc* d, size_t* fixed, size_t* per_wave) {
+  if (d->n_agents < 1 || d->n_agents > VMAS_ENV_MAX_AGENTS) return fail("vmas_world_step_env: navigation n_agents out of range");
+  if (d->agent0 < 0 || d->agent0 + d->n_agents > w->base.nE) return fail("vmas_world_step_env: navigation agents out of range");
+  for (int a = 0; a < d->n_agents; ++a)
+    if (d->goal_of[a] < 0 || d->goal_of[a] >= w->base.nE) return fail("vmas_world_step_env: navigation goal %d out of range", a);
+  if (d->collisions) {  // the epilogue casts sensor a = agent a's on the other agents: must be what the world has registered
+    if (w->n_lidars != d->n_agents) return fail("vmas_world_step_env: navigation with collisions needs one registered sensor per agent");
+    for (int a = 0; a < d->n_agents; ++a) {
+      const DevLidar& L = w->h_lidars[a];
+      if (L.entity != d->agent0 + a || L.n_rays != d->n_rays || L.angle_off != a * d->n_rays || L.max_range != d->lidar_range ||
+          L.n_targets != d->n_agents - 1)
+        return fail("vmas_world_step_env: sensor %d is not agent %d's %d-ray LIDAR of range %g on the other agents", a, a,
+                    d->n_rays, (double)d->lidar_range);
+      for (int t = 0; t < L.n_targets; ++t) {
+        const DevTarget& T = w->h_targets[L.target_off + t];
+        if (T.entity != d->agent0 + (t < a ? t : t + 1) || T.shape != VMAS_SHAPE_SPHERE || T.radius != d->agent_radius)
+          return fail("vmas_world_step_env: target %d of sensor %d is not the %d-th other agent (a sphere of the agents' radius)",
+                      t, a, t);
+      }
+    }
+  }
+  if (d->collisions && (d->n_rays < 1 || (w->n_pairs + 31) / 32 >= VMAS_ENV_MAX_AGENTS))
+    return fail("vmas_world_step_env: navigation with collisions needs n_rays >= 1 and at most %d collidable pairs",
+                32 * (VMAS_ENV_MAX_AGENTS - 1));
+  const int D = navigation_obs_dim(*d);
+  *fixed = navigation_scratch_floats(0, d->n_agents, D, d->collisions ? d->n_agents * d->n_rays : 0, d->collisions ? w->n_pairs : 0);
+  *per_wave = navigation_scratch_floats(1, d->n_agents, D) - navigation_scratch_floats(0, d->n_agents, D);
+  return 0;
+}
+
+int vmas_world_step_env_check(VmasWorld* w, int32_t post_kind, const void* post_desc) {
+  if (!w || !post_desc) return fail("vmas_world_step_env_check: null argument");
+  if (w->host_only) return fail("vmas_world_step_env_check: a planning world (device -1) cannot be stepped");
+  if (post_kind != VMAS_POST_NAVIGATION) return fail("vmas_world_step_env_check: post_kind %d", post_kind);
+  const auto* d = (const VmasNavigationDesc*)post_desc;
+  size_t fixed = 0, per_wave = 0, extra = 0;
+  if (nav_epilogue_plan(w, d, &fixed, &per_wave)) return -1;
+  Sched* S;
+  if (get_sched(w, w->lanes, &S)) return -1;
+  if (env_extra_lds(w, &S, fixed, per_wave, d->n_agents, &extra)) return -1;
+  if (d->n_agents > kNavMaxOwn * S->nw)
+    return fail("vmas_world_step_env: %d agents on %d waves per tile (at most %d agents per wave)", d->n_agents, S->nw, kNavMaxOwn);
+  return 0;
+}
 
 int vmas_world_step_env(VmasWorld* w, float* state, float* agent_ft, int64_t ld, const VmasStepArgs* args,
                         const VmasIngestArgs* ingest, uint32_t* err_flags, int32_t post_kind, const void* post_desc,
@@ -2384,13 +2387,42 @@ static int step_env_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld
                      transport_scratch_floats(0, d->n_packages),
                      transport_scratch_floats(1, d->n_packages) - transport_scratch_floats(0, d->n_packages));
   }
+  if (post_kind == VMAS_POST_NAVIGATION) {
+    const auto* d = (const VmasNavigationDesc*)post_desc;
+    const auto* o = (const VmasNavigationBuffers*)post_buffers;
+    if (vmas::check_navigation_args(d, o, w->batch, state, ld, 1)) return -1;
+    if (n_steps != 1)
+      return fail("vmas_world_rollout_env: navigation's collision penalties reduce over the whole batch after every step "
+                  "(World.collides): one step per call");
+    size_t nav_fixed = 0, nav_per_wave = 0;
+    if (nav_epilogue_plan(w, d, &nav_fixed, &nav_per_wave)) return -1;
+    env.navigation.d = *d;
+    env.navigation.o = *o;
+    // every tile resident at once (at most one per CU) and no graph capture (a replay would repeat the barrier number
+    // baked into the arguments): the reduction is made inside the launch; otherwise by a second kernel behind it
+    bool grid_sync = false;
+    if (d->collisions && blocks_of(w->batch) <= w->n_cu) {
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
+      grid_sync = cap == hipStreamCaptureStatusNone;
+    }
+    env.navigation.w = NavWorld{w->d_angles, w->d_angles_cs, w->d_mpairs, w->d_nav_mask, grid_sync ? w->d_nav_sync : nullptr,
+                                w->nav_seq, d->collisions ? w->n_pairs : 0};
+    if (grid_sync) ++w->nav_seq;
+    if (step_impl(w, state, agent_ft, ld, args, stream, n_steps, 0, &env, ENV_NAVIGATION, nav_fixed, nav_per_wave, 0, -1,
+                  d->n_agents))
+      return -1;
+    if (d->collisions && !grid_sync)
+      return vmas::launch_navigation_collisions(d, o, w->batch, state, ld, w->d_nav_mask, (w->n_pairs + 31) / 32, stream);
+    return 0;
+  }
   if (post_kind == VMAS_POST_NONE) return step_impl(w, state, agent_ft, ld, args, stream, n_steps, 0, &env, ENV_INGEST, 0, 0);
   return fail("vmas_world_step_env: post_kind %d has no fused epilogue", post_kind);
 }
 
 static int step_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld, const VmasStepArgs* args, void* stream,
                      int n_steps, int64_t ft_stride, DevEnv* env, int env_kind, size_t scratch_fixed,
-                     size_t scratch_per_wave, int env_first, int env_count) {
+                     size_t scratch_per_wave, int env_first, int env_count, int scratch_wave_cap) {
   if (!w || !state) return fail("vmas_world_step: null argument");
   if (w->host_only) return fail("vmas_world_step: a planning world (device -1) cannot be stepped");
   if (w->base.nA > 0 && !agent_ft) return fail("vmas_world_step: world has agents but agent_ft is null");
@@ -2459,16 +2491,19 @@ static int step_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld, co
                                       s, env_count, (long)ld - env_first);
   }
   if (env_kind == ENV_NONE) return launch_any_level<ENV_NONE>(w, S, state, agent_ft, ld, a, NoEnv{}, 0, s);
-  if (S->nw < 2 && env_kind != ENV_INGEST)
+  if (S->nw < 2 && env_kind != ENV_INGEST && env_kind != ENV_NAVIGATION)
     return fail("vmas_world_step_env: the fused epilogue needs at least 2 waves per tile");
-  size_t extra = (scratch_fixed + scratch_per_wave * S->nw) * sizeof(float);
-  if (S->lds_bytes + extra > 160 * 1024 && w->n_shared_rows > 0) {  // the epilogue's scratch needs the shared rows' LDS
-    if (unshare(w) || get_sched(w, w->lanes, &S)) return -1;
-    extra = (scratch_fixed + scratch_per_wave * S->nw) * sizeof(float);
-  }
+  size_t extra = 0;
+  if (env_extra_lds(w, &S, scratch_fixed, scratch_per_wave, scratch_wave_cap, &extra)) return -1;
   env->scratch_off = (int32_t)(S->lds_bytes / sizeof(float));
   if (env_kind == ENV_BALANCE) return launch_any_level<ENV_BALANCE>(w, S, state, agent_ft, ld, a, *env, extra, s);
   if (env_kind == ENV_INGEST) return launch_any_level<ENV_INGEST>(w, S, state, agent_ft, ld, a, *env, 0, s);
+  if (env_kind == ENV_NAVIGATION) {
+    if (env->navigation.d.n_agents > kNavMaxOwn * S->nw)
+      return fail("vmas_world_step_env: %d agents on %d waves per tile (at most %d agents per wave)", env->navigation.d.n_agents,
+                  S->nw, kNavMaxOwn);
+    return launch_any_level<ENV_NAVIGATION>(w, S, state, agent_ft, ld, a, *env, extra, s);
+  }
   return launch_any_level<ENV_TRANSPORT>(w, S, state, agent_ft, ld, a, *env, extra, s);
 }
 
@@ -2581,9 +2616,11 @@ int vmas_world_set_lidars(VmasWorld* w, const VmasLidarDesc* lidars, int32_t n) 
   if (w && w->host_only) return fail("vmas_world_set_lidars: a planning world (device -1) has no device side");
   if (!w || (n > 0 && !lidars)) return fail("vmas_world_set_lidars: null argument");
   HIP_TRY(hipSetDevice(w->device));
-  (void)hipFree(w->d_lidars); (void)hipFree(w->d_targets); (void)hipFree(w->d_angles);
-  w->d_lidars = nullptr; w->d_targets = nullptr; w->d_angles = nullptr;
+  (void)hipFree(w->d_lidars); (void)hipFree(w->d_targets); (void)hipFree(w->d_angles); (void)hipFree(w->d_angles_cs);
+  w->d_lidars = nullptr; w->d_targets = nullptr; w->d_angles = nullptr; w->d_angles_cs = nullptr;
   w->n_lidars = 0; w->max_rays = 0;
+  w->h_lidars.clear();
+  w->h_targets.clear();
   if (n <= 0) return 0;
   std::vector<DevLidar> dl(n);
   std::vector<DevTarget> dt;
@@ -2605,6 +2642,13 @@ int vmas_world_set_lidars(VmasWorld* w, const VmasLidarDesc* lidars, int32_t n) 
   HIP_TRY(upload(&w->d_lidars, dl));
   HIP_TRY(upload(&w->d_targets, dt));
   HIP_TRY(upload(&w->d_angles, da));
+  HIP_TRY(hipMalloc((void**)&w->d_angles_cs, da.size() * sizeof(float2)));
+  hipLaunchKernelGGL(lidar_table_kernel, dim3(((int)da.size() + 255) / 256), dim3(256), 0, (hipStream_t)0, w->d_angles,
+                     (int)da.size(), w->d_angles_cs);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize((hipStream_t)0));
+  w->h_lidars = dl;
+  w->h_targets = dt;
   w->n_lidars = n;
   return 0;
 }
@@ -2655,7 +2699,7 @@ int vmas_world_cast_rays(VmasWorld* w, const float* state, int64_t ld, float* ou
   const dim3 block(256);
   auto grid = [&](int r) { return dim3((w->batch + 255) / 256, w->n_lidars, (w->max_rays + r - 1) / r); };
 #define LAUNCH_LIDAR(R)                                                                                            \
-  hipLaunchKernelGGL(lidar_kernel<R>, grid(R), block, 0, (hipStream_t)stream, w->d_lidars, w->d_targets, w->d_angles, \
+  hipLaunchKernelGGL(lidar_kernel<R>, grid(R), block, 0, (hipStream_t)stream, w->d_lidars, w->d_targets, w->d_angles, w->d_angles_cs, \
                      w->max_rays, state, (long)ld, w->batch, out)
   switch (rpt) {
     case 1: LAUNCH_LIDAR(1); break;

@@ -343,7 +343,8 @@ class Environment:
         resets in between (like K plain ``step()`` calls: ``done`` environments keep running until the caller
         resets them); the 64 environments of a tile stay in LDS for the whole rollout.  For the scenarios whose step
         is one launch (balance, transport); others: loop over ``step()``."""
-        assert self._one_launch, "rollout() needs a scenario whose Environment.step is one launch (balance, transport)"
+        assert self._one_launch and getattr(self._post, "rollout_ok", True), \
+            "rollout() needs a scenario whose Environment.step is one launch without a batch-wide reduction (balance, transport)"
         assert len(actions) == self.n_agents, f"Expecting actions for {self.n_agents}, got {len(actions)} actions"
         K = int(actions[0].shape[0])
         self._ingest.prepare_rollout(actions, K, self.validate_actions)

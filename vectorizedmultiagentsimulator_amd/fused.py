@@ -524,6 +524,8 @@ class TransportPost(_Post):
 
 
 class NavigationPost(_Post):
+    ONE_LAUNCH_MAX_TILES_PER_CU = 1  # the one-launch step is used up to this many tiles per CU (measured, see __init__)
+
     @staticmethod
     def supports(env) -> Optional[str]:
         sc = env.scenario
@@ -554,6 +556,14 @@ class NavigationPost(_Post):
             d.n_rays, d.lidar_range = s._angles.shape[0], s._max_range
         self.desc = d
         self._side = None
+        # as the physics kernel's epilogue only if the library says this world allows it (sensors as the epilogue casts
+        # them, tile + scratch within the CU's LDS); otherwise the separate launches of __call__
+        # ... and while every 64-environment tile has a CU to itself (8192 environments: 22 us in one launch against
+        # 7.6 + 8.5 + 13 us in three; at 65536 the epilogue's LDS leaves one tile per CU and the three launches win)
+        n_cu = torch.cuda.get_device_properties(self.dev).multi_processor_count
+        if (self.B + 63) // 64 > self.ONE_LAUNCH_MAX_TILES_PER_CU * n_cu or \
+                self.lib.vmas_world_step_env_check(w._get_backend()._h, A.POST_NAVIGATION, C.byref(d)) != 0:
+            self.kind = None
         self.obs_dim = 4 + 2 * (self.n if sc.observe_all_goals else 1) + (d.n_rays if sc.collisions else 0)
         self.pos_shaping = torch.stack([a.pos_shaping for a in agents]).contiguous()
         self._shaping_rows = list(self.pos_shaping.unbind(0))
@@ -575,22 +585,49 @@ class NavigationPost(_Post):
     def persistent_tensors(self):
         return [self.pos_shaping]
 
-    def __call__(self):
+    kind = A.POST_NAVIGATION  # as the epilogue of the physics kernel: LIDAR cast and collision reduction in the launch
+    rollout_ok = False        # (the collision penalties reduce over the whole batch after every step)
+
+    def _bind_outputs(self):
+        """Output tensors + the buffer struct's pointers (nothing launched)."""
         env, sc, w = self.env, self.env.scenario, self.env.world
         agents = w.agents
         for a, row, ptr in zip(agents, self._shaping_rows, self._shaping_ptrs):  # reset() may have rebound it
             if a.pos_shaping.data_ptr() != ptr:
                 row.copy_(a.pos_shaping)
                 a.pos_shaping = row
+        fresh = self._out is None or not self.static_outputs
         obs, rew, done = self._outputs(self.obs_dim)
-        if not self.static_outputs or getattr(self, "_terms", None) is None:
-            self._terms = (torch.empty(self.n, self.B, device=self.dev), torch.empty(self.B, device=self.dev),
-                           torch.empty(self.B, device=self.dev), torch.empty(self.n, self.B, device=self.dev))
-        agent_pos_rew, sc.pos_rew, sc.final_rew, col = self._terms
+        if fresh or getattr(self, "_terms", None) is None:
+            # one block: agent_pos_rew [n] | collision_rew [n] | pos_rew | final_rew
+            self._terms = torch.empty(2 * self.n + 2, self.B, device=self.dev)
+        t = self._terms
+        rows = t.unbind(0)
+        n = self.n
+        sc.pos_rew, sc.final_rew = rows[2 * n], rows[2 * n + 1]
+        for i, a in enumerate(agents):
+            a.pos_rew, a.agent_collision_rew = rows[i], rows[n + i]
         b = self._buf
         b.obs, b.rew, b.done = obs.data_ptr(), rew.data_ptr(), done.data_ptr()
-        b.agent_pos_rew, b.pos_rew, b.final_rew, b.collision_rew = (
-            agent_pos_rew.data_ptr(), sc.pos_rew.data_ptr(), sc.final_rew.data_ptr(), col.data_ptr())
+        p, row_bytes = t.data_ptr(), 4 * self.B
+        b.agent_pos_rew, b.collision_rew = p, p + n * row_bytes
+        b.pos_rew, b.final_rew = p + 2 * n * row_bytes, p + (2 * n + 1) * row_bytes
+        b.limit.steps = env.steps.data_ptr()
+        infos = [{"pos_rew": sc.pos_rew if sc.shared_rew else a.pos_rew, "final_rew": sc.final_rew,
+                  "agent_collisions": a.agent_collision_rew} for a in env.agents]
+        return list(obs.unbind(0)), list(rew.unbind(0)), done, infos
+
+    def prepare(self):
+        """(descriptor, buffers, what env.step returns) for the one-launch step (vmas_world_step_env)."""
+        result = self._bind_outputs()
+        self.env.scenario._lidar_cache = None  # (the sensors' measurements are made inside the launch, on the LDS tile)
+        self._buf.lidar = self._buf.pair_any = None
+        return self.desc, self._buf, result
+
+    def __call__(self):
+        env, sc, w = self.env, self.env.scenario, self.env.world
+        result = self._bind_outputs()
+        b = self._buf
         main = torch.cuda.current_stream(self.dev)
         if sc.collisions:
             # the batch-global collision mask (a short latency-bound kernel) runs beside the LIDAR cast on a
@@ -608,16 +645,10 @@ class NavigationPost(_Post):
             main.wait_event(self._join)
             b.lidar, b.lidar_max_rays = lidar.data_ptr(), lidar.shape[1]
             b.pair_any = pair_any.data_ptr()
-        b.limit.steps = env.steps.data_ptr()
         st = w._packed_state()
         _check(self.lib.vmas_navigation_post_step(C.byref(self.desc), C.byref(b), self.B, st.data_ptr(), st.shape[-1],
                                                   main.cuda_stream))
-        pos_rews, cols = agent_pos_rew.unbind(0), col.unbind(0)
-        for a, pr, c in zip(agents, pos_rews, cols):
-            a.pos_rew, a.agent_collision_rew = pr, c
-        infos = [{"pos_rew": sc.pos_rew if sc.shared_rew else a.pos_rew, "final_rew": sc.final_rew,
-                  "agent_collisions": a.agent_collision_rew} for a in env.agents]
-        return list(obs.unbind(0)), list(rew.unbind(0)), done, infos
+        return result
 
 
 class FootballPost(_Post):
