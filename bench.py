@@ -396,11 +396,23 @@ def main():
             env_steps(400)  # (the first few hundred steps carry one-time costs)
             n_env = max(min(args.steps, 2000), 200)
             ev_s, wall_s = timed(env_steps, n_env)
+            env.bind(acts)  # caller-owned action tensors, static outputs: one foreign call per step
+
+            def env_steps_bound(n):
+                for _ in range(n):
+                    env.step_bound()
+
+            env_steps_bound(100)
+            ev_b, wall_b = timed(env_steps_bound, n_env)
             per_env = be.step_bytes_per_env() + POST_BYTES_PER_ENV
             env_leg = {
                 "value": world_size * args.num_envs * w.substeps * n_env / wall_s, "unit": "env-steps/s",
                 "us_per_step": wall_s / n_env * 1e6, "gpu_us_per_step": ev_s / n_env * 1e6, "steps": n_env,
                 "launches_per_step": 1 if env._one_launch else None,
+                "bound": {"value": world_size * args.num_envs * w.substeps * n_env / wall_b, "us_per_step": wall_b / n_env * 1e6,
+                          "gpu_us_per_step": ev_b / n_env * 1e6,
+                          "note": "Environment.bind(actions) + step_bound(): the same step on caller-owned action tensors and "
+                                  "static output buffers - a single foreign call per step, no host-side tensor work"},
                 "roofline": {"bound": "hbm", "achieved": per_env * args.num_envs / (ev_s / n_env) / 1e9,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": per_env * args.num_envs / (ev_s / n_env) / 1e9 / HBM_PEAK_GBS,

@@ -65,6 +65,7 @@ class Environment:
         self.reset(return_observations=False)
         self._ingest = self._post = self._masked_reset = None
         self._one_launch = self._ingest_in_step = False
+        self._bound_actions = self._bound = None
         self._setup_fused()
 
     def _setup_fused(self):
@@ -128,6 +129,7 @@ class Environment:
         self.scenario.env_reset_world_at(env_index=None)
         self.steps.zero_()  # in place: a captured step graph keeps its pointer
         self._lidar_cache = None
+        self._bound = None
         return self._observations() if return_observations else None
 
     def reset_at(self, index: int, return_observations: bool = True):
@@ -135,6 +137,7 @@ class Environment:
         self.scenario.env_reset_world_at(index)
         self.steps[index] = 0
         self._lidar_cache = None
+        self._bound = None
         return [o[index] for o in self._observations()] if return_observations else None
 
     def reset_where(self, mask: Tensor, return_observations: bool = True):
@@ -150,6 +153,7 @@ class Environment:
         own vectorised reset and blended in where the mask is set (packed state, agent forces, step counter, the
         scenario's in-place tensors).  Either way unmasked environments keep their bits."""
         mask = mask.to(self.device).reshape(self.num_envs).bool().contiguous()
+        self._bound = None
         if self._masked_reset is not None:
             # ONE launch over the masked environments (vmas_env_reset_where): World.reset + the scenario's spawn program on
             # a counter-based generator + its cached terms; unmasked environments are not touched
@@ -298,6 +302,7 @@ class Environment:
             t.copy_(s_)
         self.world.invalidate_queries()
         self._lidar_cache = None
+        self._bound = None
 
     def _persistent_tensors(self):
         """Everything a step reads and writes: the packed world state, the step counter and the scenario's
@@ -353,8 +358,44 @@ class Environment:
         self._lidar_cache = None
         return out
 
+    def bind(self, actions: List[Tensor]) -> None:
+        """Caller-owned action tensors for ``step_bound()``: the policy writes the next actions INTO these tensors
+        (``actions[i].copy_(...)``, an ``out=`` argument ...) and every ``step_bound()`` is then a single foreign call -
+        no per-step checks, allocations or views on the host (a ``step()`` from Python costs 18 us of them around an
+        11 us kernel; SURVEY.md 8f-3, the policy-in-the-loop case that ``rollout()`` does not cover).  The outputs are
+        static buffers owned by the environment, overwritten by the next ``step_bound()``.  For the scenarios whose
+        step is one launch (balance, transport, navigation while a tile has a CU to itself), ``validate_actions=False``
+        (the reference's asserts are a host sync per step)."""
+        assert self._one_launch, "bind() needs a scenario whose Environment.step is one launch"
+        assert not self.validate_actions, "bind() needs validate_actions=False (the asserts are a host sync per step)"
+        assert len(actions) == self.n_agents, f"Expecting actions for {self.n_agents}, got {len(actions)} actions"
+        self._ingest.prepare(actions)
+        assert all(k is a for k, a in zip(self._ingest._keep, actions)), (
+            "bind() takes the action tensors as they are: float32 (int64 when discrete) [num_envs, action_size], contiguous, "
+            "on the environment's device")
+        self._bound_actions, self._bound = list(actions), None
+
+    def step_bound(self):
+        """One ``Environment.step()`` on the bound action tensors: (obs, rews, dones, infos) - static buffers."""
+        b = self._bound
+        if b is None:  # first call, or a reset / step() / set_state since: pointers may have moved
+            assert self._bound_actions is not None, "step_bound() needs bind(actions) first"
+            self._ingest.prepare(self._bound_actions)
+            post = self._post
+            keep, post.static_outputs, post._out = post.static_outputs, True, None  # a set of output buffers of its own
+            if hasattr(post, "_terms"):
+                post._terms = None
+            try:
+                b = self._bound = post.prepare()
+            finally:
+                post.static_outputs = keep
+        self._launch(self._post.kind, b[0], b[1], False)
+        self._lidar_cache = None
+        return b[2]
+
     def _step_eager(self, actions):
         assert len(actions) == self.n_agents, f"Expecting actions for {self.n_agents}, got {len(actions)} actions"
+        self._bound = None
         if self._one_launch:
             self._ingest.prepare(actions)
             if self.validate_actions:
