@@ -238,8 +238,9 @@ int vmas_env_reset_where(const VmasResetArgs* args, int32_t batch, int32_t n_ent
 #define VMAS_POST_NAVIGATION 3 /* VmasNavigationDesc / VmasNavigationBuffers (lidar, lidar_max_rays, pair_any unused: the
                                 * epilogue casts the world's registered sensors - sensor a = agent a's - on the tile, and
                                 * World.collides' reduction over the batch is made in the launch itself; the collision
-                                * penalties are added by a second small kernel behind the step kernel, same stream).  One
-                                * step per call (no vmas_world_rollout_env). */
+                                * penalties are applied behind a grid-wide barrier inside the step kernel while every tile is
+                                * resident at once - else by a second small kernel behind it, same stream).
+                                * vmas_world_rollout_env: with the barrier form only (at most one tile per CU, no capture). */
 int vmas_world_step_env(VmasWorld* w, float* state, float* agent_ft, int64_t ld, const VmasStepArgs* args /* may be NULL */,
                         const VmasIngestArgs* ingest /* may be NULL */, uint32_t* err_flags /* may be NULL */,
                         int32_t post_kind, const void* post_desc, const void* post_buffers, void* stream);

@@ -1,0 +1,27 @@
+"""Environment.bind + step_bound rate (GPU-bound: the one-launch step kernel's own time): python scripts/bench_bound.py balance 32768
+With VMAS_HIP_LIB=libvmas_hip_profile.so: VMAS_ENV_ABLATE (1 queries off, 2 observations off, 4 epilogue off, 8 prologue
+off; interpreter only - set SPEC=0) attributes the kernel's time to its stages."""
+import json, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+from vectorizedmultiagentsimulator_amd.environment import make_env
+name = sys.argv[1] if len(sys.argv) > 1 else "balance"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 32768
+kw = {"balance": dict(n_agents=4), "transport": {}, "navigation": dict(n_agents=8)}[name]
+env = make_env(name, num_envs=B, device="cuda:0", seed=0, validate_actions=False, **kw)
+if os.environ.get("SPEC") == "0":
+    env.world._get_backend().set_specialized(False)
+acts = [env.get_random_action(a) for a in env.agents]
+env.bind(acts)
+for _ in range(300):
+    env.step_bound()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+n = 2000
+e0.record()
+for _ in range(n):
+    env.step_bound()
+e1.record(); torch.cuda.synchronize()
+print(json.dumps({"scenario": name, "num_envs": B, "specialized": env.world._get_backend().specialized,
+                  "ablate": os.environ.get("VMAS_ENV_ABLATE"), "lanes": env.world._get_backend().lanes_per_env,
+                  "step_bound_us": round(e0.elapsed_time(e1) / n * 1e3, 2)}))

@@ -7,7 +7,7 @@ from vectorizedmultiagentsimulator_amd.environment import make_env
 name = sys.argv[1] if len(sys.argv) > 1 else "balance"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32768
 K = int(sys.argv[3]) if len(sys.argv) > 3 else 100
-kw = {"balance": dict(n_agents=4), "transport": {}}[name]
+kw = {"balance": dict(n_agents=4), "transport": {}, "navigation": dict(n_agents=8)}[name]
 env = make_env(name, num_envs=B, device="cuda:0", seed=0, validate_actions=False, **kw)
 if os.environ.get("SPEC") == "0":  # A/B: the interpreter instead of the world-specialised kernel
     env.world._get_backend().set_specialized(False)

@@ -470,7 +470,8 @@ __host__ __device__ inline size_t navigation_scratch_floats(int nw, int n_agents
 template <bool FUSED, class Pos, class Vel, class Goal, class Rays>
 VD void navigation_post_body(const TileCtx& C, const VmasNavigationDesc& d, const VmasNavigationBuffers& o, int batch,
                              const float* per_agent, const uint32_t* collide_with, const ObsTile& T, float steps_in,
-                             Pos pos, Vel vel, Goal goal, Rays rays /* (agent, slot): its LIDAR part into T */) {
+                             Pos pos, Vel vel, Goal goal, Rays rays /* (agent, slot): its LIDAR part into T */,
+                             float* new_shaping = nullptr /* [kNavMaxOwn] out: the shaping of this wave's agents */) {
   const int A = d.n_agents;
   // agent_reward of every agent (navigation.py:232-242, 206-216), recomputed by every wave: the shared
   // terms need all of them; the wave that owns agent a stores a's terms
@@ -484,6 +485,7 @@ VD void navigation_post_body(const TileCtx& C, const VmasNavigationDesc& d, cons
     const float r = per_agent[a * 64 + C.lane] - shaping;
     if (a % C.nw == C.wave) {
       my_pos_rew[a / C.nw] = r;
+      if (new_shaping != nullptr) new_shaping[a / C.nw] = shaping;
       if (C.live) {
         o.pos_shaping[(long)a * batch + C.env] = shaping;
         o.agent_pos_rew[(long)a * batch + C.env] = r;
@@ -578,9 +580,18 @@ VD void navigation_prologue_tile(const TileCtx& C, const VmasNavigationDesc& d, 
 }
 
 // after the last substep: `rows` = the tile with the new state, every wave past the barrier behind the integration
-VD void navigation_post_tile(const TileCtx& C, const VmasNavigationDesc& d, const VmasNavigationBuffers& o,
+VD void navigation_post_tile(const TileCtx& C, const VmasNavigationDesc& d, const VmasNavigationBuffers& o_in,
                              const NavWorld& nav, int batch, const float* rows, float* scratch, float& steps_in,
-                             unsigned long long* tr = nullptr /* profiling build: s_memtime stamps of this wave */) {
+                             unsigned long long* tr = nullptr /* profiling build: s_memtime stamps of this wave */,
+                             int stp = 0 /* step of a multi-step rollout: barrier number nav.seq + stp */,
+                             bool last = true) {
+  VmasNavigationBuffers o = o_in;
+  if (stp > 0) {  // step k of a rollout writes the k-th slab of every per-step output
+    const long nb = (long)d.n_agents * batch;
+    o.obs += (long)stp * nb * navigation_obs_dim(d); o.rew += (long)stp * nb; o.agent_pos_rew += (long)stp * nb;
+    o.collision_rew += (long)stp * nb; o.pos_rew += (long)stp * batch; o.final_rew += (long)stp * batch;
+    o.done += (long)stp * batch;
+  }
   auto stamp = [&](int k) { if (tr != nullptr && (threadIdx.x & 63) == 0) tr[k] = __builtin_amdgcn_s_memtime(); };
   stamp(6);
   const int A = d.n_agents, D = navigation_obs_dim(d), n_goal = d.observe_all_goals ? A : 1;
@@ -596,7 +607,8 @@ VD void navigation_post_tile(const TileCtx& C, const VmasNavigationDesc& d, cons
   // behind the LIDAR units - and apply the collision penalties themselves.  Otherwise the bits go to nav.mask, the reward
   // is stored without the penalties and navigation_collision_kernel, launched behind this kernel, adds them.
   const bool grid_sync = nav.sync != nullptr;
-  uint32_t* slot = grid_sync ? nav.sync + 2 + (nav.seq & 1u) * (uint32_t)words : nav.mask;
+  const uint32_t seq = nav.seq + (uint32_t)stp;  // ring of four mask slots: slot seq + 2 is cleared behind barrier seq
+  uint32_t* slot = grid_sync ? nav.sync + 2 + (seq & 3u) * (uint32_t)words : nav.mask;
   const int R = d.collisions ? A * d.n_rays : 0;
   float* ray_rows0 = (float*)(tab + D * 64) + (size_t)(C.nw < A ? C.nw : A) * 64 * (D | 1);
   const float* stage = ray_rows0 + (size_t)R * 64;  // staged by navigation_prologue_tile
@@ -660,7 +672,7 @@ VD void navigation_post_tile(const TileCtx& C, const VmasNavigationDesc& d, cons
     stamp(8);
     if (grid_sync) {
       if (threadIdx.x == 0) {
-        const uint32_t target = (nav.seq + 1u) * gridDim.x;  // arrivals are never reset: every launch of this world has this grid
+        const uint32_t target = (seq + 1u) * gridDim.x;  // arrivals are never reset: every launch of this world has this grid
         int spins = 0;
         while ((int32_t)(__hip_atomic_load(nav.sync, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
           __builtin_amdgcn_s_sleep(8);
@@ -669,9 +681,11 @@ VD void navigation_post_tile(const TileCtx& C, const VmasNavigationDesc& d, cons
             break;
           }
         }
-        if (blockIdx.x == 0)  // every tile is past this launch's barrier, the previous launch is over: its slot is free
+        if (blockIdx.x == 0)  // every tile has arrived at barrier seq, i.e. is done reading the slots up to seq - 1; the one
+                              // of seq - 2 = seq + 2 (mod 4) is cleared here - no tile writes it before it has passed
+                              // barrier seq + 1, which this thread has yet to join
           for (int w_ = 0; w_ < words; ++w_)
-            __hip_atomic_store(nav.sync + 2 + ((nav.seq + 1u) & 1u) * (uint32_t)words + w_, 0u, __ATOMIC_RELAXED,
+            __hip_atomic_store(nav.sync + 2 + ((seq + 2u) & 3u) * (uint32_t)words + w_, 0u, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
       }
       __syncthreads();
@@ -700,10 +714,24 @@ VD void navigation_post_tile(const TileCtx& C, const VmasNavigationDesc& d, cons
     if (!d.collisions) return;
     for (int r = 0; r < d.n_rays; ++r) T.put(4 + 2 * n_goal + r, d.lidar_range - ray_rows[(a * d.n_rays + r) * 64]);
   };
-  if (grid_sync && d.collisions) navigation_post_body<false>(C, d, o, batch, per_agent, collide_with, T, steps_in, pos, vel, goal, rays);
-  else navigation_post_body<true>(C, d, o, batch, per_agent, nullptr, T, steps_in, pos, vel, goal, rays);
+  float shaping_out[kNavMaxOwn];
+  if (grid_sync && d.collisions)
+    navigation_post_body<false>(C, d, o, batch, per_agent, collide_with, T, steps_in, pos, vel, goal, rays, shaping_out);
+  else
+    navigation_post_body<true>(C, d, o, batch, per_agent, nullptr, T, steps_in, pos, vel, goal, rays, shaping_out);
   stamp(10);
   if (o.limit.steps != nullptr) steps_in = steps_in + 1.f;
+  if (!last) {  // the next step of the rollout: its previous shaping = this one's (from the registers of the wave that owns
+                // the agent), the work counter and the pair words re-armed
+    __syncthreads();
+    float* pa = scratch;
+#pragma unroll
+    for (int sl = 0; sl < kNavMaxOwn; ++sl) {
+      const int a = C.wave + sl * C.nw;
+      if (a < A) pa[a * 64 + C.lane] = C.live ? shaping_out[sl] : 0.f;
+    }
+    if (threadIdx.x < VMAS_ENV_MAX_AGENTS) misc[threadIdx.x] = threadIdx.x == 0 ? C.nw : 0;
+  }
 }
 
 // ------------------------------------------------------------------------------------ action ingest

@@ -1112,8 +1112,8 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
   // ---- epilogue of this step: the scenario's reward / observation / done on the tile that is still in LDS.  In a
   //      multi-step rollout (vmas_world_rollout_env) step k writes the k-th slab of every per-step output; the
   //      persistent terms (shaping, step counter) are carried in registers / re-read by the thread that wrote them.
-  if constexpr (ENV == ENV_NAVIGATION) {  // (single step: the collision penalties need a reduction over all tiles, made
-                                          //  by a kernel behind this one - see navigation_post_tile)
+  if constexpr (ENV == ENV_NAVIGATION) {  // (the collision penalties need a reduction over all tiles: a grid barrier per
+                                          //  step, or - single steps only - a kernel behind this one; navigation_post_tile)
     __syncthreads();
 #ifdef VMAS_TRACE
     unsigned long long* nav_tr = args.trace ? args.trace + ((long)blockIdx.x * 16 + wv) * 16 : nullptr;
@@ -1121,7 +1121,8 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
     unsigned long long* nav_tr = nullptr;
 #endif
     navigation_post_tile(TileCtx(batch), E.navigation.d, E.navigation.o, E.navigation.w, batch, lds, lds + E.scratch_off,
-                         post_steps, nav_tr);
+                         post_steps, nav_tr, stp, stp + 1 == n_steps);
+    if (stp + 1 < n_steps) __syncthreads();  // the next step's prologue rewrites the agent-force rows
   }
   if constexpr (ENV == ENV_BALANCE || ENV == ENV_TRANSPORT) {
     if (stp + 1 == n_steps) __syncthreads();  // (earlier steps: the substep loop ended with a barrier)
@@ -1388,7 +1389,7 @@ struct VmasWorld {
   uint32_t sync_seq = 0;
   uint32_t* d_exact_mask = nullptr;
   uint32_t* d_nav_mask = nullptr;  // navigation epilogue: World.collides' pair bits of the post-step state + a block counter
-  uint32_t* d_nav_sync = nullptr;  // its grid-barrier form: arrivals | timeout flag | two mask slots
+  uint32_t* d_nav_sync = nullptr;  // its grid-barrier form: arrivals | timeout flag | ring of four mask slots
   uint32_t nav_seq = 0;
   std::vector<DevLidar> h_lidars;  // host copy of the registered sensors (argument checks of the navigation epilogue)
   std::vector<DevTarget> h_targets;
@@ -2128,8 +2129,8 @@ int vmas_world_create(const VmasWorldDesc* d, int32_t batch, int32_t device_id, 
     HIP_TRY(hipMalloc((void**)&w->d_exact_mask, (mw ? mw : 1) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void**)&w->d_nav_mask, (mw + 1) * sizeof(uint32_t)));
     HIP_TRY(hipMemset(w->d_nav_mask, 0, (mw + 1) * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void**)&w->d_nav_sync, (2 + 2 * mw) * sizeof(uint32_t)));
-    HIP_TRY(hipMemset(w->d_nav_sync, 0, (2 + 2 * mw) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&w->d_nav_sync, (2 + 4 * mw) * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(w->d_nav_sync, 0, (2 + 4 * mw) * sizeof(uint32_t)));
   }
   if (!host_only) {
     hipDeviceProp_t prop;
@@ -2391,9 +2392,6 @@ static int step_env_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld
     const auto* d = (const VmasNavigationDesc*)post_desc;
     const auto* o = (const VmasNavigationBuffers*)post_buffers;
     if (vmas::check_navigation_args(d, o, w->batch, state, ld, 1)) return -1;
-    if (n_steps != 1)
-      return fail("vmas_world_rollout_env: navigation's collision penalties reduce over the whole batch after every step "
-                  "(World.collides): one step per call");
     size_t nav_fixed = 0, nav_per_wave = 0;
     if (nav_epilogue_plan(w, d, &nav_fixed, &nav_per_wave)) return -1;
     env.navigation.d = *d;
@@ -2408,7 +2406,11 @@ static int step_env_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld
     }
     env.navigation.w = NavWorld{w->d_angles, w->d_angles_cs, w->d_mpairs, w->d_nav_mask, grid_sync ? w->d_nav_sync : nullptr,
                                 w->nav_seq, d->collisions ? w->n_pairs : 0};
-    if (grid_sync) ++w->nav_seq;
+    if (n_steps > 1 && d->collisions && !grid_sync)
+      return fail("vmas_world_rollout_env: navigation's collision penalties reduce over the whole batch after every step "
+                  "(World.collides): several steps per launch need every tile resident at once (%d tiles, %d CUs) and a stream "
+                  "that is not being captured", blocks_of(w->batch), w->n_cu);
+    if (grid_sync) w->nav_seq += (uint32_t)n_steps;
     if (step_impl(w, state, agent_ft, ld, args, stream, n_steps, 0, &env, ENV_NAVIGATION, nav_fixed, nav_per_wave, 0, -1,
                   d->n_agents))
       return -1;

@@ -561,6 +561,8 @@ class NavigationPost(_Post):
         # ... and while every 64-environment tile has a CU to itself (8192 environments: 22 us in one launch against
         # 7.6 + 8.5 + 13 us in three; at 65536 the epilogue's LDS leaves one tile per CU and the three launches win)
         n_cu = torch.cuda.get_device_properties(self.dev).multi_processor_count
+        # several steps per launch (rollout): a grid barrier per step - every tile must be resident at once
+        self.rollout_ok = (self.B + 63) // 64 <= n_cu or not sc.collisions
         if (self.B + 63) // 64 > self.ONE_LAUNCH_MAX_TILES_PER_CU * n_cu or \
                 self.lib.vmas_world_step_env_check(w._get_backend()._h, A.POST_NAVIGATION, C.byref(d)) != 0:
             self.kind = None
@@ -586,7 +588,29 @@ class NavigationPost(_Post):
         return [self.pos_shaping]
 
     kind = A.POST_NAVIGATION  # as the epilogue of the physics kernel: LIDAR cast and collision reduction in the launch
-    rollout_ok = False        # (the collision penalties reduce over the whole batch after every step)
+    rollout_ok = True         # (instance attribute, see __init__: several steps per launch need a grid barrier per step)
+
+    def prepare_rollout(self, n_steps: int):
+        env, sc, K, n, B = self.env, self.env.scenario, int(n_steps), self.n, self.B
+        self._bind_outputs()  # (re-binds the agents' shaping rows after a reset)
+        out = {
+            "obs": torch.empty(K, n, B, self.obs_dim, device=self.dev), "rew": torch.empty(K, n, B, device=self.dev),
+            "done": torch.empty(K, B, device=self.dev, dtype=torch.bool),
+            "agent_pos_rew": torch.empty(K, n, B, device=self.dev), "pos_rew": torch.empty(K, B, device=self.dev),
+            "final_rew": torch.empty(K, B, device=self.dev), "agent_collisions": torch.empty(K, n, B, device=self.dev),
+        }
+        sc.pos_rew, sc.final_rew = out["pos_rew"][-1], out["final_rew"][-1]  # scenario / agent attributes: the last step's
+        for i, a in enumerate(env.world.agents):
+            a.pos_rew, a.agent_collision_rew = out["agent_pos_rew"][-1, i], out["agent_collisions"][-1, i]
+        sc._lidar_cache = None
+        b = A.NavigationBuffers()
+        b.pos_shaping, b.limit = self.pos_shaping.data_ptr(), self._limit()
+        b.limit.steps = env.steps.data_ptr()
+        b.pair_index = self._buf.pair_index
+        b.obs, b.rew, b.done = out["obs"].data_ptr(), out["rew"].data_ptr(), out["done"].data_ptr()
+        b.agent_pos_rew, b.collision_rew = out["agent_pos_rew"].data_ptr(), out["agent_collisions"].data_ptr()
+        b.pos_rew, b.final_rew = out["pos_rew"].data_ptr(), out["final_rew"].data_ptr()
+        return self.desc, b, out
 
     def _bind_outputs(self):
         """Output tensors + the buffer struct's pointers (nothing launched)."""
