@@ -625,14 +625,16 @@ VD void navigation_post_tile(const TileCtx& C, const VmasNavigationDesc& d, cons
       const bool hit = C.live && norm2(sa[0] - sb[0], sa[64] - sb[64]) <= P.bound_sum;
       if (__any(hit) && C.lane == 0) atomicOr((uint32_t*)&misc[1 + (k >> 5)], 1u << (k & 31));
     }
-    if (grid_sync) {  // publish and arrive now, wait behind the LIDAR units
+    if (grid_sync) {  // publish and arrive now, wait behind the LIDAR units: ONE thread does both, so that its release
+                      // orders the arrival behind the bits without a second block barrier
       __syncthreads();
-      if ((int)threadIdx.x < words) {
-        const uint32_t b = (uint32_t)misc[1 + threadIdx.x];
-        if (b != 0u) __hip_atomic_fetch_or(slot + threadIdx.x, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (threadIdx.x == 0) {
+        for (int w_ = 0; w_ < words; ++w_) {
+          const uint32_t b = (uint32_t)misc[1 + w_];
+          if (b != 0u) __hip_atomic_fetch_or(slot + w_, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __hip_atomic_fetch_add(nav.sync, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       }
-      __syncthreads();  // (vmcnt(0) + barrier: the tile's atomics have returned)
-      if (threadIdx.x == 0) __hip_atomic_fetch_add(nav.sync, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   stamp(7);
