@@ -23,7 +23,8 @@
 //     through a divmod table built once per block - coalesced 256-byte stores, ~4 instructions
 //     per element;
 //   * block barriers only separate the phases stage -> shared queries -> per-agent work, all before
-//     the first observation store (s_barrier drains vmcnt, i.e. would wait for stores in flight).
+//     the first observation store (vmcnt counts loads and stores in issue order: a wait for any later load
+//     is a wait for every store issued before it).
 // All arithmetic restates the reference's operation order with the helpers of the physics step.
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -700,6 +700,10 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
   const int first_dyn = (ABLATE(args) & 128) ? 0 : nw;  // 128: profiling toggle, fully dynamic
   if (threadIdx.x < 4) ctr[threadIdx.x] = first_dyn;  // the first unit of every wave is static (its own index)
   if (threadIdx.x >= 4 && threadIdx.x < 8) ctr[threadIdx.x] = 0;  // fired bits: set by eval_ssp (atomic or)
+  uint32_t* xmask = fired_words + 4;  // [mask_words] this tile's pair bits (in-kernel exact broad phase)
+  if constexpr (PLAIN == 0) {
+    if (args.sync != nullptr && (int)threadIdx.x < args.mask_words) xmask[threadIdx.x] = 0u;
+  }
 
   // ---- HBM -> LDS, one entity per wave at a time: six 256-byte row reads in flight, then the
   //      entity's trig straight from the registers
@@ -810,11 +814,15 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
           const float* A = tile + sgpr(P.a) * 6 * ROWF;
           const float* B = tile + sgpr(P.b) * 6 * ROWF;
           const bool hit = live && norm2(A[0] - B[0], A[ROWF] - B[ROWF]) <= P.bound_sum;
-          if (__any(hit) && lane == 0)
-            __hip_atomic_fetch_or(slot + (p >> 5), 1u << (p & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (__any(hit) && lane == 0) atomicOr(&xmask[p >> 5], 1u << (p & 31));  // (LDS)
         }
-        __syncthreads();  // (waits for this tile's atomics to be issued and returned: vmcnt(0) + barrier)
-        if (threadIdx.x == 0) {
+        __syncthreads();
+        if (threadIdx.x == 0) {  // ONE thread publishes the tile's bits and arrives: its release orders the arrival behind them
+          for (int w_ = 0; w_ < args.mask_words; ++w_) {
+            const uint32_t b = xmask[w_];
+            if (b != 0u) __hip_atomic_fetch_or(slot + w_, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            xmask[w_] = 0u;  // (re-armed for the next substep: nobody touches it before the barrier below)
+          }
           const uint32_t target = (seq + 1u) * gridDim.x;  // arrivals are never reset: every launch of this world has this grid
           __hip_atomic_fetch_add(args.sync, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
           int spins = 0;
@@ -1777,7 +1785,8 @@ static int build_sched(VmasWorld* w, int nw, Sched& S) {
   S.dw.n_owned = (int)owned.size();
   S.dw.off_blob = row_bad * ROWF;  // (row_bad: the first row after the partial sums)
   S.dw.fired_recs = w->fired_recs;
-  S.lds_bytes = ((size_t)row_bad * ROWF + S.dw.blob_words + 4 + 4) * sizeof(float);  // + work counters, fired words (2 parities x 2)
+  // + work counters, fired words (2 parities x 2), the tile's pair bits of the in-kernel exact broad phase (whole quads)
+  S.lds_bytes = ((size_t)row_bad * ROWF + S.dw.blob_words + 4 + 4 + ((((size_t)w->n_pairs + 31) / 32 + 3) & ~(size_t)3)) * sizeof(float);
   if (knob("VMAS_DEBUG_SCHED")) fprintf(stderr, "[sched nw=%d] %d segments, LDS %zu B per tile\n", nw, (int)segs.size(), S.lds_bytes);
   return 0;
 }
