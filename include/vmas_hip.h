@@ -191,9 +191,10 @@ int vmas_world_step_n(VmasWorld* w, float* state, float* agent_ft, int64_t ld, i
 int vmas_world_rollout(VmasWorld* w, float* state, float* agent_ft, int64_t ld, int64_t ft_step_stride,
                        int32_t n_steps, const VmasStepArgs* args /* may be NULL */, void* stream);
 
-/* After steps with exact_broad_phase: 0 if every in-kernel grid barrier completed, 1 if one gave up waiting (the
- * grid was not co-resident; results of that step are those of exact_broad_phase = 0), < 0 on error.  Synchronises
- * the device: a debugging / test aid. */
+/* After steps with exact_broad_phase (and after vmas_world_step_env / vmas_world_rollout_env launches with the
+ * navigation epilogue, whose collision reduction uses the same kind of barrier): 0 if every in-kernel grid barrier
+ * completed, 1 if one gave up waiting (the grid was not co-resident; that step then used the pair bits that had arrived
+ * by then), < 0 on error.  Synchronises the device: a debugging / test aid. */
 int vmas_world_exact_status(VmasWorld* w);
 
 /* Batch-global broad phase of World.collides (core.py:2797-2801): mask[p/32] bit
