@@ -13,18 +13,22 @@ gpurun-ignored (they travel to the GPU box with the built ``.so`` files).  No re
 """
 from __future__ import annotations
 
+import contextlib
 import importlib
 import importlib.util
+import json
 import os
+import pathlib
 import py_compile
 import shutil
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = "/root/reference"
+SRC = os.environ.get("VMAS_REFERENCE_SRC", "/root/reference")  # (the override lets the CPU suite exercise the sourceless tree)
 REF = os.path.join(HERE, "_ref")
 SHIM = os.path.join(HERE, "ref_shim")
 _STAMP = os.path.join(REF, "STAMP")
+_MANIFEST = os.path.join(REF, "MANIFEST.json")
 
 
 def _magic() -> str:
@@ -52,9 +56,52 @@ def build_ref(force: bool = False) -> bool:
                 py_compile.compile(os.path.join(dirpath, fn), cfile=dst, dfile=os.path.join("reference", rel, fn), doraise=True,
                                    invalidation_mode=py_compile.PycInvalidationMode.UNCHECKED_HASH)
                 n += 1
+    # data files the package reads at run time (road_traffic's map, vmas/scenarios_data/**): copied next to the byte code -
+    # into the git-ignored build output only, like the .pyc files
+    data_src = os.path.join(SRC, "vmas", "scenarios_data")
+    if os.path.isdir(data_src):
+        shutil.copytree(data_src, os.path.join(REF, "vmas", "scenarios_data"), dirs_exist_ok=True)
+    # what the reference's own discovery (tests/test_vmas.py::scenario_names, vmas/scenarios/__init__.py::load) finds by
+    # globbing ``vmas/scenarios/**/*.py``: kept as a manifest, because a sourceless tree has no ``*.py`` to glob
+    names = sorted(os.path.splitext(fn)[0] for _, _, fns in os.walk(os.path.join(SRC, "vmas", "scenarios")) for fn in fns
+                   if fn.endswith(".py") and not fn.startswith("__"))
+    with open(_MANIFEST, "w") as f:
+        json.dump({"scenarios": names}, f)
     with open(_STAMP, "w") as f:
         f.write(f"{_magic()} {n} modules byte-compiled from {SRC} (VMAS reference, sourceless)\n")
     return True
+
+
+def scenario_manifest():
+    """Scenario names the reference ships (from the sources when they are here, else the manifest build_ref() wrote)."""
+    if os.path.isdir(os.path.join(SRC, "vmas")):
+        return sorted(os.path.splitext(fn)[0] for _, _, fns in os.walk(os.path.join(SRC, "vmas", "scenarios")) for fn in fns
+                      if fn.endswith(".py") and not fn.startswith("__"))
+    with open(_MANIFEST) as f:
+        return json.load(f)["scenarios"]
+
+
+@contextlib.contextmanager
+def _sourceless_glob():
+    """The reference discovers its scenarios by globbing ``*.py`` (tests/test_vmas.py:18-24).  On the byte-compiled tree
+    those files are ``*.pyc`` (same stems): while a reference module is being executed from oracle/_ref, a ``*.py`` glob
+    INSIDE that tree also yields the ``*.pyc`` files.  Nothing outside oracle/_ref is affected."""
+    if root() != REF:
+        yield
+        return
+    orig = pathlib.Path.glob
+
+    def glob(self, pattern, *a, **kw):
+        hits = list(orig(self, pattern, *a, **kw))
+        if isinstance(pattern, str) and pattern.endswith(".py") and os.path.abspath(str(self)).startswith(REF):
+            hits += list(orig(self, pattern + "c", *a, **kw))
+        return iter(hits)
+
+    pathlib.Path.glob = glob
+    try:
+        yield
+    finally:
+        pathlib.Path.glob = orig
 
 
 def available() -> bool:
@@ -106,5 +153,6 @@ def load_test_module(relpath: str):
     spec = importlib.util.spec_from_file_location(name, path)
     mod = importlib.util.module_from_spec(spec)
     sys.modules[name] = mod
-    spec.loader.exec_module(mod)
+    with _sourceless_glob():  # (parametrize marks over scenario_names() are evaluated while the module executes)
+        spec.loader.exec_module(mod)
     return mod

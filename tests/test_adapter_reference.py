@@ -110,3 +110,89 @@ def test_attach_refuses_grad(vmas):
     env = vmas.make_env("balance", num_envs=2, device="cpu", seed=0, grad_enabled=True)
     with pytest.raises(NotImplementedError):
         attach(env, backend_factory=OracleBackend)
+
+
+# ---- mutable static inputs: the step must use what the world holds NOW ---------------------------------
+def _copy_state(src, dst, device):
+    for ea, eb in zip(src.world.entities, dst.world.entities):
+        eb.set_pos(ea.state.pos.to(device), batch_index=None)
+        eb.set_vel(ea.state.vel.to(device), batch_index=None)
+        eb.set_rot(ea.state.rot.to(device), batch_index=None)
+        eb.set_ang_vel(ea.state.ang_vel.to(device), batch_index=None)
+
+
+def _track(ref, att, device, steps, g1, g2, tol=1e-4):
+    for t in range(steps):
+        ref.step(_actions(ref, g1))
+        att.step([a.to(device) for a in _actions(att, g2)])
+        for ea, eb in zip(ref.world.entities, att.world.entities):
+            for name in ("pos", "vel"):
+                a, b = getattr(ea.state, name), getattr(eb.state, name).cpu()
+                assert torch.allclose(a, b, atol=tol, rtol=1e-4), f"{ea.name}.{name} step {t}: {(a - b).abs().max()}"
+
+
+def _het_mass_reset_is_tracked(vmas, device, attach_kw):
+    """debug/het_mass.py:50-53 redraws both agents' masses in reset_world_at (setter core.py:634-636): the attached step
+    must integrate with the NEW masses (round 2 stepped with the ones extracted at attach time)."""
+    from vectorizedmultiagentsimulator_amd.adapter import attach
+
+    ref = vmas.make_env("het_mass", num_envs=5, device="cpu", seed=0)
+    att = vmas.make_env("het_mass", num_envs=5, device=device, seed=0)
+    h = attach(att, exact_broad_phase=True, **attach_kw)
+    g1, g2 = torch.Generator().manual_seed(3), torch.Generator().manual_seed(3)
+    for round_ in range(3):
+        ref.reset()
+        att.reset()  # the scenario's reset_world_at redraws the attached world's masses
+        _copy_state(ref, att, device)
+        masses = [a.mass for a in att.world.agents]
+        assert round_ == 0 or masses != prev
+        prev = masses
+        for a, m in zip(ref.world.agents, masses):  # (the two resets drew different noise: the untouched reference
+            a.mass = m                              #  environment is given the attached one's masses, not vice versa)
+        _track(ref, att, device, 8, g1, g2)
+        assert [h.spec.entities[i].mass for i in range(len(masses))] == [float(m) for m in masses]
+    assert h.refreshes >= 2  # every reset changed the masses
+    h.detach()
+
+
+def _filter_and_setters_are_tracked(vmas, device, attach_kw):
+    """collision_filter reassigned after construction (joint_passage.py:622, setter core.py:720-722), mass and
+    linear_friction through their public setters (core.py:634-636, 696-701) - mid-episode, no reset."""
+    from vectorizedmultiagentsimulator_amd.adapter import attach
+
+    kw = dict(n_agents=3)
+    ref = vmas.make_env("balance", num_envs=4, device="cpu", seed=0, **kw)
+    att = vmas.make_env("balance", num_envs=4, device=device, seed=0, **kw)
+    _copy_state(ref, att, device)
+    h = attach(att, exact_broad_phase=True, **attach_kw)
+    g1, g2 = torch.Generator().manual_seed(5), torch.Generator().manual_seed(5)
+    _track(ref, att, device, 5, g1, g2)
+    n0 = len(h.spec.pairs)
+    for env in (ref, att):  # the package stops colliding with the agents: it falls through them
+        pkg = env.scenario.package
+        agents = list(env.world.agents)
+        pkg.collision_filter = lambda e, _agents=agents: e not in _agents
+        env.world.agents[0].mass = 2.5
+        env.scenario.line.linear_friction = 0.05
+    _track(ref, att, device, 8, g1, g2)
+    assert h.refreshes == 1 and len(h.spec.pairs) < n0
+    assert h.spec.entities[att.world.entities.index(att.world.agents[0])].mass == 2.5
+    h.detach()
+
+
+def test_attach_tracks_het_mass_resets(vmas):
+    _het_mass_reset_is_tracked(vmas, "cpu", dict(backend_factory=OracleBackend))
+
+
+def test_attach_tracks_filter_mass_friction_setters(vmas):
+    _filter_and_setters_are_tracked(vmas, "cpu", dict(backend_factory=OracleBackend))
+
+
+@pytest.mark.gpu
+def test_attach_tracks_het_mass_resets_on_the_hip_step(vmas):
+    _het_mass_reset_is_tracked(vmas, "cuda:0", {})
+
+
+@pytest.mark.gpu
+def test_attach_tracks_filter_mass_friction_setters_on_the_hip_step(vmas):
+    _filter_and_setters_are_tracked(vmas, "cuda:0", {})

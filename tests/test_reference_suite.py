@@ -191,9 +191,42 @@ def test_reference_test_on_the_hip_step(case):
     _run(case, on_gpu=True)
 
 
-def test_reference_suite_is_collected():
+def _check_collected():
     if not ref.available():
         pytest.skip("neither /root/reference nor oracle/_ref present")
     names = {c[0].split("::")[0] for c in CASES}
     assert {os.path.basename(f)[:-3] for f in FILES} <= names and "test_vmas" in names
     assert len(CASES) >= 100
+    # the scenario-parametrised tests of tests/test_vmas.py expand over EVERY scenario the reference ships - also on the
+    # byte-compiled tree, where its `*.py` glob finds nothing by itself (oracle/ref.py::_sourceless_glob + manifest)
+    scen = ref.scenario_manifest()
+    assert len(scen) >= 41
+    for t in VMAS_TESTS:
+        got = {c[4]["scenario"] for c in CASES if c[3] == t and "scenario" in c[4]}
+        if got:  # (test_seeding is not parametrised over scenarios)
+            assert got == set(scen), (t, sorted(set(scen) - got))
+
+
+def test_reference_suite_is_collected():
+    _check_collected()
+
+
+@pytest.mark.gpu
+def test_reference_suite_is_collected_on_the_gpu_box():
+    """The same count where it matters: the GPU box has only the sourceless oracle/_ref tree."""
+    _check_collected()
+
+
+def test_sourceless_tree_collects_the_same_cases():
+    """What the GPU box sees (only oracle/_ref, no /root/reference): the same 115 cases.  Run in a subprocess with the
+    reference's source directory pointed away (round 2's GPU run collected 33: the reference's `*.py` glob found nothing)."""
+    import subprocess
+
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "MANIFEST.json")):
+        pytest.skip("oracle/_ref not built (run __graft_entry__.build() where /root/reference exists)")
+    code = ("import sys; sys.path[:0] = [%r, %r]; import test_reference_suite as m; "
+            "print(len(m.CASES)); m._check_collected()") % (ROOT, os.path.dirname(__file__))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VMAS_REFERENCE_SRC="/nonexistent"),
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert int(out.stdout.split()[-1]) == len(CASES) or not os.path.isdir("/root/reference")

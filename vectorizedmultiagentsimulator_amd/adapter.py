@@ -13,9 +13,14 @@ How the state is shared
     ``copy_`` into the view instead of rebinding, so scenarios, ``reset_at`` and dynamics keep
     working and the kernel always sees current data - no gather/scatter per step.
 
-What stays dynamic
+What stays dynamic (SURVEY.md 8b "inputs that are mutable between steps")
     ``JointConstraint.fixed_rotation`` tensors and per-env entity gravity are re-read
-    every step; mass / friction / filters are re-extracted when ``refresh()`` is called.
+    every step.  The STATIC description (mass - ``debug/het_mass.py:50-53`` redraws it at every reset -,
+    drag / friction / gravity / speed limits, ``collision_filter`` - ``joint_passage.py:614-622`` filters on
+    data its reset rewrites -, movable / rotatable / collide flags, shape dimensions) is watched:
+    every step compares a cheap fingerprint of those attributes (setters ``core.py:634-636, 696-706,
+    720-722``), and the first step after any ``World.reset`` (``core.py:1234``) re-extracts the whole
+    spec - collidability matrix included - and rebuilds the native world iff it differs.
 
 ``grad_enabled`` worlds are refused (the kernels have no backward), as is a CPU device:
 there is no fallback path.
@@ -88,7 +93,17 @@ class AttachedWorld:
         self.agent_ft = torch.zeros(max(nA, 1), A.AGENT_FIELDS, self.ld, dtype=torch.float32, device=self.device)
         self._rehome()
         self.backend = self._factory(self.spec, self.batch, self.device, self.state, self.agent_ft)
+        self._fp = self._fingerprint()
+        self._check_spec = False  # set by World.reset: the scenario's reset_world_at that follows may change statics
+        self.refreshes = 0        # how many times the static description was found changed (tests, diagnostics)
         world.step = self.step
+        self._orig_reset = world.reset
+
+        def reset(env_index=None, _orig=world.reset):
+            self._check_spec = True
+            return _orig(env_index)
+
+        world.reset = reset
         self._patch_lidars()
 
     # ---- state re-homing ---------------------------------------------------------
@@ -144,10 +159,52 @@ class AttachedWorld:
                     eg[i, :, : self.batch] = e.gravity.T
         return jfr, eg
 
+    # ---- mutable static inputs ---------------------------------------------------------
+    def _fingerprint(self):
+        """The attributes of the static description that have public setters or are written by in-tree scenarios, as
+        one comparable tuple (no device sync: tensors are identified by object and version)."""
+        w = self.world
+
+        def key(x):
+            if x is None or isinstance(x, (bool, int, float, str)):
+                return x
+            if isinstance(x, torch.Tensor):
+                if x.dim() >= 2:  # per-environment values (entity.gravity [B, 2], wind_flocking.py:372 rebinds it every
+                    return ("per_env", tuple(x.shape))  # step): a dynamic input, re-read by every step anyway
+                return ("T", id(x), x._version, tuple(x.shape))
+            if isinstance(x, (tuple, list)):
+                return tuple(key(v) for v in x)
+            return ("O", id(x))
+
+        fp = [key(getattr(w, a, None)) for a in ("_drag", "_linear_friction", "_angular_friction", "_gravity", "_substeps",
+                                                  "_sub_dt", "_x_semidim", "_y_semidim", "_collision_force", "_joint_force",
+                                                  "_contact_margin", "_torque_constraint_force")]
+        fp.append(len(getattr(w, "_joints", {})))
+        for e in w.entities:
+            sh = e.shape
+            fp.append((key(e.mass), key(e.drag), key(e.linear_friction), key(e.angular_friction), key(e.gravity),
+                       key(e.max_speed), key(e.v_range), bool(e.movable), bool(e.rotatable), bool(getattr(e, "_collide", True)),
+                       id(e.collision_filter), type(sh).__name__, key(getattr(sh, "_radius", None)),
+                       key(getattr(sh, "_length", None)), key(getattr(sh, "_width", None)), key(getattr(sh, "_hollow", None)),
+                       key(getattr(e, "max_f", None)), key(getattr(e, "f_range", None)), key(getattr(e, "max_t", None)),
+                       key(getattr(e, "t_range", None))))
+        return tuple(fp)
+
+    def _sync_static(self):
+        """Rebuild the native world iff the live world's static description is no longer the one it was built from."""
+        fp = self._fingerprint()
+        if not self._check_spec and fp == self._fp:
+            return
+        self._fp, self._check_spec = fp, False
+        spec = spec_from_world(self.world)
+        if spec != self.spec:
+            self.refresh(spec)
+
     # ---- the replaced seam ----------------------------------------------------------
     def step(self):
         """World.step() (core.py:1972-2015) on the native path."""
         w = self.world
+        self._sync_static()
         jfr, eg = self._per_env_inputs()
         if self.exact_broad_phase:
             self.backend.step_exact(joint_fixed_rot=jfr, entity_gravity=eg)
@@ -158,11 +215,17 @@ class AttachedWorld:
                 if not agent.silent:
                     agent.state.c = agent.action.c
 
-    def refresh(self):
-        """Re-extract the static description (after changing masses, filters, ...)."""
-        self.spec = spec_from_world(self.world)
+    def refresh(self, spec: Optional[WorldSpec] = None):
+        """Re-extract the static description and rebuild the native world on the same packed buffers (called by ``step``
+        itself when masses, filters, ... changed; the entity list must be the one ``attach`` saw)."""
+        spec = spec_from_world(self.world) if spec is None else spec
+        assert spec.n_entities == self.spec.n_entities and spec.n_agents == self.spec.n_agents, (
+            "entities were added to or removed from an attached world: detach() and attach() again")
+        self.spec = spec
         self.backend.close()
         self.backend = self._factory(self.spec, self.batch, self.device, self.state, self.agent_ft)
+        self._fp = self._fingerprint()
+        self.refreshes += 1
 
     # ---- sensors -----------------------------------------------------------------------
     def _patch_lidars(self):
@@ -189,6 +252,7 @@ class AttachedWorld:
 
     def detach(self):
         self.world.step = self._orig_step
+        self.world.reset = self._orig_reset
         for st, cls in self._orig_classes.values():
             for k in ("_pos", "_vel", "_rot", "_ang_vel", "_force", "_torque"):
                 if k in st.__dict__ and st.__dict__[k] is not None:
