@@ -27,6 +27,10 @@ int vmas_debug_math(int32_t op, const float* a, const float* b, float* out, int3
  * kernel - from it. */
 int vmas_debug_schedule(VmasWorld* w, uint32_t* words, int64_t capacity, int32_t* meta /* [24] */);
 
+/* Sets the world's "a grid-wide barrier gave up waiting" word as a timed-out barrier would (include/vmas_hip.h,
+ * vmas_world_exact_status): the next launch on the world must fail loudly.  For the test of exactly that. */
+int vmas_debug_force_gave_up(VmasWorld* w);
+
 /* VMAS_TRACE=1 in a -DVMAS_TRACE build: copy out the per-wave s_memtime stamps of the last launch */
 int vmas_debug_trace(VmasWorld* w, unsigned long long* host, int64_t n_words);
 

@@ -191,10 +191,14 @@ int vmas_world_step_n(VmasWorld* w, float* state, float* agent_ft, int64_t ld, i
 int vmas_world_rollout(VmasWorld* w, float* state, float* agent_ft, int64_t ld, int64_t ft_step_stride,
                        int32_t n_steps, const VmasStepArgs* args /* may be NULL */, void* stream);
 
-/* After steps with exact_broad_phase (and after vmas_world_step_env / vmas_world_rollout_env launches with the
- * navigation epilogue, whose collision reduction uses the same kind of barrier): 0 if every in-kernel grid barrier
- * completed, 1 if one gave up waiting (the grid was not co-resident; that step then used the pair bits that had arrived
- * by then), < 0 on error.  Synchronises the device: a debugging / test aid. */
+/* In-kernel grid barriers (exact_broad_phase inside the step launch; the navigation epilogue's collision reduction) need
+ * every tile of the launch resident at once.  The library only uses them for grids of at most one tile per CU, but other
+ * work on the device (another stream, another process) can still keep a tile from starting: a barrier then gives up after
+ * a bounded wait (tens of ms) instead of hanging, the step goes on with the pair bits that had arrived, and a pinned
+ * host-visible word is set.  EVERY later vmas_world_step* / vmas_world_rollout* call on the world reads that word first -
+ * no synchronisation - and fails (-1, vmas_last_error says why) once, clearing it: a partial mask never passes silently.
+ * vmas_world_exact_status synchronises the device and reports the same condition without clearing it: 0 if every barrier
+ * so far completed, 1 if one gave up, < 0 on error (tests / debugging). */
 int vmas_world_exact_status(VmasWorld* w);
 
 /* Batch-global broad phase of World.collides (core.py:2797-2801): mask[p/32] bit

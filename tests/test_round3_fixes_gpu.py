@@ -1,0 +1,165 @@
+"""Round-3 regressions (GPU): the round-2 advisor's findings and the review's boundary holes.
+
+* bind -> step_bound -> rollout -> step_bound re-binds (stale ingest slots / freed output buffers before);
+* graph=True below EXACT_AUTO_BELOW environments for a scenario with a fused ingest but NO fused post-step;
+* a grid barrier that gave up is reported by the NEXT call on the world (host-visible word, no sync), once;
+* a failed launch does not advance the barrier sequence number;
+* reset(seed=s) reproduces the masked resets of a fresh environment built with seed s;
+* rollout() validates discrete action indices like step() does.
+"""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+eq = lambda x, y: torch.equal(x.contiguous().view(torch.uint8), y.contiguous().view(torch.uint8))  # noqa: E731
+
+
+@pytest.mark.parametrize("name,kw,B", [("balance", dict(n_agents=4), 4096), ("transport", {}, 700), ("navigation", dict(n_agents=4), 2048)])
+def test_step_bound_after_a_rollout_rebinds(name, kw, B):
+    from vectorizedmultiagentsimulator_amd.environment import make_env
+
+    a = make_env(name, num_envs=B, device="cuda:0", seed=3, validate_actions=False, **kw)
+    b = make_env(name, num_envs=B, device="cuda:0", seed=3, validate_actions=False, **kw)
+    b.world._state.copy_(a.world._state)
+    for ta, tb in zip(a._post.persistent_tensors(), b._post.persistent_tensors()):
+        tb.copy_(ta)
+    acts = [torch.zeros(B, 2, device="cuda:0") for _ in a.agents]
+    a.bind(acts)
+    g = torch.Generator(device="cuda:0").manual_seed(9)
+    K = 4
+    roll = [(torch.rand(K, B, 2, device="cuda:0", generator=g) * 2 - 1) * 0.7 for _ in a.agents]
+
+    def both():
+        for u in acts:
+            u.copy_((torch.rand(u.shape, device="cuda:0", generator=g) * 2 - 1) * 0.8)
+        ra, rb = a.step_bound(), b.step([u.clone() for u in acts])
+        for i in range(len(a.agents)):
+            assert eq(ra[0][i], rb[0][i]) and eq(ra[1][i], rb[1][i])
+        assert eq(ra[2], rb[2]) and eq(a.world._state, b.world._state)
+
+    both()
+    both()
+    a.rollout(roll)  # re-points the ingest slots at the K-step tensors and the post-step's buffers at fresh outputs
+    for k in range(K):
+        b.step([u[k] for u in roll])
+    assert eq(a.world._state, b.world._state)
+    del roll
+    torch.empty(1 << 22, device="cuda:0").fill_(float("nan"))  # (re-use of freed blocks would show)
+    both()
+    both()
+
+
+def test_graph_step_with_fused_ingest_but_no_fused_post_below_the_exact_threshold():
+    """Environment(graph=True) at B < EXACT_AUTO_BELOW (exact broad phase by default) for a scenario whose action path is
+    fused but whose post-step is not: the captured step must not try to carry the ingest prologue through the
+    launch-per-substep form of the exact broad phase (VmasHipError inside torch.cuda.graph before)."""
+    from vectorizedmultiagentsimulator_amd.environment import Environment
+    from vectorizedmultiagentsimulator_amd.scenarios.balance import Scenario
+
+    class NoFusedPost(Scenario):
+        def make_fused_post(self, env):
+            return None
+
+    B = 200
+    kw = dict(num_envs=B, device="cuda:0", seed=5, validate_actions=False, n_agents=3)
+    eager, graphed = Environment(NoFusedPost(), **kw), Environment(NoFusedPost(), graph=True, **kw)
+    assert eager.world.exact_broad_phase and graphed.world.exact_broad_phase and graphed._post is None
+    graphed.world._state.copy_(eager.world._state)
+    graphed.scenario.global_shaping.copy_(eager.scenario.global_shaping)
+    g = torch.Generator(device="cuda:0").manual_seed(2)
+    for t in range(6):
+        acts = [(torch.rand(B, 2, device="cuda:0", generator=g) * 2 - 1) * 0.8 for _ in eager.agents]
+        oe, re_, de, _ = eager.step(acts)
+        og, rg, dg, _ = graphed.step(acts)
+        for i in range(len(acts)):
+            assert torch.allclose(oe[i], og[i], atol=1e-6) and torch.allclose(re_[i], rg[i], atol=1e-5), f"step {t}"
+        assert torch.allclose(eager.world._state, graphed.world._state, atol=1e-6)
+
+
+def test_barrier_give_up_fails_the_next_call_once():
+    """A grid barrier that gives up sets a host-visible word; the NEXT launch on the world fails loudly (no partial mask
+    passes silently through Environment.step), clears it, and the world is usable again."""
+    from vectorizedmultiagentsimulator_amd import _abi as A
+    from vectorizedmultiagentsimulator_amd.backend import VmasHipError
+    from vectorizedmultiagentsimulator_amd.environment import make_env
+
+    env = make_env("balance", num_envs=200, device="cuda:0", seed=1, n_agents=4)
+    assert env.world.exact_broad_phase and env._one_launch
+    acts = [env.get_random_action(a) for a in env.agents]
+    env.step(acts)
+    be = env.world._get_backend()
+    assert be.exact_status() == 0
+    lib = A.load_library()
+    lib.vmas_debug_force_gave_up.argtypes = [C.c_void_p]
+    assert lib.vmas_debug_force_gave_up(be._h) == 0
+    assert be.exact_status() == 1
+    before = env.world._state.clone()
+    with pytest.raises(VmasHipError, match="gave up waiting"):
+        env.step(acts)
+    assert torch.equal(env.world._state, before)  # the failing call launched nothing
+    env.step(acts)  # reported once
+    assert be.exact_status() == 0
+
+
+def test_failed_launch_does_not_advance_the_barrier_number():
+    """A call that fails AFTER the exact broad phase was planned (here: a fused epilogue on one wave per tile) must leave
+    the barrier sequence number where the arrival counter is - every later barrier would otherwise run into its timeout
+    (tens of ms per substep, partial masks)."""
+    import time
+
+    from vectorizedmultiagentsimulator_amd.backend import VmasHipError
+    from vectorizedmultiagentsimulator_amd.environment import make_env
+
+    env = make_env("balance", num_envs=128, device="cuda:0", seed=1, n_agents=4, validate_actions=False)
+    assert env.world.exact_broad_phase and env._one_launch
+    acts = [env.get_random_action(a) for a in env.agents]
+    env.step(acts)
+    be = env.world._get_backend()
+    lanes = be.lanes_per_env
+    be.set_lanes_per_env(1)
+    with pytest.raises(VmasHipError, match="at least 2 waves"):
+        env.step(acts)
+    be.set_lanes_per_env(lanes)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(5):
+        env.step(acts)
+    torch.cuda.synchronize()
+    assert time.time() - t0 < 0.5, "the barriers after a failed launch ran into their timeout"
+    assert be.exact_status() == 0
+
+
+@pytest.mark.parametrize("name,kw", [("balance", dict(n_agents=4)), ("transport", {}), ("navigation", dict(n_agents=4))])
+def test_reseeding_reproduces_the_masked_resets(name, kw):
+    from vectorizedmultiagentsimulator_amd.environment import make_env
+
+    B = 300
+    a = make_env(name, num_envs=B, device="cuda:0", seed=11, **kw)
+    m = torch.zeros(B, dtype=torch.bool, device="cuda:0")
+    m[::3] = True
+    a.reset_where(m, return_observations=False)
+    a.reset_where(m, return_observations=False)  # episode counters now 2 on the masked environments
+    a.reset(seed=42)
+    a.reset_where(m, return_observations=False)
+    fresh = make_env(name, num_envs=B, device="cuda:0", seed=42, **kw)
+    fresh.reset_where(m, return_observations=False)
+    idx = m.nonzero().squeeze(1)
+    assert eq(a.world._state[:, :, idx], fresh.world._state[:, :, idx])
+
+
+def test_rollout_validates_discrete_actions():
+    from vectorizedmultiagentsimulator_amd.environment import make_env
+
+    B, K = 128, 3
+    env = make_env("balance", num_envs=B, device="cuda:0", seed=0, continuous_actions=False, n_agents=3)
+    acts = [torch.randint(0, 9, (K, B, 1), device="cuda:0") for _ in env.agents]
+    env.rollout(acts)
+    acts[1][2, 17, 0] = 9
+    with pytest.raises(AssertionError, match="out of range"):
+        env.rollout(acts)
+    acts[1][2, 17, 0] = -1
+    with pytest.raises(AssertionError, match="out of range"):
+        env.rollout(acts)

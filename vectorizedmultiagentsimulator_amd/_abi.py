@@ -279,6 +279,7 @@ EXPORTED_SYMBOLS = (
     "vmas_debug_math",  # include/vmas_debug_hip.h: test / profiling hooks, never called by the product path
     "vmas_debug_trace",
     "vmas_debug_schedule",
+    "vmas_debug_force_gave_up",
     "vmas_world_exact_status",
     "vmas_world_set_specialized",
     "vmas_world_get_specialized",

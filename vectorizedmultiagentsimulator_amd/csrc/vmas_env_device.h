@@ -550,6 +550,7 @@ struct NavWorld {
   uint32_t* sync;  // grid-barrier form (NULL: off): arrivals | timeout flag | two mask slots (launch parity)
   uint32_t seq;    // this launch's barrier number
   int32_t n_pairs;
+  uint32_t* gave_up;  // host-mapped word set when the barrier gives up waiting (read by the host at the world's next call)
 };
 
 // before the physics (the loads fly behind it): agent.pos_shaping of this lane and the observation flush table
@@ -680,6 +681,7 @@ VD void navigation_post_tile(const TileCtx& C, const VmasNavigationDesc& d, cons
           __builtin_amdgcn_s_sleep(8);
           if (++spins > (1 << 18)) {  // the grid is not co-resident (it should be): flag it and go on, never hang
             __hip_atomic_fetch_or(nav.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (nav.gave_up) __hip_atomic_fetch_or(nav.gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             break;
           }
         }

@@ -172,6 +172,8 @@ struct DevStepArgs {
   uint32_t* sync;              // [0] arrivals (monotonic), [1] gave-up flag, [4 + slot * mask_words ...] four mask slots
   const DevMaskPair* mpairs;   // the world's static pairs with their bounding-circle sums
   uint32_t seq0;               // barrier sequence number of this launch's first substep
+  uint32_t* gave_up;           // host-mapped word: set (system scope) when a grid barrier gave up waiting; the host reads it
+                               // without a synchronisation at the next call on this world and fails that call
   int32_t n_mpairs, mask_words;
   const float* joint_fixed_rot;
   const float* entity_gravity;
@@ -830,6 +832,7 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
             __builtin_amdgcn_s_sleep(8);
             if (++spins > (1 << 18)) {  // the grid is not co-resident (it should be): flag it and go on, never hang
               __hip_atomic_fetch_or(args.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (args.gave_up) __hip_atomic_fetch_or(args.gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
               break;
             }
           }
@@ -1395,6 +1398,11 @@ struct VmasWorld {
   // one mask for the launch-per-substep form used when the grid is larger than the chip
   uint32_t* d_sync = nullptr;
   uint32_t sync_seq = 0;
+  // Pinned, device-mapped word the grid barriers set when they give up waiting (exact broad phase, navigation epilogue):
+  // every entry point that launches on this world reads it first - no synchronisation - and fails loudly if an EARLIER
+  // launch gave up (its step used a partial pair mask); vmas_world_exact_status reports it too.
+  uint32_t* h_gave_up = nullptr;
+  uint32_t* d_gave_up = nullptr;
   uint32_t* d_exact_mask = nullptr;
   uint32_t* d_nav_mask = nullptr;  // navigation epilogue: World.collides' pair bits of the post-step state + a block counter
   uint32_t* d_nav_sync = nullptr;  // its grid-barrier form: arrivals | timeout flag | ring of four mask slots
@@ -2140,6 +2148,9 @@ int vmas_world_create(const VmasWorldDesc* d, int32_t batch, int32_t device_id, 
     HIP_TRY(hipMemset(w->d_nav_mask, 0, (mw + 1) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void**)&w->d_nav_sync, (2 + 4 * mw) * sizeof(uint32_t)));
     HIP_TRY(hipMemset(w->d_nav_sync, 0, (2 + 4 * mw) * sizeof(uint32_t)));
+    HIP_TRY(hipHostMalloc((void**)&w->h_gave_up, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    *w->h_gave_up = 0u;
+    HIP_TRY(hipHostGetDevicePointer((void**)&w->d_gave_up, w->h_gave_up, 0));
   }
   if (!host_only) {
     hipDeviceProp_t prop;
@@ -2168,6 +2179,7 @@ void vmas_world_destroy(VmasWorld* w) {
   }
   if (w->ev_fork) (void)hipEventDestroy(w->ev_fork);
   (void)hipFree(w->d_sync); (void)hipFree(w->d_exact_mask); (void)hipFree(w->d_nav_mask); (void)hipFree(w->d_nav_sync);
+  if (w->h_gave_up) (void)hipHostFree(w->h_gave_up);
   (void)hipFree(w->d_mpairs); (void)hipFree(w->d_trace);
   (void)hipFree(w->d_lidars); (void)hipFree(w->d_targets); (void)hipFree(w->d_angles); (void)hipFree(w->d_queries);
   (void)hipFree(w->d_angles_cs);
@@ -2238,7 +2250,8 @@ int vmas_world_exact_status(VmasWorld* w) {
   HIP_TRY(hipMemcpy(&flag, w->d_sync + 1, sizeof(flag), hipMemcpyDeviceToHost));
   uint32_t nav_flag = 0;  // (the navigation epilogue's barrier: same rule, same report)
   if (w->d_nav_sync) HIP_TRY(hipMemcpy(&nav_flag, w->d_nav_sync + 1, sizeof(nav_flag), hipMemcpyDeviceToHost));
-  return (int)(flag | nav_flag);
+  const uint32_t host_flag = w->h_gave_up ? __atomic_load_n(w->h_gave_up, __ATOMIC_RELAXED) : 0u;
+  return (int)((flag | nav_flag | host_flag) != 0u);
 }
 
 int vmas_world_set_queues(VmasWorld* w, int32_t queues) {
@@ -2414,15 +2427,15 @@ static int step_env_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld
       grid_sync = cap == hipStreamCaptureStatusNone;
     }
     env.navigation.w = NavWorld{w->d_angles, w->d_angles_cs, w->d_mpairs, w->d_nav_mask, grid_sync ? w->d_nav_sync : nullptr,
-                                w->nav_seq, d->collisions ? w->n_pairs : 0};
+                                w->nav_seq, d->collisions ? w->n_pairs : 0, w->d_gave_up};
     if (n_steps > 1 && d->collisions && !grid_sync)
       return fail("vmas_world_rollout_env: navigation's collision penalties reduce over the whole batch after every step "
                   "(World.collides): several steps per launch need every tile resident at once (%d tiles, %d CUs) and a stream "
                   "that is not being captured", blocks_of(w->batch), w->n_cu);
-    if (grid_sync) w->nav_seq += (uint32_t)n_steps;
     if (step_impl(w, state, agent_ft, ld, args, stream, n_steps, 0, &env, ENV_NAVIGATION, nav_fixed, nav_per_wave, 0, -1,
                   d->n_agents))
       return -1;
+    if (grid_sync) w->nav_seq += (uint32_t)n_steps;  // (only a launch that was made has arrived at its barriers)
     if (d->collisions && !grid_sync)
       return vmas::launch_navigation_collisions(d, o, w->batch, state, ld, w->d_nav_mask, (w->n_pairs + 31) / 32, stream);
     return 0;
@@ -2438,6 +2451,14 @@ static int step_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld, co
   if (w->host_only) return fail("vmas_world_step: a planning world (device -1) cannot be stepped");
   if (w->base.nA > 0 && !agent_ft) return fail("vmas_world_step: world has agents but agent_ft is null");
   if (ld < w->batch) return fail("vmas_world_step: ld (%lld) < batch (%d)", (long long)ld, w->batch);
+  if (w->h_gave_up && __atomic_load_n(w->h_gave_up, __ATOMIC_RELAXED) != 0u) {
+    // an EARLIER launch on this world flagged it (no synchronisation here: the word is host memory the device wrote)
+    __atomic_store_n(w->h_gave_up, 0u, __ATOMIC_RELAXED);
+    return fail("vmas_world_step: a grid-wide barrier of an earlier step of this world gave up waiting - the grid was not "
+                "co-resident (other work held compute units) and the steps since then used whatever broad-phase bits had "
+                "arrived: their results are not the reference's.  Reset the world's state; run exact_broad_phase / the "
+                "navigation epilogue on an otherwise idle device, or switch exact_broad_phase off");
+  }
   DevStepArgs a{};
   a.n_steps = n_steps;
   a.ft_stride = ft_stride;
@@ -2467,6 +2488,7 @@ static int step_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld, co
   Sched* S;
   if (get_sched(w, w->lanes, &S)) return -1;
   hipStream_t s = (hipStream_t)stream;
+  uint32_t seq_advance = 0;
   if (args && args->exact_broad_phase && w->n_pairs > 0) {
     // The reference's broad phase: a pair is processed - for ALL environments - iff SOME environment of the batch has the
     // pair's bounding circles overlapping (core.py:2797-2801), re-evaluated at every substep.
@@ -2481,7 +2503,8 @@ static int step_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld, co
                                                                                 // grid barrier inside the step kernel
       a.sync = w->d_sync; a.mpairs = w->d_mpairs; a.n_mpairs = w->n_pairs; a.mask_words = mask_words;
       a.seq0 = w->sync_seq;
-      w->sync_seq += (uint32_t)(run * (n_steps > 1 ? n_steps : 1));
+      a.gave_up = w->d_gave_up;
+      seq_advance = (uint32_t)(run * (n_steps > 1 ? n_steps : 1));  // (added once the launch has been made)
     } else {  // more tiles than the chip holds: a mask launch + a one-substep launch per substep
       if (env_kind != ENV_NONE || n_steps > 1)
         return fail("vmas_world_step: exact_broad_phase on %d tiles (> %d CUs) runs one launch per substep: no fused "
@@ -2496,26 +2519,33 @@ static int step_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld, co
       return 0;
     }
   }
-  if (env_count >= 0) {  // a sub-range of the batch (vmas_world_step_n over two queues): plain physics, no optional inputs
-    if (env_kind != ENV_NONE || args) return fail("vmas_world_step: environment sub-ranges take no optional inputs");
-    return launch_any_level<ENV_NONE>(w, S, state + env_first, agent_ft ? agent_ft + env_first : nullptr, ld, a, NoEnv{}, 0,
-                                      s, env_count, (long)ld - env_first);
-  }
-  if (env_kind == ENV_NONE) return launch_any_level<ENV_NONE>(w, S, state, agent_ft, ld, a, NoEnv{}, 0, s);
-  if (S->nw < 2 && env_kind != ENV_INGEST && env_kind != ENV_NAVIGATION)
-    return fail("vmas_world_step_env: the fused epilogue needs at least 2 waves per tile");
-  size_t extra = 0;
-  if (env_extra_lds(w, &S, scratch_fixed, scratch_per_wave, scratch_wave_cap, &extra)) return -1;
-  env->scratch_off = (int32_t)(S->lds_bytes / sizeof(float));
-  if (env_kind == ENV_BALANCE) return launch_any_level<ENV_BALANCE>(w, S, state, agent_ft, ld, a, *env, extra, s);
-  if (env_kind == ENV_INGEST) return launch_any_level<ENV_INGEST>(w, S, state, agent_ft, ld, a, *env, 0, s);
-  if (env_kind == ENV_NAVIGATION) {
-    if (env->navigation.d.n_agents > kNavMaxOwn * S->nw)
-      return fail("vmas_world_step_env: %d agents on %d waves per tile (at most %d agents per wave)", env->navigation.d.n_agents,
-                  S->nw, kNavMaxOwn);
-    return launch_any_level<ENV_NAVIGATION>(w, S, state, agent_ft, ld, a, *env, extra, s);
-  }
-  return launch_any_level<ENV_TRANSPORT>(w, S, state, agent_ft, ld, a, *env, extra, s);
+  // (the barrier sequence number advances only for a launch that was made: a failed call leaves the arrival counter and
+  //  the next launch's target in step)
+  auto launch = [&]() -> int {
+    if (env_count >= 0) {  // a sub-range of the batch (vmas_world_step_n over two queues): plain physics, no optional inputs
+      if (env_kind != ENV_NONE || args) return fail("vmas_world_step: environment sub-ranges take no optional inputs");
+      return launch_any_level<ENV_NONE>(w, S, state + env_first, agent_ft ? agent_ft + env_first : nullptr, ld, a, NoEnv{}, 0,
+                                        s, env_count, (long)ld - env_first);
+    }
+    if (env_kind == ENV_NONE) return launch_any_level<ENV_NONE>(w, S, state, agent_ft, ld, a, NoEnv{}, 0, s);
+    if (S->nw < 2 && env_kind != ENV_INGEST && env_kind != ENV_NAVIGATION)
+      return fail("vmas_world_step_env: the fused epilogue needs at least 2 waves per tile");
+    size_t extra = 0;
+    if (env_extra_lds(w, &S, scratch_fixed, scratch_per_wave, scratch_wave_cap, &extra)) return -1;
+    env->scratch_off = (int32_t)(S->lds_bytes / sizeof(float));
+    if (env_kind == ENV_BALANCE) return launch_any_level<ENV_BALANCE>(w, S, state, agent_ft, ld, a, *env, extra, s);
+    if (env_kind == ENV_INGEST) return launch_any_level<ENV_INGEST>(w, S, state, agent_ft, ld, a, *env, 0, s);
+    if (env_kind == ENV_NAVIGATION) {
+      if (env->navigation.d.n_agents > kNavMaxOwn * S->nw)
+        return fail("vmas_world_step_env: %d agents on %d waves per tile (at most %d agents per wave)", env->navigation.d.n_agents,
+                    S->nw, kNavMaxOwn);
+      return launch_any_level<ENV_NAVIGATION>(w, S, state, agent_ft, ld, a, *env, extra, s);
+    }
+    return launch_any_level<ENV_TRANSPORT>(w, S, state, agent_ft, ld, a, *env, extra, s);
+  };
+  const int rc = launch();
+  if (rc == 0) w->sync_seq += seq_advance;
+  return rc;
 }
 
 // profiling aid, not part of the ABI: copy out the s_memtime stamps of the last launch
@@ -2540,6 +2570,12 @@ int vmas_debug_schedule(VmasWorld* w, uint32_t* words, int64_t capacity, int32_t
     if (capacity < (int64_t)S->h_blob.size()) return fail("vmas_debug_schedule: %zu words do not fit", S->h_blob.size());
     memcpy(words, S->h_blob.data(), S->h_blob.size() * sizeof(uint32_t));
   }
+  return 0;
+}
+
+int vmas_debug_force_gave_up(VmasWorld* w) {
+  if (!w || !w->h_gave_up) return fail("vmas_debug_force_gave_up: no device side");
+  __atomic_store_n(w->h_gave_up, 1u, __ATOMIC_RELAXED);
   return 0;
 }
 

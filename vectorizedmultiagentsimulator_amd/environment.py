@@ -93,9 +93,13 @@ class Environment:
         # (the exact broad phase runs inside the step launch while every 64-environment tile has a CU of its own)
         exact_in_launch = (not w.exact_broad_phase or
                            (self.num_envs + 63) // 64 <= torch.cuda.get_device_properties(self.device).multi_processor_count)
+        # (graph=True captures the generic step - ingest prologue + physics - when the scenario has no fused post-step; under
+        # capture the exact broad phase runs one launch per substep (a replay would repeat a grid-barrier number), which
+        # cannot carry the prologue: the stand-alone ingest kernel + World.step are captured instead)
+        captured_exact = self.use_graph and w.exact_broad_phase and self._post is None
         self._ingest_in_step = (  # action ingest as the physics kernel's prologue
             self._ingest is not None and type(self.scenario).pre_step is BaseScenario.pre_step
-            and w.dim_c == 0 and exact_in_launch
+            and w.dim_c == 0 and exact_in_launch and not captured_exact
         )
         self._one_launch = (
             self._ingest_in_step and self._post is not None and self._post.kind is not None
@@ -117,7 +121,10 @@ class Environment:
             seed = 0
         self._seed = int(seed)
         if getattr(self, "_masked_reset", None) is not None:
+            # the masked resets are keyed by (seed, environment, episode): a re-seeded environment starts its episodes
+            # over, so that reset(seed=s) reproduces what a fresh environment built with seed s draws
             self._masked_reset.args.seed = self._seed & 0xFFFFFFFFFFFFFFFF
+            self._masked_reset.episode.zero_()
         torch.manual_seed(seed)
         if self.device.type == "cuda":
             torch.cuda.manual_seed(seed)
@@ -352,6 +359,7 @@ class Environment:
             "rollout() needs a scenario whose Environment.step is one launch without a batch-wide reduction (balance, transport)"
         assert len(actions) == self.n_agents, f"Expecting actions for {self.n_agents}, got {len(actions)} actions"
         K = int(actions[0].shape[0])
+        self._bound = None  # (the ingest slots and the post-step's buffer struct are re-pointed below: step_bound() re-binds)
         self._ingest.prepare_rollout(actions, K, self.validate_actions)
         desc, buffers, out = self._post.prepare_rollout(K)
         self._launch.rollout(self._post.kind, desc, buffers, K)

@@ -15,6 +15,7 @@ calls ``reward()`` / ``observation()`` directly, the environment uses the kernel
 from __future__ import annotations
 
 import ctypes as C
+import math
 from typing import List, Optional
 
 import torch
@@ -179,10 +180,15 @@ class ActionIngest:
                     bad_range = r if bad_range is None else bad_range | r
             else:
                 self.args.agents[i].action_index = act.data_ptr()
+                if validate:  # step() raises on an index outside [0, prod(nvec)) (environment.py:657-661): so does this
+                    r = ((act < 0) | (act >= math.prod(agent.discrete_action_nvec))).any()
+                    bad_range = r if bad_range is None else bad_range | r
+                    bad_nan = torch.zeros((), dtype=torch.bool, device=env.device) if bad_nan is None else bad_nan
         if validate and bad_nan is not None:
             flags = torch.stack([bad_nan, bad_range]).cpu()
             assert not bool(flags[0]), "actions contain NaN"
-            assert not bool(flags[1]), "Physical actions of an agent are out of its range"
+            assert not bool(flags[1]), ("Physical actions of an agent are out of its range" if env.continuous_actions
+                                        else "Discrete action of an agent is out of range")
         self._keep = held
 
     def check(self):
