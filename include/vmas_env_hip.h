@@ -198,6 +198,8 @@ int vmas_football_post_step(const VmasFootballDesc* desc, const VmasFootballBuff
 #define VMAS_SPAWN_UNIFORM 1 /* pos ~ U([x_lo,x_hi) x [y_lo,y_hi)), rejected within min_dist of ops [avoid_from, i) */
 #define VMAS_SPAWN_OFFSET 2  /* pos = pos(base) + (U([x_lo,x_hi)) , y_lo): x_lo == x_hi = a constant offset, no draw */
 #define VMAS_SPAWN_FIXED 3   /* pos = (x_lo, y_lo) */
+#define VMAS_SPAWN_TRIES 4096 /* UNIFORM: an infeasible placement ends after this many draws (the reference loops for ever and
+                               * warns, utils.py:311-317); every placement that gave up is counted in VmasResetArgs.gave_up */
 typedef struct VmasSpawnOp {
   int32_t kind;       /* VMAS_SPAWN_* */
   int32_t entity;     /* entity placed */
@@ -205,11 +207,18 @@ typedef struct VmasSpawnOp {
   int32_t avoid_from; /* UNIFORM: first operation whose entity must be kept at min_dist */
   float x_lo, x_hi, y_lo, y_hi;
   float min_dist;
+  int32_t has_rot;    /* != 0: the entity's rotation is set to `rot` as well (football.py:404-409, 686-1020) */
+  float rot;
 } VmasSpawnOp;
-typedef struct VmasResetTerm { /* out[env] = |pos(a) - pos(b)| * factor (shaping caches); a < 0: out[env] = factor */
+#define VMAS_TERM_DIST 0      /* out[env] = |pos(a) - pos(b)| * factor;   a < 0: out[env] = factor */
+#define VMAS_TERM_DIST_POINT 1 /* out[env] = |pos(a) - (px, py)| * factor            (football.py:536-553: ball to goal) */
+#define VMAS_TERM_MIN_DIST 2  /* out[env] = min over e in [a, a + n) of |pos(e) - pos(b)| * factor   (football.py:586-600) */
+typedef struct VmasResetTerm { /* the scenario's cached terms (shaping ...) re-initialised from the new placement */
   int32_t a, b;
   float factor;
   float* out; /* [batch] */
+  int32_t kind, n; /* VMAS_TERM_* */
+  float px, py;
 } VmasResetTerm;
 typedef struct VmasResetArgs {
   int32_t n_ops, n_terms, n_flags;
@@ -219,6 +228,7 @@ typedef struct VmasResetArgs {
   float* steps;       /* [batch] Environment.steps, zeroed; may be NULL */
   uint32_t* episode;  /* [batch] in/out: resets this environment has had (part of the generator's counter) */
   uint64_t seed;
+  uint32_t* gave_up;  /* [1] += placements that hit VMAS_SPAWN_TRIES and kept an overlapping position; may be NULL */
 } VmasResetArgs;
 int vmas_env_reset_where(const VmasResetArgs* args, int32_t batch, int32_t n_entities, int32_t n_agents,
                          const uint8_t* mask /* [batch] bool */, float* state, float* agent_ft, int64_t ld, void* stream);
@@ -241,6 +251,12 @@ int vmas_env_reset_where(const VmasResetArgs* args, int32_t batch, int32_t n_ent
                                 * penalties are applied behind a grid-wide barrier inside the step kernel while every tile is
                                 * resident at once - else by a second small kernel behind it, same stream).
                                 * vmas_world_rollout_env: with the barrier form only (at most one tile per CU, no capture). */
+#define VMAS_POST_FOOTBALL 4   /* VmasFootballDesc / VmasFootballBuffers (agent_ft unused: the epilogue reads the clamped forces
+                                * of its own tile).  Worlds that run the lane-compacted step kernel only
+                                * (vmas_world_get_compact() == 1: sphere / line worlds such as football); the agents and the
+                                * ball must be the consecutive dynamic entities agent0 .. agent0 + n, agent index = slot.
+                                * vmas_world_rollout_env: per-step outputs get a leading step axis ([K][n][batch][obs_dim],
+                                * terms [K][9][batch], touching [K][2][batch]); the ball's script runs on the tile. */
 int vmas_world_step_env(VmasWorld* w, float* state, float* agent_ft, int64_t ld, const VmasStepArgs* args /* may be NULL */,
                         const VmasIngestArgs* ingest /* may be NULL */, uint32_t* err_flags /* may be NULL */,
                         int32_t post_kind, const void* post_desc, const void* post_buffers, void* stream);
@@ -266,7 +282,9 @@ int vmas_world_rollout_env(VmasWorld* w, float* state, float* agent_ft, int64_t 
  * counterpart (kernel geometry). */
 int vmas_world_reserve_epilogue(VmasWorld* w, int32_t post_kind, int32_t n_packages);
 
-/* 0 if vmas_world_step_env(post_kind = VMAS_POST_NAVIGATION, post_desc) can run on this world as it is planned now: the
+/* (post_kind = VMAS_POST_FOOTBALL: 0 if the world runs the lane-compacted kernel and its tile plus the epilogue's
+ * observation slabs fit the CU's LDS.)
+ * 0 if vmas_world_step_env(post_kind = VMAS_POST_NAVIGATION, post_desc) can run on this world as it is planned now: the
  * world's registered sensors are what the epilogue casts (sensor a on agent a, `n_rays` rays of `lidar_range`, its targets
  * the other agents in order), and the tile plus the epilogue's scratch fit the CU's LDS (shared pair rows are given up
  * for it if that is what it takes).  -1 with vmas_last_error() otherwise: the caller keeps the separate launches

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define VMAS_ABI_VERSION 2
+#define VMAS_ABI_VERSION 3
 
 #define VMAS_STATE_FIELDS 6
 #define VMAS_AGENT_FIELDS 3
@@ -190,6 +190,14 @@ int vmas_world_step_n(VmasWorld* w, float* state, float* agent_ft, int64_t ld, i
  * back once at the end.  For scripted / pre-computed forces (no policy in the loop). */
 int vmas_world_rollout(VmasWorld* w, float* state, float* agent_ft, int64_t ld, int64_t ft_step_stride,
                        int32_t n_steps, const VmasStepArgs* args /* may be NULL */, void* stream);
+
+/* The lane-compacted step kernel (csrc/vmas_compact.h) for worlds whose pairs are all sphere-sphere or line-sphere and
+ * that have no joints: broad phase per (environment, pair) with every lane busy, narrow phase over the tile's CONTACTS
+ * packed across environments and pairs, results added by the owners in the reference's order (core.py:2176-2199) - bit
+ * for bit the results of the other kernels.  mode -1 (default): used when the world is dense (>= 64 pairs: football), 0:
+ * never, 1: whenever the world qualifies.  vmas_world_get_compact: 1 if plain steps of this world run it. */
+int vmas_world_set_compact(VmasWorld* w, int32_t mode);
+int vmas_world_get_compact(VmasWorld* w);
 
 /* In-kernel grid barriers (exact_broad_phase inside the step launch; the navigation epilogue's collision reduction) need
  * every tile of the launch resident at once.  The library only uses them for grids of at most one tile per CU, but other

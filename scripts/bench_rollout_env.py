@@ -7,7 +7,8 @@ from vectorizedmultiagentsimulator_amd.environment import make_env
 name = sys.argv[1] if len(sys.argv) > 1 else "balance"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32768
 K = int(sys.argv[3]) if len(sys.argv) > 3 else 100
-kw = {"balance": dict(n_agents=4), "transport": {}, "navigation": dict(n_agents=8)}[name]
+kw = {"balance": dict(n_agents=4), "transport": {}, "navigation": dict(n_agents=8),
+      "football": dict(n_blue_agents=5, n_red_agents=5, ai_red_agents=False)}[name]
 env = make_env(name, num_envs=B, device="cuda:0", seed=0, validate_actions=False, **kw)
 if os.environ.get("SPEC") == "0":  # A/B: the interpreter instead of the world-specialised kernel
     env.world._get_backend().set_specialized(False)
@@ -17,7 +18,7 @@ for _ in range(3):
     env.rollout(acts)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-reps = 20
+reps = int(os.environ.get('REPS', 20))
 t0 = time.perf_counter(); e0.record()
 for _ in range(reps):
     out = env.rollout(acts)

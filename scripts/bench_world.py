@@ -13,19 +13,36 @@ kw = {"balance": dict(n_agents=4), "transport": {}, "navigation": dict(n_agents=
 env = make_env(name, num_envs=B, device="cuda:0", seed=0, validate_actions=False, **kw)
 for _ in range(30):  # a few real steps so that the state is a typical mid-episode one
     env.step([env.get_random_action(a) for a in env.agents])
+forces = None
+if os.environ.get("FORCES", "fixed") == "random":
+    # SURVEY.md 8(d)'s protocol: per step and policy agent u ~ U(-u_range, u_range), pre-generated (here: the agent-force
+    # rows a real rollout of `steps` random-action steps produced, scripted agents included); FORCES=fixed (default, what
+    # rounds 1-2 measured with) holds the last action for the whole run - bodies pile up against the walls: a contact-dense
+    # stress state
+    snap = env.get_state()
+    rows = []
+    for _ in range(steps):
+        env.step([env.get_random_action(a) for a in env.agents])
+        rows.append(env.world._agent_ft.clone())
+    forces = torch.stack(rows).contiguous()
+    env.set_state(snap)
 be = env.world._get_backend()
 if lanes:
     be.set_lanes_per_env(lanes)
 if os.environ.get("SPEC"):
     be.set_specialized(os.environ["SPEC"] != "0")
+if os.environ.get("COMPACT"):
+    be.set_compact(int(os.environ["COMPACT"]))
 if os.environ.get("QUEUES"):
     be.set_queues(int(os.environ["QUEUES"]))
-be.step_n(50)
+be.step_n(min(50, steps), None if forces is None else forces[: min(50, steps)])
+if forces is not None:
+    env.set_state(snap)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-be.step_n(steps)
+be.step_n(steps, forces)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
-print(json.dumps({"scenario": name, "num_envs": B, "lanes": be.lanes_per_env, "queues": be.queues(steps), "specialized": be.specialized,
-                  "lib": os.environ.get("VMAS_HIP_LIB", "libvmas_hip.so"), "ablate": os.environ.get("VMAS_ABLATE", "0"),
+print(json.dumps({"scenario": name, "num_envs": B, "lanes": be.lanes_per_env, "queues": be.queues(steps), "specialized": be.specialized, "compact": be.compact,
+                  "lib": os.environ.get("VMAS_HIP_LIB", "libvmas_hip.so"), "ablate": os.environ.get("VMAS_ABLATE", "0"), "forces": os.environ.get("FORCES", "fixed"),
                   "world_step_us": round(dt * 1e6, 2), "env_steps_per_s": round(B / dt)}))

@@ -1,6 +1,10 @@
 """Summarise the rocprofv3 passes of scripts/gpu_counters.sh: per kernel of OUR library (step / lidar / post / mask
 kernels), mean counters per dispatch and per wave, achieved GB/s and GFLOP/s against the MI355X peaks, and which
-resource binds.  usage: pmc_summary.py WORKDIR KERNEL_STATS_CSV BYTES_PER_ENV FLOP_PER_ENV ENVS "cmd"
+resource binds.  usage: pmc_summary.py WORKDIR KERNEL_STATS_CSV BYTES_PER_ENV FLOP_PER_ENV ENVS "cmd" [RATED_KERNEL]
+
+Only the kernels whose name contains RATED_KERNEL (default "step_kernel": the physics step the per-environment figures
+belong to) get an achieved-GB/s / GFLOP/s line - the other kernels of a trace move other bytes (round 2 rated a physics
+kernel with LIDAR flops: "1.392 of peak").  A rated fraction above 1 is an error of the inputs and aborts.
 
 Peaks (MI355X_MICROARCH.md): HBM 8.0 TB/s; fp32 vector 157.3 TFLOP/s (256 CU x 4 SIMD x 32 lanes x 2 flop x 2.4 GHz).
 FETCH_SIZE is doubled (gfx950 tallies 128-B requests at 64 B; calibrated in this library's own 4 B/lane row pattern,
@@ -12,6 +16,7 @@ import glob
 import sys
 
 work, stats_csv, bpe, fpe, envs, cmd = sys.argv[1], sys.argv[2], float(sys.argv[3]), float(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
+rated = sys.argv[7] if len(sys.argv) > 7 else "step_kernel"
 OURS = ("step_kernel", "lidar_kernel", "post_kernel", "pair_mask_kernel", "ingest_kernel", "query_kernel", "reset_kernel",
         "rollout")
 
@@ -53,12 +58,15 @@ for k in sorted(acc, key=lambda k: -dur.get(k, (0,))[0]):
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         traffic = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
         print(f"   HBM traffic per launch  {traffic / 1e6:.2f} MB (FETCH x2 + WRITE)")
-    if k in dur and "step_kernel" in k or (k in dur and "lidar" in k):
+    if k in dur and rated in k:
         t = dur[k][0] * 1e-9
         gbs, gfs = bpe * envs / t / 1e9, fpe * envs / t / 1e9
         print(f"   achieved (algorithmic)  {gbs:.0f} GB/s = {gbs / 8000:.3f} of HBM peak | {gfs:.0f} GFLOP/s = {gfs / 157300:.3f} of fp32 vector peak")
+        assert gbs / 8000 <= 1.0 and gfs / 157300 <= 1.0, f"{k}: a fraction above the roof - wrong bytes / flop per environment for this kernel"
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             print(f"   traffic / algorithmic   {traffic / (bpe * envs):.3f}")
+    elif k in dur:
+        print("   (not rated: the per-environment bytes / flop given on the command line belong to another kernel)")
     if waves and "SQ_WAVE_CYCLES" in c:
         wc = c["SQ_WAVE_CYCLES"]
         parts = []

@@ -1,0 +1,189 @@
+"""The lane-compacted step kernel (csrc/vmas_compact.h: broad phase per environment, narrow phase per CONTACT) against
+the schedule interpreter, bit for bit, and against the reference's recorded numbers.
+
+Every golden fixture whose world qualifies (pairs all sphere-sphere / line-sphere, no joints: 15 of the 45 - football,
+navigation, a rotating line with torques (wheel), friction and force ranges (give_way), per-environment gravity
+(wind_flocking), torque dynamics (drone, diff_drive) ...) is stepped with the kernel forced on and off.  The golden
+teacher-forced tests (test_hip_parity.py) run football through it by default."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import FIXTURES, compare_state, load, tolerances, ulp_sensitivity
+from test_hip_parity import _dev, _down, _hip, _up, make_batch
+
+pytestmark = pytest.mark.gpu
+
+
+def _eligible(name):
+    s = load(name).spec
+    return (not s.joints) and len(s.pairs) > 0 and all(p.type in (0, 1) for p in s.pairs) and len(s.entities) <= 64
+
+
+ELIGIBLE = [n for n in FIXTURES if _eligible(n)]
+
+
+def _bits(t):
+    return t.contiguous().view(torch.int32)
+
+
+def _bits_nan(t):
+    """Bits with every NaN made the same NaN: which NaN (sign, payload) a sum of several NaNs carries depends on how the sum
+    is associated, and step_kernel adds an entity's item list segment by segment while the compacted kernel adds term by
+    term in the reference's order - on finite values the two agree bit for bit, on NaNs both are NaN."""
+    return _bits(torch.where(torch.isnan(t), torch.full_like(t, float("nan")), t))
+
+
+def _pair(g, B, lanes=0):
+    a, b = _hip(g.spec, B, lanes), _hip(g.spec, B, lanes)
+    a.set_compact(1)
+    b.set_compact(0)
+    assert a.compact and not b.compact
+    return a, b
+
+
+def test_eligible_fixture_list():
+    assert {"football_5v5", "navigation_n8", "all_wheel", "give_way", "wind_flocking"} <= set(ELIGIBLE) and len(ELIGIBLE) >= 12
+
+
+@pytest.mark.parametrize("name", ELIGIBLE)
+@pytest.mark.parametrize("B", [1000, 64 * 6])
+def test_compact_kernel_is_bitwise_the_interpreter(name, B):
+    """Free running for several steps (all substeps fused), batch with and without a tail tile; per-environment gravity
+    where the fixture has it; states AND the clamped agent forces must carry the same bits."""
+    g = load(name)
+    st0, ft0, jfr_np, eg_np = make_batch(g, B, seed=31)
+    assert jfr_np is None
+    a, b = _pair(g, B)
+    for hw in (a, b):
+        _up(hw, st0, ft0)
+    eg = _dev(a, eg_np, B)
+    rng = np.random.default_rng(3)
+    for t in range(6):
+        f = torch.from_numpy((ft0 * (1 + 0.3 * rng.normal(0, 1, ft0.shape))).astype(np.float32))
+        for hw in (a, b):
+            if ft0.shape[0]:
+                hw.agent_ft[: ft0.shape[0], :, :B].copy_(f)
+            hw.step(entity_gravity=eg)
+        assert torch.equal(_bits(a.state), _bits(b.state)), f"{name}: state differs at step {t}"
+        assert torch.equal(_bits(a.agent_ft), _bits(b.agent_ft)), f"{name}: clamped forces differ at step {t}"
+
+
+@pytest.mark.parametrize("name", ELIGIBLE)
+def test_compact_kernel_matches_the_reference_fixture(name):
+    """Teacher-forced on the reference's recorded (state, forces, recorded broad-phase mask) -> state, substep by substep:
+    the kernel's recorded-mask and partial-substep paths against the reference's own numbers."""
+    from oracle.oracle import Oracle
+
+    g = load(name)
+    o = Oracle(g.spec)
+    hw = _hip(g.spec, g.B)
+    hw.set_compact(1)
+    T, S = g.state0.shape[0], g.spec.substeps
+    for t in range(min(T, 6)):
+        st0, ft0 = np.ascontiguousarray(g.state0[t]), np.ascontiguousarray(g.ft_in[t])
+        _up(hw, st0, ft0)
+        eg = _dev(hw, None if g.egrav is None else np.ascontiguousarray(g.egrav[t]), g.B)
+        for s in range(S):
+            mask = torch.from_numpy(np.ascontiguousarray(g.masks[t, s]).view(np.int32)).cuda()
+            hw.step(pair_mask=mask, entity_gravity=eg, first_substep=s, n_substeps=1)
+        got, _ = _down(hw, g.B, g.spec.n_agents)
+
+        def ostep(a_, b_):
+            for s in range(S):
+                o.step(a_, b_, pair_mask=np.ascontiguousarray(g.masks[t, s]), first_substep=s, n_substeps=1,
+                       entity_gravity=None if g.egrav is None else np.ascontiguousarray(g.egrav[t]))
+
+        sens = ulp_sensitivity(ostep, st0, ft0)
+        compare_state(got, g.state1[t], f"{name}[t={t}] compact kernel vs reference", sens=sens)
+
+
+@pytest.mark.parametrize("name", ["football_5v5", "navigation_n8", "all_multi_give_way"])
+@pytest.mark.parametrize("B", [700, 4096])
+def test_compact_exact_broad_phase_forms(name, B):
+    """The reference's batch-global broad phase: inside the launch (grid barrier per substep) == the explicit mask +
+    substep launches, both bitwise the interpreter's."""
+    g = load(name)
+    st0, ft0, _, _ = make_batch(g, B, seed=5)
+    a, b = _pair(g, B)
+    c = _hip(g.spec, B)
+    c.set_compact(1)
+    for hw in (a, b, c):
+        _up(hw, st0, ft0)
+    for t in range(4):
+        a.step_exact()
+        b.step_exact()
+        c.step_exact_launches()
+        assert torch.equal(_bits(a.state), _bits(b.state)), f"{name}: in-launch exact, compact vs interpreter, step {t}"
+        assert torch.equal(_bits(a.state), _bits(c.state)), f"{name}: in-launch vs launch-per-substep, step {t}"
+    assert a.exact_status() == 0
+
+
+@pytest.mark.parametrize("name", ["football_5v5", "navigation_n8"])
+def test_compact_overflowing_tiles_take_the_rounds_path(name):
+    """Non-finite poses pass every broad-phase test: a tile full of them needs more contact slots than the list has and
+    is processed in rounds of CAP / 64 pairs.  NaN-for-NaN the interpreter's bits (the reference lets a non-finite pose
+    poison every pair it is in)."""
+    g = load(name)
+    B = 64 * 5
+    st0, ft0, _, _ = make_batch(g, B, seed=8)
+    dyn = [i for i, e in enumerate(g.spec.entities) if e.flags & 3]
+    st0[dyn[0], 0, 64:128] = np.nan          # one whole tile: a NaN x of one agent in every environment
+    st0[dyn[1], 1, 128:192:2] = np.inf       # half of another
+    st0[dyn[-1], 4, 200] = np.nan            # a lone NaN rotation elsewhere
+    a, b = _pair(g, B)
+    for hw in (a, b):
+        _up(hw, st0, ft0)
+    for t in range(3):
+        a.step()
+        b.step()
+        assert torch.equal(_bits_nan(a.state), _bits_nan(b.state)), f"{name}: step {t}"
+    assert torch.isnan(a.state[:, :, 64:128]).any() and torch.isfinite(a.state[:, :, :64]).all()
+
+
+@pytest.mark.parametrize("name", ["football_5v5", "give_way", "all_wheel"])
+def test_compact_rollout_and_step_n_forms(name):
+    """vmas_world_rollout (several steps in one launch, the tile resident in LDS) and vmas_world_step_n over two queues
+    (sub-ranges of the batch) on the compacted kernel == its single steps."""
+    g = load(name)
+    B, n = 64 * 9 + 17, 5
+    st0, ft0, _, _ = make_batch(g, B, seed=12)
+    rng = np.random.default_rng(1)
+    outs = []
+    forces = None
+    for mode in ("steps", "rollout", "step_n_2q"):
+        hw = _hip(g.spec, B)
+        hw.set_compact(1)
+        _up(hw, st0, ft0)
+        if forces is None:
+            forces = torch.zeros(n, *hw.agent_ft.shape, device="cuda")
+            if ft0.shape[0]:
+                for k in range(n):
+                    forces[k, : ft0.shape[0], :, :B] = torch.from_numpy((ft0 * (1 + 0.2 * rng.normal(0, 1, ft0.shape))).astype(np.float32))
+        f = forces.clone()
+        if mode == "steps":
+            for k in range(n):
+                hw.agent_ft.copy_(f[k])
+                hw.step()
+                f[k].copy_(hw.agent_ft)
+        elif mode == "rollout":
+            hw.rollout(n, f)
+        else:
+            hw.set_queues(2)
+            hw.step_n(n, f)
+        torch.cuda.synchronize()
+        outs.append((hw.state.clone(), f))
+    for other, what in ((outs[1], "rollout"), (outs[2], "step_n over two queues")):
+        assert torch.equal(_bits(outs[0][0]), _bits(other[0])), f"{name}: {what} state"
+        assert torch.equal(_bits(outs[0][1][:, :, :, :B]), _bits(other[1][:, :, :, :B])), f"{name}: {what} clamped forces"
+
+
+def test_football_default_is_the_compact_kernel():
+    g = load("football_5v5")
+    assert _hip(g.spec, 4096).compact
+    g = load("navigation_n8")
+    assert not _hip(g.spec, 4096).compact  # (28 pairs: its world-specialised kernel stays)
+    g = load("balance_n4")
+    hw = _hip(g.spec, 4096)
+    hw.set_compact(1)
+    assert not hw.compact  # boxes and line-line pairs: the world does not qualify

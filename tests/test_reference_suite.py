@@ -170,6 +170,19 @@ def _run(case, on_gpu):
         if e.name in ("cvxpy", "cvxpylayers"):
             pytest.skip(f"the reference's own test needs {e.name}, absent from this image")
         raise
+    except RuntimeError as e:
+        # The reference has device bugs of its own (kinematic_bicycle's dynamics clamp a cuda tensor with CPU bounds):
+        # if the UNTOUCHED reference fails the same way on this device, the failure is not the attached step's.
+        if not (on_gpu and "Expected all tensors to be on the same device" in str(e)):
+            raise
+
+        def plain(scenario, **kw):
+            return HostView(ref.make_env(scenario, **dict(kw, device="cuda:0")))
+
+        mod.make_env = plain
+        with pytest.raises(RuntimeError, match="Expected all tensors to be on the same device"):
+            getattr(mod, fn)(**kw) if cls is None else getattr(getattr(mod, cls)(), fn)(**kw)
+        pytest.skip("the reference's own test fails on a cuda device WITHOUT attach(): a device bug of the reference")
     finally:
         while len(ATTACHED) > n0:
             ATTACHED.pop().detach()

@@ -163,3 +163,27 @@ def test_rollout_validates_discrete_actions():
     acts[1][2, 17, 0] = -1
     with pytest.raises(AssertionError, match="out of range"):
         env.rollout(acts)
+
+
+def test_infeasible_placements_are_counted():
+    """The reset kernel ends an infeasible placement after VMAS_SPAWN_TRIES draws instead of looping for ever like the
+    reference (utils.py:276-319) - and COUNTS it: MaskedReset.gave_up is 0 for every feasible program, and names how many
+    placements kept an overlapping position otherwise."""
+    from vectorizedmultiagentsimulator_amd import fused as F
+    from vectorizedmultiagentsimulator_amd.environment import make_env
+
+    B = 256
+    env = make_env("navigation", num_envs=B, device="cuda:0", seed=0, n_agents=3)
+    m = torch.ones(B, dtype=torch.bool, device="cuda:0")
+    env.reset_where(m, return_observations=False)
+    assert int(env._masked_reset.gave_up.item()) == 0
+    w = env.world
+    a0, a1 = w.agents[0], w.agents[1]
+    prog = {"ops": [("uniform", a0, (-0.1, 0.1), (-0.1, 0.1), 0.0, 0), ("uniform", a1, (-0.1, 0.1), (-0.1, 0.1), 5.0, 0)],
+            "terms": [], "flags": []}
+    bad = F.MaskedReset(env, prog, seed=1)
+    half = m.clone()
+    half[::2] = False
+    bad(half)
+    torch.cuda.synchronize()
+    assert int(bad.gave_up.item()) == int(half.sum())  # one impossible placement per masked environment

@@ -10,7 +10,7 @@ import ctypes as C
 import os
 from typing import Optional
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 STATE_FIELDS = 6
 AGENT_FIELDS = 3
 
@@ -141,7 +141,7 @@ LIB_PATH = os.path.join(_PKG_DIR, "csrc", os.path.basename(os.environ.get("VMAS_
 ENV_MAX_AGENTS = 32
 ENV_MAX_PACKAGES = 8
 ACTION_ERR_NAN, ACTION_ERR_OUT_OF_RANGE = 1, 2
-POST_BALANCE, POST_TRANSPORT, POST_NAVIGATION = 1, 2, 3
+POST_BALANCE, POST_TRANSPORT, POST_NAVIGATION, POST_FOOTBALL = 1, 2, 3, 4
 
 
 class ActionSlot(C.Structure):
@@ -173,21 +173,24 @@ class IngestArgs(C.Structure):
 
 RESET_MAX_OPS, RESET_MAX_TERMS = 48, 36
 SPAWN_UNIFORM, SPAWN_OFFSET, SPAWN_FIXED = 1, 2, 3
+TERM_DIST, TERM_DIST_POINT, TERM_MIN_DIST = 0, 1, 2
 
 
 class SpawnOp(C.Structure):
     _fields_ = [("kind", C.c_int32), ("entity", C.c_int32), ("base", C.c_int32), ("avoid_from", C.c_int32),
-                ("x_lo", C.c_float), ("x_hi", C.c_float), ("y_lo", C.c_float), ("y_hi", C.c_float), ("min_dist", C.c_float)]
+                ("x_lo", C.c_float), ("x_hi", C.c_float), ("y_lo", C.c_float), ("y_hi", C.c_float), ("min_dist", C.c_float),
+                ("has_rot", C.c_int32), ("rot", C.c_float)]
 
 
 class ResetTerm(C.Structure):
-    _fields_ = [("a", C.c_int32), ("b", C.c_int32), ("factor", C.c_float), ("out", C.c_void_p)]
+    _fields_ = [("a", C.c_int32), ("b", C.c_int32), ("factor", C.c_float), ("out", C.c_void_p),
+                ("kind", C.c_int32), ("n", C.c_int32), ("px", C.c_float), ("py", C.c_float)]
 
 
 class ResetArgs(C.Structure):
     _fields_ = [("n_ops", C.c_int32), ("n_terms", C.c_int32), ("n_flags", C.c_int32),
                 ("ops", SpawnOp * RESET_MAX_OPS), ("terms", ResetTerm * RESET_MAX_TERMS), ("flags", C.c_void_p * 8),
-                ("steps", C.c_void_p), ("episode", C.c_void_p), ("seed", C.c_uint64)]
+                ("steps", C.c_void_p), ("episode", C.c_void_p), ("seed", C.c_uint64), ("gave_up", C.c_void_p)]
 
 
 class StepLimit(C.Structure):
@@ -281,6 +284,8 @@ EXPORTED_SYMBOLS = (
     "vmas_debug_schedule",
     "vmas_debug_force_gave_up",
     "vmas_world_exact_status",
+    "vmas_world_set_compact",
+    "vmas_world_get_compact",
     "vmas_world_set_specialized",
     "vmas_world_get_specialized",
     "vmas_world_set_queues",
@@ -345,6 +350,10 @@ def load_library() -> C.CDLL:
     lib.vmas_world_set_specialized.restype = C.c_int
     lib.vmas_world_get_specialized.argtypes = [vp]
     lib.vmas_world_get_specialized.restype = C.c_int
+    lib.vmas_world_set_compact.argtypes = [vp, i32]
+    lib.vmas_world_set_compact.restype = C.c_int
+    lib.vmas_world_get_compact.argtypes = [vp]
+    lib.vmas_world_get_compact.restype = C.c_int
     lib.vmas_world_exact_status.argtypes = [vp]
     lib.vmas_world_exact_status.restype = C.c_int
     lib.vmas_world_set_queues.argtypes = [vp, i32]

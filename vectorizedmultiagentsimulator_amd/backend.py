@@ -126,6 +126,17 @@ class HipWorld:
     def specialized(self) -> bool:
         return bool(self.lib.vmas_world_get_specialized(self._h))
 
+    def set_compact(self, mode: int):
+        """-1: the library's choice, 0: never, 1: whenever the world qualifies - the lane-compacted step kernel
+        (include/vmas_hip.h, vmas_world_set_compact)."""
+        if self.lib.vmas_world_set_compact(self._h, int(mode)) != 0:
+            raise VmasHipError(A.last_error())
+
+    @property
+    def compact(self) -> bool:
+        """True if plain steps of this world run the lane-compacted kernel (csrc/vmas_compact.h)."""
+        return bool(self.lib.vmas_world_get_compact(self._h))
+
     def reserve_epilogue(self, post_kind: int, n_packages: int = 0):
         """The steps of this world will be one-launch Environment.step calls with this post-step epilogue: let the
         library choose its kernel geometry with the epilogue's LDS included (include/vmas_env_hip.h)."""

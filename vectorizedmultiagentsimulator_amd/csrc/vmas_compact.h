@@ -1,0 +1,704 @@
+// vmas_compact.h - the LANE-COMPACTED form of the step kernel for dense sphere worlds (included by vmas_hip.hip).
+//
+// Why.  step_kernel evaluates a pair's narrow phase for all 64 environments of a tile whenever ONE of them needs it.  In
+// `football` (55 sphere-sphere + 110 line-sphere pairs, two substeps) about 50 of a tile's 165 x 64 = 10 560
+// (environment, pair) slots are in contact per substep, yet a wave can skip a pair only 4 % of the time: the narrow phase
+// ran at ~0.5 % lane utility (profiles/r02e_football131072_physics_pmc_summary.txt: 0.147 of the HBM roof, 0.094 of the
+// fp32 roof, VALU busy 21 %).  Here the work is split by what it costs:
+//
+//   A  broad phase   lane = environment, wave-uniform pair: every lane does useful work (one cheap distance test per
+//                    pair: squared centre distance for sphere-sphere, the sphere's gaps in the line's frame for
+//                    line-sphere).  The wave's ballot of "this environment needs the narrow phase" is the pair's
+//                    64-bit contact mask; the lanes that need it take consecutive slots of the tile's CONTACT LIST
+//                    (one LDS counter bump per pair with contacts) and write their key (pair, environment) there.
+//   B  narrow phase  lane = CONTACT: slot k of the list - whatever pair, whatever environment - is one lane's job.
+//                    ~50 contacts = one pass of one wave instead of ~160 wave-passes of 64 lanes.  Same device
+//                    functions (closest_point_line, contact_force) on the same operands: the same bits.
+//   C  integrate     lane = environment, wave = owner of an entity: the prologue force (core.py:1995-2004), then the
+//                    entity's pairs THAT HAVE CONTACTS in the reference's accumulation order (core.py:2176-2199) -
+//                    a per-entity bit mask set in phase A names them, a lane adds contact `base[pair] + rank of its
+//                    bit in the pair's mask` if its bit is set - then _integrate_state (core.py:2862-2908).
+//
+// Exactness.  A pair the broad phase rejects for an environment contributes, in the reference, exactly +0 to a and -0
+// to b (core.py:2836-2839: the force is zeroed beyond dist_min; the tests are conservative supersets of that, NaN/inf
+// operands always pass).  F + (-0) == F for every F; F + (+0) == F unless F == -0.  So the skipped terms are replaced by
+// ONE `+ (+0)` after the sum for lanes that skipped at least one a-side term: once the running sum is +0 only -0 terms
+// could follow without changing it, and they do not change it either - the same bits as adding the zeros one by one
+// (the argument of step_kernel's "fired" bits, at lane granularity).  Torques likewise.
+//
+// The contact list has CAP slots per tile.  A tile that needs more (piled-up bodies; non-finite poses, which pass every
+// test) is processed in rounds: runs of consecutive pairs with at most CAP contacts between them (a prefix sum over the
+// masks stored in phase A; slots re-assigned from the masks, no test is repeated), in pair order, the owners' sums
+// carried in registers: same order, same bits.
+//
+// Scope: worlds whose pairs are all sphere-sphere or line-sphere, no joints, at most 64 entities and OWN_MAX dynamic
+// entities per wave; options: recorded / in-kernel exact pair masks, per-environment entity gravity, partial substep
+// ranges, multi-step rollouts, the action-ingest prologue and the football epilogue.  Everything else runs step_kernel;
+// the two are interchangeable bit for bit (tests/test_compact_gpu.py).
+#pragma once
+
+namespace compact {
+
+constexpr int CAP = 512;                  // contact slots per tile and round
+constexpr int OWN_MAX = 4;                // dynamic entities one wave can own
+constexpr int LIST_MAX = 64;              // pairs one entity can be in (its list lives in one register, one entry per lane)
+constexpr int HW_MAX = LIST_MAX / 32;     // 32-bit words of an entity's "pairs with contacts" mask
+constexpr int UNIT_PARTNERS = 6;          // partner spheres per broad-phase unit (register arrays of this size)
+constexpr int WAVE_UNITS = 64;            // units per wave: a wave keeps its units' records in registers, one lane per unit
+
+// ---- descriptor records (32-bit words in the blob; all offsets are FLOAT offsets into the LDS tile)
+//   pair    [4] : oa | ob << 16 ; tra | type << 16 ; p0 (SS: r_a + r_b, LS: r + LINE_MIN_DIST) ; p1 (LS: L / 2)
+//   pairhm  [1] : hm_a | hm_b << 16, hm = owned index << 8 | position in that entity's pair list (0xffff: static entity)
+//   unit    [5] : o_row | tr_row << 16 ; type | n << 8 | partner stride (rows) << 16 ; first partner's offset | first pair
+//                 << 16 ; half length (LS) ; threshold (SS: (r_a + r_b + 1e-4)^2, LS: r + LINE_MIN_DIST + slack).  A unit =
+//                 one "row" entity (a line, or the a-sphere of sphere-sphere pairs) against a RUN of n <= 6 partner spheres
+//                 that are equally spaced in the tile, have consecutive pair indices and share the threshold - partner i
+//                 is at offset + i * stride rows, its pair is first pair + i: nothing per partner is fetched.  Ordered wave
+//                 by wave, <= 64 per wave.
+//   owned   [32]: entity, oe, list_begin, n_list, n_a, tr_off (-1: none), -, -, DevEntity[17], -
+//   list    : 16-bit entries, two per word: pair (13 bits) | adds a torque (bit 14: a line-sphere pair seen from a rotatable
+//             line) | side << 15 (1: the entity is b)
+//   wave    [2] : first unit, end unit
+//   entoff  [nE]: tile offset of an entity's first row (-1: none of its rows is in the tile)
+//   bounds  [nP]: the pair's bounding-circle sum R_a + R_b (World.collides core.py:2797-2801, in-kernel exact broad phase)
+constexpr int PAIR_W = 4, UNIT_W = 5, OWNED_W = 32, WAVE_W = 2;
+
+struct DevCompact {
+  const uint32_t* blob;
+  int32_t blob_words;           // multiple of 4
+  // which rows of the state the tile holds (bit e): a dynamic entity keeps all six, a static one that is in a pair its
+  // position; cos / sin rows for the lines among them.  Offsets follow from popcounts - no descriptor fetch in front of
+  // the state loads.
+  unsigned long long dyn_mask, static_mask, line_mask;
+  int32_t off_af;               // agent force rows
+  int32_t off_tr;               // trig rows (2 per line: cos, sin)
+  int32_t off_tab;              // the blob copy
+  int32_t t_owned, t_lists, t_units, t_pairs, t_pairhm, t_waves, t_entoff, t_bounds;  // word offsets inside the blob
+  int32_t n_owned, n_pairs, hw;
+  int32_t off_dyn;              // per-substep scratch: cnt[4] | hit[n_owned][hw] | ballots[n_pairs] (u64) | base[n_pairs] |
+                                // keys[CAP] | contacts[CAP][4] | xmask[mask_words]
+  int32_t mask_words;
+  const float4* trig_cache;     // [nE] {rotation, cos, sin, valid} of the static lines, made once from environment 0 (may be NULL)
+};
+
+}  // namespace compact
+
+// One launch of the compacted kernel (defined in vmas_compact.hip, its own translation unit): env_kind = ENV_NONE |
+// ENV_INGEST | ENV_FOOTBALL (`env` may be NULL for ENV_NONE), own = 1 | 2 | 4 dynamic entities per wave.  0 ok, -1 error
+// (vmas_last_error).
+int vmas_compact_launch(int env_kind, int own, int nw, size_t lds_bytes, int device, const DevWorld& W,
+                        const compact::DevCompact& P, float* state, float* agent_ft, long ld, int batch, int padded,
+                        const DevStepArgs& args, const DevEnv* env, hipStream_t stream);
+// fills P.trig_cache from environment 0 of `state` (static lines: entities of line_mask that are not in dyn_mask)
+int vmas_compact_fill_trig(const compact::DevCompact& P, const float* state, long ld, float4* cache, hipStream_t stream);
+
+#ifdef VMAS_COMPACT_KERNELS
+namespace compact {
+
+__device__ __forceinline__ uint32_t lanemask_rank(unsigned long long b) {  // set bits of b below this lane
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+}
+__device__ __forceinline__ unsigned long long sgpr64(unsigned long long v) {
+  return ((unsigned long long)(uint32_t)sgpr((int)(v >> 32)) << 32) | (uint32_t)sgpr((int)(uint32_t)v);
+}
+__device__ __forceinline__ uint32_t rdl(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ float rdlf(uint32_t v, int l) { return __uint_as_float(rdl(v, l)); }
+
+// cos / sin of the static lines' rotations in environment 0, with the very sincosf the step kernel uses
+__global__ void compact_trig_kernel(unsigned long long lines, const float* __restrict__ state, long ld, float4* __restrict__ cache) {
+  const int e = threadIdx.x;
+  if (!((lines >> e) & 1ull)) return;
+  const float rot = state[((long)e * 6 + 4) * ld];
+  float sn, cs;
+  sincosf(rot, &sn, &cs);
+  cache[e] = make_float4(rot, cs, sn, 1.f);
+}
+
+// ENV: ENV_NONE | ENV_INGEST (action ingest as the prologue) | ENV_FOOTBALL (+ football.py's post-step as the epilogue)
+// PLAIN: the launch has none of the optional inputs (pair masks / in-kernel exact broad phase, per-environment gravity,
+// partial substep ranges): their tests and the scalar registers that carry their pointers are compiled out
+template <int ENV, class EnvArgs, int OWN, bool PLAIN>
+__global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld W, DevCompact P, float* __restrict__ state,
+                                                                        float* __restrict__ agent_ft, long ld, int batch,
+                                                                        int padded, DevStepArgs args_in, const EnvArgs E) {
+  DevStepArgs args = args_in;
+  if constexpr (PLAIN) {
+    args.pair_mask = nullptr; args.sync = nullptr; args.entity_gravity = nullptr; args.first_substep = 0; args.n_substeps = 0;
+#ifndef VMAS_TRACE
+    args.trace = nullptr;
+#endif
+  }
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x & (TILE - 1);
+  const int wv = sgpr(threadIdx.x >> 6);
+  const int nw = sgpr(blockDim.x >> 6);
+  const int nA = W.nA;
+#ifdef VMAS_TRACE  // profiling build only (scripts/trace_compact.py): per-wave s_memtime stamps and phase sums
+  unsigned long long tr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tr_t = 0;
+#define CSTAMP(k) if (args.trace && lane == 0) args.trace[((long)blockIdx.x * 16 + wv) * 16 + (k)] = __builtin_amdgcn_s_memtime()
+#define CACC(k) if (args.trace) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tr_acc[k] += t_ - tr_t; tr_t = t_; }
+#define CCOUNT(k, v) if (args.trace) tr_acc[k] += (v)
+#else
+#define CSTAMP(k)
+#define CACC(k)
+#define CCOUNT(k, v)
+#endif
+  CSTAMP(0);
+  const long env = (long)blockIdx.x * TILE + lane;
+  const bool live = env < batch;
+  const bool lv = live || padded;  // planes padded to whole tiles: the tail lanes read the padding columns
+  const unsigned long long live_mask = __ballot(live);
+  float* tile = lds + lane;
+  const uint32_t* tab = (const uint32_t*)(lds + P.off_tab);
+  uint32_t* dyn = (uint32_t*)(lds + P.off_dyn);
+  uint32_t* cnt = dyn;                                       // [0] contacts of this round
+  uint32_t* hit = dyn + 4;                                   // [n_owned][hw]
+  unsigned long long* ballots = (unsigned long long*)(hit + ((P.n_owned * P.hw + 1) & ~1));
+  uint32_t* base = (uint32_t*)(ballots + P.n_pairs);
+  uint32_t* keys = base + ((P.n_pairs + 1) & ~1);
+  float4* contacts = (float4*)(dyn + ((((keys + CAP) - dyn) + 3) & ~3));  // (16-byte aligned: off_dyn is a multiple of 4 words)
+  uint32_t* xmask = (uint32_t*)(contacts + CAP);
+  const int nP = P.n_pairs;
+
+  // tile offset of entity e's first row / of its cos row, from the masks in the kernel arguments
+  auto ent_off = [&](int e) {
+    const unsigned long long below = (1ull << e) - 1ull;
+    return (6 * __builtin_popcountll(P.dyn_mask & below) + 2 * __builtin_popcountll(P.static_mask & below)) * ROWF;
+  };
+  auto trig_off = [&](int e) { return P.off_tr + 2 * ROWF * __builtin_popcountll(P.line_mask & ((1ull << e) - 1ull)); };
+
+  // ---- the agents' force rows: from agent_ft, or made from the caller's action tensors / the library's agent scripts
+  long act_row0 = 0;
+  auto load_agent_ft = [&](int a, float* f3, bool from_tile) {
+    const float* src = agent_ft + (long)a * 3 * ld + env;
+    if constexpr (ENV != ENV_NONE) {
+      const bool on = E.has_ingest;
+      const VmasActionSlot& S = E.ingest.agents[a];
+      if (on && (S.action != nullptr || S.action_index != nullptr)) {
+        uint32_t bad = 0;
+        ingest_slot(S, E.ingest.clamp, env, live, agent_ft, ld, f3, bad, act_row0);
+        if (S.action_size < 3) f3[2] = from_tile ? tile[P.off_af + (a * 3 + 2) * ROWF] : (lv ? src[2 * ld] : 0.f);
+        if (E.err_flags != nullptr && bad != 0) atomicOr(E.err_flags, bad);
+        return;
+      }
+      if (on && E.ingest.n_scripts > 0 && E.script_of_agent[a] >= 0) {  // driven by the state about to be stepped:
+        const VmasAgentScript& SC = E.ingest.scripts[E.script_of_agent[a]];
+        if (from_tile) run_script(SC, tile + ent_off(SC.entity), ROWF, env, live, agent_ft, ld, f3);
+        else run_script(SC, state + (long)SC.entity * 6 * ld + env, ld, env, live, agent_ft, ld, f3);
+        f3[2] = from_tile ? tile[P.off_af + (a * 3 + 2) * ROWF] : (lv ? src[2 * ld] : 0.f);
+        return;
+      }
+    }
+    if (from_tile) return;  // (no action source: the rows of the previous step stay)
+#pragma unroll
+    for (int f = 0; f < 3; ++f) f3[f] = lv ? src[f * ld] : 0.f;
+  };
+
+  // ---- HBM -> LDS.  Entities with rows the path reads (dynamic: all six; static and in a pair: the position, and a
+  //      line's rotation for its cos / sin), one entity per wave at a time; then the agent forces; then the blob.
+  {
+    const unsigned long long any_mask = P.dyn_mask | P.static_mask;
+    for (int e = wv; e < W.nE; e += nw) {
+      if (!((any_mask >> e) & 1ull)) continue;
+      const bool is_dyn = (P.dyn_mask >> e) & 1ull, is_line = (P.line_mask >> e) & 1ull;
+      const float* src = state + (long)e * 6 * ld + env;
+      float* dst = tile + ent_off(e);
+      float rot = 0.f;
+      if (is_dyn) {
+        float v[6];
+#pragma unroll
+        for (int f = 0; f < 6; ++f) v[f] = lv ? src[f * ld] : 0.f;
+#pragma unroll
+        for (int f = 0; f < 6; ++f) dst[f * ROWF] = v[f];
+        rot = v[4];
+      } else {
+        const float x = lv ? src[0] : 0.f, y = lv ? src[ld] : 0.f;
+        if (is_line) rot = lv ? src[4 * ld] : 0.f;
+        dst[0] = x; dst[ROWF] = y;
+      }
+      if (is_line) {
+        // cos / sin of a STATIC line: the ~110-instruction sincosf is skipped when every environment of the tile has the
+        // rotation the world's cache entry was made from - by the same sincosf, once (compact_trig_kernel): the same bits
+        float sn, cs;
+        bool cached = false;
+        if (!is_dyn && P.trig_cache != nullptr) {
+          const float4 c = P.trig_cache[e];
+          if (c.w != 0.f && __all(__float_as_uint(rot) == __float_as_uint(c.x) || !live)) { cs = c.y; sn = c.z; cached = true; }
+        }
+        if (!cached) sincosf(rot, &sn, &cs);
+        const int tr = trig_off(e);
+        tile[tr] = cs;
+        tile[tr + ROWF] = sn;
+      }
+    }
+    for (int a = wv; a < nA; a += nw) {
+      float f3[3];
+      load_agent_ft(a, f3, false);
+      float* dst = tile + P.off_af + a * 3 * ROWF;
+#pragma unroll
+      for (int f = 0; f < 3; ++f) dst[f * ROWF] = f3[f];
+    }
+    const uint4* src = (const uint4*)P.blob;
+    uint4* dst = (uint4*)(lds + P.off_tab);
+    const int n4 = P.blob_words >> 2, nt = blockDim.x;
+    for (int i0 = threadIdx.x; i0 < n4; i0 += 4 * nt) {
+      const int i1 = i0 + nt, i2 = i0 + 2 * nt, i3 = i0 + 3 * nt;
+      const uint4 a = src[i0], b = src[i1 < n4 ? i1 : i0], c = src[i2 < n4 ? i2 : i0], d = src[i3 < n4 ? i3 : i0];
+      dst[i0] = a;
+      if (i1 < n4) dst[i1] = b;
+      if (i2 < n4) dst[i2] = c;
+      if (i3 < n4) dst[i3] = d;
+    }
+    const int n_zero = 4 + P.n_owned * P.hw;
+    for (int i = threadIdx.x; i < n_zero; i += nt) dyn[i] = 0u;
+    if (args.sync != nullptr)
+      for (int i = threadIdx.x; i < P.mask_words; i += nt) xmask[i] = 0u;
+  }
+  [[maybe_unused]] float fb_prev[4] = {0.f, 0.f, 0.f, 0.f};
+  [[maybe_unused]] float post_steps = 0.f;
+  if constexpr (ENV == ENV_FOOTBALL) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) fb_prev[k] = live ? E.football.o.pos_shaping[(long)k * batch + env] : 0.f;
+    if (wv == 0) post_steps = (E.football.o.limit.steps != nullptr && live) ? E.football.o.limit.steps[env] : 0.f;
+  }
+  CSTAMP(1);
+  __syncthreads();
+  CSTAMP(2);
+
+  // ---- this wave's records, one LDS round trip for the whole launch: its broad-phase units (unit u in lane u), its owned
+  //      entities (word j of the record in lane j) and their pair lists (entry j in lane j).  Phases A and C read them with
+  //      v_readlane - no descriptor fetch on any dependent chain.
+  const int u0 = sgpr((int)tab[P.t_waves + wv * WAVE_W]), nu = sgpr((int)tab[P.t_waves + wv * WAVE_W + 1]) - u0;
+  uint32_t HU0 = 0, HU1 = 0, HU2 = 0, HU3 = 0, HU4 = 0;
+  if (lane < nu) {
+    const uint32_t* U = tab + P.t_units + (u0 + lane) * UNIT_W;
+    HU0 = U[0]; HU1 = U[1]; HU2 = U[2]; HU3 = U[3]; HU4 = U[4];
+  }
+  uint32_t OWv[OWN], LV[OWN];
+#pragma unroll
+  for (int s = 0; s < OWN; ++s) {
+    const int k = wv + s * nw;
+    OWv[s] = 0u; LV[s] = 0u;
+    if (k < P.n_owned) {
+      if (lane < OWNED_W) OWv[s] = tab[P.t_owned + k * OWNED_W + lane];
+      const int list0 = (int)rdl(OWv[s], 2), n_list = (int)rdl(OWv[s], 3);
+      if (lane < n_list) LV[s] = ((const uint16_t*)(tab + P.t_lists))[list0 + lane];
+    }
+  }
+#ifdef VMAS_TRACE
+  tr_t = __builtin_amdgcn_s_memtime();
+#endif
+
+  const float sub_dt = W.sub_dt;
+  const int s_begin = args.first_substep;
+  const int s_end = s_begin + (args.n_substeps > 0 ? args.n_substeps : W.substeps - s_begin);
+  const int n_steps = args.n_steps > 1 ? args.n_steps : 1;
+  int it = 0;
+  for (int stp = 0; stp < n_steps; ++stp) {
+    float* aft = agent_ft + (long)stp * args.ft_stride;
+    if (stp > 0) {  // multi-step launch: only this step's agent forces (or the actions they are made of) come from HBM
+      bool ingested = false;
+      if constexpr (ENV != ENV_NONE) {
+        if (E.has_ingest) {
+          ingested = true;
+          act_row0 = (long)stp * batch;
+          for (int a = wv; a < nA; a += nw) {
+            float f3[3];
+            float* dst = tile + P.off_af + a * 3 * ROWF;
+#pragma unroll
+            for (int f = 0; f < 3; ++f) f3[f] = dst[f * ROWF];
+            load_agent_ft(a, f3, true);
+#pragma unroll
+            for (int f = 0; f < 3; ++f) dst[f * ROWF] = f3[f];
+          }
+        }
+      }
+      if (!ingested)
+        for (int a = wv; a < nA; a += nw) {
+          const float* src = aft + (long)a * 3 * ld + env;
+          float* dst = tile + P.off_af + a * 3 * ROWF;
+#pragma unroll
+          for (int f = 0; f < 3; ++f) dst[f * ROWF] = lv ? src[f * ld] : 0.f;
+        }
+      __syncthreads();
+    }
+    for (int substep = s_begin; substep < s_end; ++substep, ++it) {
+      const bool last_sub = substep + 1 == s_end;
+      const bool last = last_sub && stp + 1 == n_steps;
+      const uint32_t* pmask = args.pair_mask;
+      if (args.sync != nullptr) {
+        // World.collides' batch-global rule (core.py:2797-2801) for this substep by the whole grid: see step_kernel
+        const uint32_t seq = args.seq0 + (uint32_t)it;
+        uint32_t* slot = args.sync + 4 + (seq & 3u) * (uint32_t)args.mask_words;
+        for (int p = wv; p < nP; p += nw) {  // (descriptors from the LDS tables, not from global memory)
+          const uint32_t q = (uint32_t)sgpr((int)tab[P.t_pairs + p * PAIR_W]);
+          const float* A = tile + (int)(q & 0xffffu);
+          const float* B = tile + (int)(q >> 16);
+          const bool h = live && norm2(A[0] - B[0], A[ROWF] - B[ROWF]) <= __uint_as_float(tab[P.t_bounds + p]);
+          if (__any(h) && lane == 0) atomicOr(&xmask[p >> 5], 1u << (p & 31));
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          for (int w_ = 0; w_ < args.mask_words; ++w_) {
+            const uint32_t b = xmask[w_];
+            if (b != 0u) __hip_atomic_fetch_or(slot + w_, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            xmask[w_] = 0u;
+          }
+          const uint32_t target = (seq + 1u) * gridDim.x;
+          __hip_atomic_fetch_add(args.sync, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+          int spins = 0;
+          while ((int32_t)(__hip_atomic_load(args.sync, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1 << 18)) {
+              __hip_atomic_fetch_or(args.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (args.gave_up) __hip_atomic_fetch_or(args.gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+              break;
+            }
+          }
+          if (blockIdx.x == 0) {
+            uint32_t* nxt = args.sync + 4 + ((seq + 2u) & 3u) * (uint32_t)args.mask_words;
+            for (int w_ = 0; w_ < args.mask_words; ++w_)
+              __hip_atomic_store(nxt + w_, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        __syncthreads();
+        pmask = slot;
+      }
+
+      // ---- the owners' running sums (registers: they survive the rounds of an overflowing tile)
+      v2 F[OWN];
+      float Tq[OWN];
+      uint32_t added_a[OWN], added_t[OWN];  // per lane: a-side force terms / computed torque terms actually added
+      int n_on[OWN], n_on_a[OWN];           // uniform: the entity's pairs that are on in the pair mask (all / a-side)
+#pragma unroll
+      for (int s = 0; s < OWN; ++s) { F[s] = V(0.f, 0.f); Tq[s] = 0.f; added_a[s] = 0u; added_t[s] = 0u; n_on[s] = 0; n_on_a[s] = 0; }
+
+      // ---- prologue of every owned entity core.py:1995-2004 (the statements of step_kernel)
+#pragma unroll
+      for (int s = 0; s < OWN; ++s) {
+        const int k = wv + s * nw;
+        if (k >= P.n_owned) break;
+        const int e = (int)rdl(OWv[s], 0);
+        const float* Es = tile + (int)rdl(OWv[s], 1);
+        const uint32_t fl = rdl(OWv[s], 8);
+        const float mass = rdlf(OWv[s], 12), inertia = rdlf(OWv[s], 13);
+        if (fl & VMAS_F_AGENT) {
+          const int agent_index = (int)rdl(OWv[s], 10);
+          float* Af = tile + P.off_af + agent_index * 3 * ROWF;
+          if (fl & VMAS_F_MOVABLE) {
+            v2 f = V(Af[0], Af[ROWF]);
+            if (fl & (VMAS_F_MAX_F | VMAS_F_F_RANGE)) {
+              if (fl & VMAS_F_MAX_F) f = clamp_with_norm(f, rdlf(OWv[s], 21));
+              if (fl & VMAS_F_F_RANGE) { const float fr = rdlf(OWv[s], 22); f = V(clamp_t(f.x, fr), clamp_t(f.y, fr)); }
+              Af[0] = f.x; Af[ROWF] = f.y;
+              if (last_sub && live) {
+                float* gf = aft + (long)agent_index * 3 * ld + env;
+                gf[0] = f.x; gf[ld] = f.y;
+              }
+            }
+            F[s] = F[s] + f;
+          }
+          if (fl & VMAS_F_ROTATABLE) {
+            float t = Af[2 * ROWF];
+            if (fl & (VMAS_F_MAX_T | VMAS_F_T_RANGE)) {
+              if (fl & VMAS_F_MAX_T) {
+                const float max_t = rdlf(OWv[s], 23);
+                const float n = fabsf(t);
+                const float nt = (t / n) * max_t;
+                t = n > max_t ? nt : t;
+              }
+              if (fl & VMAS_F_T_RANGE) t = clamp_t(t, rdlf(OWv[s], 24));
+              Af[2 * ROWF] = t;
+              if (last_sub && live) aft[((long)agent_index * 3 + 2) * ld + env] = t;
+            }
+            Tq[s] = Tq[s] + t;
+          }
+        }
+        if (fl & VMAS_F_LIN_FRICTION) F[s] = F[s] + friction2(V(Es[2 * ROWF], Es[3 * ROWF]), rdlf(OWv[s], 17), mass, sub_dt);
+        if (fl & VMAS_F_ANG_FRICTION) Tq[s] = Tq[s] + friction1(Es[5 * ROWF], rdlf(OWv[s], 18), inertia, sub_dt);
+        if (fl & VMAS_F_MOVABLE) {
+          if (W.has_gravity) F[s] = F[s] + V(mass * W.gx, mass * W.gy);
+          if (fl & VMAS_F_GRAVITY) {
+            v2 ge = V(rdlf(OWv[s], 19), rdlf(OWv[s], 20));
+            if (args.entity_gravity && live) {
+              const float* gp = args.entity_gravity + (long)e * 2 * ld + env;
+              ge = V(gp[0], gp[ld]);
+            }
+            F[s] = F[s] + V(mass * ge.x, mass * ge.y);
+          }
+        }
+        // how many of the entity's pairs the reference processes at all (pair mask)
+        const int n_list = (int)rdl(OWv[s], 3);
+        if (pmask == nullptr) {
+          n_on[s] = n_list; n_on_a[s] = (int)rdl(OWv[s], 4);
+        } else {
+          int c_all = 0, c_a = 0;
+          for (int j = 0; j < n_list; ++j) {
+            const uint32_t en = rdl(LV[s], j);
+            const int pr = (int)(en & 0x1fffu);
+            if ((mask_word(pmask, pr >> 5) >> (pr & 31)) & 1u) { ++c_all; c_a += (en >> 15) ? 0 : 1; }
+          }
+          n_on[s] = c_all; n_on_a[s] = c_a;
+        }
+      }
+      CACC(0);  // prologue
+
+      // a pair with contacts: its mask, the first slot of its contacts in the list, the lanes' keys, and the "has
+      // contacts" bit in the masks of its two entities
+      auto take_slots = [&](int pair, unsigned long long b) {
+        const uint32_t c = (uint32_t)__builtin_popcountll(b);
+        uint32_t s0 = 0;
+        if (lane == 0) s0 = atomicAdd(cnt, c);
+        s0 = (uint32_t)sgpr((int)s0);
+        if ((b >> lane) & 1ull) {
+          const uint32_t k = s0 + lanemask_rank(b);
+          if (k < (uint32_t)CAP) keys[k] = ((uint32_t)pair << 6) | (uint32_t)lane;
+        }
+        if (lane == 0) {
+          ballots[pair] = b;
+          base[pair] = s0;
+          const uint32_t hm = tab[P.t_pairhm + pair];
+          const uint32_t ha = hm & 0xffffu, hb = hm >> 16;
+          if (ha != 0xffffu) atomicOr(&hit[(ha >> 8) * P.hw + ((ha & 255u) >> 5)], 1u << (ha & 31u));
+          if (hb != 0xffffu) atomicOr(&hit[(hb >> 8) * P.hw + ((hb & 255u) >> 5)], 1u << (hb & 31u));
+        }
+      };
+
+      // ================= A: broad phase, lane = environment.  Per unit: the row entity's rows and the partners' positions in
+      // ONE LDS round trip (the unit's record comes from registers, partners and pairs are arithmetic), the tests, then -
+      // rarely - slots for the pairs with contacts.  `all_masks`: the re-run of an overflowing tile, which stores EVERY
+      // pair's mask (zeros too) and takes no slots.
+      auto broad_phase = [&](bool all_masks) {
+        for (int ul = 0; ul < nu; ++ul) {
+          const uint32_t h0 = rdl(HU0, ul), h1 = rdl(HU1, ul), h2 = rdl(HU2, ul);
+          const float half = rdlf(HU3, ul);
+          const uint32_t key_lo = rdl(HU4, ul) + 1u, key_span = 0x7f800000u - key_lo;  // (threshold, +inf) in bit patterns
+          const int type = (int)(h1 & 0xffu), n = (int)((h1 >> 8) & 0xffu), stride = (int)(h1 >> 16) * ROWF;
+          const int pair0 = (int)(h2 >> 16);
+          const float* R = tile + (int)(h0 & 0xffffu);
+          const float* S0 = tile + (int)(h2 & 0xffffu);
+          const v2 pr = V(R[0], R[ROWF]);
+          float cs = 0.f, sn = 0.f;
+          if (type == VMAS_PAIR_LS) { cs = tile[(int)(h0 >> 16)]; sn = tile[(int)(h0 >> 16) + ROWF]; }
+          v2 ps[UNIT_PARTNERS];
+#pragma unroll
+          for (int i = 0; i < UNIT_PARTNERS; ++i) {  // (slots beyond n repeat partner 0: always valid rows)
+            const float* S = S0 + (i < n ? i : 0) * stride;
+            ps[i] = V(S[0], S[ROWF]);
+          }
+#pragma unroll
+          for (int i = 0; i < UNIT_PARTNERS; ++i) {
+            if (i >= n) break;
+            const int pair = pair0 + i;
+            const float dx = pr.x - ps[i].x, dy = pr.y - ps[i].y;
+            // One number per pair that must NOT lie in (threshold, +inf) for the pair to be in reach: the squared centre
+            // distance (sphere-sphere), or the larger of the sphere's two gaps in the line's frame (eval_lsq) - beyond it the
+            // force is exactly 0 (core.py:2836).  Only a FINITE excess skips: NaN / inf operands go to the narrow phase,
+            // where the reference's own arithmetic decides.  Compared as integers: the bit patterns of non-negative floats,
+            // +inf and +NaN included, are ordered like the values, so "threshold < m < inf" is ONE unsigned compare of
+            // bits(m) - (bits(threshold) + 1) against a span computed once per unit; a negative gap (sign bit set) loses the
+            // signed max against the other, non-negative one.
+            uint32_t key;
+            if (type == VMAS_PAIR_SS) {
+              key = __float_as_uint(dx * dx + dy * dy);
+            } else {
+              const float along = fabsf(dx * cs + dy * sn) - half;
+              const uint32_t perp = __float_as_uint(dy * cs - dx * sn) & 0x7fffffffu;
+              const int a_ = (int)__float_as_uint(along), p_ = (int)perp;
+              key = (uint32_t)(a_ > p_ ? a_ : p_);
+            }
+            const bool need = (key - key_lo) >= key_span;
+            unsigned long long b = __ballot(need) & live_mask;
+            if (pmask != nullptr && b != 0ull && !((mask_word(pmask, pair >> 5) >> (pair & 31)) & 1u)) b = 0ull;
+            if (all_masks) {
+              if (lane == 0) ballots[pair] = b;
+            } else if (b != 0ull) {
+              take_slots(pair, b);
+            }
+          }
+        }
+      };
+      broad_phase(false);
+      // ================= A: broad phase, lane = environment.  Per unit: the row entity's rows and the partners' positions in
+      // ONE LDS round trip (the records come from registers), the tests, then - rarely - slots for the pairs with contacts.
+      CACC(1);  // A
+      __syncthreads();
+      CACC(2);  // A barrier
+
+      // ---- rounds: ONE unless the tile has more contacts than the list holds (non-finite poses pass every test); then
+      //      the pairs are taken in runs of at most CAP contacts, in pair order, slots re-assigned from the stored masks
+      int lo = 0, hi = nP;
+      bool rounds = sgpr((int)cnt[0]) > CAP;
+      if (rounds) {
+        __syncthreads();  // (every wave has read the count)
+        if (threadIdx.x == 0) cnt[0] = 0u;
+        for (int i = threadIdx.x; i < P.n_owned * P.hw; i += blockDim.x) hit[i] = 0u;
+        broad_phase(true);  // every pair's mask, zeros included (the first pass stored those with contacts only)
+        __syncthreads();
+        hi = 0;
+      }
+      for (;;) {
+        if (rounds) {
+          // the longest run [lo, hi) with at most CAP contacts: a wave-wide prefix sum over the pairs' counts, 64 at a time
+          lo = hi;
+          int acc = 0;
+          bool full = false;
+          while (!full && hi < nP) {
+            const int p = hi + lane;
+            int c = p < nP ? __builtin_popcountll(ballots[p]) : 0;
+            int pre = c;
+#pragma unroll
+            for (int d = 1; d < TILE; d <<= 1) { const int t = __shfl_up(pre, d); if (lane >= d) pre += t; }
+            const unsigned long long over = __ballot(acc + pre > CAP);
+            const int fit = over ? __builtin_ctzll(over) : TILE;  // pairs of this chunk that still fit
+            const int take = fit < nP - hi ? fit : nP - hi;
+            acc += take > 0 ? __builtin_amdgcn_readlane(pre, take - 1) : 0;
+            hi += take;
+            full = over != 0ull;
+          }
+          __syncthreads();  // (hit / cnt cleared, the previous round's contacts consumed)
+          for (int p = lo + wv; p < hi; p += nw) {
+            const unsigned long long b = sgpr64(ballots[p]);
+            if (b != 0ull) take_slots(p, b);
+          }
+          __syncthreads();
+        }
+        const uint32_t N = (uint32_t)sgpr((int)cnt[0]);
+        CCOUNT(6, N);
+        CCOUNT(7, 1);
+        // ================= B: narrow phase, lane = contact
+        for (uint32_t k = (uint32_t)((nw - 1 - wv) * TILE + lane); k < N; k += (uint32_t)(nw * TILE)) {  // (the last wave first:
+                                                                                                  //  it owns the fewest entities)
+          const uint32_t key = keys[k];
+          const int pair = (int)(key >> 6);
+          const float* col = lds + (key & 63u);
+          const uint4 Q = *(const uint4*)(tab + P.t_pairs + pair * PAIR_W);
+          const float* A = col + (Q.x & 0xffffu);
+          const float* B = col + (Q.x >> 16);
+          const v2 pa = V(A[0], A[ROWF]), pb = V(B[0], B[ROWF]);
+          const float p0 = __uint_as_float(Q.z);
+          v2 fa;
+          float ta = 0.f;
+          if ((Q.y >> 16) == (uint32_t)VMAS_PAIR_SS) {  // core.py:2294-2339
+            fa = contact_force(pa, pb, p0, W.c_coll, W.k);
+          } else {  // a = line, b = sphere  core.py:2341-2392
+            const float* T = col + (Q.y & 0xffffu);
+            const v2 cp = closest_point_line<true>(pa, T[0], T[ROWF], __uint_as_float(Q.w), pb);
+            fa = -contact_force(pb, cp, p0, W.c_coll, W.k);
+            ta = vcross(cp - pa, fa);
+          }
+          contacts[k] = make_float4(fa.x, fa.y, ta, 0.f);
+        }
+        CACC(3);  // B
+        __syncthreads();
+        CACC(4);  // B barrier
+        // ================= C (first half): every owner adds the contacts of its entity, in the reference's order
+        if (threadIdx.x == 0) cnt[0] = 0u;  // (read by every wave before the barrier above; next written in a later phase A)
+#pragma unroll
+        for (int s = 0; s < OWN; ++s) {
+          const int k = wv + s * nw;
+          if (k >= P.n_owned) break;
+          const uint32_t fl = rdl(OWv[s], 8);
+          for (int w_ = 0; w_ < P.hw; ++w_) {
+            uint32_t m = (uint32_t)sgpr((int)hit[k * P.hw + w_]);
+            if (m == 0u) continue;
+            if (lane == 0) hit[k * P.hw + w_] = 0u;  // (owner-private: re-armed for the next round / substep)
+            while (m) {
+              const int j = __builtin_ctz(m) + 32 * w_;
+              m &= m - 1u;
+              const uint32_t en = rdl(LV[s], j);
+              const int pr = (int)(en & 0x1fffu);
+              const bool is_b = (en >> 15) != 0u, has_t = ((en >> 14) & 1u) != 0u;
+              const unsigned long long b = sgpr64(ballots[pr]);
+              const uint32_t s0 = (uint32_t)sgpr((int)base[pr]);
+              const bool mine = (b >> lane) & 1ull;
+              float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+              if (mine) c = contacts[s0 + lanemask_rank(b)];
+              const uint32_t flip = is_b ? 0x80000000u : 0u;  // b's side: -f (an integer xor: see eval_item)
+              const v2 f = V(__uint_as_float(__float_as_uint(c.x) ^ flip), __uint_as_float(__float_as_uint(c.y) ^ flip));
+              if (fl & VMAS_F_MOVABLE) {
+                const v2 Fn = F[s] + f;
+                F[s] = mine ? Fn : F[s];
+                if (!is_b) added_a[s] += mine ? 1u : 0u;
+              }
+              if (has_t) {  // the line's torque (the sphere's term is the reference's literal 0: part of the `+ 0` below)
+                const float Tn = Tq[s] + c.z;
+                Tq[s] = mine ? Tn : Tq[s];
+                added_t[s] += mine ? 1u : 0u;
+              }
+            }
+          }
+        }
+        CACC(5);  // C: adding the contacts
+        if (!rounds || hi >= nP) break;
+      }
+
+      // ================= C (second half): the zeros that were skipped, then _integrate_state core.py:2862-2908
+#pragma unroll
+      for (int s = 0; s < OWN; ++s) {
+        const int k = wv + s * nw;
+        if (k >= P.n_owned) break;
+        const int e = (int)rdl(OWv[s], 0);
+        float* Es = tile + (int)rdl(OWv[s], 1);
+        const int tr_off = (int)rdl(OWv[s], 5);
+        const uint32_t fl = rdl(OWv[s], 8);
+        const float one_minus_drag = rdlf(OWv[s], 14);
+        if ((fl & VMAS_F_MOVABLE) && added_a[s] < (uint32_t)n_on_a[s]) F[s] = F[s] + V(0.f, 0.f);
+        if ((fl & VMAS_F_ROTATABLE) && added_t[s] < (uint32_t)n_on[s]) Tq[s] = Tq[s] + 0.f;
+        float es[6];
+#pragma unroll
+        for (int f = 0; f < 6; ++f) es[f] = Es[f * ROWF];
+        float* dst = state + (long)e * 6 * ld + env;
+        if (fl & VMAS_F_MOVABLE) {
+          v2 vel = V(es[2], es[3]);
+          if (substep == 0) vel = V(vel.x * one_minus_drag, vel.y * one_minus_drag);
+          const rcp_t rm = rcp_of(rdlf(OWv[s], 12));
+          const v2 acc = V(F[s].x / rm, F[s].y / rm);
+          vel = V(vel.x + acc.x * sub_dt, vel.y + acc.y * sub_dt);
+          if (fl & VMAS_F_MAX_SPEED) vel = clamp_with_norm(vel, rdlf(OWv[s], 15));
+          if (fl & VMAS_F_V_RANGE) { const float vr = rdlf(OWv[s], 16); vel = V(clamp_t(vel.x, vr), clamp_t(vel.y, vr)); }
+          v2 np = V(es[0] + vel.x * sub_dt, es[1] + vel.y * sub_dt);
+          if (W.xs == W.xs) np.x = clamp_t(np.x, W.xs);
+          if (W.ys == W.ys) np.y = clamp_t(np.y, W.ys);
+          if (last && live) { dst[0] = np.x; dst[ld] = np.y; dst[2 * ld] = vel.x; dst[3 * ld] = vel.y; }
+          if (!last || ENV != ENV_NONE) { Es[0] = np.x; Es[ROWF] = np.y; Es[2 * ROWF] = vel.x; Es[3 * ROWF] = vel.y; }
+        }
+        if (fl & VMAS_F_ROTATABLE) {
+          float av = es[5];
+          if (substep == 0) av = av * one_minus_drag;
+          av = av + (Tq[s] / rdlf(OWv[s], 13)) * sub_dt;
+          const float rot = es[4] + av * sub_dt;
+          if (last && live) { dst[4 * ld] = rot; dst[5 * ld] = av; }
+          if (!last || ENV != ENV_NONE) { Es[4 * ROWF] = rot; Es[5 * ROWF] = av; }
+          if (!last && tr_off >= 0) {
+            float sn, cs;
+            sincosf(rot, &sn, &cs);
+            tile[tr_off] = cs;
+            tile[tr_off + ROWF] = sn;
+          }
+        }
+      }
+      if (!last) __syncthreads();
+      CACC(0);  // (integration + its barrier: counted with the prologue)
+    }
+    if constexpr (ENV == ENV_FOOTBALL) {
+      if (stp + 1 == n_steps) __syncthreads();  // (earlier steps: the substep loop ended with a barrier)
+      {
+        const float* rows = tile + ent_off(E.football.d.agent0);  // (host-checked: the agents and the ball are consecutive
+        const float* af = tile + P.off_af;                        //  dynamic entities, agent index = slot)
+        football_post_tile(TileCtx(batch), E.football.d, E.football.o, batch,
+                           [&](int slot, int k) { return k < 4 ? rows[(slot * 6 + k) * ROWF] : af[(slot * 3 + (k - 4)) * ROWF]; },
+                           (float*)nullptr, fb_prev, post_steps, stp);
+      }
+      if (stp + 1 < n_steps) __syncthreads();  // the next step's prologue rewrites the agent-force rows
+    }
+  }
+  CSTAMP(3);
+#ifdef VMAS_TRACE
+  if (args.trace && lane == 0)
+    for (int k = 0; k < 8; ++k) args.trace[((long)blockIdx.x * 16 + wv) * 16 + 4 + k] = tr_acc[k];
+#endif
+}
+
+}  // namespace compact
+#endif  // VMAS_COMPACT_KERNELS

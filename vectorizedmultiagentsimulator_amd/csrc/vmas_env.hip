@@ -56,7 +56,10 @@ __global__ __launch_bounds__(256) void ingest_kernel(const VmasIngestArgs args, 
   if ((int)blockIdx.y < args.n_agents)
     ingest_slot(args.agents[blockIdx.y], args.clamp, env, env < batch, agent_ft, ld, u, bad);
   else
-    run_script(args.scripts[blockIdx.y - args.n_agents], state, env, env < batch, agent_ft, ld, u);
+  {
+    const VmasAgentScript& S = args.scripts[blockIdx.y - args.n_agents];
+    run_script(S, state + (long)S.entity * 6 * ld + (env < batch ? env : 0), ld, env, env < batch, agent_ft, ld, u);
+  }
   if (err != nullptr && bad != 0) atomicOr(err, bad);
 }
 
@@ -191,22 +194,14 @@ __global__ __launch_bounds__(256) void navigation_collision_kernel(const VmasNav
 }
 
 // ------------------------------------------------------------------------------------ football
-// football.py:1121-1515 (learning-vs-learning game).  An observation is 16 + 8 * (observed others) floats
-// - 88 for 5 v 5, 3.5 KB per environment and step over the ten agents: this kernel is a streaming
-// writer.  LDS: rows[(n + 1) * 6][64] (pos, vel, force of every agent and of the ball) | chunk tiles
-// [nw][64][33]: a wave transposes its agent's observation 32 columns at a time, so one store instruction
-// covers two 128-byte row segments.
-constexpr int kChunk = 32;
-
+// stand-alone form of football_post_tile (vmas_env_device.h).  LDS: rows[(n + 1) * 6][64] (pos, vel, force of every agent
+// and of the ball) | chunk tiles [nw][64][33]
 __global__ __launch_bounds__(512) void football_post_kernel(const VmasFootballDesc d, const VmasFootballBuffers o, int batch,
                                                             const float* __restrict__ state, long ld) {
   extern __shared__ float lds[];
   const TileCtx C(batch);
-  const int n = d.n_blue + d.n_red, ball = n;  // slot of the ball
-  float* rows = lds;                            // rows[(slot * 6 + k) * 64 + lane], k: px py vx vy fx fy
-  float* slab = lds + (n + 1) * 6 * 64 + C.wave * 64 * (kChunk + 1);
-  float* my_row = slab + C.lane * (kChunk + 1);
-
+  const int n = d.n_blue + d.n_red;
+  float* rows = lds;  // rows[(slot * 6 + k) * 64 + lane], k: px py vx vy fx fy
   stage_rows(C, rows, (n + 1) * 6, [&](int i) {
     const int slot = i / 6, k = i - slot * 6;
     return k < 4 ? state[((long)(d.agent0 + slot) * 6 + k) * ld + C.e] : o.agent_ft[((long)slot * 3 + (k - 4)) * ld + C.e];
@@ -214,116 +209,10 @@ __global__ __launch_bounds__(512) void football_post_kernel(const VmasFootballDe
   float prev[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) prev[k] = C.live ? o.pos_shaping[(long)k * batch + C.env] : 0.f;  // (every wave: all need the team rewards)
-  const float steps_in = C.wave == 0 ? load_steps(o.limit, C) : 0.f;
+  float steps_in = C.wave == 0 ? load_steps(o.limit, C) : 0.f;
   __syncthreads();
-  auto G = [&](int slot, int k) { return rows[(slot * 6 + k) * 64 + C.lane]; };
-  auto P2 = [&](int slot, int k) { return V(G(slot, k), G(slot, k + 1)); };
-  const v2 bpos = P2(ball, 0), bvel = P2(ball, 2), bforce = P2(ball, 4);
-
-  // ---- reward football.py:1121-1219 (wave 0 only stores; every wave needs the two team rewards)
-  const bool over_right = bpos.x > d.goal_x, over_left = bpos.x < -d.goal_x;
-  const bool in_mouth = bpos.y <= d.goal_half && bpos.y >= -d.goal_half;
-  const bool blue_score = over_right && in_mouth, red_score = over_left && in_mouth;
-  const float sparse_blue = d.scoring_reward * (blue_score ? 1.f : 0.f) - d.scoring_reward * (red_score ? 1.f : 0.f);
-  float dense[2] = {0.f, 0.f}, term[8];
-  if (d.dense_reward) {
-    const bool ball_moving = vnorm(bvel) > 1e-6f;
-#pragma unroll
-    for (int team = 0; team < 2; ++team) {  // 0 blue (attacks the right goal), 1 red
-      const v2 goal = V(team == 0 ? d.goal_x : -d.goal_x, 0.f);
-      const float shaping = vnorm(bpos - goal) * d.pos_shaping_factor_ball_goal;  // reward_ball_to_goal
-      float min_dist = kInf;                                                       // reward_all_agent_to_ball
-      const int a0 = team == 0 ? 0 : d.n_blue, a1 = team == 0 ? d.n_blue : n;
-      for (int a = a0; a < a1; ++a) min_dist = min_t(min_dist, vnorm(P2(a, 0) - bpos));
-      const float shaping_agent = min_dist * d.pos_shaping_factor_agent_ball;
-      term[team] = shaping; term[2 + team] = shaping_agent; term[4 + team] = min_dist;
-      term[6 + team] = prev[team] - shaping;                                       // ball.pos_rew_<team>
-      const bool quiet = (min_dist < d.distance_to_ball_trigger) || ball_moving;
-      const float rew_agent = quiet ? 0.f : prev[2 + team] - shaping_agent;
-      dense[team] = term[6 + team] + rew_agent;
-      if (C.wave == 0 && C.live) {
-        o.pos_shaping[(long)team * batch + C.env] = shaping;
-        o.pos_shaping[(long)(2 + team) * batch + C.env] = shaping_agent;
-        o.terms[(long)(1 + team) * batch + C.env] = term[6 + team];
-        o.terms[(long)(3 + team) * batch + C.env] = rew_agent;
-        o.terms[(long)(5 + team) * batch + C.env] = min_dist;
-        o.terms[(long)(7 + team) * batch + C.env] = shaping / d.pos_shaping_factor_ball_goal;
-        o.touching[(long)team * batch + C.env] = min_dist <= d.touch_dist ? 1 : 0;
-      }
-    }
-  }
-  if (C.wave == 0) {
-    const bool done = apply_step_limit(o.limit, C, steps_in, blue_score || red_score);
-    if (C.live) {
-      o.terms[C.env] = sparse_blue;
-      o.done[C.env] = done ? 1 : 0;
-    }
-  }
-  const float rew_team[2] = {sparse_blue + dense[0], (0.f - sparse_blue) + dense[1]};
-
-  // ---- observation football.py:1221-1460, agents wave, wave + nw, ...; red agents see everything mirrored in
-  //      x.  Written chunk by chunk - the 16 own/ball columns, then the observed others four at a time (32
-  //      columns) - through the wave's [64][33] LDS tile; a chunk leaves as float4 stores, two 128-byte row
-  //      segments per instruction.
-  const int n_adv_b = d.observe_adversaries ? d.n_red : 0, n_adv_r = d.observe_adversaries ? d.n_blue : 0;
-  for (int a = C.wave; a < n; a += C.nw) {
-    const bool blue = a < d.n_blue;
-    const float sx = blue ? 1.f : -1.f;
-    auto M = [&](v2 v) { return V(v.x * sx, v.y); };
-    const v2 goal = V(blue ? d.goal_x : -d.goal_x, 0.f);
-    const v2 pos = P2(a, 0), vel = P2(a, 2), force = P2(a, 4);
-    const int n_adv = blue ? n_adv_b : n_adv_r;
-    const int mate0 = blue ? 0 : d.n_blue, n_team = blue ? d.n_blue : d.n_red;
-    const int n_others = n_adv + (d.observe_teammates ? n_team - 1 : 0);
-    const int D = 16 + 8 * n_others;
-    float* out = o.obs + ((long)a * batch + C.b0) * D;
-    auto put = [&](int c, v2 v) { my_row[c] = v.x; my_row[c + 1] = v.y; };
-    // the chunk [c0, c0 + w) of the tile -> out; w is a multiple of 8
-    auto flush = [&](int c0, int w) {
-      wave_lds_fence();
-      const int w4 = w >> 2, total4 = C.n_rows * w4;
-      const float inv = 1.f / (float)w4;
-      for (int i0 = C.lane; i0 < total4; i0 += 128) {
-        float4 v[2];
-        int dst[2];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const int i = i0 + 64 * k < total4 ? i0 + 64 * k : total4 - 1;
-          int r = (int)((float)i * inv);
-          int c4 = i - r * w4;
-          if (c4 >= w4) { c4 -= w4; r += 1; }
-          if (c4 < 0) { c4 += w4; r -= 1; }
-          const float* src = slab + r * (kChunk + 1) + 4 * c4;
-          v[k] = make_float4(src[0], src[1], src[2], src[3]);
-          dst[k] = r * D + c0 + 4 * c4;
-        }
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-          if (i0 + 64 * k < total4) *(float4*)(out + dst[k]) = v[k];
-      }
-      wave_lds_fence();
-    };
-    put(0, M(force)); put(2, M(pos - bpos)); put(4, M(vel - bvel)); put(6, M(bpos - goal));
-    put(8, M(bvel)); put(10, M(bforce)); put(12, M(pos - goal)); put(14, M(vel));
-    flush(0, 16);
-    for (int j0 = 0; j0 < n_others; j0 += 4) {
-      const int m = n_others - j0 < 4 ? n_others - j0 : 4;
-      for (int jj = 0; jj < m; ++jj) {
-        const int j = j0 + jj;
-        int other;
-        if (j < n_adv) {
-          other = (blue ? d.n_blue : 0) + j;  // the other team, in order
-        } else {
-          other = mate0 + (j - n_adv);
-          if (other >= a) other += 1;         // my team, skipping myself
-        }
-        const v2 opos = P2(other, 0), ovel = P2(other, 2), oforce = P2(other, 4);
-        put(8 * jj, M(pos - opos)); put(8 * jj + 2, M(vel - ovel)); put(8 * jj + 4, M(ovel)); put(8 * jj + 6, M(oforce));
-      }
-      flush(16 + 8 * j0, 8 * m);
-    }
-    if (C.live) o.rew[(long)a * batch + C.env] = rew_team[blue ? 0 : 1];
-  }
+  football_post_tile(C, d, o, batch, [&](int slot, int k) { return rows[(slot * 6 + k) * 64 + C.lane]; }, lds + (n + 1) * 6 * 64,
+                     prev, steps_in, 0);
 }
 
 int check_launch(const char* what) {
@@ -508,7 +397,11 @@ __global__ __launch_bounds__(256) void reset_kernel(const VmasResetArgs A, int b
           const int o = A.ops[j].entity;
           overlaps = overlaps || norm2(px(o) - x, py(o) - y) < op.min_dist;  // torch.cdist(...) < min_dist
         }
-        if (!overlaps || tries >= 4096u) break;  // (an infeasible placement ends after 4096 tries instead of hanging)
+        if (!overlaps) break;
+        if (tries >= (uint32_t)VMAS_SPAWN_TRIES) {  // an infeasible placement ends instead of hanging - and is counted
+          if (A.gave_up != nullptr) atomicAdd(A.gave_up, 1u);
+          break;
+        }
       }
     } else if (op.kind == VMAS_SPAWN_OFFSET) {
       float dx = op.x_lo;
@@ -522,10 +415,21 @@ __global__ __launch_bounds__(256) void reset_kernel(const VmasResetArgs A, int b
     }
     px(op.entity) = x;
     py(op.entity) = y;
+    if (op.has_rot) state[((long)op.entity * 6 + 4) * ld + env] = op.rot;
   }
   for (int t = 0; t < A.n_terms; ++t) {
     const VmasResetTerm& T = A.terms[t];
-    T.out[env] = T.a < 0 ? T.factor : norm2(px(T.a) - px(T.b), py(T.a) - py(T.b)) * T.factor;
+    float v;
+    if (T.kind == VMAS_TERM_DIST_POINT) {
+      v = norm2(px(T.a) - T.px, py(T.a) - T.py) * T.factor;
+    } else if (T.kind == VMAS_TERM_MIN_DIST) {  // torch.cdist(...).min(): football.py:586-600
+      float m = kInf;
+      for (int e = T.a; e < T.a + T.n; ++e) m = min_t(m, norm2(px(e) - px(T.b), py(e) - py(T.b)));
+      v = m * T.factor;
+    } else {
+      v = T.a < 0 ? T.factor : norm2(px(T.a) - px(T.b), py(T.a) - py(T.b)) * T.factor;
+    }
+    T.out[env] = v;
   }
   for (int f = 0; f < A.n_flags; ++f) A.flags[f][env] = 0;
   if (A.steps != nullptr) A.steps[env] = 0.f;
@@ -548,9 +452,14 @@ int vmas_env_reset_where(const VmasResetArgs* a, int32_t batch, int32_t n_entiti
     if (op.kind == VMAS_SPAWN_UNIFORM && (op.avoid_from < 0 || op.avoid_from > i))
       return host_fail("vmas_env_reset_where: avoid_from must name an earlier operation");
   }
-  for (int t = 0; t < a->n_terms; ++t)
-    if (!a->terms[t].out || a->terms[t].a >= n_entities || (a->terms[t].a >= 0 && (a->terms[t].b < 0 || a->terms[t].b >= n_entities)))
-      return host_fail("vmas_env_reset_where: malformed shaping term");
+  for (int t = 0; t < a->n_terms; ++t) {
+    const VmasResetTerm& T = a->terms[t];
+    bool bad = !T.out || T.a >= n_entities || T.kind < VMAS_TERM_DIST || T.kind > VMAS_TERM_MIN_DIST;
+    if (T.kind == VMAS_TERM_DIST) bad = bad || (T.a >= 0 && (T.b < 0 || T.b >= n_entities));
+    if (T.kind == VMAS_TERM_DIST_POINT) bad = bad || T.a < 0;
+    if (T.kind == VMAS_TERM_MIN_DIST) bad = bad || T.a < 0 || T.n < 1 || T.a + T.n > n_entities || T.b < 0 || T.b >= n_entities;
+    if (bad) return host_fail("vmas_env_reset_where: malformed shaping term");
+  }
   for (int f = 0; f < a->n_flags; ++f)
     if (!a->flags[f]) return host_fail("vmas_env_reset_where: null flag tensor");
   hipLaunchKernelGGL(reset_kernel, dim3((batch + 255) / 256), dim3(256), 0, (hipStream_t)stream, *a, batch, n_entities,

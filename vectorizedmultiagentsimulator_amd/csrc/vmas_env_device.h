@@ -784,14 +784,15 @@ VD void ingest_slot(const VmasActionSlot& S, int clamp, long env, bool live, flo
   }
 }
 
-// A scripted agent whose script the library knows (VmasAgentScript): same contract as ingest_slot.
-VD void run_script(const VmasAgentScript& S, const float* __restrict__ state, long env, bool live,
+// A scripted agent whose script the library knows (VmasAgentScript): same contract as ingest_slot.  `E` = this
+// environment's column of the script's entity - field f at E[f * stride] - in HBM (stride = ld) or in a step kernel's LDS
+// tile (stride = 64: the state about to be stepped of a multi-step launch never left LDS).
+VD void run_script(const VmasAgentScript& S, const float* E, long stride, long env, bool live,
                    float* __restrict__ agent_ft, long ld, float u_out[3]) {
   u_out[0] = u_out[1] = u_out[2] = 0.f;
   if (!live) return;
   if (S.kind == VMAS_SCRIPT_FOOTBALL_BALL) {  // ball_action_script football.py:1620-1680
-    const float* E = state + (long)S.entity * 6 * ld + env;
-    const float x = E[0], y = E[ld], vy = E[3 * ld];
+    const float x = E[0], y = E[stride], vy = E[3 * stride];
     const float thr = S.params[0], half_w = S.params[1], half_l = S.params[2], half_goal = S.params[3];
     auto near = [&](float d) { return 1.f - min_t(d, thr) / thr; };  // 1 at the border, 0 from `thr` away
     const float upper = near(half_w - y), lower = near(half_w + y), right = near(half_l - x), left = near(half_l + x);
@@ -805,6 +806,166 @@ VD void run_script(const VmasAgentScript& S, const float* __restrict__ state, lo
   for (int k = 0; k < 2; ++k) {
     agent_ft[((long)S.agent_index * 3 + k) * ld + env] = u_out[k];
     if (S.u_out != nullptr) S.u_out[env * 2 + k] = u_out[k];
+  }
+}
+
+// ------------------------------------------------------------------------------------ football
+// football.py:1121-1515 (learning-vs-learning game) on a tile whose agent rows are reachable through `G(slot, k)`
+// (slot = blue agents, red agents, ball; k = px py vx vy fx fy): the stand-alone kernel (vmas_env.hip) stages them from
+// HBM, the compact step kernel (vmas_compact.h) reads its own tile - the post-step as the physics kernel's epilogue.
+// An observation is 16 + 8 * (observed others) floats - 88 for 5 v 5, 3.5 KB per environment and step over the ten
+// agents: a streaming writer.  `slabs`: chunk tiles [nw][64][33] - a wave transposes its agent's observation 32 columns
+// at a time, so one store instruction covers two 128-byte row segments; NULL: no staging, every lane stores its own row
+// (the step kernel's epilogue).  `prev`: the four shaping terms of this lane
+// (in: before, out: after this step), `steps_in`: wave 0's Environment.steps (in/out), `stp`: step of a multi-step
+// launch (every per-step output is offset by stp slabs).  No block barrier inside.
+constexpr int kChunk = 32;
+__host__ __device__ inline size_t football_scratch_floats(int nw) { return (size_t)nw * 64 * (kChunk + 1); }
+
+template <class Get>
+VD void football_post_tile(const TileCtx& C, const VmasFootballDesc& d, const VmasFootballBuffers& o_in, int batch, Get G,
+                           float* slabs, float (&prev)[4], float& steps_in, int stp) {
+  const int n = d.n_blue + d.n_red, ball = n;  // slot of the ball
+  VmasFootballBuffers o = o_in;
+  const int n_adv_b = d.observe_adversaries ? d.n_red : 0, n_adv_r = d.observe_adversaries ? d.n_blue : 0;
+  const int D0 = 16 + 8 * (n_adv_b + (d.observe_teammates ? d.n_blue - 1 : 0));  // (host-checked: the same for both teams)
+  if (stp > 0) {
+    o.obs += (long)stp * n * batch * D0; o.rew += (long)stp * n * batch; o.done += (long)stp * batch;
+    o.terms += (long)stp * 9 * batch; o.touching += (long)stp * 2 * batch;
+  }
+  float* slab = slabs != nullptr ? slabs + C.wave * 64 * (kChunk + 1) : nullptr;
+  float* my_row = slab != nullptr ? slab + C.lane * (kChunk + 1) : nullptr;
+  auto P2 = [&](int slot, int k) { return V(G(slot, k), G(slot, k + 1)); };
+  const v2 bpos = P2(ball, 0), bvel = P2(ball, 2), bforce = P2(ball, 4);
+
+  // ---- reward football.py:1121-1219 (wave 0 only stores; every wave needs the two team rewards)
+  const bool over_right = bpos.x > d.goal_x, over_left = bpos.x < -d.goal_x;
+  const bool in_mouth = bpos.y <= d.goal_half && bpos.y >= -d.goal_half;
+  const bool blue_score = over_right && in_mouth, red_score = over_left && in_mouth;
+  const float sparse_blue = d.scoring_reward * (blue_score ? 1.f : 0.f) - d.scoring_reward * (red_score ? 1.f : 0.f);
+  float dense[2] = {0.f, 0.f}, term[8];
+  if (d.dense_reward) {
+    const bool ball_moving = vnorm(bvel) > 1e-6f;
+#pragma unroll
+    for (int team = 0; team < 2; ++team) {  // 0 blue (attacks the right goal), 1 red
+      const v2 goal = V(team == 0 ? d.goal_x : -d.goal_x, 0.f);
+      const float shaping = vnorm(bpos - goal) * d.pos_shaping_factor_ball_goal;  // reward_ball_to_goal
+      float min_dist = kInf;                                                       // reward_all_agent_to_ball
+      const int a0 = team == 0 ? 0 : d.n_blue, a1 = team == 0 ? d.n_blue : n;
+      for (int a = a0; a < a1; ++a) min_dist = min_t(min_dist, vnorm(P2(a, 0) - bpos));
+      const float shaping_agent = min_dist * d.pos_shaping_factor_agent_ball;
+      term[team] = shaping; term[2 + team] = shaping_agent; term[4 + team] = min_dist;
+      term[6 + team] = prev[team] - shaping;                                       // ball.pos_rew_<team>
+      const bool quiet = (min_dist < d.distance_to_ball_trigger) || ball_moving;
+      const float rew_agent = quiet ? 0.f : prev[2 + team] - shaping_agent;
+      dense[team] = term[6 + team] + rew_agent;
+      if (C.wave == 0 && C.live) {
+        o.pos_shaping[(long)team * batch + C.env] = shaping;
+        o.pos_shaping[(long)(2 + team) * batch + C.env] = shaping_agent;
+        o.terms[(long)(1 + team) * batch + C.env] = term[6 + team];
+        o.terms[(long)(3 + team) * batch + C.env] = rew_agent;
+        o.terms[(long)(5 + team) * batch + C.env] = min_dist;
+        o.terms[(long)(7 + team) * batch + C.env] = shaping / d.pos_shaping_factor_ball_goal;
+        o.touching[(long)team * batch + C.env] = min_dist <= d.touch_dist ? 1 : 0;
+      }
+      prev[team] = shaping;  // (every wave computed them: the next step of a multi-step launch starts from these)
+      prev[2 + team] = shaping_agent;
+    }
+  }
+  if (C.wave == 0) {
+    const bool done = apply_step_limit(o.limit, C, steps_in, blue_score || red_score);
+    if (C.live) {
+      o.terms[C.env] = sparse_blue;
+      o.done[C.env] = done ? 1 : 0;
+    }
+    if (o.limit.steps != nullptr) steps_in = steps_in + 1.f;
+  }
+  const float rew_team[2] = {sparse_blue + dense[0], (0.f - sparse_blue) + dense[1]};
+
+  // ---- observation football.py:1221-1460, agents wave, wave + nw, ...; red agents see everything mirrored in
+  //      x.  Written chunk by chunk - the 16 own/ball columns, then the observed others four at a time (32
+  //      columns) - through the wave's [64][33] LDS tile; a chunk leaves as float4 stores, two 128-byte row
+  //      segments per instruction.
+  for (int a = C.wave; a < n; a += C.nw) {
+    const bool blue = a < d.n_blue;
+    const float sx = blue ? 1.f : -1.f;
+    auto M = [&](v2 v) { return V(v.x * sx, v.y); };
+    const v2 goal = V(blue ? d.goal_x : -d.goal_x, 0.f);
+    const v2 pos = P2(a, 0), vel = P2(a, 2), force = P2(a, 4);
+    const int n_adv = blue ? n_adv_b : n_adv_r;
+    const int mate0 = blue ? 0 : d.n_blue, n_team = blue ? d.n_blue : d.n_red;
+    const int n_others = n_adv + (d.observe_teammates ? n_team - 1 : 0);
+    const int D = 16 + 8 * n_others;
+    if (slabs == nullptr) {
+      // no LDS staging (the step kernel's epilogue: LDS is what decides how many tiles a CU holds): every lane writes its
+      // environment's row itself, four columns per store - 16 bytes per lane at a stride of the row length; the eight stores
+      // that cover a 128-byte line come from the same wave back to back and are merged in L2
+      float* row = o.obs + ((long)a * batch + C.env) * D;
+      auto put4 = [&](int c, v2 p, v2 q) { if (C.live) *(float4*)(row + c) = make_float4(p.x, p.y, q.x, q.y); };
+      put4(0, M(force), M(pos - bpos)); put4(4, M(vel - bvel), M(bpos - goal));
+      put4(8, M(bvel), M(bforce)); put4(12, M(pos - goal), M(vel));
+      for (int j = 0; j < n_others; ++j) {
+        int other;
+        if (j < n_adv) {
+          other = (blue ? d.n_blue : 0) + j;  // the other team, in order
+        } else {
+          other = mate0 + (j - n_adv);
+          if (other >= a) other += 1;         // my team, skipping myself
+        }
+        const v2 opos = P2(other, 0), ovel = P2(other, 2), oforce = P2(other, 4);
+        put4(16 + 8 * j, M(pos - opos), M(vel - ovel));
+        put4(20 + 8 * j, M(ovel), M(oforce));
+      }
+      if (C.live) o.rew[(long)a * batch + C.env] = rew_team[blue ? 0 : 1];
+      continue;
+    }
+    float* out = o.obs + ((long)a * batch + C.b0) * D;
+    auto put = [&](int c, v2 v) { my_row[c] = v.x; my_row[c + 1] = v.y; };
+    // the chunk [c0, c0 + w) of the tile -> out; w is a multiple of 8
+    auto flush = [&](int c0, int w) {
+      wave_lds_fence();
+      const int w4 = w >> 2, total4 = C.n_rows * w4;
+      const float inv = 1.f / (float)w4;
+      for (int i0 = C.lane; i0 < total4; i0 += 128) {
+        float4 v[2];
+        int dst[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int i = i0 + 64 * k < total4 ? i0 + 64 * k : total4 - 1;
+          int r = (int)((float)i * inv);
+          int c4 = i - r * w4;
+          if (c4 >= w4) { c4 -= w4; r += 1; }
+          if (c4 < 0) { c4 += w4; r -= 1; }
+          const float* src = slab + r * (kChunk + 1) + 4 * c4;
+          v[k] = make_float4(src[0], src[1], src[2], src[3]);
+          dst[k] = r * D + c0 + 4 * c4;
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+          if (i0 + 64 * k < total4) *(float4*)(out + dst[k]) = v[k];
+      }
+      wave_lds_fence();
+    };
+    put(0, M(force)); put(2, M(pos - bpos)); put(4, M(vel - bvel)); put(6, M(bpos - goal));
+    put(8, M(bvel)); put(10, M(bforce)); put(12, M(pos - goal)); put(14, M(vel));
+    flush(0, 16);
+    for (int j0 = 0; j0 < n_others; j0 += 4) {
+      const int m = n_others - j0 < 4 ? n_others - j0 : 4;
+      for (int jj = 0; jj < m; ++jj) {
+        const int j = j0 + jj;
+        int other;
+        if (j < n_adv) {
+          other = (blue ? d.n_blue : 0) + j;  // the other team, in order
+        } else {
+          other = mate0 + (j - n_adv);
+          if (other >= a) other += 1;         // my team, skipping myself
+        }
+        const v2 opos = P2(other, 0), ovel = P2(other, 2), oforce = P2(other, 4);
+        put(8 * jj, M(pos - opos)); put(8 * jj + 2, M(vel - ovel)); put(8 * jj + 4, M(ovel)); put(8 * jj + 6, M(oforce));
+      }
+      flush(16 + 8 * j0, 8 * m);
+    }
+    if (C.live) o.rew[(long)a * batch + C.env] = rew_team[blue ? 0 : 1];
   }
 }
 

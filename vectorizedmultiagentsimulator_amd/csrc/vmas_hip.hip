@@ -53,18 +53,13 @@
 
 #include "../../include/vmas_hip.h"
 #include "../../include/vmas_debug_hip.h"
-#include "vmas_env_device.h"
-
-using namespace vmas;
+#include "vmas_step_types.h"
 
 // ------------------------------------------------------------------------------------
 // device-side constant block (all wave-uniform => scalar loads)
 // ------------------------------------------------------------------------------------
-constexpr int TILE = 64;       // environments per block = lanes per wave
-constexpr int MAX_WAVES = 16;  // waves (workers) per tile (8 for the register-heavy box-box level)
 constexpr int ITEMS_LDS_BUDGET = 48 * 1024;  // stage the item descriptors in LDS when they fit
 constexpr int TASK_JOINT = 6;  // item type next to VMAS_PAIR_*
-constexpr float kSkipSlack = 1e-3f;  // fp slack of the conservative broad-phase distances
 #ifndef VMAS_X_TIGHT_LS
 #define VMAS_X_TIGHT_LS 1
 #endif
@@ -76,7 +71,6 @@ constexpr int FIRED_RECS = VMAS_X_FIRED ? 16 : 0;       // shared sphere-sphere 
 constexpr int TASK_SSQ = 7;    // up to four sphere-sphere partners of one entity in one record
 constexpr int TASK_LSQ = 8;    // up to four lines against one (owning) sphere in one record
 constexpr int TASK_SSP = 9;    // up to four SHARED sphere-sphere pairs (both spheres dynamic) in one record
-constexpr int ROWF = TILE;     // floats per LDS row
 
 enum : uint32_t { IT_A_HOLLOW = 1u << 0, IT_B_HOLLOW = 1u << 1, IT_LOCK = 1u << 2 /* joint rotate == False */ };
 
@@ -124,106 +118,13 @@ struct DevOwned {  // phase C work unit: everything the integration of one entit
 };
 static_assert(sizeof(DevOwned) == 96, "DevOwned is read as six uint4");
 
-struct DevEntity {
-  uint32_t flags;
-  int32_t shape;
-  int32_t agent_index;
-  int32_t tr_off;  // tile offset of its 4 trig rows, -1 for spheres
-  float mass, inertia, one_minus_drag;
-  float max_speed, v_range, lin_friction, ang_friction;
-  float gx, gy;
-  float max_f, f_range, max_t, t_range;
-};
 
-struct DevWorld {
-  int32_t nE, nA, substeps;
-  int32_t off_af;  // tile offset of the agent force rows
-  // Which entities need cos/sin rows (bit e: a Line or a Box | a Box), straight from the kernel arguments so that the load
-  // phase does not wait for the descriptor blob: entity e's four trig rows start at row_tr + 4 * popcount(trig_mask below e).
-  // trig_in_args == 0: more than 64 entities, shapes and offsets come from the blob behind a barrier of their own.
-  unsigned long long trig_mask, box_mask;
-  int32_t trig_in_args, row_tr;
-  float sub_dt, gx, gy;
-  int32_t has_gravity;
-  float xs, ys;  // NaN = unbounded
-  float k, tcf;
-  float c_coll, c_joint_att, c_joint_rep;  // fp32(sign * force_multiplier)
-  // One descriptor blob per schedule, staged into LDS by the whole block with coalesced loads
-  // while the state rows are in flight.  (Scalar/vector loads of descriptors from a cache that
-  // is cold at every launch cost ~600 cycles per dependent fetch - 2-4 us of a 13 us step.)
-  //   [ents | segs | owned | items]   word offsets below; counters live right after the blob
-  const uint32_t* blob;
-  int32_t blob_words;   // words staged (items only when they fit the LDS budget)
-  int32_t off_blob;     // tile offset (floats) of the blob copy in LDS
-  int32_t b_ent, b_segs, b_owned, b_refs, b_items;
-  int32_t n_segs, n_owned;
-  int32_t items_in_lds;
-  int32_t fired_recs;    // shared sphere-sphere records (eval_ssp) that publish which of their pairs fired (<= 16)
-  const DevItem* items;  // global copy, used when the item list is too big for LDS
-};
 
 // (DevMaskPair, DevLidar, DevTarget: vmas_env_device.h - the navigation epilogue uses them too)
 
-struct DevStepArgs {
-  const uint32_t* pair_mask;
-  // in-kernel exact broad phase (vmas_world_step with exact_broad_phase on a grid of at most one tile per CU): the
-  // batch-global `.any()` of World.collides (core.py:2797-2801) evaluated at the top of every substep by all tiles
-  // together - bits ORed into a ring of mask slots with device-scope atomics, then a grid-wide barrier on `sync[0]`
-  uint32_t* sync;              // [0] arrivals (monotonic), [1] gave-up flag, [4 + slot * mask_words ...] four mask slots
-  const DevMaskPair* mpairs;   // the world's static pairs with their bounding-circle sums
-  uint32_t seq0;               // barrier sequence number of this launch's first substep
-  uint32_t* gave_up;           // host-mapped word: set (system scope) when a grid barrier gave up waiting; the host reads it
-                               // without a synchronisation at the next call on this world and fails that call
-  int32_t n_mpairs, mask_words;
-  const float* joint_fixed_rot;
-  const float* entity_gravity;
-  int32_t first_substep, n_substeps;
-  int32_t n_steps;    // > 1: persistent rollout, the tile stays in LDS between steps
-  long ft_stride;     // floats between the agent-force slabs of consecutive steps
-  unsigned long long* trace;  // profiling only (env VMAS_TRACE): per-wave s_memtime stamps
-  int32_t ablate;  // profiling only (env VMAS_ABLATE): 1 skip items, 2 skip integration, 4 skip prologue
-};
 
-// The Environment.step() stages fused around the physics (vmas_world_step_env): action ingest as the
-// kernel's prologue, one scenario's reward / observation / done as its epilogue on the LDS tile.
-enum { ENV_NONE = 0, ENV_BALANCE = 1, ENV_TRANSPORT = 2, ENV_INGEST = 3, ENV_NAVIGATION = 4 };  // 3: prologue only
-struct DevEnv {
-  int32_t has_ingest;
-  int32_t ablate;       // profiling only (env VMAS_ENV_ABLATE)
-  int32_t scratch_off;  // floats from the LDS base to the epilogue's scratch (after the step's own LDS)
-  // `ingest.agents` is re-ordered by the host: slot a belongs to AGENT a (action == action_index == NULL: no action
-  // for it), so the prologue reads its slot with one kernarg fetch, no indirection.  Scripts: agent -> script or -1.
-  int8_t script_of_agent[VMAS_ENV_MAX_AGENTS];
-  uint32_t* err_flags;
-  VmasIngestArgs ingest;
-  union {
-    struct { VmasBalanceDesc d; VmasBalanceBuffers o; } balance;
-    struct { VmasTransportDesc d; VmasTransportBuffers o; } transport;
-    struct { VmasNavigationDesc d; VmasNavigationBuffers o; NavWorld w; } navigation;
-  };
-};
-struct NoEnv {};
 
-// Profiling knobs (env VMAS_ABLATE / VMAS_ENV_ABLATE) exist only in -DVMAS_PROFILE builds (scripts/gpu_ablate.sh): in the
-// product build they are the literal 0, so their tests - and the scalar register that carried them through every loop -
-// are compiled out.
-#ifdef VMAS_PROFILE
-#define ABLATE(a) ((a).ablate)
-#else
-#define ABLATE(a) 0
-#endif
 
-__device__ __forceinline__ int sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
-// One word of the pair mask.  A device-scope atomic load: the in-kernel exact broad phase fills the mask of the running
-// substep from every tile of the grid (atomic ORs), and its slots are re-used within one launch.
-__device__ __forceinline__ uint32_t mask_word(const uint32_t* mask, int w) {
-  return __hip_atomic_load(mask + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// A pair may be skipped only on a FINITE squared distance beyond its bound: a NaN or an infinite operand must reach the
-// narrow phase, where the reference's own arithmetic decides (inf * 0, cos(inf) ... = NaN poisons the pair however far
-// apart the shapes are).  Together with the NaN checks on the cos rows of Lines and Boxes this is why no separate
-// "environment has a non-finite pose" flag is needed.
-__device__ __forceinline__ bool far_apart(float d2, float thr2) { return d2 > thr2 && d2 < kInf; }
 
 // cos/sin of the rotation(s) the narrow phase needs (physics.py:300-302, 413)
 __device__ __forceinline__ void write_trig(float* tr, float rot, int shape) {
@@ -283,21 +184,7 @@ __device__ __forceinline__ ItemV load_item(const ItemW& I) {
   K.p2 = __uint_as_float(w3.x); K.p3 = __uint_as_float(w3.y); K.q0 = __uint_as_float(w3.z); K.q1 = __uint_as_float(w3.w);
   return K;
 }
-struct EntV {
-  uint32_t flags; int32_t shape, agent_index, tr_off;  // scalar
-  float mass, inertia, one_minus_drag, max_speed, v_range, lin_friction, ang_friction, gx, gy, max_f, f_range, max_t, t_range;
-};
-__device__ __forceinline__ EntV load_ent(const uint32_t* p) {
-  EntV D;
-  D.flags = (uint32_t)sgpr((int)p[0]); D.shape = sgpr((int)p[1]); D.agent_index = sgpr((int)p[2]); D.tr_off = sgpr((int)p[3]);
-  D.mass = __uint_as_float(p[4]); D.inertia = __uint_as_float(p[5]); D.one_minus_drag = __uint_as_float(p[6]);
-  D.max_speed = __uint_as_float(p[7]); D.v_range = __uint_as_float(p[8]);
-  D.lin_friction = __uint_as_float(p[9]); D.ang_friction = __uint_as_float(p[10]);
-  D.gx = __uint_as_float(p[11]); D.gy = __uint_as_float(p[12]);
-  D.max_f = __uint_as_float(p[13]); D.f_range = __uint_as_float(p[14]); D.max_t = __uint_as_float(p[15]); D.t_range = __uint_as_float(p[16]);
-  return D;
-}
-static_assert(sizeof(DevItem) == 64 && sizeof(DevEntity) == 68, "descriptor layout");
+static_assert(sizeof(DevItem) == 64, "descriptor layout");
 
 // Sphere-sphere partners packed four to a record (same 16 words as a DevItem):
 //   w0: type, n, -, -   w1: own offset, partner offsets 0..2   w2: partner 3, r_sum 0..2
@@ -657,7 +544,8 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
         return;
       }
       if (on && E.ingest.n_scripts > 0 && E.script_of_agent[a] >= 0) {  // scripted: driven by the state about to be stepped
-        run_script(E.ingest.scripts[E.script_of_agent[a]], state, env, live, agent_ft, ld, f3);
+        const VmasAgentScript& SC = E.ingest.scripts[E.script_of_agent[a]];
+        run_script(SC, state + (long)SC.entity * 6 * ld + env, ld, env, live, agent_ft, ld, f3);
         f3[2] = lv ? src[2 * ld] : 0.f;
         return;
       }
@@ -1182,6 +1070,11 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
 #include "vmas_spec_kernel.h"
 
 // ------------------------------------------------------------------------------------
+// lane-compacted form for dense sphere worlds (football): broad phase per environment, narrow phase per contact
+// ------------------------------------------------------------------------------------
+#include "vmas_compact.h"
+
+// ------------------------------------------------------------------------------------
 // batch-global broad phase (World.collides core.py:2797-2801)
 // ------------------------------------------------------------------------------------
 
@@ -1409,6 +1302,17 @@ struct VmasWorld {
   uint32_t nav_seq = 0;
   std::vector<DevLidar> h_lidars;  // host copy of the registered sensors (argument checks of the navigation epilogue)
   std::vector<DevTarget> h_targets;
+  // the lane-compacted kernel's plan (vmas_compact.h): built at creation when the world qualifies
+  struct CompactPlan {
+    bool ok = false;
+    compact::DevCompact dc{};
+    uint32_t* d_blob = nullptr;
+    size_t lds_bytes = 0;
+    int nw = 8, own = 1;
+    float4* d_trig = nullptr;  // cos / sin of the static lines' rotations (environment 0), filled at the first launch
+    bool trig_ready = false;
+  } cp;
+  int compact_mode = -1;  // -1 the library's choice (dense worlds), 0 never, 1 whenever the world qualifies (vmas_world_set_compact)
   // lidars
   DevLidar* d_lidars = nullptr;
   DevTarget* d_targets = nullptr;
@@ -2013,6 +1917,254 @@ static int launch_any_level(VmasWorld* w, Sched* S, float* state, float* aft, lo
   }
 }
 
+
+// ------------------------------------------------------------------------------------
+// the lane-compacted kernel's plan (vmas_compact.h): tile layout, broad-phase units dealt to the waves, the owners' pair
+// lists, all as one descriptor blob.  Built once at creation; worlds that do not qualify keep cp.ok == false.
+// ------------------------------------------------------------------------------------
+static int build_compact(VmasWorld* w) {
+  using namespace compact;
+  VmasWorld::CompactPlan& C = w->cp;
+  C.ok = false;
+  const int nE = w->base.nE, nA = w->base.nA, nP = (int)w->pairs.size();
+  if (nE > 64 || !w->joints.empty() || nP == 0 || nP > 8191) return 0;
+  const VmasEntityDesc* E = w->ents.data();
+  for (const VmasPairDesc& P : w->pairs) {
+    if (P.type != VMAS_PAIR_SS && P.type != VMAS_PAIR_LS) return 0;
+    if (E[P.b].shape != VMAS_SHAPE_SPHERE || (P.type == VMAS_PAIR_LS && E[P.a].shape != VMAS_SHAPE_LINE) ||
+        (P.type == VMAS_PAIR_SS && E[P.a].shape != VMAS_SHAPE_SPHERE))
+      return 0;
+  }
+  auto dyn = [&](int e) { return (E[e].flags & (VMAS_F_MOVABLE | VMAS_F_ROTATABLE)) != 0; };
+  std::vector<int> owned_of(nE, -1), owned;
+  for (int e = 0; e < nE; ++e)
+    if (dyn(e)) { owned_of[e] = (int)owned.size(); owned.push_back(e); }
+  if (owned.empty() || owned.size() > 255) return 0;
+  // the owners' pair lists, in the reference's accumulation order = pair order (core.py:2176-2199)
+  std::vector<std::vector<uint16_t>> lists(owned.size());
+  std::vector<int> pos_a(nP, -1), pos_b(nP, -1);
+  std::vector<bool> in_pair(nE, false);
+  for (int p = 0; p < nP; ++p) {
+    const VmasPairDesc& P = w->pairs[p];
+    in_pair[P.a] = in_pair[P.b] = true;
+    if (dyn(P.a)) {  // (bit 14: the entry adds a torque - a line-sphere pair seen from a rotatable line)
+      const bool tq = P.type == VMAS_PAIR_LS && (E[P.a].flags & VMAS_F_ROTATABLE);
+      pos_a[p] = (int)lists[owned_of[P.a]].size();
+      lists[owned_of[P.a]].push_back((uint16_t)(p | (tq ? 0x4000 : 0)));
+    }
+    if (dyn(P.b)) { pos_b[p] = (int)lists[owned_of[P.b]].size(); lists[owned_of[P.b]].push_back((uint16_t)(p | 0x8000)); }
+  }
+  size_t max_list = 1;
+  for (auto& l : lists) max_list = std::max(max_list, l.size());
+  if (max_list > (size_t)LIST_MAX) return 0;
+  const int hw = (int)((max_list + 31) / 32);
+  // tile layout: a dynamic entity keeps all six rows, a static one that is in a pair its position; then the agent
+  // forces; then cos / sin of every line that is in a pair.  (The kernel derives the same offsets from the three masks.)
+  compact::DevCompact D{};
+  std::vector<int> ent_off(nE, -1), tr_off(nE, -1);
+  int rows = 0;
+  for (int e = 0; e < nE; ++e) {
+    if (dyn(e)) { D.dyn_mask |= 1ull << e; ent_off[e] = rows * ROWF; rows += 6; }
+    else if (in_pair[e]) { D.static_mask |= 1ull << e; ent_off[e] = rows * ROWF; rows += 2; }
+  }
+  const int off_af = rows * ROWF;
+  rows += nA * 3;
+  const int off_tr = rows * ROWF;
+  for (int e = 0; e < nE; ++e)
+    if (in_pair[e] && E[e].shape == VMAS_SHAPE_LINE) { D.line_mask |= 1ull << e; tr_off[e] = rows * ROWF; rows += 2; }
+  if ((long)rows * ROWF >= 65536) return 0;  // (tile offsets are 16-bit fields)
+  // broad-phase units: one "row" entity (a line, or the a-sphere of sphere-sphere pairs) against a RUN of partner spheres
+  // that are equally spaced in the tile, have consecutive pair indices and share the threshold (vmas_compact.h)
+  struct Unit { int row, type, n, stride_rows, first_off, pair0; float thr, cost; };
+  std::vector<Unit> units;
+  auto fbits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+  auto pair_thr = [&](const VmasPairDesc& P) {
+    if (P.type == VMAS_PAIR_SS) { const float m = (E[P.a].radius + E[P.b].radius) + 1e-4f; return m * m; }
+    return (E[P.b].radius + kLineMinDist) + kSkipSlack;
+  };
+  for (int p = 0; p < nP;) {
+    const VmasPairDesc& P0 = w->pairs[p];
+    Unit U{P0.a, P0.type, 1, 0, ent_off[P0.b], p, pair_thr(P0), 0.f};
+    int q = p + 1;
+    while (q < nP && U.n < UNIT_PARTNERS) {
+      const VmasPairDesc& Q = w->pairs[q];
+      if (Q.a != P0.a || Q.type != P0.type || fbits(pair_thr(Q)) != fbits(U.thr)) break;
+      const int step = (ent_off[Q.b] - ent_off[w->pairs[q - 1].b]) / ROWF;
+      if (step <= 0 || step > 255 || (U.n > 1 && step != U.stride_rows)) break;
+      U.stride_rows = step;
+      ++U.n;
+      ++q;
+    }
+    U.cost = (P0.type == VMAS_PAIR_LS ? 14.f + 14.f * U.n : 10.f + 9.f * U.n);
+    units.push_back(U);
+    p = q;
+  }
+  // waves per tile: 8, more if the dynamic entities or the units need them (a wave owns <= OWN_MAX entities and keeps
+  // <= WAVE_UNITS units in its registers)
+  // (16 when every tile of the batch has a CU of its own: the tile's dependent chain is what the launch takes then)
+  int nw = blocks_of(w->batch) <= w->n_cu ? 16 : 8;
+  while (nw < MAX_WAVES && ((int)owned.size() > OWN_MAX * nw || (int)units.size() > WAVE_UNITS * nw)) nw <<= 1;
+  if ((int)owned.size() > OWN_MAX * nw || (int)units.size() > WAVE_UNITS * nw) return 0;
+  const int own_need = ((int)owned.size() + nw - 1) / nw;
+  const int own = own_need <= 1 ? 1 : (own_need <= 2 ? 2 : 4);
+  // deal the units to the waves, heaviest first, always to the least loaded wave that still has room
+  std::vector<std::vector<int>> of_wave(nw);
+  {
+    std::vector<int> order(units.size());
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return units[x].cost > units[y].cost; });
+    std::vector<float> load(nw, 0.f);
+    for (int u : order) {
+      int best = -1;
+      for (int wv = 0; wv < nw; ++wv)
+        if ((int)of_wave[wv].size() < WAVE_UNITS && (best < 0 || load[wv] < load[best])) best = wv;
+      of_wave[best].push_back(u);
+      load[best] += units[u].cost;
+    }
+  }
+  std::vector<uint32_t> blob;
+  auto align4 = [&]() { while (blob.size() % 4) blob.push_back(0); };
+  D.t_owned = (int)blob.size();
+  int list_cursor = 0;
+  for (size_t k = 0; k < owned.size(); ++k) {
+    const int e = owned[k];
+    int n_a = 0;
+    for (uint16_t en : lists[k]) n_a += (en & 0x8000) ? 0 : 1;
+    uint32_t rec[OWNED_W] = {0};
+    rec[0] = (uint32_t)e; rec[1] = (uint32_t)ent_off[e]; rec[2] = (uint32_t)list_cursor; rec[3] = (uint32_t)lists[k].size();
+    rec[4] = (uint32_t)n_a; rec[5] = (uint32_t)tr_off[e];
+    static_assert(sizeof(DevEntity) == 17 * 4 && OWNED_W >= 8 + 17, "owned record");
+    memcpy(rec + 8, &w->dev_ents[e], sizeof(DevEntity));
+    blob.insert(blob.end(), rec, rec + OWNED_W);
+    list_cursor += (int)lists[k].size();
+  }
+  align4();
+  D.t_lists = (int)blob.size();
+  {
+    std::vector<uint16_t> flat;
+    for (auto& l : lists) flat.insert(flat.end(), l.begin(), l.end());
+    if (flat.size() % 2) flat.push_back(0);
+    for (size_t i = 0; i < flat.size(); i += 2) blob.push_back((uint32_t)flat[i] | ((uint32_t)flat[i + 1] << 16));
+  }
+  align4();
+  std::vector<uint32_t> unit_words;
+  std::vector<std::pair<int, int>> wave_range(nw);
+  {
+    int cursor = 0;
+    for (int wv = 0; wv < nw; ++wv) {
+      wave_range[wv].first = cursor;
+      for (int u : of_wave[wv]) {
+        const Unit& U = units[u];
+        unit_words.push_back((uint32_t)ent_off[U.row] | ((uint32_t)(tr_off[U.row] >= 0 ? tr_off[U.row] : 0) << 16));
+        unit_words.push_back((uint32_t)U.type | ((uint32_t)U.n << 8) | ((uint32_t)U.stride_rows << 16));
+        unit_words.push_back((uint32_t)U.first_off | ((uint32_t)U.pair0 << 16));
+        unit_words.push_back(fbits(U.type == VMAS_PAIR_LS ? E[U.row].length / 2.f : 0.f));
+        unit_words.push_back(fbits(U.thr));
+        ++cursor;
+      }
+      wave_range[wv].second = cursor;
+    }
+  }
+  D.t_units = (int)blob.size();
+  blob.insert(blob.end(), unit_words.begin(), unit_words.end());
+  align4();
+  D.t_pairs = (int)blob.size();
+  for (int p = 0; p < nP; ++p) {
+    const VmasPairDesc& P = w->pairs[p];
+    blob.push_back((uint32_t)ent_off[P.a] | ((uint32_t)ent_off[P.b] << 16));
+    blob.push_back((uint32_t)(tr_off[P.a] >= 0 ? tr_off[P.a] : 0) | ((uint32_t)P.type << 16));
+    blob.push_back(fbits(P.type == VMAS_PAIR_SS ? E[P.a].radius + E[P.b].radius : E[P.b].radius + kLineMinDist));
+    blob.push_back(fbits(P.type == VMAS_PAIR_LS ? E[P.a].length / 2.f : 0.f));
+  }
+  align4();
+  D.t_pairhm = (int)blob.size();
+  for (int p = 0; p < nP; ++p) {
+    const VmasPairDesc& P = w->pairs[p];
+    const uint32_t ha = dyn(P.a) ? (uint32_t)((owned_of[P.a] << 8) | pos_a[p]) : 0xffffu;
+    const uint32_t hb = dyn(P.b) ? (uint32_t)((owned_of[P.b] << 8) | pos_b[p]) : 0xffffu;
+    blob.push_back(ha | (hb << 16));
+  }
+  align4();
+  D.t_waves = (int)blob.size();
+  for (int wv = 0; wv < nw; ++wv) { blob.push_back((uint32_t)wave_range[wv].first); blob.push_back((uint32_t)wave_range[wv].second); }
+  align4();
+  D.t_entoff = (int)blob.size();
+  for (int e = 0; e < nE; ++e) blob.push_back((uint32_t)ent_off[e]);
+  align4();
+  D.t_bounds = (int)blob.size();
+  for (int p = 0; p < nP; ++p) blob.push_back(fbits(w->pairs[p].bound_sum));
+  align4();
+  D.blob_words = (int)blob.size();
+  D.off_tr = off_tr;
+  D.off_af = off_af;
+  D.off_tab = rows * ROWF;
+  D.n_owned = (int)owned.size(); D.n_pairs = nP; D.hw = hw;
+  D.mask_words = (nP + 31) / 32;
+  int dyn_at = D.off_tab + D.blob_words;
+  dyn_at = (dyn_at + 3) & ~3;
+  D.off_dyn = dyn_at;
+  // cnt[4] | hit | ballots (u64) | base | keys[CAP] | contacts[CAP] (float4: 16-byte aligned) | xmask
+  size_t dyn_words = 4 + (size_t)((D.n_owned * hw + 1) & ~1) + 2 * (size_t)nP + (size_t)((nP + 1) & ~1) + CAP;
+  dyn_words = (dyn_words + 3) & ~(size_t)3;
+  dyn_words += 4 * (size_t)CAP + (((size_t)D.mask_words + 3) & ~(size_t)3);
+  C.lds_bytes = ((size_t)dyn_at + dyn_words) * sizeof(float);
+  if (C.lds_bytes > 160 * 1024) return 0;
+  if (!w->host_only) {
+    HIP_TRY(upload(&C.d_blob, blob));
+    D.blob = C.d_blob;
+    if (D.line_mask & ~D.dyn_mask) {
+      HIP_TRY(hipMalloc((void**)&C.d_trig, 64 * sizeof(float4)));
+      HIP_TRY(hipMemset(C.d_trig, 0, 64 * sizeof(float4)));
+    }
+  }
+  C.dc = D;
+  C.nw = nw;
+  C.own = own;
+  C.ok = true;
+  return 0;
+}
+
+static bool compact_on(const VmasWorld* w) {
+  if (!w->cp.ok || w->host_only) return false;
+  if (w->compact_mode == 0) return false;
+  if (w->compact_mode == 1) return true;
+  return w->n_pairs >= 64;  // the library's choice: dense worlds (football: 165 pairs); small ones have their specialisations
+}
+
+// one launch of the compacted kernel on `batch` environments starting at state / aft; `pad` as in launch_level
+static int launch_compact(VmasWorld* w, int env_kind, float* state, float* aft, long ld, const DevStepArgs& a, const DevEnv* env,
+                          size_t extra_lds, hipStream_t s, int batch, long pad) {
+  VmasWorld::CompactPlan& C = w->cp;
+  const size_t lds = C.lds_bytes + extra_lds;
+  if (lds > 160 * 1024) return fail("vmas_world_step: %zu bytes of LDS per tile exceed the CU's 160 KB", lds);
+  const int padded = pad >= (long)blocks_of(batch) * TILE ? 1 : 0;
+  if (!C.trig_ready && C.d_trig) {
+    // cos / sin of the static lines, once, from environment 0 (the kernel uses an entry only where a tile's rotations equal
+    // the one it was made from: a value cache, never stale).  Completed before any launch - on whatever queue - can read
+    // it; not under graph capture (no synchronisation there: the kernel computes its own until a later eager launch).
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
+    if (cap == hipStreamCaptureStatusNone) {
+      VmasWorld::CompactPlan& M = w->cp;
+      compact::DevCompact fill = M.dc;
+      if (vmas_compact_fill_trig(fill, state, ld, M.d_trig, s)) return -1;
+      HIP_TRY(hipStreamSynchronize(s));
+      M.dc.trig_cache = M.d_trig;
+      M.trig_ready = true;
+    }
+  }
+  return vmas_compact_launch(env_kind, C.own, C.nw, lds, w->device, w->base, w->cp.dc, state, aft, ld, batch, padded, a, env, s);
+}
+
+// plain physics (no environment stages): the compacted kernel where the world has one and the launch's options allow it
+static int launch_physics(VmasWorld* w, Sched* S, float* state, float* aft, long ld, const DevStepArgs& a, hipStream_t s,
+                          int batch = -1, long pad = -1) {
+  if (batch < 0) { batch = w->batch; pad = ld; }
+  if (compact_on(w) && !a.joint_fixed_rot && !ABLATE(a))
+    return launch_compact(w, ENV_NONE, state, aft, ld, a, nullptr, 0, s, batch, pad);
+  return launch_any_level<ENV_NONE>(w, S, state, aft, ld, a, NoEnv{}, 0, s, batch, pad);
+}
+
 static int step_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld, const VmasStepArgs* args, void* stream,
                      int n_steps, int64_t ft_stride, DevEnv* env = nullptr, int env_kind = ENV_NONE,
                      size_t scratch_fixed = 0, size_t scratch_per_wave = 0, int env_first = 0, int env_count = -1,
@@ -2157,6 +2309,7 @@ int vmas_world_create(const VmasWorldDesc* d, int32_t batch, int32_t device_id, 
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) w->n_cu = prop.multiProcessorCount;
   }
   if (select_config(w)) return -1;
+  if (build_compact(w)) return -1;
   Sched* S = nullptr;
   if (get_sched(w, w->lanes, &S)) return -1;
   if (S->lds_bytes > 160 * 1024) {
@@ -2180,6 +2333,7 @@ void vmas_world_destroy(VmasWorld* w) {
   if (w->ev_fork) (void)hipEventDestroy(w->ev_fork);
   (void)hipFree(w->d_sync); (void)hipFree(w->d_exact_mask); (void)hipFree(w->d_nav_mask); (void)hipFree(w->d_nav_sync);
   if (w->h_gave_up) (void)hipHostFree(w->h_gave_up);
+  (void)hipFree(w->cp.d_blob); (void)hipFree(w->cp.d_trig);
   (void)hipFree(w->d_mpairs); (void)hipFree(w->d_trace);
   (void)hipFree(w->d_lidars); (void)hipFree(w->d_targets); (void)hipFree(w->d_angles); (void)hipFree(w->d_queries);
   (void)hipFree(w->d_angles_cs);
@@ -2240,6 +2394,14 @@ int vmas_world_get_specialized(VmasWorld* w) {  // 1: plain World.step launches 
   if (get_sched(w, w->lanes, &S)) return 0;
   return (w->use_spec && S->spec_id >= 0) ? 1 : 0;
 }
+
+int vmas_world_set_compact(VmasWorld* w, int32_t mode) {
+  if (!w) return fail("vmas_world_set_compact: null world");
+  if (mode < -1 || mode > 1) return fail("vmas_world_set_compact: mode must be -1 (library's choice), 0 (off) or 1 (on), got %d", mode);
+  w->compact_mode = mode;
+  return 0;
+}
+int vmas_world_get_compact(VmasWorld* w) { return (w && compact_on(w)) ? 1 : 0; }
 
 int vmas_world_exact_status(VmasWorld* w) {
   if (!w) return fail("vmas_world_exact_status: null world");
@@ -2330,6 +2492,10 @@ static int nav_epilogue_plan(VmasWorld* w, const VmasNavigationDesc* d, size_t* 
 int vmas_world_step_env_check(VmasWorld* w, int32_t post_kind, const void* post_desc) {
   if (!w || !post_desc) return fail("vmas_world_step_env_check: null argument");
   if (w->host_only) return fail("vmas_world_step_env_check: a planning world (device -1) cannot be stepped");
+  if (post_kind == VMAS_POST_FOOTBALL) {  // the compacted kernel runs this world (its epilogue needs no LDS of its own)
+    if (!compact_on(w)) return fail("vmas_world_step_env_check: the football epilogue needs the lane-compacted step kernel");
+    return 0;
+  }
   if (post_kind != VMAS_POST_NAVIGATION) return fail("vmas_world_step_env_check: post_kind %d", post_kind);
   const auto* d = (const VmasNavigationDesc*)post_desc;
   size_t fixed = 0, per_wave = 0, extra = 0;
@@ -2353,7 +2519,7 @@ int vmas_world_rollout_env(VmasWorld* w, float* state, float* agent_ft, int64_t 
                            const void* post_buffers, int32_t n_steps, void* stream) {
   if (n_steps <= 0) return fail("vmas_world_rollout_env: n_steps must be > 0, got %d", n_steps);
   if (!ingest) return fail("vmas_world_rollout_env: the steps' actions come through `ingest`");
-  if (ingest->n_scripts > 0 && n_steps > 1)
+  if (ingest->n_scripts > 0 && n_steps > 1 && !(w && compact_on(w)))  // (the compacted kernel runs the scripts on its tile)
     return fail("vmas_world_rollout_env: scripted agents read the state in HBM, which a multi-step launch does not refresh");
   return step_env_impl(w, state, agent_ft, ld, args, ingest, err_flags, post_kind, post_desc, post_buffers, n_steps, stream);
 }
@@ -2440,6 +2606,26 @@ static int step_env_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld
       return vmas::launch_navigation_collisions(d, o, w->batch, state, ld, w->d_nav_mask, (w->n_pairs + 31) / 32, stream);
     return 0;
   }
+  if (post_kind == VMAS_POST_FOOTBALL) {
+    const auto* d = (const VmasFootballDesc*)post_desc;
+    const auto* o = (const VmasFootballBuffers*)post_buffers;
+    const int n = d->n_blue + d->n_red;
+    if (d->n_blue < 1 || d->n_red < 1 || n + 1 > VMAS_ENV_MAX_AGENTS || d->agent0 < 0 || d->agent0 + n + 1 > w->base.nE)
+      return fail("vmas_world_step_env: football team sizes / agent0 out of range");
+    for (int slot = 0; slot <= n; ++slot) {  // the epilogue reads slot k's rows at agent0 + k and its forces at agent index k
+      const VmasEntityDesc& e = w->ents[d->agent0 + slot];
+      if (!(e.flags & VMAS_F_AGENT) || e.agent_index != slot || !(e.flags & (VMAS_F_MOVABLE | VMAS_F_ROTATABLE)))
+        return fail("vmas_world_step_env: football entity %d is not the dynamic agent of index %d", d->agent0 + slot, slot);
+    }
+    const int adv = d->observe_adversaries ? 1 : 0, mates = d->observe_teammates ? 1 : 0;
+    if (d->n_red * adv + (d->n_blue - 1) * mates != d->n_blue * adv + (d->n_red - 1) * mates)
+      return fail("vmas_world_step_env: the football epilogue writes one [n_agents][batch][obs_dim] block (equal observation sizes)");
+    if (!o->pos_shaping || !o->obs || !o->rew || !o->terms || !o->touching || !o->done)
+      return fail("vmas_world_step_env: null football buffer");
+    env.football.d = *d;
+    env.football.o = *o;
+    return step_impl(w, state, agent_ft, ld, args, stream, n_steps, 0, &env, ENV_FOOTBALL, 0, 0);
+  }
   if (post_kind == VMAS_POST_NONE) return step_impl(w, state, agent_ft, ld, args, stream, n_steps, 0, &env, ENV_INGEST, 0, 0);
   return fail("vmas_world_step_env: post_kind %d has no fused epilogue", post_kind);
 }
@@ -2514,7 +2700,7 @@ static int step_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld, co
         if (vmas_world_pair_mask(w, state, ld, w->d_exact_mask, stream)) return -1;
         DevStepArgs b = a;
         b.pair_mask = w->d_exact_mask; b.first_substep = sub; b.n_substeps = 1;
-        if (launch_any_level<ENV_NONE>(w, S, state, agent_ft, ld, b, NoEnv{}, 0, s)) return -1;
+        if (launch_physics(w, S, state, agent_ft, ld, b, s)) return -1;
       }
       return 0;
     }
@@ -2524,10 +2710,18 @@ static int step_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld, co
   auto launch = [&]() -> int {
     if (env_count >= 0) {  // a sub-range of the batch (vmas_world_step_n over two queues): plain physics, no optional inputs
       if (env_kind != ENV_NONE || args) return fail("vmas_world_step: environment sub-ranges take no optional inputs");
-      return launch_any_level<ENV_NONE>(w, S, state + env_first, agent_ft ? agent_ft + env_first : nullptr, ld, a, NoEnv{}, 0,
-                                        s, env_count, (long)ld - env_first);
+      return launch_physics(w, S, state + env_first, agent_ft ? agent_ft + env_first : nullptr, ld, a, s, env_count,
+                            (long)ld - env_first);
     }
-    if (env_kind == ENV_NONE) return launch_any_level<ENV_NONE>(w, S, state, agent_ft, ld, a, NoEnv{}, 0, s);
+    if (env_kind == ENV_NONE) return launch_physics(w, S, state, agent_ft, ld, a, s);
+    const bool cp = compact_on(w) && !a.joint_fixed_rot && !ABLATE(a) && !ABLATE(*env);
+    if (env_kind == ENV_INGEST && cp) return launch_compact(w, ENV_INGEST, state, agent_ft, ld, a, env, 0, s, w->batch, ld);
+    if (env_kind == ENV_FOOTBALL) {
+      if (!cp) return fail("vmas_world_step_env: the football epilogue runs behind the compacted step kernel, which this world / "
+                           "this launch does not use (vmas_world_set_compact, per-environment joint inputs)");
+      env->scratch_off = (int32_t)(w->cp.lds_bytes / sizeof(float));  // (unused: the epilogue stores without LDS staging)
+      return launch_compact(w, ENV_FOOTBALL, state, agent_ft, ld, a, env, 0, s, w->batch, ld);
+    }
     if (S->nw < 2 && env_kind != ENV_INGEST && env_kind != ENV_NAVIGATION)
       return fail("vmas_world_step_env: the fused epilogue needs at least 2 waves per tile");
     size_t extra = 0;

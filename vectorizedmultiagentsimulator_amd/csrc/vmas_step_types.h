@@ -1,0 +1,134 @@
+// vmas_step_types.h - device-side types shared by the step kernels (vmas_hip.hip: the schedule interpreter and its
+// world-specialised form; vmas_compact.hip: the lane-compacted form) and the host code that launches them.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vmas_hip.h"
+#include "vmas_env_device.h"
+
+using namespace vmas;
+
+struct DevItem;
+
+constexpr int TILE = 64;       // environments per block = lanes per wave
+constexpr int MAX_WAVES = 16;  // waves (workers) per tile (8 for the register-heavy box-box level)
+constexpr float kSkipSlack = 1e-3f;  // fp slack of the conservative broad-phase distances
+constexpr int ROWF = TILE;     // floats per LDS row
+
+struct DevEntity {
+  uint32_t flags;
+  int32_t shape;
+  int32_t agent_index;
+  int32_t tr_off;  // tile offset of its 4 trig rows, -1 for spheres
+  float mass, inertia, one_minus_drag;
+  float max_speed, v_range, lin_friction, ang_friction;
+  float gx, gy;
+  float max_f, f_range, max_t, t_range;
+};
+
+struct DevWorld {
+  int32_t nE, nA, substeps;
+  int32_t off_af;  // tile offset of the agent force rows
+  // Which entities need cos/sin rows (bit e: a Line or a Box | a Box), straight from the kernel arguments so that the load
+  // phase does not wait for the descriptor blob: entity e's four trig rows start at row_tr + 4 * popcount(trig_mask below e).
+  // trig_in_args == 0: more than 64 entities, shapes and offsets come from the blob behind a barrier of their own.
+  unsigned long long trig_mask, box_mask;
+  int32_t trig_in_args, row_tr;
+  float sub_dt, gx, gy;
+  int32_t has_gravity;
+  float xs, ys;  // NaN = unbounded
+  float k, tcf;
+  float c_coll, c_joint_att, c_joint_rep;  // fp32(sign * force_multiplier)
+  // One descriptor blob per schedule, staged into LDS by the whole block with coalesced loads
+  // while the state rows are in flight.  (Scalar/vector loads of descriptors from a cache that
+  // is cold at every launch cost ~600 cycles per dependent fetch - 2-4 us of a 13 us step.)
+  //   [ents | segs | owned | items]   word offsets below; counters live right after the blob
+  const uint32_t* blob;
+  int32_t blob_words;   // words staged (items only when they fit the LDS budget)
+  int32_t off_blob;     // tile offset (floats) of the blob copy in LDS
+  int32_t b_ent, b_segs, b_owned, b_refs, b_items;
+  int32_t n_segs, n_owned;
+  int32_t items_in_lds;
+  int32_t fired_recs;    // shared sphere-sphere records (eval_ssp) that publish which of their pairs fired (<= 16)
+  const DevItem* items;  // global copy, used when the item list is too big for LDS
+};
+
+// (DevMaskPair, DevLidar, DevTarget: vmas_env_device.h - the navigation epilogue uses them too)
+struct DevStepArgs {
+  const uint32_t* pair_mask;
+  // in-kernel exact broad phase (vmas_world_step with exact_broad_phase on a grid of at most one tile per CU): the
+  // batch-global `.any()` of World.collides (core.py:2797-2801) evaluated at the top of every substep by all tiles
+  // together - bits ORed into a ring of mask slots with device-scope atomics, then a grid-wide barrier on `sync[0]`
+  uint32_t* sync;              // [0] arrivals (monotonic), [1] gave-up flag, [4 + slot * mask_words ...] four mask slots
+  const DevMaskPair* mpairs;   // the world's static pairs with their bounding-circle sums
+  uint32_t seq0;               // barrier sequence number of this launch's first substep
+  uint32_t* gave_up;           // host-mapped word: set (system scope) when a grid barrier gave up waiting; the host reads it
+                               // without a synchronisation at the next call on this world and fails that call
+  int32_t n_mpairs, mask_words;
+  const float* joint_fixed_rot;
+  const float* entity_gravity;
+  int32_t first_substep, n_substeps;
+  int32_t n_steps;    // > 1: persistent rollout, the tile stays in LDS between steps
+  long ft_stride;     // floats between the agent-force slabs of consecutive steps
+  unsigned long long* trace;  // profiling only (env VMAS_TRACE): per-wave s_memtime stamps
+  int32_t ablate;  // profiling only (env VMAS_ABLATE): 1 skip items, 2 skip integration, 4 skip prologue
+};
+
+// The Environment.step() stages fused around the physics (vmas_world_step_env): action ingest as the
+// kernel's prologue, one scenario's reward / observation / done as its epilogue on the LDS tile.
+enum { ENV_NONE = 0, ENV_BALANCE = 1, ENV_TRANSPORT = 2, ENV_INGEST = 3, ENV_NAVIGATION = 4, ENV_FOOTBALL = 5 };  // 3: prologue only
+struct DevEnv {
+  int32_t has_ingest;
+  int32_t ablate;       // profiling only (env VMAS_ENV_ABLATE)
+  int32_t scratch_off;  // floats from the LDS base to the epilogue's scratch (after the step's own LDS)
+  // `ingest.agents` is re-ordered by the host: slot a belongs to AGENT a (action == action_index == NULL: no action
+  // for it), so the prologue reads its slot with one kernarg fetch, no indirection.  Scripts: agent -> script or -1.
+  int8_t script_of_agent[VMAS_ENV_MAX_AGENTS];
+  uint32_t* err_flags;
+  VmasIngestArgs ingest;
+  union {
+    struct { VmasBalanceDesc d; VmasBalanceBuffers o; } balance;
+    struct { VmasTransportDesc d; VmasTransportBuffers o; } transport;
+    struct { VmasNavigationDesc d; VmasNavigationBuffers o; NavWorld w; } navigation;
+    struct { VmasFootballDesc d; VmasFootballBuffers o; } football;  // (epilogue of the compact kernel only, vmas_compact.h)
+  };
+};
+struct NoEnv {};
+
+// Profiling knobs (env VMAS_ABLATE / VMAS_ENV_ABLATE) exist only in -DVMAS_PROFILE builds (scripts/gpu_ablate.sh): in the
+// product build they are the literal 0, so their tests - and the scalar register that carried them through every loop -
+// are compiled out.
+#ifdef VMAS_PROFILE
+#define ABLATE(a) ((a).ablate)
+#else
+#define ABLATE(a) 0
+#endif
+
+__device__ __forceinline__ int sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// One word of the pair mask.  A device-scope atomic load: the in-kernel exact broad phase fills the mask of the running
+// substep from every tile of the grid (atomic ORs), and its slots are re-used within one launch.
+__device__ __forceinline__ uint32_t mask_word(const uint32_t* mask, int w) {
+  return __hip_atomic_load(mask + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// A pair may be skipped only on a FINITE squared distance beyond its bound: a NaN or an infinite operand must reach the
+// narrow phase, where the reference's own arithmetic decides (inf * 0, cos(inf) ... = NaN poisons the pair however far
+// apart the shapes are).  Together with the NaN checks on the cos rows of Lines and Boxes this is why no separate
+// "environment has a non-finite pose" flag is needed.
+__device__ __forceinline__ bool far_apart(float d2, float thr2) { return d2 > thr2 && d2 < kInf; }
+
+struct EntV {
+  uint32_t flags; int32_t shape, agent_index, tr_off;  // scalar
+  float mass, inertia, one_minus_drag, max_speed, v_range, lin_friction, ang_friction, gx, gy, max_f, f_range, max_t, t_range;
+};
+__device__ __forceinline__ EntV load_ent(const uint32_t* p) {
+  EntV D;
+  D.flags = (uint32_t)sgpr((int)p[0]); D.shape = sgpr((int)p[1]); D.agent_index = sgpr((int)p[2]); D.tr_off = sgpr((int)p[3]);
+  D.mass = __uint_as_float(p[4]); D.inertia = __uint_as_float(p[5]); D.one_minus_drag = __uint_as_float(p[6]);
+  D.max_speed = __uint_as_float(p[7]); D.v_range = __uint_as_float(p[8]);
+  D.lin_friction = __uint_as_float(p[9]); D.ang_friction = __uint_as_float(p[10]);
+  D.gx = __uint_as_float(p[11]); D.gy = __uint_as_float(p[12]);
+  D.max_f = __uint_as_float(p[13]); D.f_range = __uint_as_float(p[14]); D.max_t = __uint_as_float(p[15]); D.t_range = __uint_as_float(p[16]);
+  return D;
+}
+static_assert(sizeof(DevEntity) == 68, "descriptor layout");

@@ -372,7 +372,7 @@ class Environment:
         no per-step checks, allocations or views on the host (a ``step()`` from Python costs 18 us of them around an
         11 us kernel; SURVEY.md 8f-3, the policy-in-the-loop case that ``rollout()`` does not cover).  The outputs are
         static buffers owned by the environment, overwritten by the next ``step_bound()``.  For the scenarios whose
-        step is one launch (balance, transport, navigation while a tile has a CU to itself), ``validate_actions=False``
+        step is one launch (balance, transport, football, navigation while a tile has a CU to itself), ``validate_actions=False``
         (the reference's asserts are a host sync per step)."""
         assert self._one_launch, "bind() needs a scenario whose Environment.step is one launch"
         assert not self.validate_actions, "bind() needs validate_actions=False (the asserts are a host sync per step)"
@@ -399,7 +399,8 @@ class Environment:
                 post.static_outputs = keep
         self._launch(self._post.kind, b[0], b[1], False)
         self._lidar_cache = None
-        return b[2]
+        fin = getattr(self._post, "finish", None)  # (tensor ops on the step's outputs: football's red rewards)
+        return b[2] if fin is None else fin(b[2])
 
     def _step_eager(self, actions):
         assert len(actions) == self.n_agents, f"Expecting actions for {self.n_agents}, got {len(actions)} actions"
@@ -411,7 +412,8 @@ class Environment:
             desc, buffers, result = self._post.prepare()
             self._launch(self._post.kind, desc, buffers, False)
             self._lidar_cache = None
-            return result
+            fin = getattr(self._post, "finish", None)  # (tensor ops on the step's outputs: football's red rewards, ball_pos)
+            return result if fin is None else fin(result)
         if self._ingest_in_step:
             self._ingest.prepare(actions)
             if self.validate_actions:

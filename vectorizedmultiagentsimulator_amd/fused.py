@@ -225,10 +225,13 @@ class MaskedReset:
     """``vmas_env_reset_where``: Environment.reset_at for every masked environment in one launch.
 
     The scenario describes its ``reset_world_at`` as a spawn program (``scenario.fused_reset_program()``):
-    ``ops``   - ("uniform", entity, (x_lo, x_hi), (y_lo, y_hi), min_dist, avoid_from_op) |
-                ("offset", entity, base_entity, (dx_lo, dx_hi), dy) | ("fixed", entity, x, y), in placement order;
+    ``ops``   - ("uniform", entity, (x_lo, x_hi), (y_lo, y_hi), min_dist, avoid_from_op[, rot]) |
+                ("offset", entity, base_entity, (dx_lo, dx_hi), dy) | ("fixed", entity, x, y[, rot]), in placement order
+                (``rot``: the entity's rotation is set as well);
     ``terms`` - (tensor [B], entity_a, entity_b, factor): tensor[env] = |pos(a) - pos(b)| * factor, or
-                (tensor [B], None, None, value): tensor[env] = value;
+                (tensor [B], None, None, value): tensor[env] = value, or
+                (tensor [B], "point", entity, (px, py), factor): |pos(entity) - (px, py)| * factor, or
+                (tensor [B], "min", [entities], entity_b, factor): min over the (consecutive) entities of |pos - pos(b)| * factor;
     ``flags`` - bool tensors [B] cleared for a reset environment."""
 
     def __init__(self, env, program: dict, seed: int):
@@ -241,23 +244,41 @@ class MaskedReset:
         for i, op in enumerate(ops):
             o = args.ops[i]
             if op[0] == "uniform":
-                _, ent, xb, yb, min_dist, avoid_from = op
+                _, ent, xb, yb, min_dist, avoid_from = op[:6]
                 o.kind, o.entity, o.avoid_from = A.SPAWN_UNIFORM, ent._index, int(avoid_from)
                 o.x_lo, o.x_hi, o.y_lo, o.y_hi, o.min_dist = float(xb[0]), float(xb[1]), float(yb[0]), float(yb[1]), float(min_dist)
+                if len(op) > 6 and op[6] is not None:
+                    o.has_rot, o.rot = 1, float(op[6])
             elif op[0] == "offset":
                 _, ent, base, dxb, dy = op
                 o.kind, o.entity, o.base = A.SPAWN_OFFSET, ent._index, base._index
                 o.x_lo, o.x_hi, o.y_lo = float(dxb[0]), float(dxb[1]), float(dy)
             else:
-                _, ent, x, y = op
+                _, ent, x, y = op[:4]
                 o.kind, o.entity, o.x_lo, o.y_lo = A.SPAWN_FIXED, ent._index, float(x), float(y)
+                if len(op) > 4 and op[4] is not None:
+                    o.has_rot, o.rot = 1, float(op[4])
         self._terms = terms
-        for i, (t, a, b, f) in enumerate(terms):
+        for i, term in enumerate(terms):
             T = args.terms[i]
-            T.a, T.b, T.factor = (a._index, b._index, float(f)) if a is not None else (-1, -1, float(f))
+            if term[1] == "point":
+                _, _, ent, (px, py), f = term
+                T.kind, T.a, T.b, T.px, T.py, T.factor = A.TERM_DIST_POINT, ent._index, -1, float(px), float(py), float(f)
+            elif term[1] == "min":
+                _, _, ents, b, f = term
+                idx = [e._index for e in ents]
+                assert idx == list(range(idx[0], idx[0] + len(idx))), "a 'min' term takes consecutive entities"
+                T.kind, T.a, T.n, T.b, T.factor = A.TERM_MIN_DIST, idx[0], len(idx), b._index, float(f)
+            else:
+                t, a, b, f = term
+                T.kind = A.TERM_DIST
+                T.a, T.b, T.factor = (a._index, b._index, float(f)) if a is not None else (-1, -1, float(f))
         self._flags = flags
         self.episode = torch.zeros(env.num_envs, dtype=torch.int32, device=env.device)
         args.episode = self.episode.data_ptr()
+        #: [1] placements that hit the kernel's try cap and kept an overlapping position (0 for every feasible program)
+        self.gave_up = torch.zeros(1, dtype=torch.int32, device=env.device)
+        args.gave_up = self.gave_up.data_ptr()
         args.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         self.args = args
         self.nE, self.nA = len(w.entities), len(w.agents)
@@ -716,49 +737,98 @@ class FootballPost(_Post):
         for n, row in zip(names, self._shaping_rows):  # the ball's shaping terms live in one [4, B] block
             setattr(ball, n, row)
         self._shaping_names = names
+        # as the epilogue of the step kernel (one launch per Environment.step, K steps per launch in rollout()): worlds that
+        # run the lane-compacted kernel (csrc/vmas_compact.h) - the default for football
+        be = w._get_backend()
+        self.kind = A.POST_FOOTBALL if (be.compact and self.lib.vmas_world_step_env_check(be._h, A.POST_FOOTBALL, C.byref(d)) == 0) else None
 
     def persistent_tensors(self):
         return [self.pos_shaping]
 
-    def __call__(self):
-        env, sc, w = self.env, self.env.scenario, self.env.world
-        ball = sc.ball
+    def _rebind_shaping(self):
+        ball = self.env.scenario.ball
         for n, row in zip(self._shaping_names, self._shaping_rows):  # reset() may have rebound them
             cur = getattr(ball, n)
             if cur.data_ptr() != row.data_ptr():
                 row.copy_(cur)
                 setattr(ball, n, row)
+
+    def prepare(self):
+        """(descriptor, buffers, what env.step returns) - outputs allocated and bound to the scenario's attributes, nothing
+        launched.  ``finish(result)`` completes the infos once the step has been enqueued."""
+        env, sc, w = self.env, self.env.scenario, self.env.world
+        ball = sc.ball
+        self._rebind_shaping()
         obs, rew, done = self._outputs(self.obs_dim)
         if not self.static_outputs or getattr(self, "_terms", None) is None:
             self._terms = (torch.empty(len(self.TERMS), self.B, device=self.dev),
                            torch.empty(2, self.B, device=self.dev, dtype=torch.bool))
         terms, touching = self._terms
-        b = A.FootballBuffers()
+        b = self._buffers(A.FootballBuffers)
         b.pos_shaping = self.pos_shaping.data_ptr()
         b.obs, b.rew, b.done = obs.data_ptr(), rew.data_ptr(), done.data_ptr()
         b.terms, b.touching = terms.data_ptr(), touching.data_ptr()
         b.agent_ft = w._packed_agent_ft().data_ptr()
-        b.limit = self._limit()
-        st, ld = self._state()
-        _check(self.lib.vmas_football_post_step(C.byref(self.desc), C.byref(b), self.B, st, ld, _stream(self.dev)))
         t = dict(zip(self.TERMS, terms.unbind(0)))
         sc._sparse_reward_blue, sc._done = t["sparse_reward_blue"], done
         ball.pos_rew_blue, ball.pos_rew_red = t["pos_rew_blue"], t["pos_rew_red"]
         ball.pos_rew_agent_blue, ball.pos_rew_agent_red = t["pos_rew_agent_blue"], t["pos_rew_agent_red"]
         sc.min_agent_dist_to_ball_blue, sc.min_agent_dist_to_ball_red = (
             t["min_agent_dist_to_ball_blue"], t["min_agent_dist_to_ball_red"])
-        ball_pos = ball.state.pos if self.static_outputs else ball.state.pos.clone()  # (not a live view of the state)
-        sparse_red = None
         infos = []
         for a in env.agents:
             side = "blue" if a in sc.blue_agents else "red"
-            if side == "red" and sparse_red is None:
-                sparse_red = sc._sparse_reward_red = -t["sparse_reward_blue"]
             infos.append({
-                "sparse_reward": t["sparse_reward_blue"] if side == "blue" else sparse_red,
+                "sparse_reward": t["sparse_reward_blue"],  # (red: negated in finish(), once the kernel has been enqueued)
                 "ball_goal_pos_rew": t[f"pos_rew_{side}"], "all_agent_ball_pos_rew": t[f"pos_rew_agent_{side}"],
-                "ball_pos": ball_pos, "dist_ball_to_goal": t[f"dist_ball_to_goal_{side}"],
+                "ball_pos": None, "dist_ball_to_goal": t[f"dist_ball_to_goal_{side}"],
                 "min_agent_dist_to_ball": t[f"min_agent_dist_to_ball_{side}"],
                 "touching_ball": touching[0 if side == "blue" else 1],
             })
-        return list(obs.unbind(0)), list(rew.unbind(0)), done, infos
+        return self.desc, b, (list(obs.unbind(0)), list(rew.unbind(0)), done, infos)
+
+    def finish(self, result):
+        """The parts of the infos that are tensor ops on the step's outputs (stream-ordered behind the launch)."""
+        env, sc = self.env, self.env.scenario
+        ball = sc.ball
+        ball_pos = ball.state.pos if self.static_outputs else ball.state.pos.clone()  # (not a live view of the state)
+        sparse_red = None
+        for a, info in zip(env.agents, result[3]):
+            info["ball_pos"] = ball_pos
+            if a not in sc.blue_agents:
+                if sparse_red is None:
+                    sparse_red = sc._sparse_reward_red = -sc._sparse_reward_blue
+                info["sparse_reward"] = sparse_red
+        return result
+
+    def prepare_rollout(self, n_steps: int):
+        env, sc, K, n, B = self.env, self.env.scenario, int(n_steps), self.n, self.B
+        self._rebind_shaping()
+        out = {
+            "obs": torch.empty(K, n, B, self.obs_dim, device=self.dev), "rew": torch.empty(K, n, B, device=self.dev),
+            "done": torch.empty(K, B, device=self.dev, dtype=torch.bool),
+            "terms": torch.empty(K, len(self.TERMS), B, device=self.dev),
+            "touching_ball": torch.empty(K, 2, B, device=self.dev, dtype=torch.bool),
+        }
+        b = A.FootballBuffers()
+        b.limit = self._limit()
+        b.pos_shaping = self.pos_shaping.data_ptr()
+        b.obs, b.rew, b.done = out["obs"].data_ptr(), out["rew"].data_ptr(), out["done"].data_ptr()
+        b.terms, b.touching = out["terms"].data_ptr(), out["touching_ball"].data_ptr()
+        b.agent_ft = env.world._packed_agent_ft().data_ptr()
+        t = dict(zip(self.TERMS, out["terms"][-1].unbind(0)))  # scenario / ball attributes: the last step's
+        ball = sc.ball
+        sc._sparse_reward_blue, sc._done = t["sparse_reward_blue"], out["done"][-1]
+        ball.pos_rew_blue, ball.pos_rew_red = t["pos_rew_blue"], t["pos_rew_red"]
+        ball.pos_rew_agent_blue, ball.pos_rew_agent_red = t["pos_rew_agent_blue"], t["pos_rew_agent_red"]
+        sc.min_agent_dist_to_ball_blue, sc.min_agent_dist_to_ball_red = (
+            t["min_agent_dist_to_ball_blue"], t["min_agent_dist_to_ball_red"])
+        for i, name in enumerate(self.TERMS):
+            out[name] = out["terms"][:, i]
+        return self.desc, b, out
+
+    def __call__(self):
+        desc, b, result = self.prepare()
+        st, ld = self._state()
+        _check(self.lib.vmas_football_post_step(C.byref(desc), C.byref(b), self.B, st, ld, _stream(self.dev)))
+        return self.finish(result)

@@ -327,6 +327,33 @@ class Scenario(BaseScenario):
         return [dict(kind=_abi.SCRIPT_FOOTBALL_BALL, agent=self.ball,
                      params=[self.agent_size * 2, self.pitch_width / 2, self.pitch_length / 2, self.goal_size / 2])]
 
+    def fused_reset_program(self):
+        """``reset_world_at`` (football.py:162-171: reset_agents 388-414, reset_ball 512-584, reset_walls / reset_goals
+        686-1020) as a spawn program for ``vmas_env_reset_where``: blue agents uniform in the left half, red agents uniform
+        in the right half and turned by pi, the ball at the centre (World.reset zeroed it), every wall and goal line at its
+        fixed pose; then the ball's four shaping terms and the two closest-agent distances.  Formation spawning draws a
+        permutation on the host: tensor path."""
+        if self.spawn_in_formation:
+            return None
+        import math
+        L, Wd, r = self.pitch_length, self.pitch_width, self.agent_size
+        # torch.rand * [L / 2, W] + offset (football.py:465-490): U([offset, offset + range))
+        blue_x, red_x, ys = (-L / 2 + r, r), (-r, L / 2 - r), (-Wd / 2, Wd / 2)
+        ops = [("uniform", a, blue_x, ys, 0.0, i) for i, a in enumerate(self.blue_agents)]
+        ops += [("uniform", a, red_x, ys, 0.0, len(self.blue_agents) + i, math.pi) for i, a in enumerate(self.red_agents)]
+        ops += [("fixed", lm, pos[0], pos[1], rot) for lm, (_, _, _, pos, rot) in zip(self._static_landmarks, self._static)]
+        ball = self.ball
+        right, left = self.right_goal_pos.tolist(), self.left_goal_pos.tolist()
+        terms = [
+            (lambda: self.min_agent_dist_to_ball_blue, "min", self.blue_agents, ball, 1.0),
+            (lambda: self.min_agent_dist_to_ball_red, "min", self.red_agents, ball, 1.0),
+            (lambda: ball.pos_shaping_blue, "point", ball, right, self.pos_shaping_factor_ball_goal),
+            (lambda: ball.pos_shaping_red, "point", ball, left, self.pos_shaping_factor_ball_goal),
+            (lambda: ball.pos_shaping_agent_blue, "min", self.blue_agents, ball, self.pos_shaping_factor_agent_ball),
+            (lambda: ball.pos_shaping_agent_red, "min", self.red_agents, ball, self.pos_shaping_factor_agent_ball),
+        ]
+        return {"ops": ops, "terms": terms, "flags": [lambda: self._done]}
+
     def make_fused_post(self, env):
         """reward + observation + done + info of every agent as one kernel (fused.FootballPost)."""
         from .. import _abi
