@@ -51,6 +51,8 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10000)
     ap.add_argument("--warmup", type=int, default=500)
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the K-step window is timed this many times (each between its own fences); `value` = the median window")
     ap.add_argument("--num-envs", type=int, default=32768, help="environments PER GPU")
     ap.add_argument("--n-agents", type=int, default=4)
     ap.add_argument("--lanes", type=int, default=0, help="lanes per environment (0 = library default)")
@@ -230,11 +232,13 @@ def cpu_reference(w, actions, state0_cpu, n_agents, budget_s=10.0):
 
 
 # ------------------------------------------------------------------------------------------------ gather
-def time_rollout_gather(dist, shard_cls, gather_cls, rank, world_size, device, per_gpu_envs, t_steps=100,
+def time_rollout_gather(dist, shard_cls, packed_cls, rank, world_size, device, per_gpu_envs, t_steps=100,
                         max_chunk_bytes=2 << 30, shrink=1):
-    """End-of-rollout all-gather, the ONLY collective of the pipeline: obs [T, b, A, D], rew [T, b, A],
-    done [T, b] of a T-step rollout, for the shapes of BASELINE configs 2 / 4 / 5, gathered in chunks of steps so
-    that the gathered chunk stays below ``max_chunk_bytes`` (config 5: 46 GB per 100-step rollout on 8 GPUs)."""
+    """End-of-rollout all-gather, the ONLY collective of the pipeline, for the shapes of BASELINE configs
+    2 / 4 / 5: every rank's rollout chunk is ONE packed buffer [b, T, W] (environment axis first: observations, rewards,
+    done of a step side by side, shard.PackedRollout) and the exchange ONE all_gather_into_tensor per chunk, straight into
+    the global buffer - no copies around it.  Chunks of steps keep the gathered buffer below ``max_chunk_bytes`` (config 5:
+    46 GB per 100-step rollout on 8 GPUs)."""
     import torch
 
     shapes = {  # name: (envs per GPU, agents, obs dim)
@@ -245,30 +249,28 @@ def time_rollout_gather(dist, shard_cls, gather_cls, rank, world_size, device, p
     out = {}
     for name, (b, A, D) in shapes.items():
         shard = shard_cls(b * world_size, rank, world_size)
-        g = gather_cls(shard)
-        step_bytes = b * (A * D * 4 + A * 4 + 1) * world_size
+        step_bytes = b * (A * D + A + 1) * 4 * world_size
         tc = max(1, min(t_steps, max_chunk_bytes // step_bytes))
-        bufs = {"obs": torch.zeros(tc, b, A, D, device=device), "rew": torch.zeros(tc, b, A, device=device),
-                "done": torch.zeros(tc, b, device=device, dtype=torch.bool)}
-        g.gather(bufs, env_dim=1)  # warm-up (communicator set-up)
+        pr = packed_cls(shard, tc, A, D, device)
+        pr.gather()  # warm-up (communicator set-up, the output buffer)
         _sync(device)
         dist.barrier()
         t0 = time.perf_counter()
         done = 0
         while done < t_steps:
-            n = min(tc, t_steps - done)
-            res = g.gather({k: v[:n] for k, v in bufs.items()}, env_dim=1)
-            done += n
+            res = pr.gather()
+            done += tc
         _sync(device)
         el = time.perf_counter() - t0
-        assert res["obs"].shape[1] == b * world_size
-        del res
+        assert res["obs"].shape[0] == b * world_size
+        del res, pr
         t = torch.tensor([el], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
-        out[name] = {"ms_per_100_step_rollout": el * 1e3, "steps_per_chunk": tc, "envs_per_gpu": b,
-                     "gathered_GB": step_bytes * t_steps / 1e9,
-                     "GBps_received_per_gpu": step_bytes * t_steps * (world_size - 1) / world_size / el / 1e9}
+        gathered = step_bytes * done
+        out[name] = {"ms_per_100_step_rollout": el * 1e3 * t_steps / done, "steps_per_chunk": tc, "envs_per_gpu": b,
+                     "collectives_per_chunk": 1, "gathered_GB_per_100_steps": step_bytes * t_steps / 1e9,
+                     "GBps_received_per_gpu": gathered * (world_size - 1) / world_size / el / 1e9}
     return out
 
 
@@ -290,7 +292,7 @@ def main():
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     if world_size != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world_size} ranks")
-    from vectorizedmultiagentsimulator_amd.shard import EnvShard, RolloutGather, max_over_ranks
+    from vectorizedmultiagentsimulator_amd.shard import EnvShard, PackedRollout, max_over_ranks
 
     dist = None
     if args.dry_run:
@@ -321,7 +323,7 @@ def main():
 
     gather = None
     if world_size > 1 and not args.no_gather:
-        gather = time_rollout_gather(dist, EnvShard, RolloutGather, rank, world_size, device,
+        gather = time_rollout_gather(dist, EnvShard, PackedRollout, rank, world_size, device,
                                      args.num_envs if not args.dry_run else 64, t_steps=100 if not args.dry_run else 4,
                                      shrink=512 if args.dry_run else 1)
 
@@ -369,13 +371,14 @@ def main():
         ev1.record(stream)
         fence()
         wall = time.perf_counter() - t0
-        return max_over_ranks(ev0.elapsed_time(ev1) * 1e-3, device), max_over_ranks(wall, device)
+        own = ev0.elapsed_time(ev1) * 1e-3
+        return max_over_ranks(own, device), max_over_ranks(wall, device), own
 
     # ---- secondary legs first: they also bring the GPU to its steady clocks before the headline region
     persistent = env_leg = None
     if not args.no_fused and not args.fused:
         run(EPISODE, fused=True)
-        ev_s, wall_s = timed(lambda n: run(n, fused=True), args.steps)
+        ev_s, wall_s, _ = timed(lambda n: run(n, fused=True), args.steps)
         persistent = {
             "value": world_size * args.num_envs * w.substeps * args.steps / ev_s, "unit": "env-steps/s",
             "us_per_step": ev_s / args.steps * 1e6,
@@ -395,7 +398,7 @@ def main():
 
             env_steps(400)  # (the first few hundred steps carry one-time costs)
             n_env = max(min(args.steps, 2000), 200)
-            ev_s, wall_s = timed(env_steps, n_env)
+            ev_s, wall_s, _ = timed(env_steps, n_env)
             env.bind(acts)  # caller-owned action tensors, static outputs: one foreign call per step
 
             def env_steps_bound(n):
@@ -403,7 +406,7 @@ def main():
                     env.step_bound()
 
             env_steps_bound(100)
-            ev_b, wall_b = timed(env_steps_bound, n_env)
+            ev_b, wall_b, _ = timed(env_steps_bound, n_env)
             per_env = be.step_bytes_per_env() + POST_BYTES_PER_ENV
             env_leg = {
                 "value": world_size * args.num_envs * w.substeps * n_env / wall_s, "unit": "env-steps/s",
@@ -430,17 +433,27 @@ def main():
     if not args.fused and be.queues(min(EPISODE, args.steps)) > 1:
         be.set_queues(1)
         run(args.warmup)
-        ev_1, wall_1 = timed(lambda n: run(n, start=args.warmup), args.steps)
+        ev_1, wall_1, _ = timed(lambda n: run(n, start=args.warmup), args.steps)
         single = {"value": world_size * args.num_envs * w.substeps * args.steps / ev_1, "unit": "env-steps/s",
                   "us_per_step": ev_1 / args.steps * 1e6,
                   "note": "vmas_world_set_queues(1): one launch per step on one HIP queue; its time per step is the "
                           "kernel's launch-to-launch time and agrees with rocprofv3's per-kernel duration + launch gap"}
         be.set_queues(args.queues)
-    # ---- headline: W warm-up steps, then exactly K World.step launches
+    # ---- headline: W warm-up steps, then exactly K World.step launches between fences - R times over (every window is a
+    #      complete measurement by the contract; `value` is the MEDIAN window, min / max beside it)
     run(args.warmup)
-    ev_s, wall_s = timed(lambda n: run(n, start=args.warmup), args.steps)
+    windows = [timed(lambda n: run(n, start=args.warmup), args.steps) for _ in range(max(1, args.repeats))]
+    order = sorted(range(len(windows)), key=lambda i: windows[i][0])
+    ev_s, wall_s, _ = windows[order[len(order) // 2]]
     kernel_s = ev_s / args.steps
     n_queues = 1 if args.fused else be.queues(min(EPISODE, args.steps))
+    # every rank's own time per step (the headline takes the slowest rank, window by window)
+    per_rank_us = [ev_s / args.steps * 1e6]
+    if dist is not None:
+        mine = torch.tensor([windows[order[len(order) // 2]][2]], dtype=torch.float64, device=device)
+        allr = [torch.zeros_like(mine) for _ in range(world_size)]
+        dist.all_gather(allr, mine)
+        per_rank_us = [float(x.item()) / args.steps * 1e6 for x in allr]
 
     if rank == 0:
         bytes_per_env = be.step_bytes_per_env()
@@ -455,6 +468,13 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": kernel_s * 1e3,
+            "repeats": {"windows": len(windows), "steps_per_window": args.steps,
+                        "ms_per_step_min": min(w_[0] for w_ in windows) / args.steps * 1e3,
+                        "ms_per_step_median": kernel_s * 1e3,
+                        "ms_per_step_max": max(w_[0] for w_ in windows) / args.steps * 1e3,
+                        "note": "each window = exactly `steps` launches between barrier + synchronize fences; `value` and "
+                                "`ms_per_step` are the median window"},
+            "per_rank_us_per_step": per_rank_us,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -518,6 +538,8 @@ def main():
                 tr = json.load(open(tpath))
                 if tr.get("num_envs") == args.num_envs:
                     out["roofline"]["traffic"] = tr["bytes_per_launch"]
+                    out["roofline"]["traffic_source"] = ("from profiles/latest_traffic.json (rocprofv3 PMC passes of this kernel, "
+                                                         "scripts/gpu_prof.sh) - NOT measured in this run")
                     out["roofline"]["traffic_note"] = tr["note"]
             except Exception:
                 pass

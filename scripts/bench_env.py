@@ -16,15 +16,18 @@ for fused in (False, True):
         env = make_env(name, num_envs=B, device="cuda:0", seed=0, validate_actions=False, graph=graph, fused=fused, **kw)
         if os.environ.get("SPEC") == "0":  # A/B: the interpreter instead of the world-specialised kernel
             env.world._get_backend().set_specialized(False)
-        acts = [env.get_random_action(a) for a in env.agents]
-        for _ in range(300 if (graph or fused) else 5):  # (the first few hundred steps carry one-time costs)
-            env.step(acts)
+        # ACTIONS=random (default; SURVEY.md 8d: u ~ U(-u_range, u_range) per step and agent, pre-generated): a pool of 64
+        # action sets cycled; ACTIONS=fixed: one set held for the whole run (rounds 1-2: bodies pile up against the walls)
+        pool = 1 if os.environ.get("ACTIONS", "random") == "fixed" else 64
+        acts = [[env.get_random_action(a) for a in env.agents] for _ in range(pool)]
+        for k in range(300 if (graph or fused) else 5):  # (the first few hundred steps carry one-time costs)
+            env.step(acts[k % pool])
         torch.cuda.synchronize()
         n = 1000 if (graph or fused) else 30
         t0 = time.perf_counter()
-        for _ in range(n):
-            env.step(acts)
+        for k in range(n):
+            env.step(acts[k % pool])
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
-        print(json.dumps({"scenario": name, "num_envs": B, "specialized": env.world._get_backend().specialized, "fused": fused, "graph": graph, "env_step_us": round(dt * 1e6, 2),
+        print(json.dumps({"scenario": name, "num_envs": B, "specialized": env.world._get_backend().specialized, "fused": fused, "graph": graph, "actions": os.environ.get("ACTIONS", "random"), "env_step_us": round(dt * 1e6, 2),
                           "env_steps_per_s": round(B / dt)}), flush=True)

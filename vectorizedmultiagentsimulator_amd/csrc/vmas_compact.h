@@ -39,7 +39,7 @@
 
 namespace compact {
 
-constexpr int CAP = 512;                  // contact slots per tile and round
+constexpr int CAP = 1024;                 // contact slots per tile and round
 constexpr int OWN_MAX = 4;                // dynamic entities one wave can own
 constexpr int LIST_MAX = 64;              // pairs one entity can be in (its list lives in one register, one entry per lane)
 constexpr int HW_MAX = LIST_MAX / 32;     // 32-bit words of an entity's "pairs with contacts" mask
@@ -76,7 +76,8 @@ struct DevCompact {
   int32_t t_owned, t_lists, t_units, t_pairs, t_pairhm, t_waves, t_entoff, t_bounds;  // word offsets inside the blob
   int32_t n_owned, n_pairs, hw;
   int32_t off_dyn;              // per-substep scratch: cnt[4] | hit[n_owned][hw] | ballots[n_pairs] (u64) | base[n_pairs] |
-                                // keys[CAP] | contacts[CAP][4] | xmask[mask_words]
+                                // keys[CAP] | contacts[CAP] (fx, fy) | [torques[CAP] if has_torque] | xmask[mask_words]
+  int32_t has_torque;           // some pair exerts a torque (a rotatable line): the contacts carry a third number
   int32_t mask_words;
   const float4* trig_cache;     // [nE] {rotation, cos, sin, valid} of the static lines, made once from environment 0 (may be NULL)
 };
@@ -156,8 +157,9 @@ __global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld
   unsigned long long* ballots = (unsigned long long*)(hit + ((P.n_owned * P.hw + 1) & ~1));
   uint32_t* base = (uint32_t*)(ballots + P.n_pairs);
   uint32_t* keys = base + ((P.n_pairs + 1) & ~1);
-  float4* contacts = (float4*)(dyn + ((((keys + CAP) - dyn) + 3) & ~3));  // (16-byte aligned: off_dyn is a multiple of 4 words)
-  uint32_t* xmask = (uint32_t*)(contacts + CAP);
+  float2* contacts = (float2*)(keys + CAP);   // (8-byte aligned: every part in front of it has an even number of words)
+  float* torques = (float*)(contacts + CAP);  // [CAP] only if P.has_torque
+  uint32_t* xmask = (uint32_t*)(torques + (P.has_torque ? CAP : 0));
   const int nP = P.n_pairs;
 
   // tile offset of entity e's first row / of its cos row, from the masks in the kernel arguments
@@ -195,64 +197,105 @@ __global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld
   };
 
   // ---- HBM -> LDS.  Entities with rows the path reads (dynamic: all six; static and in a pair: the position, and a
-  //      line's rotation for its cos / sin), one entity per wave at a time; then the agent forces; then the blob.
+  //      line's rotation for its cos / sin), the agent forces and the descriptor blob: EVERY global load of the wave is
+  //      issued before the first LDS store, so that the phase costs one HBM latency, not one per entity (a load -> store
+  //      loop waits for each entity's rows in turn: 9 k of the kernel's 47 k cycles per wave in the first version).
   {
+    constexpr int LB = 4;  // entities per wave and batch (4 x 8 waves >= football's 23 entities: one batch)
     const unsigned long long any_mask = P.dyn_mask | P.static_mask;
-    for (int e = wv; e < W.nE; e += nw) {
-      if (!((any_mask >> e) & 1ull)) continue;
-      const bool is_dyn = (P.dyn_mask >> e) & 1ull, is_line = (P.line_mask >> e) & 1ull;
-      const float* src = state + (long)e * 6 * ld + env;
-      float* dst = tile + ent_off(e);
-      float rot = 0.f;
-      if (is_dyn) {
-        float v[6];
+    const uint4* bsrc = (const uint4*)P.blob;
+    uint4* bdst = (uint4*)(lds + P.off_tab);
+    const int n4 = P.blob_words >> 2, nt = blockDim.x;
+    for (int e0 = wv; e0 < W.nE || e0 == wv; e0 += LB * nw) {
+      float v[LB][6];
+      float4 tc[LB];
 #pragma unroll
-        for (int f = 0; f < 6; ++f) v[f] = lv ? src[f * ld] : 0.f;
+      for (int j = 0; j < LB; ++j) {
+        const int e = e0 + j * nw;
+        const bool on = e < W.nE && ((any_mask >> e) & 1ull);
+        const bool is_dyn = on && ((P.dyn_mask >> e) & 1ull), is_line = on && ((P.line_mask >> e) & 1ull);
+        const int rows = !on ? 0 : (is_dyn ? 0x3f : (0x03 | (is_line ? 0x10 : 0)));
+        const float* src = state + (long)(on ? e : 0) * 6 * ld + env;
 #pragma unroll
-        for (int f = 0; f < 6; ++f) dst[f * ROWF] = v[f];
-        rot = v[4];
-      } else {
-        const float x = lv ? src[0] : 0.f, y = lv ? src[ld] : 0.f;
-        if (is_line) rot = lv ? src[4 * ld] : 0.f;
-        dst[0] = x; dst[ROWF] = y;
+        for (int f = 0; f < 6; ++f) v[j][f] = (((rows >> f) & 1) && lv) ? src[f * ld] : 0.f;
+        tc[j] = (is_line && !is_dyn && P.trig_cache != nullptr) ? P.trig_cache[e] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      if (is_line) {
-        // cos / sin of a STATIC line: the ~110-instruction sincosf is skipped when every environment of the tile has the
-        // rotation the world's cache entry was made from - by the same sincosf, once (compact_trig_kernel): the same bits
-        float sn, cs;
-        bool cached = false;
-        if (!is_dyn && P.trig_cache != nullptr) {
-          const float4 c = P.trig_cache[e];
-          if (c.w != 0.f && __all(__float_as_uint(rot) == __float_as_uint(c.x) || !live)) { cs = c.y; sn = c.z; cached = true; }
+      // (first batch only) the agent forces that are plain loads, and this thread's share of the blob
+      auto plain_row = [&](int a) {
+        bool plain = a < nA;
+        if constexpr (ENV != ENV_NONE) {
+          if (a < nA && E.has_ingest) {
+            const VmasActionSlot& S = E.ingest.agents[a];
+            plain = !(S.action != nullptr || S.action_index != nullptr) && !(E.ingest.n_scripts > 0 && E.script_of_agent[a] >= 0);
+          }
         }
-        if (!cached) sincosf(rot, &sn, &cs);
-        const int tr = trig_off(e);
-        tile[tr] = cs;
-        tile[tr + ROWF] = sn;
+        return plain;
+      };
+      const bool first = e0 == wv;
+      const bool pa0 = first && plain_row(wv), pa1 = first && plain_row(wv + nw);
+      const float* fs0 = agent_ft + (long)(pa0 ? wv : 0) * 3 * ld + env;
+      const float* fs1 = agent_ft + (long)(pa1 ? wv + nw : 0) * 3 * ld + env;
+      const float g00 = (pa0 && lv) ? fs0[0] : 0.f, g01 = (pa0 && lv) ? fs0[ld] : 0.f, g02 = (pa0 && lv) ? fs0[2 * ld] : 0.f;
+      const float g10 = (pa1 && lv) ? fs1[0] : 0.f, g11 = (pa1 && lv) ? fs1[ld] : 0.f, g12 = (pa1 && lv) ? fs1[2 * ld] : 0.f;
+      const int bi0 = (int)threadIdx.x, bi1 = (int)threadIdx.x + nt;
+      uint4 bq0 = make_uint4(0, 0, 0, 0), bq1 = make_uint4(0, 0, 0, 0);
+      if (first) { bq0 = bsrc[bi0 < n4 ? bi0 : 0]; bq1 = bsrc[bi1 < n4 ? bi1 : 0]; }
+      // ---- stores (and the lines' cos / sin)
+#pragma unroll
+      for (int j = 0; j < LB; ++j) {
+        const int e = e0 + j * nw;
+        if (!(e < W.nE && ((any_mask >> e) & 1ull))) continue;
+        const bool is_dyn = (P.dyn_mask >> e) & 1ull, is_line = (P.line_mask >> e) & 1ull;
+        float* dst = tile + ent_off(e);
+        if (is_dyn) {
+#pragma unroll
+          for (int f = 0; f < 6; ++f) dst[f * ROWF] = v[j][f];
+        } else {
+          dst[0] = v[j][0]; dst[ROWF] = v[j][1];
+        }
+        if (is_line) {
+          // cos / sin of a STATIC line: the ~110-instruction sincosf is skipped when every environment of the tile has the
+          // rotation the world's cache entry was made from - by the same sincosf, once (compact_trig_kernel): the same bits
+          const float rot = v[j][4];
+          float sn, cs;
+          bool cached = false;
+          if (!is_dyn && tc[j].w != 0.f && __all(__float_as_uint(rot) == __float_as_uint(tc[j].x) || !live)) {
+            cs = tc[j].y; sn = tc[j].z; cached = true;
+          }
+          if (!cached) sincosf(rot, &sn, &cs);
+          const int tr = trig_off(e);
+          tile[tr] = cs;
+          tile[tr + ROWF] = sn;
+        }
+      }
+      if (first) {
+        if (pa0) { float* dst = tile + P.off_af + wv * 3 * ROWF; dst[0] = g00; dst[ROWF] = g01; dst[2 * ROWF] = g02; }
+        if (pa1) { float* dst = tile + P.off_af + (wv + nw) * 3 * ROWF; dst[0] = g10; dst[ROWF] = g11; dst[2 * ROWF] = g12; }
+        if (bi0 < n4) bdst[bi0] = bq0;
+        if (bi1 < n4) bdst[bi1] = bq1;
       }
     }
+    // agents beyond the first two per wave, and agents whose forces are made from actions / scripts (the ingest prologue)
     for (int a = wv; a < nA; a += nw) {
+      bool done = (a - wv) / nw < 2;
+      if constexpr (ENV != ENV_NONE) {
+        if (done && E.has_ingest) {
+          const VmasActionSlot& S = E.ingest.agents[a];
+          done = !(S.action != nullptr || S.action_index != nullptr) && !(E.ingest.n_scripts > 0 && E.script_of_agent[a] >= 0);
+        }
+      }
+      if (done) continue;
       float f3[3];
       load_agent_ft(a, f3, false);
       float* dst = tile + P.off_af + a * 3 * ROWF;
 #pragma unroll
       for (int f = 0; f < 3; ++f) dst[f * ROWF] = f3[f];
     }
-    const uint4* src = (const uint4*)P.blob;
-    uint4* dst = (uint4*)(lds + P.off_tab);
-    const int n4 = P.blob_words >> 2, nt = blockDim.x;
-    for (int i0 = threadIdx.x; i0 < n4; i0 += 4 * nt) {
-      const int i1 = i0 + nt, i2 = i0 + 2 * nt, i3 = i0 + 3 * nt;
-      const uint4 a = src[i0], b = src[i1 < n4 ? i1 : i0], c = src[i2 < n4 ? i2 : i0], d = src[i3 < n4 ? i3 : i0];
-      dst[i0] = a;
-      if (i1 < n4) dst[i1] = b;
-      if (i2 < n4) dst[i2] = c;
-      if (i3 < n4) dst[i3] = d;
-    }
+    for (int i = (int)threadIdx.x + 2 * nt; i < n4; i += nt) bdst[i] = bsrc[i];  // (blobs beyond 32 bytes per thread)
     const int n_zero = 4 + P.n_owned * P.hw;
-    for (int i = threadIdx.x; i < n_zero; i += nt) dyn[i] = 0u;
+    for (int i = threadIdx.x; i < n_zero; i += blockDim.x) dyn[i] = 0u;
     if (args.sync != nullptr)
-      for (int i = threadIdx.x; i < P.mask_words; i += nt) xmask[i] = 0u;
+      for (int i = threadIdx.x; i < P.mask_words; i += blockDim.x) xmask[i] = 0u;
   }
   [[maybe_unused]] float fb_prev[4] = {0.f, 0.f, 0.f, 0.f};
   [[maybe_unused]] float post_steps = 0.f;
@@ -587,7 +630,8 @@ __global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld
             fa = -contact_force(pb, cp, p0, W.c_coll, W.k);
             ta = vcross(cp - pa, fa);
           }
-          contacts[k] = make_float4(fa.x, fa.y, ta, 0.f);
+          contacts[k] = make_float2(fa.x, fa.y);
+          if (P.has_torque) torques[k] = ta;
         }
         CACC(3);  // B
         __syncthreads();
@@ -612,8 +656,12 @@ __global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld
               const unsigned long long b = sgpr64(ballots[pr]);
               const uint32_t s0 = (uint32_t)sgpr((int)base[pr]);
               const bool mine = (b >> lane) & 1ull;
-              float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
-              if (mine) c = contacts[s0 + lanemask_rank(b)];
+              float2 c = make_float2(0.f, 0.f);
+              float ct = 0.f;
+              if (mine) {
+                c = contacts[s0 + lanemask_rank(b)];
+                if (has_t) ct = torques[s0 + lanemask_rank(b)];
+              }
               const uint32_t flip = is_b ? 0x80000000u : 0u;  // b's side: -f (an integer xor: see eval_item)
               const v2 f = V(__uint_as_float(__float_as_uint(c.x) ^ flip), __uint_as_float(__float_as_uint(c.y) ^ flip));
               if (fl & VMAS_F_MOVABLE) {
@@ -622,7 +670,7 @@ __global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld
                 if (!is_b) added_a[s] += mine ? 1u : 0u;
               }
               if (has_t) {  // the line's torque (the sphere's term is the reference's literal 0: part of the `+ 0` below)
-                const float Tn = Tq[s] + c.z;
+                const float Tn = Tq[s] + ct;
                 Tq[s] = mine ? Tn : Tq[s];
                 added_t[s] += mine ? 1u : 0u;
               }

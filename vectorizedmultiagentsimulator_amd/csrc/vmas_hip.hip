@@ -2103,10 +2103,11 @@ static int build_compact(VmasWorld* w) {
   int dyn_at = D.off_tab + D.blob_words;
   dyn_at = (dyn_at + 3) & ~3;
   D.off_dyn = dyn_at;
-  // cnt[4] | hit | ballots (u64) | base | keys[CAP] | contacts[CAP] (float4: 16-byte aligned) | xmask
+  // cnt[4] | hit | ballots (u64) | base | keys[CAP] | contacts[CAP] (float2) | torques[CAP] (worlds with rotatable lines) | xmask
+  for (const VmasPairDesc& P : w->pairs)
+    if (P.type == VMAS_PAIR_LS && (E[P.a].flags & VMAS_F_ROTATABLE)) D.has_torque = 1;
   size_t dyn_words = 4 + (size_t)((D.n_owned * hw + 1) & ~1) + 2 * (size_t)nP + (size_t)((nP + 1) & ~1) + CAP;
-  dyn_words = (dyn_words + 3) & ~(size_t)3;
-  dyn_words += 4 * (size_t)CAP + (((size_t)D.mask_words + 3) & ~(size_t)3);
+  dyn_words += 2 * (size_t)CAP + (D.has_torque ? (size_t)CAP : 0) + (((size_t)D.mask_words + 3) & ~(size_t)3);
   C.lds_bytes = ((size_t)dyn_at + dyn_words) * sizeof(float);
   if (C.lds_bytes > 160 * 1024) return 0;
   if (!w->host_only) {

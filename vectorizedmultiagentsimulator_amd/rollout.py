@@ -12,7 +12,7 @@ from typing import Callable, Dict, List, Optional
 import torch
 from torch import Tensor
 
-from .shard import EnvShard, RolloutGather
+from .shard import EnvShard, PackedRollout, RolloutGather
 
 
 def collect(env, policy: Callable[[List[Tensor]], List[Tensor]], n_steps: int,
@@ -45,3 +45,19 @@ def collect(env, policy: Callable[[List[Tensor]], List[Tensor]], n_steps: int,
 def gather_rollout(buffers: Dict[str, Tensor], shard: EnvShard) -> Dict[str, Tensor]:
     """Global rollout on every rank (env axis = dim 1, global environment order)."""
     return RolloutGather(shard).gather(buffers, env_dim=1)
+
+
+def collect_packed(env, policy: Callable[[List[Tensor]], List[Tensor]], n_steps: int, shard: EnvShard,
+                   obs: Optional[List[Tensor]] = None, auto_reset: bool = False) -> PackedRollout:
+    """``collect`` straight into the gather's layout (``PackedRollout``: one ``[b, T, W]`` buffer, environment axis first):
+    ``.views()`` are this shard's ``obs [b, T, A, D]`` / ``rew [b, T, A]`` / ``done [b, T]``, ``.gather()`` the global rollout
+    on every rank with ONE collective and no copies around it."""
+    if obs is None:
+        obs = env.reset()
+    pr = PackedRollout(shard, n_steps, len(env.agents), obs[0].shape[-1], obs[0].device)
+    for t in range(n_steps):
+        obs, rews, dones, _ = env.step(policy(obs))
+        pr.write(t, obs, rews, dones)
+        if auto_reset:
+            obs = env.reset_where(dones)
+    return pr
