@@ -191,6 +191,13 @@ int vmas_world_step_n(VmasWorld* w, float* state, float* agent_ft, int64_t ld, i
 int vmas_world_rollout(VmasWorld* w, float* state, float* agent_ft, int64_t ld, int64_t ft_step_stride,
                        int32_t n_steps, const VmasStepArgs* args /* may be NULL */, void* stream);
 
+/* A world-specialised kernel made at RUN TIME for this world: `code_object_path` is a gfx950 code object compiled from
+ * csrc/vmas_spec_kernel.h with the tables of the schedule this world runs (the Python side generates and compiles it:
+ * vectorizedmultiagentsimulator_amd/specialize.py, cached on disk).  The library loads it, reads the tables back out of
+ * the module (`vmas_rt_check`) and accepts it only if they are word for word its own schedule - the rule of the built-in
+ * specialisations; launch forms the module does not contain keep the interpreter.  0 ok, -1 refused (vmas_last_error). */
+int vmas_world_load_spec(VmasWorld* w, const char* code_object_path);
+
 /* The lane-compacted step kernel (csrc/vmas_compact.h) for worlds whose pairs are all sphere-sphere or line-sphere and
  * that have no joints: broad phase per (environment, pair) with every lane busy, narrow phase over the tile's CONTACTS
  * packed across environments and pairs, results added by the owners in the reference's order (core.py:2176-2199) - bit

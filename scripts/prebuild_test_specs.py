@@ -1,0 +1,30 @@
+"""Compile, ahead of time and without a GPU, the run-time specialisations the GPU tests ask for (tests/test_specialize_gpu.py)
+into the package's on-disk cache, so that the test box loads them instead of compiling (~10 s each):
+python scripts/prebuild_test_specs.py"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from golden_util import load  # noqa: E402
+from vectorizedmultiagentsimulator_amd import _abi as A  # noqa: E402
+from vectorizedmultiagentsimulator_amd import specialize as S  # noqa: E402
+
+lib = A.load_library()
+for name, B in [("balance_n3", 4096), ("transport_2pkg", 1024), ("all_joint_passage_size", 700), ("ball_trajectory", 1000),
+                ("give_way", 4096), ("all_wheel", 64 * 7 + 3)]:
+    g = load(name)
+    cd = g.spec.to_ctypes()
+    h = C.c_void_p()
+    assert lib.vmas_world_create(C.byref(cd.world), B, -1, C.byref(h)) == 0, A.last_error()
+    try:
+        meta, words = S.schedule(h)
+    finally:
+        lib.vmas_world_destroy(h)
+    if meta[23] >= 0:
+        print(name, "has a built-in specialisation")
+        continue
+    p = S.code_object(S.render(meta, words, int(g.spec.substeps), 0))
+    print(name, B, "->", os.path.basename(p), os.path.getsize(p))

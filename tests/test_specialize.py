@@ -1,0 +1,59 @@
+"""Run-time specialisation (vectorizedmultiagentsimulator_amd/specialize.py), host side: the schedule of a world the
+library has no built-in specialisation for is rendered as the tables of csrc/vmas_spec_kernel.h and compiled for gfx950
+(hipcc cross-compiles without a GPU); the GPU tests load it and compare it with the interpreter bit for bit."""
+import ctypes as C
+import importlib
+import os
+import subprocess
+
+import pytest
+
+from vectorizedmultiagentsimulator_amd import _abi as A
+from vectorizedmultiagentsimulator_amd import specialize as S
+
+
+def _planned(name, batch, **kw):
+    lib = A.load_library()
+    sc = importlib.import_module(f"vectorizedmultiagentsimulator_amd.scenarios.{name}").Scenario()
+    world = sc.env_make_world(batch, "cpu", **kw)
+    cd = world.spec.to_ctypes()
+    h = C.c_void_p()
+    assert lib.vmas_world_create(C.byref(cd.world), batch, -1, C.byref(h)) == 0, A.last_error()
+    try:
+        hint = getattr(world, "epilogue_hint", None)
+        if hint is not None:
+            assert lib.vmas_world_reserve_epilogue(h, *hint) == 0
+        meta, words = S.schedule(h)
+    finally:
+        lib.vmas_world_destroy(h)
+    return world, meta, words
+
+
+def test_render_and_compile_a_world_without_a_builtin_specialisation(tmp_path):
+    world, meta, words = _planned("balance", 32768, n_agents=3)  # BASELINE config 1's world at config 2's batch
+    assert meta[23] == -1, "balance n_agents=3 has no built-in specialisation"
+    src = S.render(meta, words, int(world.spec.substeps), 1)
+    assert "struct SpecRT" in src and "vmas_rt_lean_t0" in src and "vmas_rt_multi_e1_o1_t0" in src and "vmas_rt_check" in src
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc here")
+    path = S.code_object(src, cache_dir=str(tmp_path))
+    assert os.path.getsize(path) > 10000
+    again = S.code_object(src, cache_dir=str(tmp_path))  # the cache: same key, no second compilation
+    assert again == path
+    nm = "/opt/rocm/lib/llvm/bin/llvm-nm"
+    if os.path.exists(nm):
+        syms = subprocess.run([nm, path], capture_output=True, text=True).stdout
+        for want in ("vmas_rt_lean_t0", "vmas_rt_lean_t1", "vmas_rt_multi_e0_o0_t0", "vmas_rt_multi_e3_o1_t1", "vmas_rt_multi_e1_o1_t0",
+                     "vmas_rt_check"):
+            assert want in syms, want
+
+
+def test_builtin_worlds_are_not_recompiled():
+    _, meta, _ = _planned("balance", 32768, n_agents=4)
+    assert meta[23] >= 0  # SpecBalance4 serves it: specialize() returns at once
+
+
+def test_worlds_whose_items_do_not_fit_lds_are_refused():
+    meta = [8, 2, 1, 4, 0, 0, 0, 0, 0, 1, 1, 10, 0, 0, 3, 1, 0, 0, 0, 0, 0, 0, 1, -1]  # items_in_lds == 0
+    with pytest.raises(S.SpecializeError):
+        S.render(meta, [0, 0, 0, 0], 1, 0)

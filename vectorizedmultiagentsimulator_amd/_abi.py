@@ -284,6 +284,7 @@ EXPORTED_SYMBOLS = (
     "vmas_debug_schedule",
     "vmas_debug_force_gave_up",
     "vmas_world_exact_status",
+    "vmas_world_load_spec",
     "vmas_world_set_compact",
     "vmas_world_get_compact",
     "vmas_world_set_specialized",
@@ -350,6 +351,8 @@ def load_library() -> C.CDLL:
     lib.vmas_world_set_specialized.restype = C.c_int
     lib.vmas_world_get_specialized.argtypes = [vp]
     lib.vmas_world_get_specialized.restype = C.c_int
+    lib.vmas_world_load_spec.argtypes = [vp, C.c_char_p]
+    lib.vmas_world_load_spec.restype = C.c_int
     lib.vmas_world_set_compact.argtypes = [vp, i32]
     lib.vmas_world_set_compact.restype = C.c_int
     lib.vmas_world_get_compact.argtypes = [vp]

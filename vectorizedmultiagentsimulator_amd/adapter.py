@@ -74,7 +74,8 @@ def _patch_state_class(cls) -> None:
 class AttachedWorld:
     """Handle returned by ``attach``; ``detach()`` restores the reference behaviour."""
 
-    def __init__(self, world, backend_factory: Callable = _default_backend, exact_broad_phase: Optional[bool] = None):
+    def __init__(self, world, backend_factory: Callable = _default_backend, exact_broad_phase: Optional[bool] = None,
+                 specialize: bool = False):
         from .core import EXACT_AUTO_BELOW
 
         self.world = world
@@ -93,6 +94,9 @@ class AttachedWorld:
         self.agent_ft = torch.zeros(max(nA, 1), A.AGENT_FIELDS, self.ld, dtype=torch.float32, device=self.device)
         self._rehome()
         self.backend = self._factory(self.spec, self.batch, self.device, self.state, self.agent_ft)
+        self.specialize = bool(specialize)  # a step kernel compiled for this world (specialize.py), also after a refresh()
+        if self.specialize and hasattr(self.backend, "specialize"):
+            self.backend.specialize()
         self._fp = self._fingerprint()
         self._check_spec = False  # set by World.reset: the scenario's reset_world_at that follows may change statics
         self.refreshes = 0        # how many times the static description was found changed (tests, diagnostics)
@@ -224,6 +228,9 @@ class AttachedWorld:
         self.spec = spec
         self.backend.close()
         self.backend = self._factory(self.spec, self.batch, self.device, self.state, self.agent_ft)
+        self.specialize = bool(specialize)  # a step kernel compiled for this world (specialize.py), also after a refresh()
+        if self.specialize and hasattr(self.backend, "specialize"):
+            self.backend.specialize()
         self._fp = self._fingerprint()
         self.refreshes += 1
 
@@ -264,11 +271,13 @@ class AttachedWorld:
 
 
 def attach(env_or_world, backend_factory: Callable = _default_backend,
-           exact_broad_phase: Optional[bool] = None) -> AttachedWorld:
+           exact_broad_phase: Optional[bool] = None, specialize: bool = False) -> AttachedWorld:
     """Put a reference ``Environment`` (or ``World``) on the MI355X-native physics step.  ``exact_broad_phase``: the
     reference's batch-global ``.any()`` broad phase (core.py:2797-2801) exactly; None = below 1024 environments, where
-    it can matter (above, every pair that matters has SOME environment overlapping)."""
+    it can matter (above, every pair that matters has SOME environment overlapping).  ``specialize``: compile (once, cached
+    on disk) a step kernel for this very world - any scenario the reference ships then runs at the speed of the built-in
+    BASELINE specialisations instead of the schedule interpreter's (specialize.py)."""
     world = getattr(env_or_world, "world", env_or_world)
     if getattr(env_or_world, "grad_enabled", False):
         raise NotImplementedError("grad_enabled=True needs the reference's autograd path; the HIP step has no backward")
-    return AttachedWorld(world, backend_factory, exact_broad_phase)
+    return AttachedWorld(world, backend_factory, exact_broad_phase, specialize)

@@ -126,6 +126,13 @@ class HipWorld:
     def specialized(self) -> bool:
         return bool(self.lib.vmas_world_get_specialized(self._h))
 
+    def specialize(self, post: int = 0, cache_dir: Optional[str] = None) -> bool:
+        """Compile (or fetch from the cache) and load a world-specialised kernel for THIS world and batch geometry
+        (specialize.py; tens of seconds on a cache miss).  ``post``: the fused epilogue its steps carry (VMAS_POST_*)."""
+        from .specialize import specialize
+
+        return specialize(self, post, cache_dir)
+
     def set_compact(self, mode: int):
         """-1: the library's choice, 0: never, 1: whenever the world qualifies - the lane-compacted step kernel
         (include/vmas_hip.h, vmas_world_set_compact)."""

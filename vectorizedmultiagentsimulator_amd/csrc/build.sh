@@ -13,7 +13,7 @@ OBJ=.obj
 mkdir -p "$OBJ"
 COMMON="vmas_device.h vmas_env_device.h ../../include/vmas_hip.h ../../include/vmas_env_hip.h ../../include/vmas_debug_hip.h"
 declare -A DEPS=(
-  [vmas_hip]="vmas_hip.hip vmas_step_types.h vmas_spec_gen.h vmas_spec_kernel.h vmas_compact.h $COMMON"
+  [vmas_hip]="vmas_hip.hip vmas_step_device.h vmas_step_types.h vmas_spec_gen.h vmas_spec_kernel.h vmas_compact.h $COMMON"
   [vmas_env]="vmas_env.hip $COMMON"
   [vmas_compact]="vmas_compact.hip vmas_compact.h vmas_step_types.h $COMMON"
 )

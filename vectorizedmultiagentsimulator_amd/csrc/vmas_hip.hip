@@ -55,423 +55,7 @@
 #include "../../include/vmas_debug_hip.h"
 #include "vmas_step_types.h"
 
-// ------------------------------------------------------------------------------------
-// device-side constant block (all wave-uniform => scalar loads)
-// ------------------------------------------------------------------------------------
-constexpr int ITEMS_LDS_BUDGET = 48 * 1024;  // stage the item descriptors in LDS when they fit
-constexpr int TASK_JOINT = 6;  // item type next to VMAS_PAIR_*
-#ifndef VMAS_X_TIGHT_LS
-#define VMAS_X_TIGHT_LS 1
-#endif
-#ifndef VMAS_X_FIRED
-#define VMAS_X_FIRED 1
-#endif
-constexpr int FIRED_RECS = VMAS_X_FIRED ? 16 : 0;       // shared sphere-sphere records whose fired bits are published in LDS (two words per
-                                     // substep parity: 4 bits per record, 64 pairs)
-constexpr int TASK_SSQ = 7;    // up to four sphere-sphere partners of one entity in one record
-constexpr int TASK_LSQ = 8;    // up to four lines against one (owning) sphere in one record
-constexpr int TASK_SSP = 9;    // up to four SHARED sphere-sphere pairs (both spheres dynamic) in one record
-
-enum : uint32_t { IT_A_HOLLOW = 1u << 0, IT_B_HOLLOW = 1u << 1, IT_LOCK = 1u << 2 /* joint rotate == False */ };
-
-// One evaluation of a joint/pair FOR ONE SIDE of it.  Static data pre-resolved on the host
-// with the same fp32 operations the reference performs at run time.  All LDS positions are
-// float offsets into the tile, so row accesses become ds_read with an immediate offset.
-struct DevItem {
-  int32_t type;   // VMAS_PAIR_* or TASK_JOINT
-  int32_t side;   // low 2 bits  0: the force on a, 1: on b, 2: SHARED - evaluated once, results to the LDS rows at
-                  // tile offset (side >> 2): [fx fy] of a, then the torque on a, then the torque on b
-  uint32_t flags; // IT_*
-  int32_t index;  // pair index (mask bit) or joint index (per-env fixed-rotation row)
-  int32_t oa, ob;    // tile offsets of the first state row of a / b (role order of the reference)
-  int32_t tra, trb;  // tile offsets of their trig rows (unused for spheres)
-  float thr2;     // (R_a + R_b + LINE_MIN_DIST + slack)^2: bounding-circle skip
-  float reach;    // box items: the other shape's reach + LINE_MIN_DIST + slack (oriented-box skip)
-  float p0, p1, p2, p3, q0, q1;  // type-specific dims, see build_items()
-};
-
-struct DevSegment {
-  int32_t entity;    // -1: a run of shared pairs/joints (no prologue, no partial rows; every item has its own rows)
-  int32_t oe;        // tile offset of the entity's first state row
-  int32_t item_begin, item_end;
-  int32_t first;     // 1: this segment starts from the entity's prologue force
-  int32_t part_off;  // tile offset of its 3 partial-sum rows (fx, fy, torque)
-  uint32_t eflags;   // the entity's VMAS_F_* flags (saves the dependent fetch of its descriptor)
-  int32_t pad;       // (32 bytes: the record is two ds_read_b128)
-};
-
-struct DevOwned {  // phase C work unit: everything the integration of one entity needs, ONE LDS round trip (6 x 16 bytes)
-  int32_t entity;
-  int32_t oe;
-  int32_t part_off, n_parts;  // partial rows of the entity's segments, in order
-  // the entity's side of every shared pair/joint it is in, in the reference's accumulation order; one word each:
-  //   bits 0..15 row of [fx fy] | bit 16 side (1: the entity is b, the force flips its sign) | bits 17..18 row delta
-  //   of its torque (0: none).  The first eight are inlined below, the rest follow at blob[b_refs + ref_begin + 8].
-  int32_t ref_begin, n_refs;
-  uint32_t flags;
-  int32_t shape;
-  int32_t tr_off;
-  float mass, inertia, one_minus_drag;
-  float max_speed, v_range;
-  uint32_t pad[2];
-  uint32_t refs8[8];
-};
-static_assert(sizeof(DevOwned) == 96, "DevOwned is read as six uint4");
-
-
-
-// (DevMaskPair, DevLidar, DevTarget: vmas_env_device.h - the navigation epilogue uses them too)
-
-
-
-
-
-// cos/sin of the rotation(s) the narrow phase needs (physics.py:300-302, 413)
-__device__ __forceinline__ void write_trig(float* tr, float rot, int shape) {
-  float sn, cs;
-  sincosf(rot, &sn, &cs);  // one range reduction for both (ocml), same values as cosf/sinf
-  tr[0 * ROWF] = cs;
-  tr[1 * ROWF] = sn;
-  if (shape == VMAS_SHAPE_BOX) {
-    const float rot2 = rot + kHalfPi;
-    sincosf(rot2, &sn, &cs);
-    tr[2 * ROWF] = cs;
-    tr[3 * ROWF] = sn;
-  }
-}
-
-// squared distance from point p to the solid oriented box (centre c, axes (cs,sn)), 0 inside
-__device__ __forceinline__ float obb_dist2(v2 p, v2 c, float cs, float sn, float half_l, float half_w) {
-  const float dx = p.x - c.x, dy = p.y - c.y;
-  const float lx = fabsf(dx * cs + dy * sn) - half_l;
-  const float ly = fabsf(dy * cs - dx * sn) - half_w;
-  const float ex = fmaxf(lx, 0.f), ey = fmaxf(ly, 0.f);
-  return ex * ex + ey * ey;
-}
-
-// separating-axis lower bound of the distance between a segment (centre p, direction (lc,ls),
-// half length h) and the oriented box: the larger of the two gaps along the box axes
-__device__ __forceinline__ float seg_obb_gap(v2 p, float lc, float ls, float h, v2 c, float cs, float sn, float half_l,
-                                             float half_w) {
-  const float dx = p.x - c.x, dy = p.y - c.y;
-  const float px = dx * cs + dy * sn, py = dy * cs - dx * sn;            // segment centre in the box frame
-  const float ex = fabsf(h * (lc * cs + ls * sn)), ey = fabsf(h * (ls * cs - lc * sn));  // its half extents
-  const float gx = fabsf(px) - ex - half_l, gy = fabsf(py) - ey - half_w;
-  return fmaxf(gx, gy);
-}
-
-// Register views of descriptors read from the LDS blob (uniform address => broadcast read):
-// control words go to SGPRs, offsets and float parameters stay in (uniform) VGPRs.
-struct ItemV {
-  int32_t type, side; uint32_t flags; int32_t index;  // scalar
-  int32_t oa, ob, tra, trb;
-  float thr2, reach, p0, p1, p2, p3, q0, q1;
-};
-// The 16 words of one item record, as fetched (uniform address: broadcast read).  The gather loops fetch record i + 1
-// while record i is evaluated: the record's LDS round trip is off the wave's dependent chain.
-struct ItemW { uint4 w0, w1, w2, w3; };
-__device__ __forceinline__ ItemW fetch_words(const uint32_t* p) {
-  ItemW r;
-  r.w0 = ((const uint4*)p)[0]; r.w1 = ((const uint4*)p)[1]; r.w2 = ((const uint4*)p)[2]; r.w3 = ((const uint4*)p)[3];
-  return r;
-}
-__device__ __forceinline__ ItemV load_item(const ItemW& I) {
-  const uint4 w0 = I.w0, w1 = I.w1, w2 = I.w2, w3 = I.w3;
-  ItemV K;
-  K.type = sgpr((int)w0.x); K.side = sgpr((int)w0.y); K.flags = (uint32_t)sgpr((int)w0.z); K.index = sgpr((int)w0.w);
-  K.oa = (int)w1.x; K.ob = (int)w1.y; K.tra = (int)w1.z; K.trb = (int)w1.w;
-  K.thr2 = __uint_as_float(w2.x); K.reach = __uint_as_float(w2.y); K.p0 = __uint_as_float(w2.z); K.p1 = __uint_as_float(w2.w);
-  K.p2 = __uint_as_float(w3.x); K.p3 = __uint_as_float(w3.y); K.q0 = __uint_as_float(w3.z); K.q1 = __uint_as_float(w3.w);
-  return K;
-}
-static_assert(sizeof(DevItem) == 64, "descriptor layout");
-
-// Sphere-sphere partners packed four to a record (same 16 words as a DevItem):
-//   w0: type, n, -, -   w1: own offset, partner offsets 0..2   w2: partner 3, r_sum 0..2
-//   w3: r_sum 3, pair index 0|1<<16, pair index 2|3<<16, -
-// One descriptor fetch and eight position reads in flight instead of four dependent round
-// trips; the forces are added to F one by one, in the reference's order.  Both sides of a
-// sphere pair see force(own, other): cf(a,b) == -cf(b,a) bit for bit, so no sign flip is needed.
-__device__ __forceinline__ void eval_ssq(const ItemW& I, const DevWorld& W, const DevStepArgs& args,
-                                         const float* tile, bool movable, v2& F) {
-  const uint4 w0 = I.w0, w1 = I.w1, w2 = I.w2, w3 = I.w3;
-  const int n = sgpr((int)w0.y);
-  const float* E = tile + (int)w1.x;
-  const v2 pe = V(E[0], E[ROWF]);
-  const int ob[4] = {(int)w1.y, (int)w1.z, (int)w1.w, (int)w2.x};
-  const float rs[4] = {__uint_as_float(w2.y), __uint_as_float(w2.z), __uint_as_float(w2.w), __uint_as_float(w3.x)};
-  const int idx[4] = {(int)(w3.y & 0xffffu), (int)(w3.y >> 16), (int)(w3.z & 0xffffu), (int)(w3.z >> 16)};
-  v2 po[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const float* O = tile + ob[k];
-    po[k] = V(O[0], O[ROWF]);  // unused slots repeat partner 0 on the host: always a valid row
-  }
-  uint32_t needbits = 0;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const float dx = pe.x - po[k].x, dy = pe.y - po[k].y;
-    const float m = rs[k] + 1e-4f;  // the force is exactly 0 for dist > r_a + r_b (core.py:2836)
-    bool need = !far_apart(dx * dx + dy * dy, m * m);
-    bool on = k < n;
-    if (args.pair_mask) on = on && ((mask_word(args.pair_mask, sgpr(idx[k]) >> 5) >> (sgpr(idx[k]) & 31)) & 1u);
-    needbits |= (on && __any(need)) ? (1u << k) : 0u;
-  }
-  if (!needbits || (ABLATE(args) & 32)) return;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    if (needbits & (1u << k)) {
-      const v2 f = contact_force(pe, po[k], rs[k], W.c_coll, W.k);
-      if (movable) F = F + f;
-    }
-  }
-}
-
-// Line-sphere pairs seen from the SPHERE (the owner; lines are mostly static walls), four lines to a record:
-//   w0: type, n, own offset, r + LINE_MIN_DIST   w1: line offsets 0|1, 2|3, trig offsets 0|1, 2|3 (16 bit each)
-//   w2: half lengths 0..3   w3: pair index 0|1<<16, 2|3<<16
-// Same arithmetic as the unpacked item (own(-cf(sphere, cp)) with the b-side sign flip == cf(sphere, cp) bit for
-// bit), one descriptor fetch and sixteen operand reads in flight instead of four dependent round trips.
-__device__ __forceinline__ void eval_lsq(const ItemW& I, const DevWorld& W, const DevStepArgs& args,
-                                         const float* tile, bool movable, v2& F) {
-  const uint4 w0 = I.w0, w1 = I.w1, w2 = I.w2, w3 = I.w3;
-  const int n = sgpr((int)w0.y);
-  const float* E = tile + (int)w0.z;
-  const float dist_min = __uint_as_float(w0.w);
-  const v2 ps = V(E[0], E[ROWF]);
-  const int lo[4] = {(int)(w1.x & 0xffffu), (int)(w1.x >> 16), (int)(w1.y & 0xffffu), (int)(w1.y >> 16)};
-  const int to[4] = {(int)(w1.z & 0xffffu), (int)(w1.z >> 16), (int)(w1.w & 0xffffu), (int)(w1.w >> 16)};
-  const float half[4] = {__uint_as_float(w2.x), __uint_as_float(w2.y), __uint_as_float(w2.z), __uint_as_float(w2.w)};
-  const int idx[4] = {(int)(w3.x & 0xffffu), (int)(w3.x >> 16), (int)(w3.y & 0xffffu), (int)(w3.y >> 16)};
-  v2 pl[4];
-  float cs[4], sn[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {  // unused slots repeat line 0 on the host: always valid rows
-    const float* L = tile + lo[k];
-    const float* T = tile + to[k];
-    pl[k] = V(L[0], L[ROWF]);
-    cs[k] = T[0];
-    sn[k] = T[ROWF];
-  }
-  uint32_t needbits = 0;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    // In the line's frame: the sphere's centre is farther than `m` from the segment's supporting line, or farther than
-    // `m` beyond one of its ends -> the closest point of the segment is farther than dist_min and the force is exactly 0
-    // (core.py:2836).  Football's walls span the pitch, their bounding circles never reject anything.  Only FINITE
-    // gaps skip: a NaN cos (non-finite rotation) or an infinite position makes both gaps NaN / inf.
-    const float dx = pl[k].x - ps.x, dy = pl[k].y - ps.y;
-#if VMAS_X_TIGHT_LS
-    const float m = dist_min + kSkipSlack;
-    const float along = fabsf(dx * cs[k] + dy * sn[k]) - half[k];
-    const float perp = fabsf(dy * cs[k] - dx * sn[k]);
-    bool need = !((along > m && along < kInf) || (perp > m && perp < kInf));
-#else
-    const float m = half[k] + dist_min + kSkipSlack;  // bounding circles
-    bool need = !far_apart(dx * dx + dy * dy, m * m) || cs[k] != cs[k];
-#endif
-    bool on = k < n;
-    if (args.pair_mask) on = on && ((mask_word(args.pair_mask, sgpr(idx[k]) >> 5) >> (sgpr(idx[k]) & 31)) & 1u);
-    needbits |= (on && __any(need)) ? (1u << k) : 0u;
-  }
-  if (!needbits || (ABLATE(args) & 32)) return;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    if (needbits & (1u << k)) {  // core.py:2341-2392
-      const v2 cp = closest_point_line<true>(pl[k], cs[k], sn[k], half[k], ps);
-      const v2 f = contact_force(ps, cp, dist_min, W.c_coll, W.k);
-      if (movable) F = F + f;
-    }
-  }
-}
-
-// SHARED sphere-sphere pairs (both spheres dynamic), four pairs to a record, each evaluated ONCE: the force on a goes
-// to the pair's two LDS rows, b's owner reads it with the sign flipped (cf(a,b) == -cf(b,a) bit for bit).
-//   w0: type, n, tile offset of the first pair's rows (pair k: + 2k rows), -
-//   w1: a offsets 0|1<<16, 2|3<<16, b offsets 0|1<<16, 2|3<<16   w2: r_sum 0..3   w3: pair index 0|1<<16, 2|3<<16
-__device__ __forceinline__ void eval_ssp(const ItemW& I, const DevWorld& W, const DevStepArgs& args, float* tile,
-                                         uint32_t* fired) {
-  const uint4 w0 = I.w0, w1 = I.w1, w2 = I.w2, w3 = I.w3;
-  const int n = sgpr((int)w0.y);
-  const int rec = sgpr((int)w0.w);  // ordinal among the shared sphere-sphere records
-  float* R = tile + (int)w0.z;
-  const int oa[4] = {(int)(w1.x & 0xffffu), (int)(w1.x >> 16), (int)(w1.y & 0xffffu), (int)(w1.y >> 16)};
-  const int ob[4] = {(int)(w1.z & 0xffffu), (int)(w1.z >> 16), (int)(w1.w & 0xffffu), (int)(w1.w >> 16)};
-  const float rs[4] = {__uint_as_float(w2.x), __uint_as_float(w2.y), __uint_as_float(w2.z), __uint_as_float(w2.w)};
-  const int idx[4] = {(int)(w3.x & 0xffffu), (int)(w3.x >> 16), (int)(w3.y & 0xffffu), (int)(w3.y >> 16)};
-  v2 pa[4], pb[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {  // unused slots repeat pair 0 on the host: always valid rows
-    const float* A = tile + oa[k];
-    const float* B = tile + ob[k];
-    pa[k] = V(A[0], A[ROWF]);
-    pb[k] = V(B[0], B[ROWF]);
-  }
-  uint32_t needbits = 0;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const float dx = pa[k].x - pb[k].x, dy = pa[k].y - pb[k].y;
-    const float m = rs[k] + 1e-4f;  // the force is exactly 0 for dist > r_a + r_b (core.py:2836)
-    bool need = !far_apart(dx * dx + dy * dy, m * m);
-    bool on = k < n;
-    if (args.pair_mask) on = on && ((mask_word(args.pair_mask, sgpr(idx[k]) >> 5) >> (sgpr(idx[k]) & 31)) & 1u);
-    needbits |= (on && __any(need)) ? (1u << k) : 0u;
-  }
-  if (ABLATE(args) & 32) needbits = 0;
-  // Which pairs fired (some environment of the tile within reach) is published, four bits per record: the owners skip
-  // the rows of a pair that did not fire in phase C - its force is +0 on a, -0 on b in every environment, and
-  // F + (-0) == F, F + (+0) == F except for F == -0 (handled there) - so those rows are not even written.
-  const bool published = rec < FIRED_RECS;
-  if (published && needbits && (threadIdx.x & (TILE - 1)) == 0)
-    atomicOr(fired + (rec >> 3), needbits << ((rec & 7) * 4));  // (LDS atomic, no return value)
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    if (k < n && (!published || (needbits & (1u << k)))) {
-      v2 f = V(0.f, 0.f);
-      if (needbits & (1u << k)) f = contact_force(pa[k], pb[k], rs[k], W.c_coll, W.k);
-      R[(2 * k) * ROWF] = f.x;
-      R[(2 * k + 1) * ROWF] = f.y;
-    }
-  }
-}
-
-// Force (and torque) one item contributes to ITS side.  LEVEL prunes code (and registers):
-// 0: SS LS BS   1: + LL BL joints   2: + BB
-template <int LEVEL>
-__device__ __forceinline__ void eval_item(const ItemV& K, const DevWorld& W, const DevStepArgs& args,
-                                          const float* tile, long env, bool live, long ld, v2& f_out, float& t_out,
-                                          float& tb_out) {
-  const float* A = tile + K.oa;
-  const float* B = tile + K.ob;
-  const v2 pa = V(A[0], A[ROWF]), pb = V(B[0], B[ROWF]);
-  const float k = W.k;
-  // Every joint/pair applies f to a and exactly -f to b (core.py:2839), so only the force on
-  // a is computed and the b side flips its sign bit.  (Written as an integer xor on purpose:
-  // hipcc 7.2 mis-folds `side ? -f : f` - the negation is dropped - which the golden parity
-  // tests caught.)  Torques use the side's own lever arm.
-  // A SHARED item (side 2, both entities dynamic) is evaluated once: f_out/t_out are a's, tb_out is the torque on b.
-  const int side = K.side & 3;
-  const uint32_t flip = side == 1 ? 0x80000000u : 0u;
-  auto own = [&](v2 fa) { return V(__uint_as_float(__float_as_uint(fa.x) ^ flip), __uint_as_float(__float_as_uint(fa.y) ^ flip)); };
-  auto neg = [&](v2 fa) { return V(__uint_as_float(__float_as_uint(fa.x) ^ 0x80000000u), __uint_as_float(__float_as_uint(fa.y) ^ 0x80000000u)); };
-  // torques of a pair whose force on a is fa: each side's own lever arm, b's with the flipped force
-  auto levers = [&](v2 lever_a, v2 lever_b, v2 fa) {
-    if (side != 1) t_out = vcross(lever_a, fa);
-    if (side == 1) t_out = vcross(lever_b, neg(fa));
-    if (side == 2) tb_out = vcross(lever_b, neg(fa));
-  };
-  if (LEVEL >= 1 && K.type == TASK_JOINT) {  // _vectorized_joint_constraints core.py:2201-2292
-    const float ra = A[4 * ROWF], rb = B[4 * ROWF];
-    float sa, ca, sb, cb;
-    sincosf(ra, &sa, &ca);
-    sincosf(rb, &sb, &cb);
-    const v2 pja = pa + rotate(V(K.p0, K.p1), ca, sa);  // joints.py:209-216
-    const v2 pjb = pb + rotate(V(K.q0, K.q1), cb, sb);
-    const v2 f_att = constraint_force<true>(pja, pjb, K.p2, W.c_joint_att, k);
-    const v2 f_rep = constraint_force<false>(pja, pjb, K.p2, W.c_joint_rep, k);
-    const v2 fa = f_att + f_rep;  // (-f_att) + (-f_rep) == -(f_att + f_rep) bitwise
-    levers(pja - pa, pjb - pb, fa);
-    if (K.flags & IT_LOCK) {
-      float fr = K.p3;
-      if (args.joint_fixed_rot && live) fr = args.joint_fixed_rot[(long)K.index * ld + env];
-      const float lock = constraint_torque(ra, rb + fr, W.tcf);
-      t_out = t_out + (side == 1 ? lock : -lock);
-      if (side == 2) tb_out = tb_out + lock;
-    }
-    f_out = own(fa);
-    return;
-  }
-  if (args.pair_mask && !((mask_word(args.pair_mask, K.index >> 5) >> (K.index & 31)) & 1u)) return;
-  const float* TA = tile + K.tra;
-  const float* TB = tile + K.trb;
-  {  // conservative per-environment broad phase: beyond it the force is exactly zero
-    const float dx = pa.x - pb.x, dy = pa.y - pb.y;
-    bool need = !far_apart(dx * dx + dy * dy, K.thr2);
-    if (VMAS_X_TIGHT_LS && K.type == VMAS_PAIR_LS) {  // a is a line: the sphere's gaps to the segment in the line's frame (see eval_lsq)
-      const float along = fabsf(dx * TA[0] + dy * TA[ROWF]) - K.p0;
-      const float perp = fabsf(dy * TA[0] - dx * TA[ROWF]);
-      need = need && !((along > K.reach && along < kInf) || (perp > K.reach && perp < kInf));
-    }
-    if (K.type >= VMAS_PAIR_BS) {  // a is a box: test against the oriented box, much tighter
-      if (K.type == VMAS_PAIR_BL) {
-        const float gap = seg_obb_gap(pb, TB[0], TB[ROWF], K.p2, pa, TA[0], TA[ROWF], K.p0 * 0.5f, K.p1 * 0.5f);
-        need = need && !(gap > K.reach);
-      } else {
-        const float d2 = obb_dist2(pb, pa, TA[0], TA[ROWF], K.p0 * 0.5f, K.p1 * 0.5f);
-        need = need && !(d2 > K.reach * K.reach);
-      }
-    }
-    // a Line/Box with a non-finite rotation has NaN edges at any distance
-    if (K.type != VMAS_PAIR_SS) need = need || TA[0] != TA[0];
-    if (K.type == VMAS_PAIR_LL || K.type == VMAS_PAIR_BL || K.type == VMAS_PAIR_BB) need = need || TB[0] != TB[0];
-    if (!__any(need) || (ABLATE(args) & 32)) return;  // 32: broad phase only (profiling)
-  }
-  switch (K.type) {
-    case VMAS_PAIR_SS: {  // core.py:2294-2339; p0 = r_a + r_b
-      f_out = own(contact_force(pa, pb, K.p0, W.c_coll, k));
-    } break;
-    case VMAS_PAIR_LS: {  // a = line, b = sphere; p0 = L/2, p1 = r + LMD  core.py:2341-2392
-      const v2 cp = closest_point_line<true>(pa, TA[0], TA[ROWF], K.p0, pb);
-      const v2 f = own(-contact_force(pb, cp, K.p1, W.c_coll, k));
-      f_out = f;
-      t_out = side == 1 ? 0.f : vcross(cp - pa, f);
-    } break;
-    case VMAS_PAIR_BS: {  // a = box, b = sphere; p0 = L, p1 = W, p2 = r + LMD  core.py:2459-2552
-      seg_t be[4];
-      box_edges(pa, TA[0], TA[ROWF], TA[2 * ROWF], TA[3 * ROWF], K.p0, K.p1, be);
-      const v2 cp = closest_point_box(be, pb);
-      v2 ip = cp;
-      float d = 0.f;
-      if (!(K.flags & IT_A_HOLLOW)) ip = inner_point_box(pb, cp, pa, d);
-      const v2 f = own(-contact_force(pb, ip, K.p2 + d, W.c_coll, k));
-      f_out = f;
-      t_out = side == 1 ? 0.f : vcross(cp - pa, f);
-    } break;
-    case VMAS_PAIR_LL:
-      if (LEVEL >= 1) {  // p0 = La/2, p1 = Lb/2  core.py:2394-2457
-        seg_t l1 = {pa, TA[0], TA[ROWF], K.p0};
-        seg_t l2 = {pb, TB[0], TB[ROWF], K.p1};
-        v2 qa, qb;
-        closest_points_seg_seg(l1, l2, qa, qb);
-        const v2 fa = contact_force(qa, qb, kLineMinDist, W.c_coll, k);
-        f_out = own(fa);
-        levers(qa - pa, qb - pb, fa);
-      }
-      break;
-    case VMAS_PAIR_BL:
-      if (LEVEL >= 1) {  // a = box, b = line; p0 = L, p1 = W, p2 = Lb/2  core.py:2554-2653
-        seg_t be[4];
-        box_edges(pa, TA[0], TA[ROWF], TA[2 * ROWF], TA[3 * ROWF], K.p0, K.p1, be);
-        seg_t ln = {pb, TB[0], TB[ROWF], K.p2};
-        v2 qb, ql;
-        closest_seg_box(be, ln, qb, ql);
-        v2 ip = qb;
-        float d = 0.f;
-        if (!(K.flags & IT_A_HOLLOW)) ip = inner_point_box(ql, qb, pa, d);
-        const v2 fa = contact_force(ip, ql, kLineMinDist + d, W.c_coll, k);
-        f_out = own(fa);
-        levers(qb - pa, ql - pb, fa);
-      }
-      break;
-    case VMAS_PAIR_BB:
-      if (LEVEL >= 2) {  // p0,p1 = L,W of a; p2,p3 = L,W of b  core.py:2655-2786
-        seg_t ea[4], eb[4];
-        box_edges(pa, TA[0], TA[ROWF], TA[2 * ROWF], TA[3 * ROWF], K.p0, K.p1, ea);
-        box_edges(pb, TB[0], TB[ROWF], TB[2 * ROWF], TB[3 * ROWF], K.p2, K.p3, eb);
-        v2 qa, qb;
-        closest_box_box(ea, eb, qa, qb);
-        v2 ia = qa, ib = qb;
-        float da = 0.f, db = 0.f;
-        if (!(K.flags & IT_A_HOLLOW)) ia = inner_point_box(qb, qa, pa, da);
-        if (!(K.flags & IT_B_HOLLOW)) ib = inner_point_box(qa, qb, pb, db);
-        const v2 fa = contact_force(ia, ib, da + db + kLineMinDist, W.c_coll, k);
-        f_out = own(fa);
-        levers(qa - pa, qb - pb, fa);
-      }
-      break;
-    default: break;
-  }
-}
+#include "vmas_step_device.h"
 
 // ------------------------------------------------------------------------------------
 // the fused step kernel: grid = ceil(batch / 64) tiles, block = 64 x W threads
@@ -1242,9 +826,19 @@ struct Sched {
   std::vector<uint32_t> h_blob;  // host copy of the descriptor blob (planning worlds; the world-specialised kernel's match)
   int spec_id = -1;              // >= 0: this schedule is word for word the one a generated specialisation was built from
   uint32_t* d_blob = nullptr;
+  // a specialisation compiled at RUN TIME for exactly this schedule (vmas_world_load_spec): its kernels by launch form
+  struct Rt {
+    hipModule_t mod = nullptr;
+    hipFunction_t lean[2] = {nullptr, nullptr};                 // [tail]
+    hipFunction_t multi[5][2][2] = {};                           // [ENV_*][one][tail]
+    int post = 0;
+    bool ok = false;
+  } rt;
   void release() {
     (void)hipFree(d_blob);
     d_blob = nullptr;
+    if (rt.mod) (void)hipModuleUnload(rt.mod);
+    rt = Rt{};
   }
 };
 
@@ -1890,6 +1484,39 @@ static int launch_level(VmasWorld* w, Sched* S, float* state, float* aft, long l
       if (rc <= 0) return rc;
     }
   }
+  // ... or the specialisation compiled at run time for this very schedule (vmas_world_load_spec)
+  if (plain && S->rt.ok && w->use_spec && !ABLATE(a) && !a.trace) {
+    bool rt_ok = true;
+    if constexpr (ENV != ENV_NONE) rt_ok = env.ingest.n_scripts == 0 && !ABLATE(env);
+    if constexpr (ENV == ENV_BALANCE) rt_ok = rt_ok && S->rt.post == 1;
+    if constexpr (ENV == ENV_TRANSPORT) rt_ok = rt_ok && S->rt.post == 2;
+    if constexpr (ENV == ENV_NAVIGATION) rt_ok = rt_ok && S->rt.post == 3;
+    const size_t lds_rt = ((size_t)S->rows * ROWF + 8) * sizeof(float) + extra_lds;
+    if (rt_ok && lds_rt <= 64 * 1024) {
+      const int tail = batch % TILE != 0 ? 1 : 0;
+      const int n = a.n_steps > 1 ? a.n_steps : 1;
+      hipFunction_t fn = nullptr;
+      DevWorld Wk = S->dw;
+      float* st_ = state;
+      float* af_ = aft;
+      long ld_ = ld, stride_ = (long)a.ft_stride;
+      int batch_ = batch, n_ = n;
+      EnvArgs env_ = env;
+      void* lean_args[] = {&Wk, &st_, &af_, &ld_, &batch_};
+      void* multi_args[] = {&Wk, &st_, &af_, &ld_, &batch_, &n_, &stride_, &env_};
+      void** args_ = multi_args;
+      if (ENV == ENV_NONE && S->dw.substeps == 1 && n == 1) {
+        fn = S->rt.lean[tail];
+        args_ = lean_args;
+      } else {
+        fn = S->rt.multi[ENV][n == 1 ? 1 : 0][tail];
+      }
+      if (fn != nullptr) {
+        HIP_TRY(hipModuleLaunchKernel(fn, (unsigned)blocks, 1, 1, (unsigned)(TILE * S->nw), 1, 1, (unsigned)lds_rt, s, args_, nullptr));
+        return 0;
+      }
+    }
+  }
   if (mode == 3)
     hipLaunchKernelGGL((step_kernel<LEVEL, ENV, EnvArgs, 3>), dim3(blocks), dim3(TILE * S->nw), lds, s, S->dw, state, aft,
                        ld, batch, a, env);
@@ -2393,7 +2020,54 @@ int vmas_world_get_specialized(VmasWorld* w) {  // 1: plain World.step launches 
   if (!w) return 0;
   Sched* S;
   if (get_sched(w, w->lanes, &S)) return 0;
-  return (w->use_spec && S->spec_id >= 0) ? 1 : 0;
+  return (w->use_spec && (S->spec_id >= 0 || S->rt.ok)) ? 1 : 0;
+}
+
+int vmas_world_load_spec(VmasWorld* w, const char* code_object_path) {
+  if (!w || !code_object_path) return fail("vmas_world_load_spec: null argument");
+  if (w->host_only) return fail("vmas_world_load_spec: a planning world (device -1) has no device side");
+  HIP_TRY(hipSetDevice(w->device));
+  Sched* S;
+  if (get_sched(w, w->lanes, &S)) return -1;
+  if (S->rt.mod) { (void)hipModuleUnload(S->rt.mod); S->rt = Sched::Rt{}; }
+  hipModule_t mod = nullptr;
+  if (hipModuleLoad(&mod, code_object_path) != hipSuccess) return fail("vmas_world_load_spec: cannot load %s", code_object_path);
+  struct Unload { hipModule_t m; ~Unload() { if (m) (void)hipModuleUnload(m); } } guard{mod};
+  // the tables the module was generated from must be, word for word, the schedule this world runs
+  hipDeviceptr_t dptr = nullptr;
+  size_t bytes = 0;
+  if (hipModuleGetGlobal(&dptr, &bytes, mod, "vmas_rt_check") != hipSuccess) return fail("vmas_world_load_spec: %s has no vmas_rt_check", code_object_path);
+  std::vector<uint32_t> got(bytes / 4);
+  HIP_TRY(hipMemcpy(got.data(), dptr, bytes, hipMemcpyDeviceToHost));
+  const DevWorld& D = S->dw;
+  const uint32_t meta[23] = {(uint32_t)S->nw, (uint32_t)w->share_mode, (uint32_t)w->level, (uint32_t)S->h_blob.size(), (uint32_t)D.b_ent,
+                             (uint32_t)D.b_segs, (uint32_t)D.b_owned, (uint32_t)D.b_refs, (uint32_t)D.b_items, (uint32_t)D.n_segs,
+                             (uint32_t)D.n_owned, (uint32_t)S->rows, (uint32_t)D.fired_recs, (uint32_t)D.items_in_lds, (uint32_t)D.nE,
+                             (uint32_t)D.nA, (uint32_t)D.off_af, (uint32_t)D.row_tr, (uint32_t)(D.trig_mask & 0xffffffffu),
+                             (uint32_t)(D.trig_mask >> 32), (uint32_t)(D.box_mask & 0xffffffffu), (uint32_t)(D.box_mask >> 32),
+                             (uint32_t)D.trig_in_args};
+  if (got.size() != 25 + S->h_blob.size() || memcmp(got.data(), meta, sizeof(meta)) != 0 || got[23] != (uint32_t)D.substeps ||
+      memcmp(got.data() + 25, S->h_blob.data(), S->h_blob.size() * sizeof(uint32_t)) != 0)
+    return fail("vmas_world_load_spec: %s was generated from another schedule (world, batch geometry or library version)",
+                code_object_path);
+  Sched::Rt rt;
+  rt.post = (int)got[24];
+  char name[64];
+  for (int t = 0; t < 2; ++t) {
+    snprintf(name, sizeof(name), "vmas_rt_lean_t%d", t);
+    if (hipModuleGetFunction(&rt.lean[t], mod, name) != hipSuccess) rt.lean[t] = nullptr;
+    for (int e = 0; e < 5; ++e)
+      for (int o = 0; o < 2; ++o) {
+        snprintf(name, sizeof(name), "vmas_rt_multi_e%d_o%d_t%d", e, o, t);
+        if (hipModuleGetFunction(&rt.multi[e][o][t], mod, name) != hipSuccess) rt.multi[e][o][t] = nullptr;
+      }
+  }
+  (void)hipGetLastError();  // (missing forms are expected: they run the interpreter)
+  rt.mod = mod;
+  rt.ok = true;
+  guard.m = nullptr;
+  S->rt = rt;
+  return 0;
 }
 
 int vmas_world_set_compact(VmasWorld* w, int32_t mode) {

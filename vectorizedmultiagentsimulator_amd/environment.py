@@ -39,6 +39,7 @@ class Environment:
         validate_actions: bool = True,
         graph: bool = False,
         fused: Optional[bool] = None,
+        specialize: bool = False,
         **kwargs,
     ):
         self.scenario = scenario
@@ -67,6 +68,9 @@ class Environment:
         self._one_launch = self._ingest_in_step = False
         self._bound_actions = self._bound = None
         self._setup_fused()
+        if specialize and self.device.type == "cuda":
+            # a step kernel compiled for THIS world (specialize.py): tens of seconds once, then from the on-disk cache
+            self.world.specialize()
 
     def _setup_fused(self):
         """``fused``: run action ingest and the scenario's reward/observation/done/info as one HIP
@@ -473,6 +477,7 @@ def make_env(
     validate_actions: bool = True,
     graph: bool = False,
     fused: Optional[bool] = None,
+    specialize: bool = False,
     **kwargs,
 ) -> Environment:
     """vmas.make_env(...) for the scenarios shipped in ``vectorizedmultiagentsimulator_amd.scenarios``."""
@@ -486,5 +491,5 @@ def make_env(
     return Environment(
         scenario, num_envs=num_envs, device=device, continuous_actions=continuous_actions, max_steps=max_steps,
         seed=seed, clamp_actions=clamp_actions, validate_actions=validate_actions, graph=graph, fused=fused,
-        **kwargs,
+        specialize=specialize, **kwargs,
     )
