@@ -228,7 +228,6 @@ class AttachedWorld:
         self.spec = spec
         self.backend.close()
         self.backend = self._factory(self.spec, self.batch, self.device, self.state, self.agent_ft)
-        self.specialize = bool(specialize)  # a step kernel compiled for this world (specialize.py), also after a refresh()
         if self.specialize and hasattr(self.backend, "specialize"):
             self.backend.specialize()
         self._fp = self._fingerprint()
