@@ -5,13 +5,22 @@ import json, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 from vectorizedmultiagentsimulator_amd.environment import make_env
+if os.environ.get("NAV_TILES"):  # A/B: navigation's one-launch step up to this many tiles per CU
+    from vectorizedmultiagentsimulator_amd import fused as _F
+    _F.NavigationPost.ONE_LAUNCH_MAX_TILES_PER_CU = int(os.environ["NAV_TILES"])
 name = sys.argv[1] if len(sys.argv) > 1 else "balance"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32768
 kw = {"balance": dict(n_agents=4), "transport": {}, "navigation": dict(n_agents=8)}[name]
 env = make_env(name, num_envs=B, device="cuda:0", seed=0, validate_actions=False, **kw)
 if os.environ.get("SPEC") == "0":
     env.world._get_backend().set_specialized(False)
+if os.environ.get("LANES"):
+    env.world._get_backend().set_lanes_per_env(int(os.environ["LANES"]))
 acts = [env.get_random_action(a) for a in env.agents]
+if os.environ.get("ACTIONS") == "zero":  # a typical mid-episode configuration held still (one fixed random action drives
+    for _ in range(100):                 # the agents apart for good: no sensor has anything in reach, no contact is live)
+        env.step([env.get_random_action(a) for a in env.agents])
+    acts = [torch.zeros_like(a) for a in acts]
 env.bind(acts)
 for _ in range(300):
     env.step_bound()
@@ -23,5 +32,5 @@ for _ in range(n):
     env.step_bound()
 e1.record(); torch.cuda.synchronize()
 print(json.dumps({"scenario": name, "num_envs": B, "specialized": env.world._get_backend().specialized,
-                  "ablate": os.environ.get("VMAS_ENV_ABLATE"), "lanes": env.world._get_backend().lanes_per_env,
+                  "ablate": os.environ.get("VMAS_ENV_ABLATE"), "actions": os.environ.get("ACTIONS", "fixed"), "lanes": env.world._get_backend().lanes_per_env,
                   "step_bound_us": round(e0.elapsed_time(e1) / n * 1e3, 2)}))

@@ -8,6 +8,9 @@ name = sys.argv[1] if len(sys.argv) > 1 else "balance"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32768
 kw = {"balance": dict(n_agents=4), "transport": {}, "navigation": dict(n_agents=8),
       "football": dict(n_blue_agents=5, n_red_agents=5, ai_red_agents=False)}[name]
+if os.environ.get("NAV_TILES"):  # A/B: navigation's one-launch step up to this many tiles per CU
+    from vectorizedmultiagentsimulator_amd import fused as _F
+    _F.NavigationPost.ONE_LAUNCH_MAX_TILES_PER_CU = int(os.environ["NAV_TILES"])
 only = os.environ.get("ONLY")  # e.g. ONLY=fused-eager
 for fused in (False, True):
     for graph in (False, True):

@@ -290,6 +290,26 @@ VD void closest_box_box(const seg_t ea[4], const seg_t eb[4], v2& pa, v2& pb) {
   pa = qa; pb = qb;
 }
 
+// squared distance from point p to the solid oriented box (centre c, axes (cs,sn)), 0 inside
+VD float obb_dist2(v2 p, v2 c, float cs, float sn, float half_l, float half_w) {
+  const float dx = p.x - c.x, dy = p.y - c.y;
+  const float lx = fabsf(dx * cs + dy * sn) - half_l;
+  const float ly = fabsf(dy * cs - dx * sn) - half_w;
+  const float ex = fmaxf(lx, 0.f), ey = fmaxf(ly, 0.f);
+  return ex * ex + ey * ey;
+}
+
+// separating-axis lower bound of the distance between a segment (centre p, direction (lc,ls),
+// half length h) and the oriented box: the larger of the two gaps along the box axes
+VD float seg_obb_gap(v2 p, float lc, float ls, float h, v2 c, float cs, float sn, float half_l,
+                                             float half_w) {
+  const float dx = p.x - c.x, dy = p.y - c.y;
+  const float px = dx * cs + dy * sn, py = dy * cs - dx * sn;            // segment centre in the box frame
+  const float ex = fabsf(h * (lc * cs + ls * sn)), ey = fabsf(h * (ls * cs - lc * sn));  // its half extents
+  const float gx = fabsf(px) - ex - half_l, gy = fabsf(py) - ey - half_w;
+  return fmaxf(gx, gy);
+}
+
 // get_friction_force core.py:2055-2073
 VD v2 friction2(v2 vel, float coeff, float mass, float sub_dt) {
   float speed = vnorm(vel);

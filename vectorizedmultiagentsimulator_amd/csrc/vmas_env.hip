@@ -152,28 +152,38 @@ __global__ __launch_bounds__(256) void navigation_collision_kernel(const VmasNav
                                                                   uint32_t* __restrict__ mask, int mask_words) {
   __shared__ uint32_t collide_with[VMAS_ENV_MAX_AGENTS];
   const int A = d.n_agents;
-  if ((int)threadIdx.x < A) {
-    uint32_t m = 0;
-    for (int j = 0; j < A; ++j) {
-      const int pi = pair_index[threadIdx.x * A + j];
-      if (j != (int)threadIdx.x && pi >= 0 && ((__builtin_nontemporal_load(&mask[pi >> 5]) >> (pi & 31)) & 1u)) m |= 1u << j;
-    }
-    collide_with[threadIdx.x] = m;
+  if ((int)threadIdx.x < VMAS_ENV_MAX_AGENTS) collide_with[threadIdx.x] = 0u;
+  __syncthreads();
+  const long env = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long e = env < batch ? env : (long)batch - 1;
+  // Two round trips instead of one per use (a thread per agent walking its row of pair_index chained 2 * A dependent
+  // loads: most of this kernel's time): the pair indices with every position and reward of this environment, then the
+  // mask words.
+  extern __shared__ float sh[];  // xy[2 * A][256] | rw[A][256]
+  float* xy = sh + threadIdx.x;
+  float* rw = xy + 2 * A * 256;
+  const int first = (int)threadIdx.x < A * A ? pair_index[threadIdx.x] : -1;
+  // (positions and rewards in ONE burst: rows 0 .. 2A - 1 = xy, 2A .. 3A - 1 = rw, contiguous in `sh`)
+  burst<32>(3 * A,
+            [&](int i) {
+              return i < 2 * A ? state[((long)(d.agent0 + (i >> 1)) * 6 + (i & 1)) * ld + e] : rew[(long)(i - 2 * A) * batch + e];
+            },
+            [&](int i, float v) { xy[i * 256] = v; });
+  // bit j of collide_with[a]: World.collides(agent a, agent j), a thread per (a, j)
+  auto look = [&](int i, int pi) {
+    const int a = i / A, j = i - a * A;
+    if (j != a && pi >= 0 && ((__builtin_nontemporal_load(&mask[pi >> 5]) >> (pi & 31)) & 1u)) atomicOr(&collide_with[a], 1u << j);
+  };
+  const uint32_t word = first >= 0 ? __builtin_nontemporal_load(&mask[first >> 5]) : 0u;
+  if ((int)threadIdx.x < A * A) {
+    const int a = threadIdx.x / A, j = threadIdx.x - a * A;
+    if (j != a && ((word >> (first & 31)) & 1u)) atomicOr(&collide_with[a], 1u << j);
   }
+  for (int i = threadIdx.x + blockDim.x; i < A * A; i += blockDim.x) look(i, pair_index[i]);  // (more than 16 agents)
   __syncthreads();
   if (threadIdx.x == 0 && atomicAdd(&mask[mask_words], 1u) == gridDim.x - 1) {  // every block has read the mask
     for (int k = 0; k <= mask_words; ++k) mask[k] = 0u;
   }
-  const long env = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long e = env < batch ? env : (long)batch - 1;
-  // every position and reward of this environment in one burst of independent loads (a load per use would chain a
-  // dozen L2 round trips: 12 us for this kernel at 8192 environments)
-  extern __shared__ float sh[];  // xy[2 * A][256] | rw[A][256]
-  float* xy = sh + threadIdx.x;
-  float* rw = xy + 2 * A * 256;
-  burst<16>(2 * A, [&](int i) { return state[((long)(d.agent0 + (i >> 1)) * 6 + (i & 1)) * ld + e]; },
-            [&](int i, float v) { xy[i * 256] = v; });
-  burst<16>(A, [&](int a) { return rew[(long)a * batch + e]; }, [&](int a, float v) { rw[a * 256] = v; });
   if (env >= batch) return;
   auto pos = [&](int a) { return V(xy[2 * a * 256], xy[(2 * a + 1) * 256]); };
   for (int a = 0; a < A; ++a) {

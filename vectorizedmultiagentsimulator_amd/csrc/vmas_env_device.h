@@ -139,15 +139,16 @@ VD bool apply_step_limit(const VmasStepLimit& lim, const TileCtx& C, float steps
 }
 
 // ------------------------------------------------------------------------------------ balance
-// balance.py:218-267.  scratch: flags[2][64] (line-floor, package-floor) | tab[16][64] | tiles[nw][64][17].
-// Preconditions: `rows` complete and the flush table built (balance_build_table), both visible to the block;
-// the caller loaded prev_shaping (Scenario.global_shaping) and steps_in for this lane.  One block barrier: the
-// two overlap queries (waves 0 and 1) run beside the observations of the other waves, the reward follows it.
+// balance.py:218-267.  scratch: flags[2][64] (line-floor, package-floor).
+// Preconditions: `rows` complete and visible to the block; the caller loaded prev_shaping (Scenario.global_shaping) and
+// steps_in for this lane.  One block barrier: the two overlap queries (waves 0 and 1) run beside the observations of the
+// other waves, the reward follows it.  Observations: a row is 16 floats = 64 bytes, every lane stores its environment's
+// row itself with four 16-byte stores (the four stores of a wave cover whole 128-byte lines back to back and merge in
+// L2) - round 2 staged the 64 x 16 tile through LDS and streamed it out through a divmod table: 35 KB of LDS per tile
+// and two wave-level fences on the step's dependent chain.
 constexpr int kBalanceObsDim = 16;
-VD void balance_build_table(const TileCtx& C, float* scratch) {
-  build_flush_table(C, (int*)(scratch + 2 * 64), kBalanceObsDim, kBalanceObsDim | 1);
-}
-__host__ __device__ inline size_t balance_scratch_floats(int nw) { return 2 * 64 + kBalanceObsDim * 64 + (size_t)nw * 64 * (kBalanceObsDim | 1); }
+VD void balance_build_table(const TileCtx&, float*) {}  // (kept for the callers' sake: nothing to build any more)
+__host__ __device__ inline size_t balance_scratch_floats(int) { return 2 * 64; }
 
 VD void balance_post_tile(const TileCtx& C, const VmasBalanceDesc& d, const VmasBalanceBuffers& o, int batch,
                           const float* rows, float* scratch, float& prev_shaping /* in: before, out: after this step */,
@@ -155,8 +156,6 @@ VD void balance_post_tile(const TileCtx& C, const VmasBalanceDesc& d, const Vmas
                           const float* floor_trig = nullptr /* this lane's cos, sin, cos2, sin2 rows (stride 64) */) {
   constexpr int D = kBalanceObsDim;
   float* flags = scratch;
-  int* tab = (int*)(flags + 2 * 64);
-  const ObsTile T = obs_tile(C, (float*)(tab + D * 64), tab, D);
   auto R = [&](int ent, int f) { return rows[(ent * 6 + f) * 64 + C.lane]; };
   auto P2 = [&](int ent, int f) { return V(R(ent, f), R(ent, f + 1)); };
 
@@ -178,8 +177,19 @@ VD void balance_post_tile(const TileCtx& C, const VmasBalanceDesc& d, const Vmas
     }
     const bool is_line = C.wave == 0;
     const v2 body = P2(is_line ? d.line : d.package, 0);
-    const float reach = (is_line ? d.line_length / 2.f : d.package_radius) + kLineMinDist + 1e-3f;
-    const bool near = !(box_outside_distance(floor, fc, fs, d.floor_length, d.floor_width, body) > reach);
+    // Early out, exact: a sphere whose centre is farther than r + LINE_MIN_DIST outside the box cannot overlap it; a
+    // segment whose separating-axis gap to the box (a lower bound of their distance) exceeds LINE_MIN_DIST has a positive
+    // World.get_distance (core.py:1880-1893).  The centre-to-box distance the line used to be tested with never fired: the
+    // line rides 6 cm above the floor, well within its half length - the four-edge solve ran on every step.
+    float ls = 0.f, lc = 1.f;
+    bool near;
+    if (is_line) {
+      sincosf(R(d.line, 4), &ls, &lc);
+      near = !(seg_obb_gap(body, lc, ls, d.line_length / 2.f, floor, fc, fs, d.floor_length / 2.f, d.floor_width / 2.f) >
+               kLineMinDist + 1e-3f);
+    } else {
+      near = !(box_outside_distance(floor, fc, fs, d.floor_length, d.floor_width, body) > d.package_radius + kLineMinDist + 1e-3f);
+    }
     int hit = 0;
     if (__any(near)) {
       float fs2, fc2;
@@ -192,8 +202,6 @@ VD void balance_post_tile(const TileCtx& C, const VmasBalanceDesc& d, const Vmas
       seg_t be[4];
       box_edges(floor, fc, fs, fc2, fs2, d.floor_length, d.floor_width, be);
       if (is_line) {
-        float ls, lc;
-        sincosf(R(d.line, 4), &ls, &lc);
         const seg_t l = {body, lc, ls, d.line_length / 2.f};
         v2 qb, ql;
         closest_seg_box(be, l, qb, ql);
@@ -215,9 +223,14 @@ VD void balance_post_tile(const TileCtx& C, const VmasBalanceDesc& d, const Vmas
   const int first = (C.wave + C.nw - (2 % C.nw)) % C.nw;
   for (int a = first; a < d.n_agents && !(ablate & 2); a += C.nw) {  // (2: profiling, observations off)
     const v2 p = P2(d.agent0 + a, 0), v = P2(d.agent0 + a, 2);
-    T.put(0, p); T.put(2, v); T.put(4, p - pkg); T.put(6, p - line); T.put(8, pkg_goal_rel);
-    T.put(10, pkg_vel); T.put(12, line_vel); T.put(14, line_av); T.put(15, rot_mod);
-    T.flush(o.obs + ((long)a * batch + C.b0) * D, C.n_rows);
+    if (C.live) {
+      float4* row = (float4*)(o.obs + ((long)a * batch + C.env) * D);
+      const v2 dp = p - pkg, dl = p - line;
+      row[0] = make_float4(p.x, p.y, v.x, v.y);
+      row[1] = make_float4(dp.x, dp.y, dl.x, dl.y);
+      row[2] = make_float4(pkg_goal_rel.x, pkg_goal_rel.y, pkg_vel.x, pkg_vel.y);
+      row[3] = make_float4(line_vel.x, line_vel.y, line_av, rot_mod);
+    }
   }
   __syncthreads();
 
@@ -458,18 +471,40 @@ constexpr int kNavMaxOwn = VMAS_ENV_MAX_AGENTS / 4;  // agents one wave can own:
 __host__ __device__ inline int navigation_obs_dim(const VmasNavigationDesc& d) {
   return 4 + 2 * (d.observe_all_goals ? d.n_agents : 1) + (d.collisions ? d.n_rays : 0);
 }
-// scratch of the fused epilogue: per_agent[A][64] (agent.pos_shaping in) | misc[2 * MAX_AGENTS] (work counter, this tile's
-// pair bits, collide_with[MAX_AGENTS]) | tab[D][64] | tiles[min(nw, A)][64][D|1] | rays[A * n_rays][64] (LIDAR
-// measurements of the tile)
-// | staged descriptors: cos, sin[R] | angles[R] | pairs[n_pairs] | pair_index[A * A] (R = A * n_rays)
+// scratch of the fused epilogue: per_agent[A][64] (agent.pos_shaping in) | misc[2 * MAX_AGENTS] (LIDAR queue length, this
+// tile's pair bits | collide_with[MAX_AGENTS]) | staged descriptors: cos, sin[R] | angles[R] |
+// pairs[n_pairs] | pair_index[A * A] | the LIDAR queue: 16 bits per (environment, sensor, target) within reach |
+// measured[R][65]: lidar_range - measurement of every ray, as the bits of a non-negative float (R = A * n_rays).
+// Round 2 staged every wave's observation tile AND the rays' rows ([R][64] floats) here - 19 + 24 KB at eight agents, one
+// tile per CU; writing every lane's own row of the observation matrix straight to HBM instead was measured too: a
+// quarter of the kernel went into 8-byte stores 72 bytes apart (one L2 request per lane and store - the L2's request
+// rate, not its bandwidth, is the bound).  Now a wave writes the 64 x D block of its agent as ONE contiguous run, each
+// lane gathering its two consecutive elements from where they already are: the state tile and `measured`.
+constexpr int kNavMeasuredStride = 65;  // (lanes of one environment read consecutive rays: consecutive banks)
+__host__ __device__ inline size_t navigation_fixed_floats(int n_agents, int n_rays_total, int n_pairs) {
+  return (size_t)n_agents * 64 + 2 * VMAS_ENV_MAX_AGENTS + (size_t)n_rays_total * 3 + (size_t)n_pairs * 3 +
+         (n_rays_total > 0 ? (size_t)n_agents * n_agents + (size_t)n_agents * (n_agents - 1) * 32 +
+                                 (size_t)n_rays_total * kNavMeasuredStride
+                           : 0) + 2;
+}
+// ... | per wave: own[D - n_rays][65], the other columns of the observation of the agent the wave is writing
 __host__ __device__ inline size_t navigation_scratch_floats(int nw, int n_agents, int D, int n_rays_total = 0, int n_pairs = 0) {
-  return (size_t)n_agents * 64 + 2 * VMAS_ENV_MAX_AGENTS + (size_t)D * 64 + (size_t)nw * 64 * (D | 1) + (size_t)n_rays_total * 64 +
-         (size_t)n_rays_total * 3 + (size_t)n_pairs * 3 + (n_rays_total > 0 ? (size_t)n_agents * n_agents : 0);
+  const int n_rays = n_agents > 0 ? n_rays_total / n_agents : 0;
+  return navigation_fixed_floats(n_agents, n_rays_total, n_pairs) + (size_t)nw * (D - n_rays) * kNavMeasuredStride;
 }
 
-template <bool FUSED, class Pos, class Vel, class Goal, class Rays>
+// The observation writer of the fused epilogue: nothing is staged (put is a no-op), the caller's `rays(a, slot)` writes
+// agent a's block (navigation_post_tile).  The stand-alone kernel keeps ObsTile.
+struct ObsGather {
+  float* own;  // this wave's [D - n_rays][65] columns, + lane
+  int dim;
+  VD void put(int k, float v) const { own[k * kNavMeasuredStride] = v; }
+  VD void put(int k, v2 v) const { own[k * kNavMeasuredStride] = v.x; own[(k + 1) * kNavMeasuredStride] = v.y; }
+};
+
+template <bool FUSED, class Tile, class Pos, class Vel, class Goal, class Rays>
 VD void navigation_post_body(const TileCtx& C, const VmasNavigationDesc& d, const VmasNavigationBuffers& o, int batch,
-                             const float* per_agent, const uint32_t* collide_with, const ObsTile& T, float steps_in,
+                             const float* per_agent, const uint32_t* collide_with, Tile T, float steps_in,
                              Pos pos, Vel vel, Goal goal, Rays rays /* (agent, slot): its LIDAR part into T */,
                              float* new_shaping = nullptr /* [kNavMaxOwn] out: the shaping of this wave's agents */) {
   const int A = d.n_agents;
@@ -536,7 +571,7 @@ VD void navigation_post_body(const TileCtx& C, const VmasNavigationDesc& d, cons
       T.put(4, p - goal(a));
     }
     rays(a, s);
-    T.flush(o.obs + ((long)a * batch + C.b0) * T.dim, C.n_rows);
+    if constexpr (std::is_same<Tile, ObsTile>::value) T.flush(o.obs + ((long)a * batch + C.b0) * T.dim, C.n_rows);
   }
 }
 
@@ -551,6 +586,7 @@ struct NavWorld {
   uint32_t seq;    // this launch's barrier number
   int32_t n_pairs;
   uint32_t* gave_up;  // host-mapped word set when the barrier gives up waiting (read by the host at the world's next call)
+  int32_t ablate;     // profiling builds only (VMAS_ENV_ABLATE): 1 LIDAR off, 2 observation / reward off, 4 the whole epilogue off
 };
 
 // before the physics (the loads fly behind it): agent.pos_shaping of this lane and the observation flush table
@@ -558,16 +594,13 @@ VD void navigation_prologue_tile(const TileCtx& C, const VmasNavigationDesc& d, 
                                  const NavWorld& nav, int batch, float* scratch) {
   const int A = d.n_agents;
   float* per_agent = scratch;
-  int* misc = (int*)(per_agent + A * 64);  // [0] the LIDAR units' work counter, [1..] this tile's pair bits
-  int* tab = misc + 2 * VMAS_ENV_MAX_AGENTS;
+  int* misc = (int*)(per_agent + A * 64);  // [0] the LIDAR queue's length, [1..] this tile's pair bits
   for (int a = C.wave; a < A; a += C.nw)
     per_agent[a * 64 + C.lane] = C.live ? o.pos_shaping[(long)a * batch + C.env] : 0.f;
-  if (threadIdx.x < 2 * VMAS_ENV_MAX_AGENTS) misc[threadIdx.x] = threadIdx.x == 0 ? C.nw : 0;
-  const int D = navigation_obs_dim(d);
-  build_flush_table(C, tab, D, D | 1);
+  for (int i = threadIdx.x; i < 2 * VMAS_ENV_MAX_AGENTS; i += blockDim.x) misc[i] = 0;  // (a tile may be a single wave)
   if (d.collisions) {  // the epilogue's descriptors: a dependent global load per use would chain microseconds behind the physics
     const int R = A * d.n_rays;
-    float* stage = (float*)(tab + D * 64) + (size_t)(C.nw < A ? C.nw : A) * 64 * (D | 1) + (size_t)R * 64;
+    float* stage = (float*)(misc + 2 * VMAS_ENV_MAX_AGENTS) + 2;  // (8-byte aligned: cos / sin pairs first)
     for (int i = threadIdx.x; i < R; i += blockDim.x) {
       const float2 cs = nav.angles_cs[i];  // (cos, sin first: 8-byte aligned whatever R is)
       stage[2 * i] = cs.x; stage[2 * i + 1] = cs.y;
@@ -577,6 +610,8 @@ VD void navigation_prologue_tile(const TileCtx& C, const VmasNavigationDesc& d, 
     for (int i = threadIdx.x; i < nav.n_pairs * 3; i += blockDim.x) stage[3 * R + i] = pw[i];
     int* pidx = (int*)(stage + 3 * R + 3 * nav.n_pairs);
     for (int i = threadIdx.x; i < A * A; i += blockDim.x) pidx[i] = o.pair_index[i];
+    uint32_t* measured = (uint32_t*)(pidx + A * A) + A * (A - 1) * 32;  // (behind the queue)
+    for (int i = threadIdx.x; i < R * kNavMeasuredStride; i += blockDim.x) measured[i] = 0u;  // = lidar_range - max_range
   }
 }
 
@@ -595,12 +630,16 @@ VD void navigation_post_tile(const TileCtx& C, const VmasNavigationDesc& d, cons
   }
   auto stamp = [&](int k) { if (tr != nullptr && (threadIdx.x & 63) == 0) tr[k] = __builtin_amdgcn_s_memtime(); };
   stamp(6);
+#ifdef VMAS_PROFILE
+  const int ablate = nav.ablate;
+#else
+  constexpr int ablate = 0;
+#endif
+  if (ablate & 4) return;
   const int A = d.n_agents, D = navigation_obs_dim(d), n_goal = d.observe_all_goals ? A : 1;
   const float* per_agent = scratch;
   int* misc = (int*)(scratch + A * 64);
-  const int* tab = misc + 2 * VMAS_ENV_MAX_AGENTS;
   uint32_t* collide_with = (uint32_t*)(misc + VMAS_ENV_MAX_AGENTS);
-  const ObsTile T = obs_tile(C, (float*)(tab + D * 64), tab, D);
   const float* col = rows + C.lane;
   const int words = (nav.n_pairs + 31) >> 5;
   // World.collides' reduction over the batch, two ways.  nav.sync != NULL (every tile of the grid resident at once, at
@@ -611,12 +650,14 @@ VD void navigation_post_tile(const TileCtx& C, const VmasNavigationDesc& d, cons
   const uint32_t seq = nav.seq + (uint32_t)stp;  // ring of four mask slots: slot seq + 2 is cleared behind barrier seq
   uint32_t* slot = grid_sync ? nav.sync + 2 + (seq & 3u) * (uint32_t)words : nav.mask;
   const int R = d.collisions ? A * d.n_rays : 0;
-  float* ray_rows0 = (float*)(tab + D * 64) + (size_t)(C.nw < A ? C.nw : A) * 64 * (D | 1);
-  const float* stage = ray_rows0 + (size_t)R * 64;  // staged by navigation_prologue_tile
+  const float* stage = (const float*)(misc + 2 * VMAS_ENV_MAX_AGENTS) + 2;  // staged by navigation_prologue_tile
   const float2* st_cs = (const float2*)stage;
   const float* st_angles = stage + 2 * R;
   const DevMaskPair* st_pairs = (const DevMaskPair*)(stage + 3 * R);
   const int* st_pair_index = (const int*)(stage + 3 * R + 3 * nav.n_pairs);
+  const int ray0 = 4 + 2 * n_goal;  // (= D - n_rays: the columns that are not rays)
+  float* own_cols = scratch + navigation_fixed_floats(A, R, nav.n_pairs) + (size_t)C.wave * ray0 * kNavMeasuredStride;
+  const ObsGather T{own_cols + C.lane, D};
   if (d.collisions) {  // World.collides' reduction over the batch (core.py:2797-2801), this tile's share: into LDS words
                        // now, into the world's mask by one lane of the tile behind the LIDAR barrier
     for (int k = C.wave; k < nav.n_pairs; k += C.nw) {
@@ -642,36 +683,108 @@ VD void navigation_post_tile(const TileCtx& C, const VmasNavigationDesc& d, cons
   auto pos = [&](int a) { const float* e = col + (d.agent0 + a) * 6 * 64; return V(e[0], e[64]); };
   auto vel = [&](int a) { const float* e = col + (d.agent0 + a) * 6 * 64; return V(e[2 * 64], e[3 * 64]); };
   auto goal = [&](int a) { const float* e = col + d.goal_of[a] * 6 * 64; return V(e[0], e[64]); };
-  // LIDAR: units of CH rays of one sensor, dealt round-robin to ALL waves of the tile (a wave per agent would leave half
-  // of a 16-wave tile idle behind 12-ray chains); measurements through LDS to the wave that assembles the observation
-  float* ray_rows = ray_rows0 + C.lane;
-  if (d.collisions && d.n_rays > 0) {
-    auto cast_units = [&](auto ch_tag) {
-      constexpr int CH = decltype(ch_tag)::value;
-      const int per = (d.n_rays + CH - 1) / CH;
-      auto grab = [&]() {  // units differ (targets within reach): the first is static, the rest are pulled
-        int v = 0;
-        if (C.lane == 0) v = atomicAdd(&misc[0], 1);
-        return __builtin_amdgcn_readfirstlane(v);
-      };
-      for (int u = C.wave; u < A * per; u = grab()) {
-        const int a = u / per, r0 = (u - a * per) * CH;
-        // sensor a: on agent a, its targets the other agents in order - spheres of the agents' radius (host-checked
-        // against the world's registered sensors, whose descriptors the stand-alone lidar_kernel reads)
-        const DevLidar L = {d.agent0 + a, d.n_rays, A - 1, 0, a * d.n_rays, d.lidar_range, d.lidar_range * 0.5f};
-        auto target = [&](int ti) {
-          return DevTarget{d.agent0 + (ti < a ? ti : ti + 1), VMAS_SHAPE_SPHERE, 0.f, 0.f, d.agent_radius};
-        };
-        const float* sp = col + L.entity * 6 * 64;
-        float best[CH];
-        lidar_cast_chunk<CH>(L, target, st_angles, st_cs, col, 64, V(sp[0], sp[64]), sp[4 * 64], r0, best);
+  // LIDAR, lane-compacted.  A lane per environment walking its sensor's targets spends most of its time on nothing: of
+  // the 7 other agents ~1 is within reach of a sensor, but a wave loops as often as its unluckiest lane (~3 times), and of
+  // the 12 rays ~2 can touch a sphere that is.  Instead:
+  //   1. every (sensor, target) pair of every environment of the tile is tested for reach (the very test of
+  //      lidar_cast_chunk) and the near ones are queued in LDS - ballot + one LDS atomic per wave and pair;
+  //   2. a lane per queued (environment, sensor, target): a conservative filter over its rays (distance of the target's
+  //      centre from the ray's line against radius + a margin far above the rounding of the exact expression; the sign
+  //      test is the exact one), then the reference's arithmetic (core.py:1414-1490, expression for expression that of
+  //      lidar_cast_chunk) for the rays that pass.  A ray that is filtered out measures max_range against this target
+  //      in the reference too, which never lowers the minimum (core.py:1672-1674, 1785);
+  //   3. the observation holds lidar_range - min(distances): `measured` starts at zero (= lidar_range - max_range) and
+  //      every hit nearer than max_range is folded in with an LDS atomic max on the float's bits - x -> lidar_range - x
+  //      is monotone under rounding, so max(lidar_range - d_i) IS lidar_range - min(d_i), bit for bit; the values are
+  //      positive floats, which order like their bit patterns.
+  if (d.collisions && d.n_rays > 0 && !(ablate & 1)) {
+    stamp(11);
+    uint16_t* queue = (uint16_t*)const_cast<int*>(st_pair_index + A * A);  // lane | sensor << 6 | target << 11
+    uint32_t* measured = (uint32_t*)(st_pair_index + A * A) + A * (A - 1) * 32;
+    const float lim = d.lidar_range + d.agent_radius + 1e-4f;
+    // (eight pairs at a time: their tests first, then ONE LDS atomic for the wave's slots - an atomic and its round trip
+    // per pair was a third of this phase)
+    const int n_unordered = A * (A - 1) / 2;
+    for (int k0 = C.wave; k0 < n_unordered; k0 += 8 * C.nw) {
+      unsigned long long bal[8];
+      int sensor[8], target[8], total = 0;
 #pragma unroll
-        for (int i = 0; i < CH; ++i)
-          if (r0 + i < d.n_rays) ray_rows[(a * d.n_rays + r0 + i) * 64] = best[i];
+      for (int j = 0; j < 8; ++j) {
+        const int k = k0 + j * C.nw;
+        bal[j] = 0ull; sensor[j] = target[j] = 0;
+        if (k >= n_unordered) continue;
+        int a = 0, rem = k;
+        while (rem >= A - 1 - a) { rem -= A - 1 - a; ++a; }
+        const int t = a + 1 + rem;
+        const float* pa = col + (d.agent0 + a) * 6 * 64;
+        const float* pt = col + (d.agent0 + t) * 6 * 64;
+        const float dx = pt[0] - pa[0], dy = pt[64] - pa[64];
+        const bool near = C.live && !(dx * dx + dy * dy > lim * lim);  // NaN counts as near
+        bal[j] = __ballot(near);
+        sensor[j] = a; target[j] = t;
+        total += 2 * __popcll(bal[j]);
       }
-    };
-    if (A * ((d.n_rays + 3) / 4) < 2 * C.nw) cast_units(std::integral_constant<int, 2>{});
-    else cast_units(std::integral_constant<int, 4>{});
+      if (total == 0) continue;
+      int base = 0;
+      if (C.lane == 0) base = atomicAdd(&misc[0], total);
+      base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (bal[j] == 0ull) continue;
+        if ((bal[j] >> C.lane) & 1ull) {
+          const int slot = base + 2 * (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[j], 0u));
+          queue[slot] = (uint16_t)(C.lane | sensor[j] << 6 | target[j] << 11);      // sensor a on target t ...
+          queue[slot + 1] = (uint16_t)(C.lane | target[j] << 6 | sensor[j] << 11);  // ... and sensor t on target a
+        }
+        base += 2 * __popcll(bal[j]);
+      }
+    }
+    stamp(12);
+    __syncthreads();
+    stamp(14);
+    const int n_items = misc[0];
+    const float radius = d.agent_radius, range = d.lidar_range, half_range = d.lidar_range * 0.5f;
+    for (int i0 = C.wave * 64; i0 < n_items; i0 += C.nw * 64) {
+      const bool on = i0 + C.lane < n_items;
+      const uint32_t item = on ? queue[i0 + C.lane] : 0u;
+      const int e = item & 63, sa = (item >> 6) & 31, ta = item >> 11;
+      const float* ps = rows + e + (d.agent0 + sa) * 6 * 64;
+      const float* pg = rows + e + (d.agent0 + ta) * 6 * 64;
+      const v2 op = V(ps[0], ps[64]), tpos = V(pg[0], pg[64]);
+      const float arot = ps[4 * 64];
+      const v2 u = tpos - op;
+      const float margin = radius + 1e-4f + 1e-5f * (fabsf(op.x) + fabsf(op.y) + fabsf(tpos.x) + fabsf(tpos.y));
+      const bool table = __all(!on || arot == 0.f);  // (see lidar_cast_chunk: the same sincosf made the table)
+      auto direction = [&](int r, float& c, float& sn) {
+        if (table) { const float2 cs = st_cs[sa * d.n_rays + r]; c = cs.x; sn = cs.y; }
+        else sincosf(st_angles[sa * d.n_rays + r] + arot, &sn, &c);  // sensors.py:118
+      };
+      unsigned long long cand = 0ull;
+      for (int r = 0; r < d.n_rays; ++r) {
+        float c, sn;
+        direction(r, c, sn);
+        const bool maybe = !(fabsf(u.x * sn - u.y * c) > margin) && vdot(u, V(c, sn)) > 0.f;
+        if (on && maybe) cand |= 1ull << r;
+      }
+      uint32_t* mrow = measured + sa * d.n_rays * kNavMeasuredStride + e;
+      while (__any(cand != 0ull)) {
+        if (cand != 0ull) {
+          const int r = __ffsll((long long)cand) - 1;
+          cand &= cand - 1ull;
+          float c, sn;
+          direction(r, c, sn);
+          const v2 dir = V(c, sn);  // _cast_rays_to_sphere core.py:1414-1490
+          const v2 lp = V(op.x + dir.x * half_range, op.y + dir.y * half_range);
+          const v2 cp = closest_point_line<false>(lp, c, sn, 0.f, tpos);
+          const float dn = vnorm(tpos - cp);
+          const bool ok = (dn < radius) && (vdot(u, dir) > 0.f);
+          const float a2 = radius * radius - dn * dn;
+          const float m = sqrt_n(a2 > 0.f ? a2 : 1e-8f);
+          const float dist = vnorm(cp - op) - m;
+          if (ok && dist < range) atomicMax(mrow + r * kNavMeasuredStride, __float_as_uint(range - dist));
+        }
+      }
+    }
     stamp(8);
     if (grid_sync) {
       if (threadIdx.x == 0) {
@@ -714,12 +827,34 @@ VD void navigation_post_tile(const TileCtx& C, const VmasNavigationDesc& d, cons
     }
   }
   stamp(9);
+  // agent a's 64 x D block of the observation matrix (navigation.py:244-263) as one contiguous run: every lane gathers two
+  // consecutive elements (one if D is odd) - the columns the body just put into `own`, the rays from `measured`
   auto rays = [&](int a, int) {
-    if (!d.collisions) return;
-    for (int r = 0; r < d.n_rays; ++r) T.put(4 + 2 * n_goal + r, d.lidar_range - ray_rows[(a * d.n_rays + r) * 64]);
+    wave_lds_fence();
+    float* out = o.obs + ((long)a * batch + C.b0) * D;
+    const int total = C.n_rows * D;
+    const float* mr = (const float*)((const uint32_t*)(st_pair_index + A * A) + A * (A - 1) * 32) + a * d.n_rays * kNavMeasuredStride;
+    const float inv_d = 1.f / (float)D;
+    auto elem = [&](int env, int k) {  // (one LDS read whichever array holds the column)
+      const float* src = k < ray0 ? own_cols + k * kNavMeasuredStride : mr + (k - ray0) * kNavMeasuredStride;
+      return src[env];
+    };
+    if ((D & 1) == 0) {  // (every block starts 8-byte aligned: 64 * D * 4 bytes per tile, batch * D * 4 per agent)
+      for (int i = 2 * C.lane; i < total; i += 128) {
+        const int env = (int)(((float)i + 0.5f) * inv_d), k = i - env * D;
+        *(float2*)(out + i) = make_float2(elem(env, k), elem(env, k + 1));
+      }
+    } else {
+      for (int i = C.lane; i < total; i += 64) {
+        const int env = (int)(((float)i + 0.5f) * inv_d);
+        out[i] = elem(env, i - env * D);
+      }
+    }
+    wave_lds_fence();
   };
-  float shaping_out[kNavMaxOwn];
-  if (grid_sync && d.collisions)
+  float shaping_out[kNavMaxOwn] = {};
+  if (ablate & 2) {}
+  else if (grid_sync && d.collisions)
     navigation_post_body<false>(C, d, o, batch, per_agent, collide_with, T, steps_in, pos, vel, goal, rays, shaping_out);
   else
     navigation_post_body<true>(C, d, o, batch, per_agent, nullptr, T, steps_in, pos, vel, goal, rays, shaping_out);
@@ -734,7 +869,11 @@ VD void navigation_post_tile(const TileCtx& C, const VmasNavigationDesc& d, cons
       const int a = C.wave + sl * C.nw;
       if (a < A) pa[a * 64 + C.lane] = C.live ? shaping_out[sl] : 0.f;
     }
-    if (threadIdx.x < VMAS_ENV_MAX_AGENTS) misc[threadIdx.x] = threadIdx.x == 0 ? C.nw : 0;
+    if (threadIdx.x < VMAS_ENV_MAX_AGENTS) misc[threadIdx.x] = 0;
+    if (d.collisions) {
+      uint32_t* measured = (uint32_t*)(st_pair_index + A * A) + A * (A - 1) * 32;
+      for (int i = threadIdx.x; i < R * kNavMeasuredStride; i += blockDim.x) measured[i] = 0u;
+    }
   }
 }
 
@@ -743,13 +882,29 @@ VD void navigation_post_tile(const TileCtx& C, const VmasNavigationDesc& d, cons
 // .process_action for ONE agent slot and this lane's environment: returns the (up to 3) scaled
 // action components, stores agent_ft / u_out, and ORs VMAS_ACTION_ERR_* into `bad`.
 // `row0`: first row of this step's actions in the caller's [n_steps * batch, action_size] tensor (multi-step rollouts).
-VD void ingest_slot(const VmasActionSlot& S, int clamp, long env, bool live, float* __restrict__ agent_ft, long ld,
-                    float u_out[3], uint32_t& bad, long row0 = 0) {
+// Two halves, so that a wave with several agents has all their action loads in flight before it touches the first:
+// ingest_fetch issues the loads of one slot (nothing else), ingest_apply is the arithmetic and the stores.  A load per
+// agent behind the previous agent's stores chained one HBM round trip per agent along the step kernel's critical path.
+struct IngestRaw { float u[3]; long flat; };
+VD void ingest_fetch(const VmasActionSlot& S, long env, bool live, long row0, IngestRaw& r) {
+  r.u[0] = r.u[1] = r.u[2] = 0.f;
+  r.flat = 0;
+  if (!live) return;
+  if (S.action_index != nullptr) {
+    r.flat = S.action_index[row0 + env];
+  } else if (S.action_size == 2 && ((uintptr_t)S.action & 7) == 0) {  // (rows of two floats: one 8-byte load)
+    const float2 v = *(const float2*)(S.action + (row0 + env) * 2);
+    r.u[0] = v.x; r.u[1] = v.y;
+  } else {
+    for (int k = 0; k < S.action_size; ++k) r.u[k] = S.action[(row0 + env) * S.action_size + k];
+  }
+}
+VD void ingest_apply(const VmasActionSlot& S, int clamp, long env, bool live, float* __restrict__ agent_ft, long ld,
+                     float u_out[3], uint32_t& bad, const IngestRaw& r) {
   u_out[0] = u_out[1] = u_out[2] = 0.f;
   if (!live) return;
-  long flat = 0;
+  long flat = r.flat;
   if (S.action_index != nullptr) {  // flat index -> per-dimension index -> [-u_range, u_range] (environment.py:657-705)
-    flat = S.action_index[row0 + env];
     long total = 1;
     for (int k = 0; k < S.action_size; ++k) total *= S.nvec[k];
     if (flat < 0 || flat >= total) {
@@ -768,7 +923,7 @@ VD void ingest_slot(const VmasActionSlot& S, int clamp, long env, bool live, flo
       if (n & 1) a = a == 0 ? n / 2 : (a <= n / 2 ? a - 1 : a);  // odd count: index 0 is "stay"
       u = ((float)a / (float)(n - 1)) * (2.f * S.u_range[k]) - S.u_range[k];
     } else {
-      u = S.action[(row0 + env) * S.action_size + k];
+      u = r.u[k];
     }
     if (u != u) bad |= VMAS_ACTION_ERR_NAN;
     if (S.action_index != nullptr) {
@@ -782,6 +937,13 @@ VD void ingest_slot(const VmasActionSlot& S, int clamp, long env, bool live, flo
     agent_ft[((long)S.agent_index * 3 + k) * ld + env] = u;
     if (S.u_out != nullptr) S.u_out[env * S.action_size + k] = u;
   }
+}
+
+VD void ingest_slot(const VmasActionSlot& S, int clamp, long env, bool live, float* __restrict__ agent_ft, long ld,
+                    float u_out[3], uint32_t& bad, long row0 = 0) {
+  IngestRaw r;
+  ingest_fetch(S, env, live, row0, r);
+  ingest_apply(S, clamp, env, live, agent_ft, ld, u_out, bad, r);
 }
 
 // A scripted agent whose script the library knows (VmasAgentScript): same contract as ingest_slot.  `E` = this

@@ -2155,12 +2155,13 @@ static int nav_epilogue_plan(VmasWorld* w, const VmasNavigationDesc* d, size_t* 
       }
     }
   }
-  if (d->collisions && (d->n_rays < 1 || (w->n_pairs + 31) / 32 >= VMAS_ENV_MAX_AGENTS))
-    return fail("vmas_world_step_env: navigation with collisions needs n_rays >= 1 and at most %d collidable pairs",
+  if (d->collisions && (d->n_rays < 1 || d->n_rays > 64 || (w->n_pairs + 31) / 32 >= VMAS_ENV_MAX_AGENTS))
+    return fail("vmas_world_step_env: navigation with collisions needs 1 <= n_rays <= 64 and at most %d collidable pairs",
                 32 * (VMAS_ENV_MAX_AGENTS - 1));
   const int D = navigation_obs_dim(*d);
   *fixed = navigation_scratch_floats(0, d->n_agents, D, d->collisions ? d->n_agents * d->n_rays : 0, d->collisions ? w->n_pairs : 0);
-  *per_wave = navigation_scratch_floats(1, d->n_agents, D) - navigation_scratch_floats(0, d->n_agents, D);
+  *per_wave = navigation_scratch_floats(1, d->n_agents, D, d->collisions ? d->n_agents * d->n_rays : 0) -
+              navigation_scratch_floats(0, d->n_agents, D, d->collisions ? d->n_agents * d->n_rays : 0);
   return 0;
 }
 
@@ -2268,7 +2269,7 @@ static int step_env_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld
       grid_sync = cap == hipStreamCaptureStatusNone;
     }
     env.navigation.w = NavWorld{w->d_angles, w->d_angles_cs, w->d_mpairs, w->d_nav_mask, grid_sync ? w->d_nav_sync : nullptr,
-                                w->nav_seq, d->collisions ? w->n_pairs : 0, w->d_gave_up};
+                                w->nav_seq, d->collisions ? w->n_pairs : 0, w->d_gave_up, env.ablate};
     if (n_steps > 1 && d->collisions && !grid_sync)
       return fail("vmas_world_rollout_env: navigation's collision penalties reduce over the whole batch after every step "
                   "(World.collides): several steps per launch need every tile resident at once (%d tiles, %d CUs) and a stream "
@@ -2340,6 +2341,7 @@ static int step_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld, co
         HIP_TRY(hipMemset(w->d_trace, 0, n * 8));
       }
       a.trace = w->d_trace;
+      if (trace == 2 && env != nullptr) { env->trace = w->d_trace; a.trace = nullptr; }  // (the specialised kernel's stamps)
     }
   }
   {

@@ -90,25 +90,7 @@ __device__ __forceinline__ void write_trig(float* tr, float rot, int shape) {
   }
 }
 
-// squared distance from point p to the solid oriented box (centre c, axes (cs,sn)), 0 inside
-__device__ __forceinline__ float obb_dist2(v2 p, v2 c, float cs, float sn, float half_l, float half_w) {
-  const float dx = p.x - c.x, dy = p.y - c.y;
-  const float lx = fabsf(dx * cs + dy * sn) - half_l;
-  const float ly = fabsf(dy * cs - dx * sn) - half_w;
-  const float ex = fmaxf(lx, 0.f), ey = fmaxf(ly, 0.f);
-  return ex * ex + ey * ey;
-}
-
-// separating-axis lower bound of the distance between a segment (centre p, direction (lc,ls),
-// half length h) and the oriented box: the larger of the two gaps along the box axes
-__device__ __forceinline__ float seg_obb_gap(v2 p, float lc, float ls, float h, v2 c, float cs, float sn, float half_l,
-                                             float half_w) {
-  const float dx = p.x - c.x, dy = p.y - c.y;
-  const float px = dx * cs + dy * sn, py = dy * cs - dx * sn;            // segment centre in the box frame
-  const float ex = fabsf(h * (lc * cs + ls * sn)), ey = fabsf(h * (ls * cs - lc * sn));  // its half extents
-  const float gx = fabsf(px) - ex - half_l, gy = fabsf(py) - ey - half_w;
-  return fmaxf(gx, gy);
-}
+// (obb_dist2, seg_obb_gap: vmas_device.h - the balance epilogue uses the separating-axis gap too)
 
 // Register views of descriptors read from the LDS blob (uniform address => broadcast read):
 // control words go to SGPRs, offsets and float parameters stay in (uniform) VGPRs.

@@ -86,6 +86,7 @@ struct DevEnv {
   // for it), so the prologue reads its slot with one kernarg fetch, no indirection.  Scripts: agent -> script or -1.
   int8_t script_of_agent[VMAS_ENV_MAX_AGENTS];
   uint32_t* err_flags;
+  unsigned long long* trace;  // profiling only (VMAS_TRACE=2): per-wave s_memtime stamps of the world-specialised kernel
   VmasIngestArgs ingest;
   union {
     struct { VmasBalanceDesc d; VmasBalanceBuffers o; } balance;

@@ -551,7 +551,7 @@ class TransportPost(_Post):
 
 
 class NavigationPost(_Post):
-    ONE_LAUNCH_MAX_TILES_PER_CU = 1  # the one-launch step is used up to this many tiles per CU (measured, see __init__)
+    ONE_LAUNCH_MAX_TILES_PER_CU = 64  # the one-launch step is used up to this many tiles per CU (measured, see __init__)
 
     @staticmethod
     def supports(env) -> Optional[str]:
@@ -585,8 +585,9 @@ class NavigationPost(_Post):
         self._side = None
         # as the physics kernel's epilogue only if the library says this world allows it (sensors as the epilogue casts
         # them, tile + scratch within the CU's LDS); otherwise the separate launches of __call__
-        # ... and while every 64-environment tile has a CU to itself (8192 environments: 22 us in one launch against
-        # 7.6 + 8.5 + 13 us in three; at 65536 the epilogue's LDS leaves one tile per CU and the three launches win)
+        # (round 2 kept the one-launch step to one tile per CU: its epilogue staged 43 KB of observation and ray rows in
+        # LDS and lost to the separate launches beyond that.  With the lane-compacted LIDAR and the block writer -
+        # DESIGN.md 3.4 - it wins at every size measured: 65 536 environments 64 us against 99 in four launches)
         n_cu = torch.cuda.get_device_properties(self.dev).multi_processor_count
         # several steps per launch (rollout): a grid barrier per step - every tile must be resident at once
         self.rollout_ok = (self.B + 63) // 64 <= n_cu or not sc.collisions
