@@ -117,3 +117,23 @@ def test_large_schedules_are_not_specialised():
     assert hw.specialize() is False and not hw.specialized
     with pytest.raises(S.SpecializeError, match="too large"):
         S.specialize(hw, strict=True)
+
+
+def test_navigation_between_the_built_in_geometries_specialises_at_run_time():
+    """navigation n_agents=8 has built-in specialisations for 4 waves per tile (65 536 environments) and 16 (up to 16 384);
+    in between the planner chooses 8 - served by the run-time specialiser, one-launch step (ingest + physics + LIDAR /
+    observation / reward epilogue with > 64 KB of LDS) included: bitwise the interpreter."""
+    from vectorizedmultiagentsimulator_amd.environment import make_env
+
+    B = 24576
+    a = make_env("navigation", num_envs=B, device="cuda:0", seed=5, n_agents=8, validate_actions=False, specialize=True)
+    b = make_env("navigation", num_envs=B, device="cuda:0", seed=5, n_agents=8, validate_actions=False)
+    assert a.world._get_backend().lanes_per_env == 8
+    assert a.world._get_backend().specialized and not b.world._get_backend().specialized and a._one_launch
+    for t in range(8):
+        acts = [a.get_random_action(ag) for ag in a.agents]
+        oa, ra, da, _ = a.step([x.clone() for x in acts])
+        ob, rb, db, _ = b.step(acts)
+        assert torch.equal(_bits(a.world._state), _bits(b.world._state)), f"state differs at step {t}"
+        assert torch.equal(_bits(torch.stack(oa)), _bits(torch.stack(ob))), f"observations differ at step {t}"
+        assert torch.equal(_bits(torch.stack(ra)), _bits(torch.stack(rb))) and torch.equal(da, db), f"rewards / done differ at step {t}"

@@ -756,8 +756,8 @@ class World:
     def specialize(self, cache_dir: Optional[str] = None) -> bool:
         """A world-specialised step kernel for this world as it is now (specialize.py): compiled once, cached on disk."""
         be = self._get_backend()
-        hint = getattr(self, "epilogue_hint", None)
-        return be.specialize(post=hint[0] if hint is not None else 0, cache_dir=cache_dir)
+        hint = getattr(self, "epilogue_hint", None)  # (epilogues the planner reserves LDS for; else the scenario's fused_post)
+        return be.specialize(post=hint[0] if hint is not None else getattr(self, "fused_post", 0), cache_dir=cache_dir)
 
     # ---- reference API ---------------------------------------------------------------
     batch_dim = property(lambda s: s._batch_dim)

@@ -734,9 +734,18 @@ __global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld
       {
         const float* rows = tile + ent_off(E.football.d.agent0);  // (host-checked: the agents and the ball are consecutive
         const float* af = tile + P.off_af;                        //  dynamic entities, agent index = slot)
+        // observation staging (E.scratch_off >= 0: the host found room): a [64][17] tile per wave - the first waves in
+        // the per-substep scratch from the ballots to the contact list (ballots | base | keys | forces | torques: written
+        // before they are read in every substep, and the next one is a barrier away), the others behind the kernel's own LDS
+        float* slab = nullptr;
+        if (E.scratch_off >= 0) {
+          constexpr int kSlab = 64 * (kFootballStageChunk + 1);
+          const int in_dead = (int)((const float*)xmask - (const float*)ballots) / kSlab;
+          slab = wv < in_dead ? (float*)ballots + wv * kSlab : lds + E.scratch_off + (wv - in_dead) * kSlab;
+        }
         football_post_tile(TileCtx(batch), E.football.d, E.football.o, batch,
                            [&](int slot, int k) { return k < 4 ? rows[(slot * 6 + k) * ROWF] : af[(slot * 3 + (k - 4)) * ROWF]; },
-                           (float*)nullptr, fb_prev, post_steps, stp);
+                           slab, kFootballStageChunk, fb_prev, post_steps, stp);
       }
       if (stp + 1 < n_steps) __syncthreads();  // the next step's prologue rewrites the agent-force rows
     }

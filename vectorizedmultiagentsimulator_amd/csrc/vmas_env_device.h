@@ -976,17 +976,20 @@ VD void run_script(const VmasAgentScript& S, const float* E, long stride, long e
 // (slot = blue agents, red agents, ball; k = px py vx vy fx fy): the stand-alone kernel (vmas_env.hip) stages them from
 // HBM, the compact step kernel (vmas_compact.h) reads its own tile - the post-step as the physics kernel's epilogue.
 // An observation is 16 + 8 * (observed others) floats - 88 for 5 v 5, 3.5 KB per environment and step over the ten
-// agents: a streaming writer.  `slabs`: chunk tiles [nw][64][33] - a wave transposes its agent's observation 32 columns
-// at a time, so one store instruction covers two 128-byte row segments; NULL: no staging, every lane stores its own row
-// (the step kernel's epilogue).  `prev`: the four shaping terms of this lane
+// agents: a streaming writer.  `slab`: THIS wave's chunk tile [64][chunk + 1] (chunk = 16 or 32 columns) - the wave
+// transposes its agent's observation `chunk` columns at a time, so that the lanes of one store instruction cover whole
+// 64-byte (chunk 16) or 128-byte (32) pieces of the rows; NULL: no staging, every lane stores its own row 16 bytes at a
+// time (one L2 request per lane and store: the L2's request rate bounds that form - 22 requests per row of 88 floats
+// where six would do).  `prev`: the four shaping terms of this lane
 // (in: before, out: after this step), `steps_in`: wave 0's Environment.steps (in/out), `stp`: step of a multi-step
 // launch (every per-step output is offset by stp slabs).  No block barrier inside.
-constexpr int kChunk = 32;
+constexpr int kChunk = 32;               // the stand-alone kernel's chunk
+constexpr int kFootballStageChunk = 16;  // the step kernel's: 64-byte pieces, a quarter of the LDS
 __host__ __device__ inline size_t football_scratch_floats(int nw) { return (size_t)nw * 64 * (kChunk + 1); }
 
 template <class Get>
 VD void football_post_tile(const TileCtx& C, const VmasFootballDesc& d, const VmasFootballBuffers& o_in, int batch, Get G,
-                           float* slabs, float (&prev)[4], float& steps_in, int stp) {
+                           float* slab, int chunk, float (&prev)[4], float& steps_in, int stp) {
   const int n = d.n_blue + d.n_red, ball = n;  // slot of the ball
   VmasFootballBuffers o = o_in;
   const int n_adv_b = d.observe_adversaries ? d.n_red : 0, n_adv_r = d.observe_adversaries ? d.n_blue : 0;
@@ -995,8 +998,7 @@ VD void football_post_tile(const TileCtx& C, const VmasFootballDesc& d, const Vm
     o.obs += (long)stp * n * batch * D0; o.rew += (long)stp * n * batch; o.done += (long)stp * batch;
     o.terms += (long)stp * 9 * batch; o.touching += (long)stp * 2 * batch;
   }
-  float* slab = slabs != nullptr ? slabs + C.wave * 64 * (kChunk + 1) : nullptr;
-  float* my_row = slab != nullptr ? slab + C.lane * (kChunk + 1) : nullptr;
+  float* my_row = slab != nullptr ? slab + C.lane * (chunk + 1) : nullptr;
   auto P2 = [&](int slot, int k) { return V(G(slot, k), G(slot, k + 1)); };
   const v2 bpos = P2(ball, 0), bvel = P2(ball, 2), bforce = P2(ball, 4);
 
@@ -1045,9 +1047,8 @@ VD void football_post_tile(const TileCtx& C, const VmasFootballDesc& d, const Vm
   const float rew_team[2] = {sparse_blue + dense[0], (0.f - sparse_blue) + dense[1]};
 
   // ---- observation football.py:1221-1460, agents wave, wave + nw, ...; red agents see everything mirrored in
-  //      x.  Written chunk by chunk - the 16 own/ball columns, then the observed others four at a time (32
-  //      columns) - through the wave's [64][33] LDS tile; a chunk leaves as float4 stores, two 128-byte row
-  //      segments per instruction.
+  //      x.  Written chunk by chunk - the 16 own/ball columns, then the observed others chunk / 8 at a time -
+  //      through the wave's LDS tile; a chunk leaves as float4 stores.
   for (int a = C.wave; a < n; a += C.nw) {
     const bool blue = a < d.n_blue;
     const float sx = blue ? 1.f : -1.f;
@@ -1058,10 +1059,9 @@ VD void football_post_tile(const TileCtx& C, const VmasFootballDesc& d, const Vm
     const int mate0 = blue ? 0 : d.n_blue, n_team = blue ? d.n_blue : d.n_red;
     const int n_others = n_adv + (d.observe_teammates ? n_team - 1 : 0);
     const int D = 16 + 8 * n_others;
-    if (slabs == nullptr) {
-      // no LDS staging (the step kernel's epilogue: LDS is what decides how many tiles a CU holds): every lane writes its
-      // environment's row itself, four columns per store - 16 bytes per lane at a stride of the row length; the eight stores
-      // that cover a 128-byte line come from the same wave back to back and are merged in L2
+    if (slab == nullptr) {
+      // no LDS staging (a step kernel whose LDS has no room for it): every lane writes its environment's row itself, four
+      // columns per store - 16 bytes per lane at a stride of the row length
       float* row = o.obs + ((long)a * batch + C.env) * D;
       auto put4 = [&](int c, v2 p, v2 q) { if (C.live) *(float4*)(row + c) = make_float4(p.x, p.y, q.x, q.y); };
       put4(0, M(force), M(pos - bpos)); put4(4, M(vel - bvel), M(bpos - goal));
@@ -1098,7 +1098,7 @@ VD void football_post_tile(const TileCtx& C, const VmasFootballDesc& d, const Vm
           int c4 = i - r * w4;
           if (c4 >= w4) { c4 -= w4; r += 1; }
           if (c4 < 0) { c4 += w4; r -= 1; }
-          const float* src = slab + r * (kChunk + 1) + 4 * c4;
+          const float* src = slab + r * (chunk + 1) + 4 * c4;
           v[k] = make_float4(src[0], src[1], src[2], src[3]);
           dst[k] = r * D + c0 + 4 * c4;
         }
@@ -1111,8 +1111,9 @@ VD void football_post_tile(const TileCtx& C, const VmasFootballDesc& d, const Vm
     put(0, M(force)); put(2, M(pos - bpos)); put(4, M(vel - bvel)); put(6, M(bpos - goal));
     put(8, M(bvel)); put(10, M(bforce)); put(12, M(pos - goal)); put(14, M(vel));
     flush(0, 16);
-    for (int j0 = 0; j0 < n_others; j0 += 4) {
-      const int m = n_others - j0 < 4 ? n_others - j0 : 4;
+    const int per = chunk >> 3;  // observed others per chunk
+    for (int j0 = 0; j0 < n_others; j0 += per) {
+      const int m = n_others - j0 < per ? n_others - j0 : per;
       for (int jj = 0; jj < m; ++jj) {
         const int j = j0 + jj;
         int other;

@@ -833,6 +833,7 @@ struct Sched {
     hipFunction_t multi[5][2][2] = {};                           // [ENV_*][one][tail]
     int post = 0;
     bool ok = false;
+    std::map<hipFunction_t, size_t> lds_set;                     // dynamic LDS each function was opted in to (> 64 KB)
   } rt;
   void release() {
     (void)hipFree(d_blob);
@@ -1492,7 +1493,7 @@ static int launch_level(VmasWorld* w, Sched* S, float* state, float* aft, long l
     if constexpr (ENV == ENV_TRANSPORT) rt_ok = rt_ok && S->rt.post == 2;
     if constexpr (ENV == ENV_NAVIGATION) rt_ok = rt_ok && S->rt.post == 3;
     const size_t lds_rt = ((size_t)S->rows * ROWF + 8) * sizeof(float) + extra_lds;
-    if (rt_ok && lds_rt <= 64 * 1024) {
+    if (rt_ok && lds_rt <= 160 * 1024) {
       const int tail = batch % TILE != 0 ? 1 : 0;
       const int n = a.n_steps > 1 ? a.n_steps : 1;
       hipFunction_t fn = nullptr;
@@ -1512,6 +1513,10 @@ static int launch_level(VmasWorld* w, Sched* S, float* state, float* aft, long l
         fn = S->rt.multi[ENV][n == 1 ? 1 : 0][tail];
       }
       if (fn != nullptr) {
+        if (lds_rt > 64 * 1024 && S->rt.lds_set[fn] < lds_rt) {  // (a fused epilogue's scratch: opt in to the large LDS)
+          HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rt));
+          S->rt.lds_set[fn] = lds_rt;
+        }
         HIP_TRY(hipModuleLaunchKernel(fn, (unsigned)blocks, 1, 1, (unsigned)(TILE * S->nw), 1, 1, (unsigned)lds_rt, s, args_, nullptr));
         return 0;
       }
@@ -1736,6 +1741,9 @@ static int build_compact(VmasWorld* w) {
   size_t dyn_words = 4 + (size_t)((D.n_owned * hw + 1) & ~1) + 2 * (size_t)nP + (size_t)((nP + 1) & ~1) + CAP;
   dyn_words += 2 * (size_t)CAP + (D.has_torque ? (size_t)CAP : 0) + (((size_t)D.mask_words + 3) & ~(size_t)3);
   C.lds_bytes = ((size_t)dyn_at + dyn_words) * sizeof(float);
+  if (knob("VMAS_DEBUG_SCHED"))
+    fprintf(stderr, "[compact nw=%d] rows %d, tables %d words, per-substep scratch %zu words, LDS %zu B per tile\n", nw, rows,
+            D.blob_words, dyn_words, C.lds_bytes);
   if (C.lds_bytes > 160 * 1024) return 0;
   if (!w->host_only) {
     HIP_TRY(upload(&C.d_blob, blob));
@@ -2396,8 +2404,19 @@ static int step_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld, co
     if (env_kind == ENV_FOOTBALL) {
       if (!cp) return fail("vmas_world_step_env: the football epilogue runs behind the compacted step kernel, which this world / "
                            "this launch does not use (vmas_world_set_compact, per-environment joint inputs)");
-      env->scratch_off = (int32_t)(w->cp.lds_bytes / sizeof(float));  // (unused: the epilogue stores without LDS staging)
-      return launch_compact(w, ENV_FOOTBALL, state, agent_ft, ld, a, env, 0, s, w->batch, ld);
+      // observation staging (football_post_tile): [64][17] floats per wave, the first waves' in the per-substep scratch
+      // that is dead by then (ballots, base, keys, contact forces, torques: vmas_compact.h).
+      const size_t slab = 64 * (kFootballStageChunk + 1);
+      const compact::DevCompact& dc = w->cp.dc;
+      const int in_dead = (int)((2 * (size_t)dc.n_pairs + (size_t)((dc.n_pairs + 1) & ~1) + (size_t)compact::CAP * (dc.has_torque ? 4 : 3)) / slab);
+      const size_t stage = w->cp.nw > in_dead ? (size_t)(w->cp.nw - in_dead) * slab * sizeof(float) : 0;
+      // Only in the latency regime (16 waves per tile: one tile per CU whatever its LDS).  With 8 waves per tile the
+      // 79 KB leave the CU two tiles on paper, but measured (131 072 environments, rollout): 657 us per step against 180
+      // without - 16 384 environments: 24.0 against 28.9.
+      static const bool no_stage = knob("VMAS_FOOTBALL_NO_STAGE") != nullptr && knob("VMAS_FOOTBALL_NO_STAGE")[0] == '1';  // (A/B)
+      const bool staged = !no_stage && w->cp.nw >= 16 && w->cp.lds_bytes + stage <= 160 * 1024;
+      env->scratch_off = staged ? (int32_t)(w->cp.lds_bytes / sizeof(float)) : -1;
+      return launch_compact(w, ENV_FOOTBALL, state, agent_ft, ld, a, env, staged ? stage : 0, s, w->batch, ld);
     }
     if (S->nw < 2 && env_kind != ENV_INGEST && env_kind != ENV_NAVIGATION)
       return fail("vmas_world_step_env: the fused epilogue needs at least 2 waves per tile");

@@ -53,6 +53,7 @@ class Scenario(BaseScenario):
             world.add_landmark(goal)
             agent.goal = goal
         self._lidar_cache = None
+        world.fused_post = 3  # VMAS_POST_NAVIGATION: the epilogue a run-time specialisation of this world carries (World.specialize)
         return world
 
     def reset_world_at(self, env_index: Optional[int] = None):
