@@ -1325,7 +1325,7 @@ static int get_sched(VmasWorld* w, int nw, Sched** out) {
 // football at 16384 envs 23.6 us with 8 waves, 18.7 with 16), fewer if not (throughput regime: less synchronisation per
 // tile - balance at 1 M envs 156 us with 4 waves, 191 with 8), and a choice that keeps all tiles resident beats one that
 // does not (balance at 32768 envs: 8.2 us with 2 x 8 waves per CU, 11.2 with 1 x 16).
-struct LaneChoice { int nw = 0; long running = 0; bool resident = false; size_t lds = 0; };
+struct LaneChoice { int nw = 0; long running = 0; bool resident = false; size_t lds = 0; bool spec = false; };
 static int choose_lanes(VmasWorld* w, int n_cu, LaneChoice* out) {
   const long tiles = ((long)w->batch + TILE - 1) / TILE;
   const long need = (tiles + n_cu - 1) / n_cu;  // tiles per CU the batch asks for
@@ -1347,10 +1347,13 @@ static int choose_lanes(VmasWorld* w, int n_cu, LaneChoice* out) {
     c.nw = nw; c.lds = lds;
     c.running = std::min(hold, need) * nw;
     c.resident = hold >= need;
+    c.spec = S->spec_id >= 0;  // a built-in specialisation serves this geometry (1.4-1.8x the interpreter's rate)
     bool better;
     if (best.nw == 0) better = true;
     else if (c.running != best.running) better = c.running > best.running;
     else if (c.resident != best.resident) better = c.resident;
+    else if (c.spec != best.spec) better = c.spec;  // (balance at 1 M environments: 4 and 8 waves per tile tie - 179 us on
+                                                    //  the interpreter with 4, 99 on the specialised kernel with 8)
     else better = c.resident;  // tie: the larger nw (visited later) in the latency regime, the smaller in the throughput regime
     if (better) best = c;
   }
@@ -1380,6 +1383,7 @@ static int select_config(VmasWorld* w) {
     if (best_mode < 0) better = true;
     else if (c.running != best.running) better = c.running > best.running;
     else if (c.resident != best.resident) better = c.resident;
+    else if (c.spec != best.spec) better = c.spec;
     else if (c.nw != best.nw) better = c.resident ? c.nw > best.nw : c.nw < best.nw;
     else better = false;  // same geometry: the higher mode (visited first) stays
     if (better) {
@@ -2412,7 +2416,7 @@ static int step_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld, co
       const size_t stage = w->cp.nw > in_dead ? (size_t)(w->cp.nw - in_dead) * slab * sizeof(float) : 0;
       // Only in the latency regime (16 waves per tile: one tile per CU whatever its LDS).  With 8 waves per tile the
       // 79 KB leave the CU two tiles on paper, but measured (131 072 environments, rollout): 657 us per step against 180
-      // without - 16 384 environments: 24.0 against 28.9.
+      // without; half tiles ([32][17], a chunk in two passes, 61 KB per tile): 191 - 16 384 environments: 23.6 against 28.9.
       static const bool no_stage = knob("VMAS_FOOTBALL_NO_STAGE") != nullptr && knob("VMAS_FOOTBALL_NO_STAGE")[0] == '1';  // (A/B)
       const bool staged = !no_stage && w->cp.nw >= 16 && w->cp.lds_bytes + stage <= 160 * 1024;
       env->scratch_off = staged ? (int32_t)(w->cp.lds_bytes / sizeof(float)) : -1;
