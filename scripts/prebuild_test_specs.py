@@ -12,9 +12,13 @@ from golden_util import load  # noqa: E402
 from vectorizedmultiagentsimulator_amd import _abi as A  # noqa: E402
 from vectorizedmultiagentsimulator_amd import specialize as S  # noqa: E402
 
+from golden_util import FIXTURES  # noqa: E402
+
 lib = A.load_library()
-for name, B in [("balance_n3", 4096), ("transport_2pkg", 1024), ("all_joint_passage_size", 700), ("ball_trajectory", 1000),
-                ("give_way", 4096), ("all_wheel", 64 * 7 + 3)]:
+BATCH = {"balance_n3": 4096, "transport_2pkg": 1024, "all_joint_passage_size": 700, "ball_trajectory": 1000, "give_way": 4096,
+         "all_wheel": 64 * 7 + 3}  # (tests/test_specialize_gpu.py; every other fixture: 640 + 7 environments)
+for name in FIXTURES:
+    B = BATCH.get(name, 647)
     g = load(name)
     cd = g.spec.to_ctypes()
     h = C.c_void_p()
@@ -24,7 +28,11 @@ for name, B in [("balance_n3", 4096), ("transport_2pkg", 1024), ("all_joint_pass
     finally:
         lib.vmas_world_destroy(h)
     if meta[23] >= 0:
-        print(name, "has a built-in specialisation")
+        print(name, "has a built-in specialisation", flush=True)
         continue
-    p = S.code_object(S.render(meta, words, int(g.spec.substeps), 0))
-    print(name, B, "->", os.path.basename(p), os.path.getsize(p))
+    try:
+        p = S.code_object(S.render(meta, words, int(g.spec.substeps), 0))
+    except S.SpecializeError as e:
+        print(name, B, "refused:", str(e)[:100], flush=True)
+        continue
+    print(name, B, "->", os.path.basename(p), os.path.getsize(p), flush=True)

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import load
+from golden_util import FIXTURES, load
 from test_hip_parity import _hip, _up, make_batch
 
 pytestmark = pytest.mark.gpu
@@ -18,16 +18,30 @@ def _bits(t):
     return t.contiguous().view(torch.int32)
 
 
-@pytest.mark.parametrize("name,B", [("balance_n3", 4096), ("transport_2pkg", 1024), ("all_joint_passage_size", 700),
-                                    ("ball_trajectory", 1000), ("give_way", 4096), ("all_wheel", 64 * 7 + 3)])
-def test_runtime_specialisation_is_bitwise_the_interpreter(name, B):
+_BATCH = {"balance_n3": 4096, "transport_2pkg": 1024, "all_joint_passage_size": 700, "ball_trajectory": 1000, "give_way": 4096,
+          "all_wheel": 64 * 7 + 3}  # (scripts/prebuild_test_specs.py compiles the same geometries ahead of time)
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_runtime_specialisation_is_bitwise_the_interpreter(name):
+    """EVERY golden fixture: the world's own kernels against the schedule interpreter.  Skipped - with the reason - where
+    the library has a built-in specialisation at this geometry, where the launch is not a plain one (per-environment
+    joint rotations / gravity) and where the size guard refuses the schedule (football, waterfall, ...)."""
+    from vectorizedmultiagentsimulator_amd.specialize import SpecializeError
+
+    B = _BATCH.get(name, 647)
     g = load(name)
     st0, ft0, jfr_np, eg_np = make_batch(g, B, seed=17)
     if jfr_np is not None or eg_np is not None:
         pytest.skip("per-environment inputs run the interpreter (PLAIN launches only are specialised)")
     a, b = _hip(g.spec, B), _hip(g.spec, B)
-    assert not a.specialized, f"{name} unexpectedly has a built-in specialisation"
-    assert a.specialize() and a.specialized and not b.specialized
+    if a.specialized:
+        pytest.skip("a built-in specialisation serves this geometry (tests/test_hip_parity.py pins it)")
+    try:
+        ok = a.specialize()
+    except SpecializeError as e:
+        pytest.skip(f"refused by the size guard: {e}")
+    assert ok and a.specialized and not b.specialized
     for hw in (a, b):
         _up(hw, st0, ft0)
     rng = np.random.default_rng(5)

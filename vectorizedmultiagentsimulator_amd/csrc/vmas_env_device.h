@@ -581,12 +581,14 @@ struct NavWorld {
   const float* angles;         // [n_agents * n_rays] sensor a = agent a's, its targets = the other agents in order (host-checked)
   const float2* angles_cs;
   const DevMaskPair* pairs;
-  uint32_t* mask;  // [(n_pairs + 31) / 32] words, then the collision kernel's block counter
+  uint32_t* mask;  // [(n_pairs + 31) / 32] words, zero when the launch starts
   uint32_t* sync;  // grid-barrier form (NULL: off): arrivals | timeout flag | two mask slots (launch parity)
   uint32_t seq;    // this launch's barrier number
   int32_t n_pairs;
   uint32_t* gave_up;  // host-mapped word set when the barrier gives up waiting (read by the host at the world's next call)
   int32_t ablate;     // profiling builds only (VMAS_ENV_ABLATE): 1 LIDAR off, 2 observation / reward off, 4 the whole epilogue off
+  uint32_t* mask_clear;  // NULL, or the OTHER mask of the two the launches alternate between: the one the previous launch's
+                         // collision kernel read - zeroed here by tile 0 for the launch after this one
 };
 
 // before the physics (the loads fly behind it): agent.pos_shaping of this lane and the observation flush table
@@ -819,6 +821,7 @@ VD void navigation_post_tile(const TileCtx& C, const VmasNavigationDesc& d, cons
       __syncthreads();
     } else {
       __syncthreads();
+      if (blockIdx.x == 0 && nav.mask_clear != nullptr && (int)threadIdx.x < words) nav.mask_clear[threadIdx.x] = 0u;
       // (the mask only grows during a step: a stale read is harmless - and a thousand tiles hammering one word is not)
       if ((int)threadIdx.x < words) {
         const uint32_t b = (uint32_t)misc[1 + threadIdx.x];

@@ -892,7 +892,9 @@ struct VmasWorld {
   uint32_t* h_gave_up = nullptr;
   uint32_t* d_gave_up = nullptr;
   uint32_t* d_exact_mask = nullptr;
-  uint32_t* d_nav_mask = nullptr;  // navigation epilogue: World.collides' pair bits of the post-step state + a block counter
+  uint32_t* d_nav_mask = nullptr;  // navigation epilogue: World.collides' pair bits of the post-step state: two masks that
+  int nav_flip = 0;                //   eager launches alternate between (nav_flip: the one the next launch fills; it is zero)
+                                   //   and a third for captured launches
   uint32_t* d_nav_sync = nullptr;  // its grid-barrier form: arrivals | timeout flag | ring of four mask slots
   uint32_t nav_seq = 0;
   std::vector<DevLidar> h_lidars;  // host copy of the registered sensors (argument checks of the navigation epilogue)
@@ -1936,8 +1938,8 @@ int vmas_world_create(const VmasWorldDesc* d, int32_t batch, int32_t device_id, 
     HIP_TRY(hipMalloc((void**)&w->d_sync, (4 + 4 * mw) * sizeof(uint32_t)));
     HIP_TRY(hipMemset(w->d_sync, 0, (4 + 4 * mw) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void**)&w->d_exact_mask, (mw ? mw : 1) * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void**)&w->d_nav_mask, (mw + 1) * sizeof(uint32_t)));
-    HIP_TRY(hipMemset(w->d_nav_mask, 0, (mw + 1) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&w->d_nav_mask, (3 * mw + 1) * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(w->d_nav_mask, 0, (3 * mw + 1) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void**)&w->d_nav_sync, (2 + 4 * mw) * sizeof(uint32_t)));
     HIP_TRY(hipMemset(w->d_nav_sync, 0, (2 + 4 * mw) * sizeof(uint32_t)));
     HIP_TRY(hipHostMalloc((void**)&w->h_gave_up, 64, hipHostMallocMapped | hipHostMallocCoherent));
@@ -2274,14 +2276,22 @@ static int step_env_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld
     env.navigation.o = *o;
     // every tile resident at once (at most one per CU) and no graph capture (a replay would repeat the barrier number
     // baked into the arguments): the reduction is made inside the launch; otherwise by a second kernel behind it
-    bool grid_sync = false;
-    if (d->collisions && blocks_of(w->batch) <= w->n_cu) {
+    bool grid_sync = false, capturing = false;
+    if (d->collisions) {
       hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
       if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
-      grid_sync = cap == hipStreamCaptureStatusNone;
+      capturing = cap != hipStreamCaptureStatusNone;
+      grid_sync = !capturing && blocks_of(w->batch) <= w->n_cu;
     }
-    env.navigation.w = NavWorld{w->d_angles, w->d_angles_cs, w->d_mpairs, w->d_nav_mask, grid_sync ? w->d_nav_sync : nullptr,
-                                w->nav_seq, d->collisions ? w->n_pairs : 0, w->d_gave_up, env.ablate};
+    // the second-kernel form: the tiles OR into one of two masks (zero by now), the collision kernel reads it, and the NEXT
+    // eager launch - which fills the other mask - zeroes it.  A captured launch cannot alternate (a replay repeats its
+    // arguments): it has a third mask of its own, which a memset node behind the collision kernel zeroes again.
+    const int mw = (w->n_pairs + 31) / 32;
+    uint32_t* mask = w->d_nav_mask ? w->d_nav_mask + (size_t)(capturing ? 2 : w->nav_flip) * mw : nullptr;
+    uint32_t* mask_other = (w->d_nav_mask && !capturing) ? w->d_nav_mask + (size_t)(w->nav_flip ^ 1) * mw : nullptr;
+    env.navigation.w = NavWorld{w->d_angles, w->d_angles_cs, w->d_mpairs, mask, grid_sync ? w->d_nav_sync : nullptr,
+                                w->nav_seq, d->collisions ? w->n_pairs : 0, w->d_gave_up, env.ablate,
+                                grid_sync ? nullptr : mask_other};
     if (n_steps > 1 && d->collisions && !grid_sync)
       return fail("vmas_world_rollout_env: navigation's collision penalties reduce over the whole batch after every step "
                   "(World.collides): several steps per launch need every tile resident at once (%d tiles, %d CUs) and a stream "
@@ -2290,8 +2300,11 @@ static int step_env_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld
                   d->n_agents))
       return -1;
     if (grid_sync) w->nav_seq += (uint32_t)n_steps;  // (only a launch that was made has arrived at its barriers)
-    if (d->collisions && !grid_sync)
-      return vmas::launch_navigation_collisions(d, o, w->batch, state, ld, w->d_nav_mask, (w->n_pairs + 31) / 32, stream);
+    if (d->collisions && !grid_sync) {
+      if (vmas::launch_navigation_collisions(d, o, w->batch, state, ld, mask, mw, stream)) return -1;
+      if (capturing) HIP_TRY(hipMemsetAsync(mask, 0, (size_t)mw * sizeof(uint32_t), (hipStream_t)stream));
+      else w->nav_flip ^= 1;
+    }
     return 0;
   }
   if (post_kind == VMAS_POST_FOOTBALL) {
