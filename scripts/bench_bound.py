@@ -25,12 +25,28 @@ env.bind(acts)
 for _ in range(300):
     env.step_bound()
 torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+import time
 n = 2000
-e0.record()
-for _ in range(n):
-    env.step_bound()
-e1.record(); torch.cuda.synchronize()
+windows = []
+for _ in range(int(os.environ.get("WINDOWS", "5"))):  # (each window: n steps between synchronisations, HIP events inside)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(n):
+        env.step_bound()
+    t1 = time.perf_counter()
+    e1.record(); torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    windows.append((e0.elapsed_time(e1) / n * 1e3, (t1 - t0) / n * 1e6, (t2 - t0) / n * 1e6))
+windows.sort()
+med = windows[len(windows) // 2]
+if os.environ.get("DIAG"):
+    st = env.world._state
+    print("DIAG state nan", int(torch.isnan(st).sum()), "absmax", float(st[:, :2].abs().max()), "pos std", float(st[:8, :2, :B].std()),
+          "vel absmax", float(st[:8, 2:4, :B].abs().max()), file=sys.stderr)
+    o = env.step_bound()[0]
+    print("DIAG obs lidar mean", float(torch.stack(o)[..., 6:].mean()), "nonzero frac", float((torch.stack(o)[..., 6:] > 0).float().mean()), file=sys.stderr)
 print(json.dumps({"scenario": name, "num_envs": B, "specialized": env.world._get_backend().specialized,
                   "ablate": os.environ.get("VMAS_ENV_ABLATE"), "actions": os.environ.get("ACTIONS", "fixed"), "lanes": env.world._get_backend().lanes_per_env,
-                  "step_bound_us": round(e0.elapsed_time(e1) / n * 1e3, 2)}))
+                  "step_bound_us": round(med[0], 2), "enqueue_us": round(med[1], 2), "wall_us": round(med[2], 2),
+                  "windows_us": [round(w[0], 2) for w in windows]}))

@@ -27,7 +27,7 @@ t0 = t[:, :, 0].min()
 print("specialized", be.specialized, "VMAS_TRACE", os.environ["VMAS_TRACE"])
 names = ["start", "loads", "load barrier", "gather end", "barrier", "integrate end", "epilogue in", "pair bits", "lidar units",
          "lidar barrier", "obs+reward"]
-print("lanes", lanes, "tiles", tiles, "(s_memtime ticks of 10 ns)")
+print("lanes", lanes, "tiles", tiles, "(s_memtime ticks)")
 for k in range(1, 11):
     d = t[:, :, k] - t[:, :, k - 1]
     print("  %-14s mean %7.0f  max-wave-of-tile mean %7.0f  max %7d" % (names[k], d.mean(), d.max(axis=1).mean(), d.max()))

@@ -669,15 +669,20 @@ VD void navigation_post_tile(const TileCtx& C, const VmasNavigationDesc& d, cons
       const bool hit = C.live && norm2(sa[0] - sb[0], sa[64] - sb[64]) <= P.bound_sum;
       if (__any(hit) && C.lane == 0) atomicOr((uint32_t*)&misc[1 + (k >> 5)], 1u << (k & 31));
     }
-    if (grid_sync) {  // publish and arrive now, wait behind the LIDAR units: ONE thread does both, so that its release
-                      // orders the arrival behind the bits without a second block barrier
+    if (grid_sync) {  // publish and arrive now, wait behind the LIDAR units: ONE thread does both, so that the arrival
+                      // is ordered behind the bits without a second block barrier
       __syncthreads();
       if (threadIdx.x == 0) {
+        uint32_t seen = 0u;
         for (int w_ = 0; w_ < words; ++w_) {
           const uint32_t b = (uint32_t)misc[1 + w_];
-          if (b != 0u) __hip_atomic_fetch_or(slot + w_, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (b != 0u) seen |= __hip_atomic_fetch_or(slot + w_, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        __hip_atomic_fetch_add(nav.sync, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        // (no release fence: at agent scope it writes the XCD's whole L2 back - 5 us of this thread's time, measured.  The
+        //  bits travel in agent-scope atomics only: it is enough that they have been PERFORMED - their old values are
+        //  back - before the arrival is sent)
+        asm volatile("s_waitcnt vmcnt(0)" ::"v"(seen) : "memory");
+        __hip_atomic_fetch_add(nav.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   }
@@ -792,7 +797,7 @@ VD void navigation_post_tile(const TileCtx& C, const VmasNavigationDesc& d, cons
       if (threadIdx.x == 0) {
         const uint32_t target = (seq + 1u) * gridDim.x;  // arrivals are never reset: every launch of this world has this grid
         int spins = 0;
-        while ((int32_t)(__hip_atomic_load(nav.sync, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+        while ((int32_t)(__hip_atomic_load(nav.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
           __builtin_amdgcn_s_sleep(8);
           if (++spins > (1 << 18)) {  // the grid is not co-resident (it should be): flag it and go on, never hang
             __hip_atomic_fetch_or(nav.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

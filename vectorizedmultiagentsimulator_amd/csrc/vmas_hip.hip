@@ -292,15 +292,20 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
         }
         __syncthreads();
         if (threadIdx.x == 0) {  // ONE thread publishes the tile's bits and arrives: its release orders the arrival behind them
+          uint32_t seen = 0u;
           for (int w_ = 0; w_ < args.mask_words; ++w_) {
             const uint32_t b = xmask[w_];
-            if (b != 0u) __hip_atomic_fetch_or(slot + w_, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (b != 0u) seen |= __hip_atomic_fetch_or(slot + w_, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             xmask[w_] = 0u;  // (re-armed for the next substep: nobody touches it before the barrier below)
           }
           const uint32_t target = (seq + 1u) * gridDim.x;  // arrivals are never reset: every launch of this world has this grid
-          __hip_atomic_fetch_add(args.sync, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+          // (no release fence: at agent scope it writes the XCD's whole L2 back - microseconds.  The tile's bits travel in
+          //  agent-scope atomics only, so it is enough that they have been PERFORMED - their old values are back - before
+          //  the arrival is sent)
+          asm volatile("s_waitcnt vmcnt(0)" ::"v"(seen) : "memory");
+          __hip_atomic_fetch_add(args.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           int spins = 0;
-          while ((int32_t)(__hip_atomic_load(args.sync, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+          while ((int32_t)(__hip_atomic_load(args.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
             __builtin_amdgcn_s_sleep(8);
             if (++spins > (1 << 18)) {  // the grid is not co-resident (it should be): flag it and go on, never hang
               __hip_atomic_fetch_or(args.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
