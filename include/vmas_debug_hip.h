@@ -31,6 +31,11 @@ int vmas_debug_schedule(VmasWorld* w, uint32_t* words, int64_t capacity, int32_t
  * vmas_world_exact_status): the next launch on the world must fail loudly.  For the test of exactly that. */
 int vmas_debug_force_gave_up(VmasWorld* w);
 
+/* The adaptive choice between the lane-compacted step kernel and the interpreter (vmas_world_set_compact(-1), the default):
+ * out[0] = contacts counted by plain compacted launches, out[1] = (tile, substep)s those launches had, out[2] = times the
+ * world was sent to the interpreter, out[3] = plain launches it still stays there.  Synchronises the device. */
+int vmas_debug_compact_stats(VmasWorld* w, int64_t out[4]);
+
 /* VMAS_TRACE=1 in a -DVMAS_TRACE build: copy out the per-wave s_memtime stamps of the last launch */
 int vmas_debug_trace(VmasWorld* w, unsigned long long* host, int64_t n_words);
 

@@ -43,6 +43,8 @@ t0 = time.perf_counter()
 be.step_n(steps, forces)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
+if os.environ.get("COMPACT_STATS"):
+    print("compact stats", be.compact_stats(), file=sys.stderr)
 print(json.dumps({"scenario": name, "num_envs": B, "lanes": be.lanes_per_env, "queues": be.queues(steps), "specialized": be.specialized, "compact": be.compact,
                   "lib": os.environ.get("VMAS_HIP_LIB", "libvmas_hip.so"), "ablate": os.environ.get("VMAS_ABLATE", "0"), "forces": os.environ.get("FORCES", "fixed"),
                   "world_step_us": round(dt * 1e6, 2), "env_steps_per_s": round(B / dt)}))

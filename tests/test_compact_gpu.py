@@ -187,3 +187,42 @@ def test_football_default_is_the_compact_kernel():
     hw = _hip(g.spec, 4096)
     hw.set_compact(1)
     assert not hw.compact  # boxes and line-line pairs: the world does not qualify
+
+
+def test_the_library_leaves_the_compacted_kernel_when_its_contact_lists_overflow():
+    """vmas_world_set_compact(-1), the default: the compacted kernel counts its contacts and the host sends a world whose
+    tiles are dense with them to the interpreter, which is faster there (and probes again later).  Football driven into the
+    walls by one held action is such a world.  The choice depends on the states alone: two such worlds stay bitwise identical;
+    and whatever kernel made the last state, one more step of it is the oracle's within the north-star tolerance."""
+    from oracle.oracle import Oracle
+    from vectorizedmultiagentsimulator_amd.environment import make_env
+
+    kw = dict(n_blue_agents=5, n_red_agents=5, ai_red_agents=False)
+    B = 4096
+    envs = [make_env("football", num_envs=B, device="cuda:0", seed=2, validate_actions=False, **kw) for _ in range(2)]
+    acts = [envs[0].get_random_action(a) for a in envs[0].agents]
+    for env in envs:
+        for _ in range(20):
+            env.step([a.clone() for a in acts])
+    a, b = (e.world._get_backend() for e in envs)
+    assert a.compact and b.compact
+    for chunk in range(12):  # the last action held: 12 x 100 steps
+        a.step_n(100)
+        for _ in range(100):  # (the same launches one by one: the bookkeeping counts launches, not calls)
+            b.step()
+        sa, sb = envs[0].world._state, envs[1].world._state
+        assert torch.equal(sa.view(torch.int32), sb.view(torch.int32)), f"two runs differ after {100 * (chunk + 1)} held steps"
+    st = a.compact_stats()
+    print("compact stats after 1200 held steps:", st)
+    assert st["tiles"] > 0 and st == b.compact_stats()
+    assert st["switches"] >= 1, f"a held action packs the bodies against the walls: the compacted kernel should have been left ({st})"
+    # one more step against the oracle, every environment
+    spec = envs[0].world.spec
+    nE, nA = spec.n_entities, spec.n_agents
+    s0 = envs[0].world._state[:nE, :, :B].cpu().numpy().copy()
+    f0 = envs[0].world._agent_ft[:nA, :, :B].cpu().numpy().copy()
+    Oracle(spec).step(s0, f0, threads=16)
+    a.step()
+    got = envs[0].world._state[:nE, :, :B].cpu().numpy()
+    err = np.abs(got - s0)
+    assert (err <= 1e-5 + 1e-5 * np.abs(s0)).all(), f"max err {err.max():.3g}"

@@ -283,6 +283,7 @@ EXPORTED_SYMBOLS = (
     "vmas_debug_trace",
     "vmas_debug_schedule",
     "vmas_debug_force_gave_up",
+    "vmas_debug_compact_stats",
     "vmas_world_exact_status",
     "vmas_world_load_spec",
     "vmas_world_set_compact",

@@ -139,6 +139,15 @@ class HipWorld:
         if self.lib.vmas_world_set_compact(self._h, int(mode)) != 0:
             raise VmasHipError(A.last_error())
 
+    def compact_stats(self) -> dict:
+        """Test / diagnostics hook (include/vmas_debug_hip.h): what the adaptive choice between the compacted kernel and the
+        interpreter has seen.  Synchronises the device."""
+        out = (C.c_int64 * 4)()
+        self.lib.vmas_debug_compact_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        if self.lib.vmas_debug_compact_stats(self._h, out) != 0:
+            raise VmasHipError(A.last_error())
+        return {"contacts": int(out[0]), "tiles": int(out[1]), "switches": int(out[2]), "backoff": int(out[3])}
+
     @property
     def compact(self) -> bool:
         """True if plain steps of this world run the lane-compacted kernel (csrc/vmas_compact.h)."""

@@ -577,6 +577,8 @@ __global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld
       //      the pairs are taken in runs of at most CAP contacts, in pair order, slots re-assigned from the stored masks
       int lo = 0, hi = nP;
       bool rounds = sgpr((int)cnt[0]) > CAP;
+      if (threadIdx.x == 0 && args.contacts != nullptr)  // (what the host chooses the kernel by, vmas_hip.hip CompactAdapt)
+        atomicAdd(args.contacts, (unsigned long long)cnt[0]);
       if (rounds) {
         __syncthreads();  // (every wave has read the count)
         if (threadIdx.x == 0) cnt[0] = 0u;

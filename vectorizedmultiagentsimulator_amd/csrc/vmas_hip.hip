@@ -896,6 +896,29 @@ struct VmasWorld {
   // launch gave up (its step used a partial pair mask); vmas_world_exact_status reports it too.
   uint32_t* h_gave_up = nullptr;
   uint32_t* d_gave_up = nullptr;
+  // The compacted kernel against the interpreter, chosen by what the tiles do (compact_mode -1 only).  The compacted kernel
+  // wins while contacts are sparse and loses as they get denser (football, 131 072 environments, one queue: random actions
+  // - 1.9 contacts per tile and substep - 80 us against 83.5; one action held for 20 / 100 / 600 steps - the bodies drift
+  // into the walls, ~50 contacts per tile after 100 steps - 97 / 115 / 178 us against 92 / 98 / 130).  So the kernel adds
+  // every (tile, substep)'s contact count to a device counter; every kWindow-th step's worth of API calls that make plain
+  // launches copies it out on the caller's stream (read one window later, behind its event); a window with more than
+  // kContactsPerTile on average sends the next kBackoff plain launches to the interpreter, after which the compacted kernel
+  // is probed again for a window.  Both kernels are within the parity tolerance of the reference but not bit-identical to
+  // each other where an entity has three or more contacts (the interpreter adds an entity's items segment by segment, the
+  // compacted kernel in the reference's pair order: 1-ulp differences); the choice is a function of the states alone, so
+  // reruns are bitwise identical, and vmas_world_set_compact(0 | 1) pins one kernel.
+  struct CompactAdapt {
+    static constexpr int kWindow = 16, kBackoff = 512;
+    static constexpr double kContactsPerTile = 4.0;
+    unsigned long long* d_count = nullptr;   // device counter (DevStepArgs.contacts)
+    unsigned long long* h_count = nullptr;   // pinned copy
+    hipEvent_t copied = nullptr;   // fires when h_count holds the count as of `tiles_at_copy`
+    bool pending = false;
+    int in_window = 0, backoff = 0;
+    long tiles = 0, tiles_at_copy = 0, tiles_seen = 0;
+    unsigned long long count_seen = 0;
+    long switches = 0;
+  } adapt;
   uint32_t* d_exact_mask = nullptr;
   uint32_t* d_nav_mask = nullptr;  // navigation epilogue: World.collides' pair bits of the post-step state: two masks that
   int nav_flip = 0;                //   eager launches alternate between (nav_flip: the one the next launch fills; it is zero)
@@ -1804,11 +1827,51 @@ static int launch_compact(VmasWorld* w, int env_kind, float* state, float* aft, 
 }
 
 // plain physics (no environment stages): the compacted kernel where the world has one and the launch's options allow it
+// VmasWorld::CompactAdapt: once per API call that makes plain launches, on the caller's stream BEFORE the call's launches
+// (every queue of the previous calls has been joined into it: the count it copies is a function of the states alone)
+static int compact_adapt_tick(VmasWorld* w, hipStream_t s, int n_steps) {
+  VmasWorld::CompactAdapt& A = w->adapt;
+  if (w->compact_mode != -1 || A.d_count == nullptr || !compact_on(w)) return 0;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return 0;  // (a graph keeps its kernel)
+  A.in_window += n_steps > 1 ? n_steps : 1;
+  if (A.in_window < VmasWorld::CompactAdapt::kWindow) return 0;
+  A.in_window = 0;
+  if (A.pending) {  // the count as of the previous window's end.  WAITED for, not polled: the choice must depend on the
+                    // states alone, never on how far the host has run ahead (reruns stay bitwise identical); the host is
+                    // at most two windows of calls ahead of the device here, which keeps the queue full
+    HIP_TRY(hipEventSynchronize(A.copied));
+    const unsigned long long now = __atomic_load_n(A.h_count, __ATOMIC_RELAXED);
+    const long tiles = A.tiles_at_copy - A.tiles_seen;
+    if (tiles > 0 && (double)(now - A.count_seen) > VmasWorld::CompactAdapt::kContactsPerTile * (double)tiles) {
+      A.backoff = VmasWorld::CompactAdapt::kBackoff;
+      ++A.switches;
+    }
+    A.count_seen = now;
+    A.tiles_seen = A.tiles_at_copy;
+    A.pending = false;
+  }
+  HIP_TRY(hipMemcpyAsync(A.h_count, A.d_count, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipEventRecord(A.copied, s));
+  A.tiles_at_copy = A.tiles;
+  A.pending = true;
+  return 0;
+}
+
 static int launch_physics(VmasWorld* w, Sched* S, float* state, float* aft, long ld, const DevStepArgs& a, hipStream_t s,
                           int batch = -1, long pad = -1) {
   if (batch < 0) { batch = w->batch; pad = ld; }
-  if (compact_on(w) && !a.joint_fixed_rot && !ABLATE(a))
-    return launch_compact(w, ENV_NONE, state, aft, ld, a, nullptr, 0, s, batch, pad);
+  if (compact_on(w) && !a.joint_fixed_rot && !ABLATE(a)) {
+    const bool adaptive = w->compact_mode == -1 && w->adapt.d_count != nullptr;
+    if (adaptive && w->adapt.backoff > 0) {
+      --w->adapt.backoff;  // (the tiles were overflowing: the interpreter's turn, see VmasWorld::CompactAdapt)
+    } else {
+      DevStepArgs ac = a;
+      if (adaptive) ac.contacts = w->adapt.d_count;
+      if (adaptive) w->adapt.tiles += (long)blocks_of(batch) * w->base.substeps * (a.n_steps > 1 ? a.n_steps : 1);
+      return launch_compact(w, ENV_NONE, state, aft, ld, ac, nullptr, 0, s, batch, pad);
+    }
+  }
   return launch_any_level<ENV_NONE>(w, S, state, aft, ld, a, NoEnv{}, 0, s, batch, pad);
 }
 
@@ -1947,6 +2010,11 @@ int vmas_world_create(const VmasWorldDesc* d, int32_t batch, int32_t device_id, 
     HIP_TRY(hipMemset(w->d_nav_mask, 0, (3 * mw + 1) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void**)&w->d_nav_sync, (2 + 4 * mw) * sizeof(uint32_t)));
     HIP_TRY(hipMemset(w->d_nav_sync, 0, (2 + 4 * mw) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&w->adapt.d_count, sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(w->adapt.d_count, 0, sizeof(unsigned long long)));
+    HIP_TRY(hipHostMalloc((void**)&w->adapt.h_count, 64, hipHostMallocDefault));
+    *w->adapt.h_count = 0ull;
+    HIP_TRY(hipEventCreateWithFlags(&w->adapt.copied, hipEventDisableTiming));
     HIP_TRY(hipHostMalloc((void**)&w->h_gave_up, 64, hipHostMallocMapped | hipHostMallocCoherent));
     *w->h_gave_up = 0u;
     HIP_TRY(hipHostGetDevicePointer((void**)&w->d_gave_up, w->h_gave_up, 0));
@@ -1980,6 +2048,9 @@ void vmas_world_destroy(VmasWorld* w) {
   if (w->ev_fork) (void)hipEventDestroy(w->ev_fork);
   (void)hipFree(w->d_sync); (void)hipFree(w->d_exact_mask); (void)hipFree(w->d_nav_mask); (void)hipFree(w->d_nav_sync);
   if (w->h_gave_up) (void)hipHostFree(w->h_gave_up);
+  (void)hipFree(w->adapt.d_count);
+  if (w->adapt.h_count) (void)hipHostFree(w->adapt.h_count);
+  if (w->adapt.copied) (void)hipEventDestroy(w->adapt.copied);
   (void)hipFree(w->cp.d_blob); (void)hipFree(w->cp.d_trig);
   (void)hipFree(w->d_mpairs); (void)hipFree(w->d_trace);
   (void)hipFree(w->d_lidars); (void)hipFree(w->d_targets); (void)hipFree(w->d_angles); (void)hipFree(w->d_queries);
@@ -2381,6 +2452,8 @@ static int step_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld, co
   Sched* S;
   if (get_sched(w, w->lanes, &S)) return -1;
   hipStream_t s = (hipStream_t)stream;
+  // (a whole-batch call on the caller's stream; the sub-range calls of a multi-queue vmas_world_step_n tick there, before the fork)
+  if ((env_kind == ENV_NONE || env_kind == ENV_INGEST) && env_count < 0 && compact_adapt_tick(w, s, n_steps)) return -1;
   uint32_t seq_advance = 0;
   if (args && args->exact_broad_phase && w->n_pairs > 0) {
     // The reference's broad phase: a pair is processed - for ALL environments - iff SOME environment of the batch has the
@@ -2485,6 +2558,17 @@ int vmas_debug_schedule(VmasWorld* w, uint32_t* words, int64_t capacity, int32_t
   return 0;
 }
 
+int vmas_debug_compact_stats(VmasWorld* w, int64_t out[4]) {
+  if (!w || !out) return fail("vmas_debug_compact_stats: null argument");
+  if (!w->adapt.d_count) return fail("vmas_debug_compact_stats: no device side");
+  HIP_TRY(hipSetDevice(w->device));
+  HIP_TRY(hipDeviceSynchronize());
+  unsigned long long c = 0;
+  HIP_TRY(hipMemcpy(&c, w->adapt.d_count, sizeof(c), hipMemcpyDeviceToHost));
+  out[0] = (int64_t)c; out[1] = (int64_t)w->adapt.tiles; out[2] = (int64_t)w->adapt.switches; out[3] = (int64_t)w->adapt.backoff;
+  return 0;
+}
+
 int vmas_debug_force_gave_up(VmasWorld* w) {
   if (!w || !w->h_gave_up) return fail("vmas_debug_force_gave_up: no device side");
   __atomic_store_n(w->h_gave_up, 1u, __ATOMIC_RELAXED);
@@ -2523,20 +2607,27 @@ int vmas_world_step_n(VmasWorld* w, float* state, float* agent_ft, int64_t ld, i
     // queue q steps the tiles [q * tiles / nq, (q + 1) * tiles / nq): queue 0 = the caller's stream, the others are side
     // streams forked from it here and joined back at the end
     auto first_env = [&](int q) { return (int)((long)tiles * q / nq) * TILE; };
-    HIP_TRY(hipEventRecord(w->ev_fork, s));
-    for (int q = 0; q < nq - 1; ++q) HIP_TRY(hipStreamWaitEvent(w->side[q], w->ev_fork, 0));
+    // (in chunks: where the library chooses between two kernels by what the tiles do - VmasWorld::CompactAdapt - it looks
+    //  at the joined stream between chunks; a fork / join pair per 64 steps is noise)
+    const int chunk = (w->compact_mode == -1 && compact_on(w)) ? 64 : n_steps;
     int rc = 0;
-    for (int i = 0; i < n_steps && !rc; ++i) {
-      float* ft = agent_ft ? agent_ft + (int64_t)i * ft_step_stride : nullptr;
-      for (int q = 0; q < nq && !rc; ++q) {
-        const int lo = first_env(q), hi = q + 1 == nq ? w->batch : first_env(q + 1);
-        rc = step_impl(w, state, ft, ld, nullptr, q == 0 ? (void*)s : (void*)w->side[q - 1], 1, 0, nullptr, ENV_NONE, 0, 0,
-                       lo, hi - lo);
+    for (int i0 = 0; i0 < n_steps && !rc; i0 += chunk) {
+      const int i1 = std::min(n_steps, i0 + chunk);
+      if (compact_adapt_tick(w, s, i1 - i0)) return -1;
+      HIP_TRY(hipEventRecord(w->ev_fork, s));
+      for (int q = 0; q < nq - 1; ++q) HIP_TRY(hipStreamWaitEvent(w->side[q], w->ev_fork, 0));
+      for (int i = i0; i < i1 && !rc; ++i) {
+        float* ft = agent_ft ? agent_ft + (int64_t)i * ft_step_stride : nullptr;
+        for (int q = 0; q < nq && !rc; ++q) {
+          const int lo = first_env(q), hi = q + 1 == nq ? w->batch : first_env(q + 1);
+          rc = step_impl(w, state, ft, ld, nullptr, q == 0 ? (void*)s : (void*)w->side[q - 1], 1, 0, nullptr, ENV_NONE, 0, 0,
+                         lo, hi - lo);
+        }
       }
-    }
-    for (int q = 0; q < nq - 1; ++q) {  // (joined even after a failed launch: the caller's stream stays ordered)
-      HIP_TRY(hipEventRecord(w->ev_join[q], w->side[q]));
-      HIP_TRY(hipStreamWaitEvent(s, w->ev_join[q], 0));
+      for (int q = 0; q < nq - 1; ++q) {  // (joined even after a failed launch: the caller's stream stays ordered)
+        HIP_TRY(hipEventRecord(w->ev_join[q], w->side[q]));
+        HIP_TRY(hipStreamWaitEvent(s, w->ev_join[q], 0));
+      }
     }
     return rc;
   }

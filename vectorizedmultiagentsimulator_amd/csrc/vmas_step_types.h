@@ -71,6 +71,7 @@ struct DevStepArgs {
   int32_t first_substep, n_substeps;
   int32_t n_steps;    // > 1: persistent rollout, the tile stays in LDS between steps
   long ft_stride;     // floats between the agent-force slabs of consecutive steps
+  unsigned long long* contacts;  // compacted kernel: device counter, + the contacts of every (tile, substep) (NULL: not counted)
   unsigned long long* trace;  // profiling only (env VMAS_TRACE): per-wave s_memtime stamps
   int32_t ablate;  // profiling only (env VMAS_ABLATE): 1 skip items, 2 skip integration, 4 skip prologue
 };
