@@ -904,7 +904,9 @@ VD void ingest_fetch(const VmasActionSlot& S, long env, bool live, long row0, In
     const float2 v = *(const float2*)(S.action + (row0 + env) * 2);
     r.u[0] = v.x; r.u[1] = v.y;
   } else {
-    for (int k = 0; k < S.action_size; ++k) r.u[k] = S.action[(row0 + env) * S.action_size + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)  // (constant bounds: a run-time trip count would index r.u dynamically - a stack slot)
+      if (k < S.action_size) r.u[k] = S.action[(row0 + env) * S.action_size + k];
   }
 }
 VD void ingest_apply(const VmasActionSlot& S, int clamp, long env, bool live, float* __restrict__ agent_ft, long ld,
@@ -920,7 +922,9 @@ VD void ingest_apply(const VmasActionSlot& S, int clamp, long env, bool live, fl
       flat = 0;
     }
   }
-  for (int k = 0; k < S.action_size; ++k) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    if (k >= S.action_size) break;
     float u;
     if (S.action_index != nullptr) {
       long m = 1;
