@@ -1,6 +1,6 @@
 """Compile, ahead of time and without a GPU, the run-time specialisations the GPU tests ask for (tests/test_specialize_gpu.py)
-into the package's on-disk cache, so that the test box loads them instead of compiling (~10 s each):
-python scripts/prebuild_test_specs.py"""
+into the package's on-disk cache, so that the test box loads them instead of compiling (~10-60 s each; eight at a time here):
+python scripts/prebuild_test_specs.py [--quiet]   (also run by __graft_entry__.build())"""
 import ctypes as C
 import os
 import sys
@@ -17,7 +17,9 @@ from golden_util import FIXTURES  # noqa: E402
 lib = A.load_library()
 BATCH = {"balance_n3": 4096, "transport_2pkg": 1024, "all_joint_passage_size": 700, "ball_trajectory": 1000, "give_way": 4096,
          "all_wheel": 64 * 7 + 3}  # (tests/test_specialize_gpu.py; every other fixture: 640 + 7 environments)
-for name in FIXTURES:
+
+
+def one(name):
     B = BATCH.get(name, 647)
     g = load(name)
     cd = g.spec.to_ctypes()
@@ -28,11 +30,19 @@ for name in FIXTURES:
     finally:
         lib.vmas_world_destroy(h)
     if meta[23] >= 0:
-        print(name, "has a built-in specialisation", flush=True)
-        continue
+        return f"{name} has a built-in specialisation"
     try:
         p = S.code_object(S.render(meta, words, int(g.spec.substeps), 0))
     except S.SpecializeError as e:
-        print(name, B, "refused:", str(e)[:100], flush=True)
-        continue
-    print(name, B, "->", os.path.basename(p), os.path.getsize(p), flush=True)
+        return f"{name} {B} refused: {str(e)[:100]}"
+    return f"{name} {B} -> {os.path.basename(p)} {os.path.getsize(p)}"
+
+
+if __name__ == "__main__":
+    from concurrent.futures import ThreadPoolExecutor  # (hipcc runs as a subprocess: threads are enough)
+
+    quiet = "--quiet" in sys.argv
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+        for line in pool.map(one, FIXTURES):
+            if not quiet:
+                print(line, flush=True)

@@ -73,7 +73,6 @@ __global__ __launch_bounds__(512) void balance_post_kernel(const VmasBalanceDesc
   stage_rows(C, lds, nE * 6, [&](int i) { return state[(long)i * ld + C.e]; });
   float prev_shaping = C.live ? o.global_shaping[C.env] : 0.f;
   float steps_in = C.wave == 0 ? load_steps(o.limit, C) : 0.f;
-  balance_build_table(C, lds + nE * 6 * 64);
   __syncthreads();
   balance_post_tile(C, d, o, batch, lds, lds + nE * 6 * 64, prev_shaping, steps_in);
 }

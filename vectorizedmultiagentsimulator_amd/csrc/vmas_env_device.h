@@ -147,7 +147,6 @@ VD bool apply_step_limit(const VmasStepLimit& lim, const TileCtx& C, float steps
 // L2) - round 2 staged the 64 x 16 tile through LDS and streamed it out through a divmod table: 35 KB of LDS per tile
 // and two wave-level fences on the step's dependent chain.
 constexpr int kBalanceObsDim = 16;
-VD void balance_build_table(const TileCtx&, float*) {}  // (kept for the callers' sake: nothing to build any more)
 __host__ __device__ inline size_t balance_scratch_floats(int) { return 2 * 64; }
 
 VD void balance_post_tile(const TileCtx& C, const VmasBalanceDesc& d, const VmasBalanceBuffers& o, int batch,

@@ -142,7 +142,6 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
   [[maybe_unused]] float post_prev = 0.f, post_steps = 0.f;
   if constexpr (ENV == ENV_BALANCE) {
     post_prev = live ? E.balance.o.global_shaping[env] : 0.f;
-    balance_build_table(TileCtx(batch), lds + E.scratch_off);  // (published by the load barrier below)
     if (wv == 0) post_steps = (E.balance.o.limit.steps != nullptr && live) ? E.balance.o.limit.steps[env] : 0.f;
   }
   if constexpr (ENV == ENV_TRANSPORT) {
