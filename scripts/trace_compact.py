@@ -13,6 +13,10 @@ env = make_env(name, num_envs=B, device="cuda:0", seed=0, validate_actions=False
 for _ in range(30):
     env.step([env.get_random_action(a) for a in env.agents])
 be = env.world._get_backend()
+hold = int(os.environ.get("HOLD", "0"))  # the last action held for this many steps first: bodies drift into the walls
+if hold:
+    be.set_compact(0)
+    be.step_n(hold); torch.cuda.synchronize()
 be.set_compact(1)
 be.set_queues(1)
 assert be.compact
@@ -27,7 +31,7 @@ t = buf.reshape(tiles, 16, 16).astype(np.int64)
 nw = int((t[:, :, 0] > 0).sum(axis=1).max())
 t = t[:, :nw]
 t0 = t[:, :, 0].min()
-print(f"{name} {B}: tiles {tiles}, waves/tile {nw}; kernel span {t[:, :, 3].max() - t0} ticks (s_memtime, 100 MHz: x10 ns)")
+print(f"{name} {B} (held {hold} steps): tiles {tiles}, waves/tile {nw}; kernel span {t[:, :, 3].max() - t0} ticks (s_memtime, 100 MHz: x10 ns)")
 print("per wave means (ticks): load %.0f | load barrier %.0f | total %.0f" % (
     (t[:, :, 1] - t[:, :, 0]).mean(), (t[:, :, 2] - t[:, :, 1]).mean(), (t[:, :, 3] - t[:, :, 0]).mean()))
 names = ["prologue+integrate", "A broad", "A barrier", "B narrow", "B barrier", "C add contacts", "contacts N", "rounds"]
