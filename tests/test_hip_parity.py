@@ -542,7 +542,7 @@ def test_degenerate_worlds_and_batch_sizes(kind, B):
     assert np.array_equal(got[:, :, B:], np.zeros_like(got[:, :, B:])), "padding columns were written"
 
 
-@pytest.mark.parametrize("B", [32768, 32700, 20480])
+@pytest.mark.parametrize("B", [32768, 32700, 20480, 65536, 70001])  # (from 65 536 on: SpecBalance4Wide, 4 waves per tile)
 def test_specialised_kernel_is_bitwise_the_generic_one(B):
     """The world-specialised step kernel (csrc/vmas_spec_kernel.h: balance n_agents=4 at BASELINE config 2's geometry,
     schedule tables generated from the library's own planner) must give, bit for bit, what the interpreter gives - state
