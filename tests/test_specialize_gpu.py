@@ -89,7 +89,7 @@ def test_make_env_specialize_runs_the_one_launch_step_on_its_own_kernel():
 
     B = 4096
     a = make_env("balance", num_envs=B, device="cuda:0", seed=3, n_agents=3, validate_actions=False, specialize=True)
-    b = make_env("balance", num_envs=B, device="cuda:0", seed=3, n_agents=3, validate_actions=False)
+    b = make_env("balance", num_envs=B, device="cuda:0", seed=3, n_agents=3, validate_actions=False, specialize=False)
     assert a.world._get_backend().specialized and not b.world._get_backend().specialized and a._one_launch
     assert torch.equal(a.world._state, b.world._state)
     for t in range(10):
@@ -143,7 +143,7 @@ def test_navigation_between_the_built_in_geometries_specialises_at_run_time():
 
     B = 24576
     a = make_env("navigation", num_envs=B, device="cuda:0", seed=5, n_agents=8, validate_actions=False, specialize=True)
-    b = make_env("navigation", num_envs=B, device="cuda:0", seed=5, n_agents=8, validate_actions=False)
+    b = make_env("navigation", num_envs=B, device="cuda:0", seed=5, n_agents=8, validate_actions=False, specialize=False)
     assert a.world._get_backend().lanes_per_env == 8
     assert a.world._get_backend().specialized and not b.world._get_backend().specialized and a._one_launch
     for t in range(8):
@@ -153,3 +153,16 @@ def test_navigation_between_the_built_in_geometries_specialises_at_run_time():
         assert torch.equal(_bits(a.world._state), _bits(b.world._state)), f"state differs at step {t}"
         assert torch.equal(_bits(torch.stack(oa)), _bits(torch.stack(ob))), f"observations differ at step {t}"
         assert torch.equal(_bits(torch.stack(ra)), _bits(torch.stack(rb))) and torch.equal(da, db), f"rewards / done differ at step {t}"
+
+
+def test_make_env_takes_a_cached_specialisation_and_never_compiles_by_default(tmp_path, monkeypatch):
+    """make_env(specialize=None), the default: a world whose code object is in the cache runs its own kernels; one whose is
+    not keeps the interpreter and NOTHING is compiled (an empty cache directory stays empty)."""
+    from vectorizedmultiagentsimulator_amd import specialize as S
+    from vectorizedmultiagentsimulator_amd.environment import make_env
+
+    hit = make_env("balance", num_envs=4096, device="cuda:0", seed=3, n_agents=3, validate_actions=False)  # (PREBUILD)
+    assert hit.world._get_backend().specialized, "balance n_agents=3 at 4096 environments is pre-compiled by build()"
+    monkeypatch.setattr(S, "CACHE", str(tmp_path))
+    miss = make_env("balance", num_envs=4096, device="cuda:0", seed=3, n_agents=3, validate_actions=False)
+    assert not miss.world._get_backend().specialized and not any(tmp_path.iterdir())

@@ -126,12 +126,12 @@ class HipWorld:
     def specialized(self) -> bool:
         return bool(self.lib.vmas_world_get_specialized(self._h))
 
-    def specialize(self, post: int = 0, cache_dir: Optional[str] = None) -> bool:
+    def specialize(self, post: int = 0, cache_dir: Optional[str] = None, cached_only: bool = False) -> bool:
         """Compile (or fetch from the cache) and load a world-specialised kernel for THIS world and batch geometry
         (specialize.py; tens of seconds on a cache miss).  ``post``: the fused epilogue its steps carry (VMAS_POST_*)."""
         from .specialize import specialize
 
-        return specialize(self, post, cache_dir)
+        return specialize(self, post, cache_dir, cached_only=cached_only)
 
     def set_compact(self, mode: int):
         """-1: the library's choice, 0: never, 1: whenever the world qualifies - the lane-compacted step kernel

@@ -753,11 +753,12 @@ class World:
                 self._backend.reserve_epilogue(*hint)
         return self._backend
 
-    def specialize(self, cache_dir: Optional[str] = None) -> bool:
+    def specialize(self, cache_dir: Optional[str] = None, cached_only: bool = False) -> bool:
         """A world-specialised step kernel for this world as it is now (specialize.py): compiled once, cached on disk."""
         be = self._get_backend()
         hint = getattr(self, "epilogue_hint", None)  # (epilogues the planner reserves LDS for; else the scenario's fused_post)
-        return be.specialize(post=hint[0] if hint is not None else getattr(self, "fused_post", 0), cache_dir=cache_dir)
+        return be.specialize(post=hint[0] if hint is not None else getattr(self, "fused_post", 0), cache_dir=cache_dir,
+                             cached_only=cached_only)
 
     # ---- reference API ---------------------------------------------------------------
     batch_dim = property(lambda s: s._batch_dim)

@@ -39,7 +39,7 @@ class Environment:
         validate_actions: bool = True,
         graph: bool = False,
         fused: Optional[bool] = None,
-        specialize: bool = False,
+        specialize: Optional[bool] = None,
         **kwargs,
     ):
         self.scenario = scenario
@@ -68,9 +68,11 @@ class Environment:
         self._one_launch = self._ingest_in_step = False
         self._bound_actions = self._bound = None
         self._setup_fused()
-        if specialize and self.device.type == "cuda":
-            # a step kernel compiled for THIS world (specialize.py): tens of seconds once, then from the on-disk cache
-            self.world.specialize()
+        if specialize is not False and self.device.type == "cuda":
+            # a step kernel compiled for THIS world (specialize.py).  True: compile it if the on-disk cache does not have
+            # it (tens of seconds, once); None (default): take it from the cache if it is there (milliseconds) - worlds
+            # someone has specialised before, or __graft_entry__.build() pre-compiled - and never compile; False: never
+            self.world.specialize(cached_only=specialize is None)
 
     def _setup_fused(self):
         """``fused``: run action ingest and the scenario's reward/observation/done/info as one HIP
@@ -477,7 +479,7 @@ def make_env(
     validate_actions: bool = True,
     graph: bool = False,
     fused: Optional[bool] = None,
-    specialize: bool = False,
+    specialize: Optional[bool] = None,
     **kwargs,
 ) -> Environment:
     """vmas.make_env(...) for the scenarios shipped in ``vectorizedmultiagentsimulator_amd.scenarios``."""
