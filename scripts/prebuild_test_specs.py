@@ -19,7 +19,8 @@ BATCH = {"balance_n3": 4096, "transport_2pkg": 1024, "all_joint_passage_size": 7
          "all_wheel": 64 * 7 + 3}  # (tests/test_specialize_gpu.py; every other fixture: 640 + 7 environments)
 
 
-def one(name):
+def plan(name):
+    """(label, source or None, note): the world is planned here, on the calling thread."""
     B = BATCH.get(name, 647)
     g = load(name)
     cd = g.spec.to_ctypes()
@@ -30,19 +31,20 @@ def one(name):
     finally:
         lib.vmas_world_destroy(h)
     if meta[23] >= 0:
-        return f"{name} has a built-in specialisation"
+        return f"{name}", None, "has a built-in specialisation"
     try:
-        p = S.code_object(S.render(meta, words, int(g.spec.substeps), 0))
+        return f"{name} {B}", S.render(meta, words, int(g.spec.substeps), 0), ""
     except S.SpecializeError as e:
-        return f"{name} {B} refused: {str(e)[:100]}"
-    return f"{name} {B} -> {os.path.basename(p)} {os.path.getsize(p)}"
+        return f"{name} {B}", None, f"refused: {str(e)[:100]}"
 
 
 if __name__ == "__main__":
     from concurrent.futures import ThreadPoolExecutor  # (hipcc runs as a subprocess: threads are enough)
 
     quiet = "--quiet" in sys.argv
+    jobs = [plan(name) for name in FIXTURES]  # planned one after the other, compiled eight at a time
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
-        for line in pool.map(one, FIXTURES):
-            if not quiet:
-                print(line, flush=True)
+        paths = list(pool.map(lambda j: S.code_object(j[1]) if j[1] is not None else None, jobs))
+    if not quiet:
+        for (label, src, note), p in zip(jobs, paths):
+            print(label, note if p is None else f"-> {os.path.basename(p)} {os.path.getsize(p)}", flush=True)
