@@ -23,8 +23,10 @@ for fused in (False, True):
         # action sets cycled; ACTIONS=fixed: one set held for the whole run (rounds 1-2: bodies pile up against the walls)
         pool = 1 if os.environ.get("ACTIONS", "random") == "fixed" else 64
         acts = [[env.get_random_action(a) for a in env.agents] for _ in range(pool)]
-        for k in range(300 if (graph or fused) else 5):  # (the first few hundred steps carry one-time costs)
-            env.step(acts[k % pool])
+        t_warm, k = time.perf_counter(), 0
+        while k < (300 if (graph or fused) else 5) or time.perf_counter() - t_warm < 0.25:  # (one-time costs, and the clocks
+            env.step(acts[k % pool])                                                      #  of a just-started process)
+            k += 1
         torch.cuda.synchronize()
         n = 1000 if (graph or fused) else 30
         t0 = time.perf_counter()

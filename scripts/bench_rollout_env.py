@@ -14,9 +14,10 @@ if os.environ.get("SPEC") == "0":  # A/B: the interpreter instead of the world-s
     env.world._get_backend().set_specialized(False)
 g = torch.Generator(device="cuda:0").manual_seed(1)
 acts = [(torch.rand(K, B, 2, device="cuda:0", generator=g) * 2 - 1) for _ in env.agents]
-for _ in range(3):
+t_warm = time.perf_counter()  # (at least a quarter of a second of the measured work first: a process that has just been
+while time.perf_counter() - t_warm < 0.25:  #  set up finds the GPU's clocks ramping - the first ~0.1 s reads up to 5x slow)
     env.rollout(acts)
-torch.cuda.synchronize()
+    torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 reps = int(os.environ.get('REPS', 20))
 t0 = time.perf_counter(); e0.record()

@@ -35,7 +35,12 @@ if os.environ.get("COMPACT"):
     be.set_compact(int(os.environ["COMPACT"]))
 if os.environ.get("QUEUES"):
     be.set_queues(int(os.environ["QUEUES"]))
-be.step_n(min(50, steps), None if forces is None else forces[: min(50, steps)])
+t_warm = time.perf_counter()  # (a quarter of a second of launches first: the clocks of a just-started process are ramping)
+while time.perf_counter() - t_warm < 0.25:
+    be.step_n(min(50, steps), None if forces is None else forces[: min(50, steps)])
+    torch.cuda.synchronize()
+    if os.environ.get("FORCES", "fixed") != "random":
+        break  # (a held action changes the state it is timed on: keep the protocol of the earlier rounds, one warm-up call)
 if forces is not None:
     env.set_state(snap)
 torch.cuda.synchronize()
