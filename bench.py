@@ -51,6 +51,8 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10000)
     ap.add_argument("--warmup", type=int, default=500)
+    ap.add_argument("--clock-warmup", type=float, default=0.25,
+                    help="seconds of untimed launches before the W warm-up steps (the GPU's clocks ramp up: see bench.py)")
     ap.add_argument("--repeats", type=int, default=5,
                     help="the K-step window is timed this many times (each between its own fences); `value` = the median window")
     ap.add_argument("--num-envs", type=int, default=32768, help="environments PER GPU")
@@ -440,7 +442,14 @@ def main():
                           "kernel's launch-to-launch time and agrees with rocprofv3's per-kernel duration + launch gap"}
         be.set_queues(args.queues)
     # ---- headline: W warm-up steps, then exactly K World.step launches between fences - R times over (every window is a
-    #      complete measurement by the contract; `value` is the MEDIAN window, min / max beside it)
+    #      complete measurement by the contract; `value` is the MEDIAN window, min / max beside it).  In front of the W
+    #      steps, untimed: `clock_warmup_s` seconds of the same launches - a process that has just been set up finds the
+    #      GPU's clocks ramping (the first ~0.1 s of kernels reads up to several times slow: profiles/README.md), and with
+    #      the driver's small K every window would fall inside that ramp.
+    t_clock = time.perf_counter()
+    while time.perf_counter() - t_clock < args.clock_warmup:
+        run(EPISODE)
+        torch.cuda.synchronize()
     run(args.warmup)
     windows = [timed(lambda n: run(n, start=args.warmup), args.steps) for _ in range(max(1, args.repeats))]
     order = sorted(range(len(windows)), key=lambda i: windows[i][0])
@@ -466,7 +475,7 @@ def main():
             "n_gpus": world_size,
             "ranks_seen": ranks_seen,
             "steps": args.steps,
-            "warmup": args.warmup,
+            "warmup": args.warmup, "clock_warmup_s": args.clock_warmup,
             "ms_per_step": kernel_s * 1e3,
             "repeats": {"windows": len(windows), "steps_per_window": args.steps,
                         "ms_per_step_min": min(w_[0] for w_ in windows) / args.steps * 1e3,
