@@ -227,6 +227,11 @@ int vmas_world_set_lidars(VmasWorld* w, const VmasLidarDesc* lidars, int32_t n_l
 /* ... then out[(l * max_rays + r) * ld + env] = measured distance; max_rays is the
  * largest n_rays of the registered set. */
 int vmas_world_cast_rays(VmasWorld* w, const float* state, int64_t ld, float* out, void* stream);
+/* Sensor sets whose targets are all spheres are cast lane-compacted (only the (environment, sensor, target) triples within
+ * reach are evaluated; same bits).  -1 (default): the library's choice, 0: the plain kernel, 1: whenever the set qualifies.
+ * vmas_world_get_lidar_compact: 1 if the next vmas_world_cast_rays takes the compacted form. */
+int vmas_world_set_lidar_compact(VmasWorld* w, int32_t mode);
+int vmas_world_get_lidar_compact(VmasWorld* w);
 
 /* Scenario-side geometric queries (World.get_distance core.py:1822-1905,
  * World.is_overlapping core.py:1907-1969) evaluated for a registered list of entity pairs in

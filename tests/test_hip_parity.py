@@ -609,3 +609,43 @@ def test_other_specialised_worlds_are_bitwise_the_interpreter(scenario, kw, B, n
     same = lambda a, b: torch.equal(a.view(torch.int32), b.view(torch.int32))  # noqa: E731
     assert all(same(x, y) for x, y in zip(outs[0], outs[1]))
     assert torch.isfinite(outs[0][0]).all()
+
+
+@pytest.mark.parametrize("B", [64 * 3 + 7, 8192, 65536])
+def test_lane_compacted_cast_rays_is_bitwise_the_plain_kernel(B):
+    """vmas_world_cast_rays on navigation's sensors (eight agents, twelve rays, the other agents as sphere targets): the
+    lane-compacted kernel against the plain one, bit for bit - at the spawn, mid-episode, with rotated sensors (the direction
+    table is off: sincosf per ray), with agents overlapping (negative distances) and with a non-finite pose."""
+    from vectorizedmultiagentsimulator_amd.environment import make_env
+
+    env = make_env("navigation", num_envs=B, device="cuda:0", n_agents=8, seed=4, validate_actions=False)
+    be = env.world._get_backend()
+    assert be.lidar_compact == (B > 64 * 128), "the library's choice: the compacted cast once the batch has more tiles than half the CUs"
+    be.set_lidar_compact(1)
+    assert be.lidar_compact, "navigation's sensor set (sphere targets only) must qualify"
+
+    def both(what):
+        be.set_lidar_compact(1)
+        a = be.cast_rays().clone()
+        be.set_lidar_compact(0)
+        assert not be.lidar_compact
+        b = be.cast_rays().clone()
+        be.set_lidar_compact(-1)
+        assert torch.equal(a[:, :, :B].view(torch.int32), b[:, :, :B].view(torch.int32)), what
+        return a
+
+    both("at the spawn")
+    for _ in range(40):
+        env.step([env.get_random_action(a) for a in env.agents])
+    out = both("mid-episode")
+    assert (out[:, :, :B] < 0.35).any(), "some ray should see an agent"
+    st = env.world._state
+    g = torch.Generator(device="cuda:0").manual_seed(2)
+    st[:8, 4, :B] = (torch.rand(8, B, device="cuda:0", generator=g) - 0.5) * 6.0  # rotated sensors
+    both("rotated sensors")
+    st[1, 0:2, :B] = st[0, 0:2, :B] + 0.03  # agent 1 almost on top of agent 0: the sensor sits inside the sphere
+    both("overlapping agents")
+    st[2, 0, : min(B, 5)] = float("nan")
+    st[3, 1, : min(B, 3)] = float("inf")
+    a = be.cast_rays()
+    both("non-finite poses")

@@ -275,6 +275,8 @@ EXPORTED_SYMBOLS = (
     "vmas_world_pair_mask",
     "vmas_world_set_lidars",
     "vmas_world_cast_rays",
+    "vmas_world_set_lidar_compact",
+    "vmas_world_get_lidar_compact",
     "vmas_world_set_queries",
     "vmas_world_run_queries",
     "vmas_world_set_lanes_per_env",

@@ -333,6 +333,16 @@ class HipWorld:
             raise VmasHipError(A.last_error())
         return self._query_out
 
+    def set_lidar_compact(self, mode: int):
+        """-1: the library's choice, 0: the plain kernel, 1: whenever the sensor set qualifies - the lane-compacted
+        World.cast_rays of sphere-only sensor sets (include/vmas_hip.h, vmas_world_set_lidar_compact)."""
+        if self.lib.vmas_world_set_lidar_compact(self._h, int(mode)) != 0:
+            raise VmasHipError(A.last_error())
+
+    @property
+    def lidar_compact(self) -> bool:
+        return bool(self.lib.vmas_world_get_lidar_compact(self._h))
+
     def cast_rays(self, stream=None) -> torch.Tensor:
         """World.cast_rays for every registered Lidar: [n_lidars, max_rays, ld]."""
         if self._lidar_out is None:

@@ -739,6 +739,151 @@ __global__ __launch_bounds__(256) void lidar_kernel(const DevLidar* __restrict__
   }
 }
 
+// World.cast_rays for sensor sets whose targets are all SPHERES (navigation: every agent's LIDAR sees the other agents),
+// lane-compacted like the navigation epilogue's cast (vmas_env_device.h, navigation_post_tile):
+//   1. a block owns 64 environments; every (sensor, target) of every environment is tested for reach - the very test of
+//      lidar_cast_chunk - and the near ones are queued in LDS (ballot + one LDS atomic per wave and pair);
+//   2. a lane per queued (environment, sensor, target): a conservative filter over its rays, then the reference's
+//      arithmetic (core.py:1414-1490, expression for expression lidar_cast_chunk's) for the rays that pass; a filtered-out
+//      ray measures max_range against this target in the reference too, which never lowers the minimum;
+//   3. min over the targets: an LDS atomic min on an order-preserving integer image of the distance (it can be negative:
+//      a sensor inside a sphere); the rows start at max_range (core.py:1672-1674).
+// A lane walking its own sensor's targets spends ~3 trips where ~1 target is in reach, 12 rays where ~2 can hit:
+// 65 536 environments x 8 sensors x 12 rays x 7 targets: see DESIGN.md 3.3.
+// LDS: pos[n_ent][2][64] | arot[n_lidars][64] | measured[n_lidars * max_rays][65] | count | queue[n_pairs_total * 64] (u32)
+__device__ __forceinline__ int float_order(float f) { const int b = __float_as_int(f); return b ^ ((b >> 31) & 0x7fffffff); }
+__device__ __forceinline__ float order_float(int k) { return __int_as_float(k ^ ((k >> 31) & 0x7fffffff)); }
+constexpr int kLidarStride = 65;
+
+// tables (host-built, staged into LDS - a descriptor read from global memory per use chained three dependent loads in front of
+// every queued item): sensor l = 6 words: slot of its entity | n_rays | first angle | first pair | max_range | half_range;
+// pair k = 2 words: sensor | target's slot << 16 ; target's radius
+constexpr int kLidarSensorWords = 6, kLidarPairWords = 2;
+__global__ __launch_bounds__(1024) void lidar_compact_kernel(const uint32_t* __restrict__ tab, const float* __restrict__ angles,
+                                                            const float2* __restrict__ angles_cs,
+                                                            const int* __restrict__ slot_ent /* [n_slots] */, int n_slots,
+                                                            int n_lidars, int n_pairs_total, int max_rays,
+                                                            const float* __restrict__ state, long ld, int batch,
+                                                            float* __restrict__ out) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x & 63, wave = sgpr(threadIdx.x >> 6), nw = sgpr(blockDim.x >> 6);
+  const long b0 = (long)blockIdx.x * 64, env = b0 + lane;
+  const bool live = env < batch;
+  const long e = live ? env : (long)batch - 1;
+  float* pos = lds;                                   // [n_slots][2][64]
+  float* arot = pos + n_slots * 128;                  // [n_lidars][64]
+  int* measured = (int*)(arot + n_lidars * 64);       // [n_lidars * max_rays][65]
+  int* count = measured + n_lidars * max_rays * kLidarStride;
+  uint32_t* sens = (uint32_t*)(count + 2);            // [n_lidars][6]
+  uint32_t* pairs = sens + n_lidars * kLidarSensorWords;  // [n_pairs_total][2]
+  uint32_t* queue = pairs + n_pairs_total * kLidarPairWords;  // lane | pair << 6
+  // ---- stage: the tables, the positions of every entity that casts or is seen, the sensors' rotations; measured = max_range
+  const int n_tab = n_lidars * kLidarSensorWords + n_pairs_total * kLidarPairWords;
+  for (int i = threadIdx.x; i < n_tab; i += blockDim.x) sens[i] = tab[i];
+  for (int i = wave; i < 2 * n_slots; i += nw) pos[i * 64 + lane] = state[((long)slot_ent[i >> 1] * 6 + (i & 1)) * ld + e];
+  for (int l = wave; l < n_lidars; l += nw)
+    arot[l * 64 + lane] = state[((long)slot_ent[tab[l * kLidarSensorWords]] * 6 + 4) * ld + e];
+  for (int l = 0; l < n_lidars; ++l) {
+    const int init = float_order(__uint_as_float(tab[l * kLidarSensorWords + 4]));
+    for (int i = threadIdx.x; i < max_rays * kLidarStride; i += blockDim.x) measured[l * max_rays * kLidarStride + i] = init;
+  }
+  if (threadIdx.x == 0) count[0] = 0;
+  __syncthreads();
+  // ---- 1. the near (sensor, target) pairs: eight pairs per trip, ONE LDS atomic for the wave's slots
+  for (int k0 = wave; k0 < n_pairs_total; k0 += 8 * nw) {
+    unsigned long long bal[8];
+    int total = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = k0 + j * nw;
+      bal[j] = 0ull;
+      if (k >= n_pairs_total) continue;
+      const uint32_t p0 = (uint32_t)sgpr((int)pairs[k * kLidarPairWords]);
+      const float radius = __uint_as_float((uint32_t)sgpr((int)pairs[k * kLidarPairWords + 1]));
+      const int l = (int)(p0 & 0xffffu), tslot = (int)(p0 >> 16);
+      const int sslot = sgpr((int)sens[l * kLidarSensorWords]);
+      const float max_range = __uint_as_float((uint32_t)sgpr((int)sens[l * kLidarSensorWords + 4]));
+      const float* ps = pos + sslot * 128 + lane;
+      const float* pt = pos + tslot * 128 + lane;
+      const float dx = pt[0] - ps[0], dy = pt[64] - ps[64];
+      const float lim = max_range + radius + 1e-4f;
+      const bool near = live && !(dx * dx + dy * dy > lim * lim);  // NaN counts as near
+      bal[j] = __ballot(near);
+      total += __popcll(bal[j]);
+    }
+    if (total == 0) continue;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&count[0], total);
+    base = sgpr(base);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (bal[j] == 0ull) continue;
+      if ((bal[j] >> lane) & 1ull)
+        queue[base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[j], 0u))] =
+            (uint32_t)lane | (uint32_t)(k0 + j * nw) << 6;
+      base += __popcll(bal[j]);
+    }
+  }
+  __syncthreads();
+  // ---- 2. a lane per queued item
+  const int n_items = count[0];
+  for (int i0 = wave * 64; i0 < n_items; i0 += nw * 64) {
+    const bool on = i0 + lane < n_items;
+    const uint32_t item = on ? queue[i0 + lane] : 0u;
+    const int el = item & 63, k = (int)(item >> 6);
+    const uint32_t p0 = pairs[k * kLidarPairWords];
+    const float radius = __uint_as_float(pairs[k * kLidarPairWords + 1]);
+    const int l = (int)(p0 & 0xffffu), tslot = (int)(p0 >> 16);
+    const uint32_t* S = sens + l * kLidarSensorWords;
+    const int n_rays = (int)S[1], angle_off = (int)S[2];
+    const float half_range = __uint_as_float(S[5]);
+    const float* ps = pos + (int)S[0] * 128 + el;
+    const float* pt = pos + tslot * 128 + el;
+    const v2 op = V(ps[0], ps[64]), tpos = V(pt[0], pt[64]);
+    const float rot = arot[l * 64 + el];
+    const v2 u = tpos - op;
+    const float margin = radius + 1e-4f + 1e-5f * (fabsf(op.x) + fabsf(op.y) + fabsf(tpos.x) + fabsf(tpos.y));
+    const bool table = __all(!on || rot == 0.f);  // (see lidar_cast_chunk: the same sincosf made the table)
+    auto direction = [&](int r, float& c, float& sn) {
+      if (table) { const float2 cs = angles_cs[angle_off + r]; c = cs.x; sn = cs.y; }
+      else sincosf(angles[angle_off + r] + rot, &sn, &c);  // sensors.py:118
+    };
+    unsigned long long cand = 0ull;
+    for (int r = 0; r < max_rays; ++r) {  // (sensors may differ in n_rays: the surplus is masked)
+      float c = 1.f, sn = 0.f;
+      const bool in = r < n_rays;
+      if (in) direction(r, c, sn);
+      const bool maybe = !(fabsf(u.x * sn - u.y * c) > margin) && vdot(u, V(c, sn)) > 0.f;
+      if (on && in && maybe) cand |= 1ull << r;
+    }
+    int* mrow = measured + l * max_rays * kLidarStride + el;
+    while (__any(cand != 0ull)) {
+      if (cand != 0ull) {
+        const int r = __ffsll((long long)cand) - 1;
+        cand &= cand - 1ull;
+        float c, sn;
+        direction(r, c, sn);
+        const v2 dir = V(c, sn);  // _cast_rays_to_sphere core.py:1414-1490
+        const v2 lp = V(op.x + dir.x * half_range, op.y + dir.y * half_range);
+        const v2 cp = closest_point_line<false>(lp, c, sn, 0.f, tpos);
+        const float dn = vnorm(tpos - cp);
+        const bool ok = (dn < radius) && (vdot(u, dir) > 0.f);
+        const float a2 = radius * radius - dn * dn;
+        const float m = sqrt_n(a2 > 0.f ? a2 : 1e-8f);
+        const float dist = vnorm(cp - op) - m;
+        if (ok) atomicMin(mrow + r * kLidarStride, float_order(dist));  // (min(best, dist): best starts at max_range)
+      }
+    }
+  }
+  __syncthreads();
+  // ---- 3. out[(l * max_rays + r) * ld + env]
+  if (live)
+    for (int i = wave; i < n_lidars * max_rays; i += nw) {
+      const int l = i / max_rays, r = i - l * max_rays;
+      if (r < (int)sens[l * kLidarSensorWords + 1]) out[(long)i * ld + env] = order_float(measured[i * kLidarStride + lane]);
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // scenario-side queries: World.get_distance core.py:1822-1905, World.is_overlapping core.py:1907-1969
 // one thread per environment, blockIdx.y = query (wave-uniform shape dispatch)
@@ -906,6 +1051,9 @@ struct VmasWorld {
   // each other where an entity has three or more contacts (the interpreter adds an entity's items segment by segment, the
   // compacted kernel in the reference's pair order: 1-ulp differences); the choice is a function of the states alone, so
   // reruns are bitwise identical, and vmas_world_set_compact(0 | 1) pins one kernel.
+  // the lane-compacted cast of sphere-only sensor sets (lidar_compact_kernel): its entity staging tables and LDS need
+  struct LidarCompact { bool ok = false; int mode = -1; uint32_t* d_ent_slot = nullptr /* the tables */; int* d_slot_ent = nullptr; int n_slots = 0,
+                        n_pairs_total = 0; size_t lds = 0; } lc;
   struct CompactAdapt {
     static constexpr int kWindow = 16, kBackoff = 512;
     static constexpr double kContactsPerTile = 4.0;
@@ -2047,6 +2195,7 @@ void vmas_world_destroy(VmasWorld* w) {
   if (w->ev_fork) (void)hipEventDestroy(w->ev_fork);
   (void)hipFree(w->d_sync); (void)hipFree(w->d_exact_mask); (void)hipFree(w->d_nav_mask); (void)hipFree(w->d_nav_sync);
   if (w->h_gave_up) (void)hipHostFree(w->h_gave_up);
+  (void)hipFree(w->lc.d_ent_slot); (void)hipFree(w->lc.d_slot_ent);
   (void)hipFree(w->adapt.d_count);
   if (w->adapt.h_count) (void)hipHostFree(w->adapt.h_count);
   if (w->adapt.copied) (void)hipEventDestroy(w->adapt.copied);
@@ -2699,7 +2848,64 @@ int vmas_world_set_lidars(VmasWorld* w, const VmasLidarDesc* lidars, int32_t n) 
   w->h_lidars = dl;
   w->h_targets = dt;
   w->n_lidars = n;
+  // the lane-compacted cast (lidar_compact_kernel) serves sets whose targets are all spheres and whose tables fit in LDS
+  {
+    VmasWorld::LidarCompact& LC = w->lc;
+    (void)hipFree(LC.d_ent_slot); (void)hipFree(LC.d_slot_ent);
+    LC.d_ent_slot = nullptr;
+    LC.d_slot_ent = nullptr;
+    LC.ok = false;
+    bool spheres = n <= 1023 && w->max_rays <= 64;
+    std::vector<int> ent_slot(w->base.nE, -1), slot_ent;
+    auto slot = [&](int e) { if (ent_slot[e] < 0) { ent_slot[e] = (int)slot_ent.size(); slot_ent.push_back(e); } };
+    size_t pairs = 0;
+    for (int i = 0; i < n && spheres; ++i) {
+      if (dl[i].n_targets > 65535) spheres = false;
+      slot(dl[i].entity);
+      pairs += (size_t)dl[i].n_targets;
+      for (int t = 0; t < dl[i].n_targets; ++t) {
+        const DevTarget& T = dt[dl[i].target_off + t];
+        if (T.shape != VMAS_SHAPE_SPHERE) spheres = false;
+        slot(T.entity);
+      }
+    }
+    const size_t words = slot_ent.size() * 128 + (size_t)n * 64 + (size_t)n * w->max_rays * kLidarStride + 2 +
+                         (size_t)n * kLidarSensorWords + pairs * kLidarPairWords + pairs * 64;
+    if (spheres && n <= 65535 && slot_ent.size() <= 65535 && pairs > 0 && pairs < (1u << 26) && words * sizeof(float) <= 160 * 1024) {
+      auto fb = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+      std::vector<uint32_t> tab;
+      uint32_t pair0 = 0;
+      for (int i = 0; i < n; ++i) {
+        tab.push_back((uint32_t)ent_slot[dl[i].entity]); tab.push_back((uint32_t)dl[i].n_rays); tab.push_back((uint32_t)dl[i].angle_off);
+        tab.push_back(pair0); tab.push_back(fb(dl[i].max_range)); tab.push_back(fb(dl[i].half_range));
+        pair0 += (uint32_t)dl[i].n_targets;
+      }
+      for (int i = 0; i < n; ++i)
+        for (int t = 0; t < dl[i].n_targets; ++t) {
+          const DevTarget& T = dt[dl[i].target_off + t];
+          tab.push_back((uint32_t)i | (uint32_t)ent_slot[T.entity] << 16);
+          tab.push_back(fb(T.radius));
+        }
+      HIP_TRY(upload(&LC.d_ent_slot, tab));
+      HIP_TRY(upload(&LC.d_slot_ent, slot_ent));
+      LC.n_slots = (int)slot_ent.size();
+      LC.n_pairs_total = (int)pairs;
+      LC.lds = words * sizeof(float);
+      LC.ok = true;
+    }
+  }
   return 0;
+}
+
+int vmas_world_set_lidar_compact(VmasWorld* w, int32_t mode) {
+  if (!w) return fail("vmas_world_set_lidar_compact: null world");
+  if (mode < -1 || mode > 1) return fail("vmas_world_set_lidar_compact: mode %d (-1 library's choice, 0 never, 1 whenever the sensor set qualifies)", mode);
+  w->lc.mode = mode;
+  return 0;
+}
+
+int vmas_world_get_lidar_compact(VmasWorld* w) {
+  return (w && w->lc.ok && (w->lc.mode == 1 || (w->lc.mode == -1 && 2 * blocks_of(w->batch) > w->n_cu))) ? 1 : 0;
 }
 
 int vmas_world_set_queries(VmasWorld* w, const VmasQuery* queries, int32_t n) {
@@ -2740,6 +2946,27 @@ int vmas_world_cast_rays(VmasWorld* w, const float* state, int64_t ld, float* ou
   if (w && w->host_only) return fail("vmas_world_cast_rays: a planning world (device -1) has no device side");
   if (!w || !state || !out) return fail("vmas_world_cast_rays: null argument");
   if (w->n_lidars <= 0) return fail("vmas_world_cast_rays: no sensors registered (vmas_world_set_lidars)");
+  // sphere-only sensor sets: the lane-compacted cast - the library's choice once the batch has more tiles than half the CUs
+  // (at 8 192 environments = 128 tiles the plain kernel's shorter chain still wins: 9.1 us against 10.0)
+  if (w->lc.ok && (w->lc.mode == 1 || (w->lc.mode == -1 && 2 * blocks_of(w->batch) > w->n_cu))) {
+    const VmasWorld::LidarCompact& LC = w->lc;
+    if (LC.lds > 64 * 1024) {
+      static std::atomic<size_t> set_for_dev[64];
+      std::atomic<size_t>& set_for = set_for_dev[w->device & 63];
+      if (set_for.load() < LC.lds) {
+        HIP_TRY(hipFuncSetAttribute((const void*)lidar_compact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LC.lds));
+        set_for = LC.lds;
+      }
+    }
+    // 16 waves per tile while the chip holds every tile at once or nearly (16 384 environments 10.5 us, plain kernel 14.4), 8
+    // beyond (65 536: 23.7 us with 8 waves, 26.3 with 16; plain kernel 37.2)
+    const int threads = blocks_of(w->batch) <= 2 * w->n_cu ? 1024 : 512;
+    hipLaunchKernelGGL(lidar_compact_kernel, dim3((w->batch + 63) / 64), dim3(threads), LC.lds, (hipStream_t)stream, LC.d_ent_slot,
+                       w->d_angles, w->d_angles_cs, LC.d_slot_ent, LC.n_slots, w->n_lidars, LC.n_pairs_total, w->max_rays, state,
+                       (long)ld, w->batch, out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   // rays per thread: few when the batch alone cannot fill the chip (latency-bound), more when it
   // can (each thread then reads its targets once for several rays); VMAS_LIDAR_RPT overrides
   static const int force_rpt = knob("VMAS_LIDAR_RPT") ? atoi(knob("VMAS_LIDAR_RPT")) : 0;
