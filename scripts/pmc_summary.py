@@ -17,7 +17,7 @@ import sys
 
 work, stats_csv, bpe, fpe, envs, cmd = sys.argv[1], sys.argv[2], float(sys.argv[3]), float(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
 rated = sys.argv[7] if len(sys.argv) > 7 else "step_kernel"
-OURS = ("step_kernel", "lidar_kernel", "post_kernel", "pair_mask_kernel", "ingest_kernel", "query_kernel", "reset_kernel",
+OURS = ("step_kernel", "lidar_kernel", "lidar_compact_kernel", "collision_kernel", "post_kernel", "pair_mask_kernel", "ingest_kernel", "query_kernel", "reset_kernel",
         "rollout")
 
 
