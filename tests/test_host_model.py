@@ -136,3 +136,28 @@ def test_planning_world_matches_the_generated_tables():
         assert b"planning world" in lib.vmas_last_error()
     finally:
         lib.vmas_world_destroy(h)
+
+
+def test_lidar_kernel_choice_validates_its_mode_without_a_gpu():
+    """vmas_world_set_lidar_compact on a planning world: the mode is checked (-1 library's choice, 0 plain kernel, 1 the
+    lane-compacted cast), and a world without a registered sphere-only sensor set never reports the compacted form."""
+    import ctypes as C
+
+    from vectorizedmultiagentsimulator_amd import _abi as A
+    from vectorizedmultiagentsimulator_amd.scenarios.balance import Scenario
+
+    w = Scenario().env_make_world(4096, "cpu", n_agents=3)
+    cd = w.spec.to_ctypes()
+    lib = A.load_library()
+    h = C.c_void_p()
+    assert lib.vmas_world_create(C.byref(cd.world), 4096, -1, C.byref(h)) == 0, A.last_error()
+    try:
+        for mode in (-1, 0, 1):
+            assert lib.vmas_world_set_lidar_compact(h, mode) == 0, A.last_error()
+            assert lib.vmas_world_get_lidar_compact(h) == 0  # (no sensors registered)
+        for mode in (-2, 2):
+            assert lib.vmas_world_set_lidar_compact(h, mode) != 0 and b"mode" in lib.vmas_last_error()
+        assert lib.vmas_world_set_lidar_compact(None, 0) != 0 and b"null world" in lib.vmas_last_error()
+        assert lib.vmas_world_get_lidar_compact(None) == 0
+    finally:
+        lib.vmas_world_destroy(h)
