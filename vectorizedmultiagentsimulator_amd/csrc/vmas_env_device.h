@@ -54,10 +54,12 @@ struct TileCtx {
   int lane, wave, nw, n_rows;
   long b0, env, e;  // e = env clamped into the batch (loads of the tail lanes stay in bounds)
   bool live;
-  VD TileCtx(int batch) {
+  // nw_known: the waves per tile where the caller knows them at compile time (the world-specialised kernels) - blockDim.x is
+  // a vector load from the implicit kernel arguments with a wait behind it, at the top of the kernel
+  VD TileCtx(int batch, int nw_known = 0) {
     lane = threadIdx.x & 63;
     wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    nw = __builtin_amdgcn_readfirstlane(blockDim.x >> 6);
+    nw = nw_known > 0 ? nw_known : __builtin_amdgcn_readfirstlane(blockDim.x >> 6);
     b0 = (long)blockIdx.x * 64;
     env = b0 + lane;
     live = env < batch;
@@ -598,21 +600,21 @@ VD void navigation_prologue_tile(const TileCtx& C, const VmasNavigationDesc& d, 
   int* misc = (int*)(per_agent + A * 64);  // [0] the LIDAR queue's length, [1..] this tile's pair bits
   for (int a = C.wave; a < A; a += C.nw)
     per_agent[a * 64 + C.lane] = C.live ? o.pos_shaping[(long)a * batch + C.env] : 0.f;
-  for (int i = threadIdx.x; i < 2 * VMAS_ENV_MAX_AGENTS; i += blockDim.x) misc[i] = 0;  // (a tile may be a single wave)
+  for (int i = threadIdx.x; i < 2 * VMAS_ENV_MAX_AGENTS; i += C.nw * 64) misc[i] = 0;  // (a tile may be a single wave)
   if (d.collisions) {  // the epilogue's descriptors: a dependent global load per use would chain microseconds behind the physics
     const int R = A * d.n_rays;
     float* stage = (float*)(misc + 2 * VMAS_ENV_MAX_AGENTS) + 2;  // (8-byte aligned: cos / sin pairs first)
-    for (int i = threadIdx.x; i < R; i += blockDim.x) {
+    for (int i = threadIdx.x; i < R; i += C.nw * 64) {
       const float2 cs = nav.angles_cs[i];  // (cos, sin first: 8-byte aligned whatever R is)
       stage[2 * i] = cs.x; stage[2 * i + 1] = cs.y;
       stage[2 * R + i] = nav.angles[i];
     }
     const float* pw = (const float*)nav.pairs;
-    for (int i = threadIdx.x; i < nav.n_pairs * 3; i += blockDim.x) stage[3 * R + i] = pw[i];
+    for (int i = threadIdx.x; i < nav.n_pairs * 3; i += C.nw * 64) stage[3 * R + i] = pw[i];
     int* pidx = (int*)(stage + 3 * R + 3 * nav.n_pairs);
-    for (int i = threadIdx.x; i < A * A; i += blockDim.x) pidx[i] = o.pair_index[i];
+    for (int i = threadIdx.x; i < A * A; i += C.nw * 64) pidx[i] = o.pair_index[i];
     uint32_t* measured = (uint32_t*)(pidx + A * A) + A * (A - 1) * 32;  // (behind the queue)
-    for (int i = threadIdx.x; i < R * kNavMeasuredStride; i += blockDim.x) measured[i] = 0u;  // = lidar_range - max_range
+    for (int i = threadIdx.x; i < R * kNavMeasuredStride; i += C.nw * 64) measured[i] = 0u;  // = lidar_range - max_range
   }
 }
 
@@ -879,7 +881,7 @@ VD void navigation_post_tile(const TileCtx& C, const VmasNavigationDesc& d, cons
     if (threadIdx.x < VMAS_ENV_MAX_AGENTS) misc[threadIdx.x] = 0;
     if (d.collisions) {
       uint32_t* measured = (uint32_t*)(st_pair_index + A * A) + A * (A - 1) * 32;
-      for (int i = threadIdx.x; i < R * kNavMeasuredStride; i += blockDim.x) measured[i] = 0u;
+      for (int i = threadIdx.x; i < R * kNavMeasuredStride; i += C.nw * 64) measured[i] = 0u;
     }
   }
 }
@@ -893,19 +895,41 @@ VD void navigation_post_tile(const TileCtx& C, const VmasNavigationDesc& d, cons
 // ingest_fetch issues the loads of one slot (nothing else), ingest_apply is the arithmetic and the stores.  A load per
 // agent behind the previous agent's stores chained one HBM round trip per agent along the step kernel's critical path.
 struct IngestRaw { float u[3]; long flat; };
+// Pointers out of a slot that went through registers (load_action_slot) have lost the "loaded from the kernel arguments: global
+// memory" inference and would be dereferenced with FLAT instructions - which count on lgkmcnt too, so that the next wait for a
+// scalar load or an LDS read would also wait for the action load.  These casts say what they are.
+#define VMAS_GLOBAL __attribute__((address_space(1)))
+template <class T> VD const VMAS_GLOBAL T* as_global(const T* p) { return (const VMAS_GLOBAL T*)p; }
+template <class T> VD VMAS_GLOBAL T* as_global(T* p) { return (VMAS_GLOBAL T*)p; }
+// An agent's action slot out of the kernel-argument block, whole and at once: read field by field where it is used, every
+// field is its own scalar load with its own wait in front of the branch that needs it - some thirty dependent round trips
+// to the scalar cache on the prologue's chain.  18 words in one batch of wide loads, pinned in scalar registers.
+VD VmasActionSlot load_action_slot(const VmasActionSlot* p) {
+  static_assert(sizeof(VmasActionSlot) == 72, "load_action_slot reads the slot as 18 words");
+  const uint32_t* w = (const uint32_t*)p;
+  uint32_t r[18];
+#pragma unroll
+  for (int i = 0; i < 18; ++i) r[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)w[i]);  // (uniform by construction; said so)
+  asm volatile("" : "+s"(r[0]), "+s"(r[1]), "+s"(r[2]), "+s"(r[3]), "+s"(r[4]), "+s"(r[5]), "+s"(r[6]), "+s"(r[7]), "+s"(r[8]),
+               "+s"(r[9]), "+s"(r[10]), "+s"(r[11]), "+s"(r[12]), "+s"(r[13]), "+s"(r[14]), "+s"(r[15]), "+s"(r[16]), "+s"(r[17]));
+  VmasActionSlot s;
+  __builtin_memcpy(&s, r, sizeof(s));
+  return s;
+}
 VD void ingest_fetch(const VmasActionSlot& S, long env, bool live, long row0, IngestRaw& r) {
   r.u[0] = r.u[1] = r.u[2] = 0.f;
   r.flat = 0;
   if (!live) return;
   if (S.action_index != nullptr) {
-    r.flat = S.action_index[row0 + env];
+    r.flat = as_global(S.action_index)[row0 + env];
   } else if (S.action_size == 2 && ((uintptr_t)S.action & 7) == 0) {  // (rows of two floats: one 8-byte load)
-    const float2 v = *(const float2*)(S.action + (row0 + env) * 2);
+    typedef float vf2 __attribute__((ext_vector_type(2)));  // (float2 is a class: no copy out of a qualified address space)
+    const vf2 v = *as_global((const vf2*)(S.action + (row0 + env) * 2));
     r.u[0] = v.x; r.u[1] = v.y;
   } else {
 #pragma unroll
     for (int k = 0; k < 3; ++k)  // (constant bounds: a run-time trip count would index r.u dynamically - a stack slot)
-      if (k < S.action_size) r.u[k] = S.action[(row0 + env) * S.action_size + k];
+      if (k < S.action_size) r.u[k] = as_global(S.action)[(row0 + env) * S.action_size + k];
   }
 }
 VD void ingest_apply(const VmasActionSlot& S, int clamp, long env, bool live, float* __restrict__ agent_ft, long ld,
@@ -915,7 +939,9 @@ VD void ingest_apply(const VmasActionSlot& S, int clamp, long env, bool live, fl
   long flat = r.flat;
   if (S.action_index != nullptr) {  // flat index -> per-dimension index -> [-u_range, u_range] (environment.py:657-705)
     long total = 1;
-    for (int k = 0; k < S.action_size; ++k) total *= S.nvec[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)  // (constant bounds, here and below: a run-time trip count would index the slot dynamically -
+      if (k < S.action_size) total *= S.nvec[k];  //  a slot held in registers, load_action_slot, would move to the stack)
     if (flat < 0 || flat >= total) {
       bad |= VMAS_ACTION_ERR_OUT_OF_RANGE;
       flat = 0;
@@ -927,7 +953,9 @@ VD void ingest_apply(const VmasActionSlot& S, int clamp, long env, bool live, fl
     float u;
     if (S.action_index != nullptr) {
       long m = 1;
-      for (int j = k + 1; j < S.action_size; ++j) m *= S.nvec[j];
+#pragma unroll
+      for (int j = 1; j < 3; ++j)
+        if (j > k && j < S.action_size) m *= S.nvec[j];
       const int n = S.nvec[k];
       int a = (int)(flat / m);
       flat = flat % m;
@@ -946,7 +974,7 @@ VD void ingest_apply(const VmasActionSlot& S, int clamp, long env, bool live, fl
     u = u * S.u_multiplier[k];
     u_out[k] = u;
     agent_ft[((long)S.agent_index * 3 + k) * ld + env] = u;
-    if (S.u_out != nullptr) S.u_out[env * S.action_size + k] = u;
+    if (S.u_out != nullptr) as_global(S.u_out)[env * S.action_size + k] = u;
   }
 }
 
