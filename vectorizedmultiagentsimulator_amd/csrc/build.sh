@@ -24,7 +24,8 @@ for unit in vmas_hip vmas_env vmas_compact; do
   o="$OBJ/$unit.$key.o"
   objs+=("$o")
   if [ -n "${VMAS_BUILD_FORCE:-}" ] || [ ! -s "$o" ]; then
-    ls -t "$OBJ/$unit".*.o 2>/dev/null | tail -n +4 | xargs -r rm -f  # (keep the three latest variants: product, profile, trace)
+    # (keep the three latest variants: product, profile, trace; `ls` fails on a fresh tree - no object yet - and must not end the script)
+    (ls -t "$OBJ/$unit".*.o 2>/dev/null || true) | tail -n +4 | xargs -r rm -f
     ( "$HIPCC" $FLAGS -c "$unit.hip" -o "$o.tmp" && mv "$o.tmp" "$o" ) &
     pids+=($!)
   fi
