@@ -2897,6 +2897,13 @@ int vmas_world_set_lidars(VmasWorld* w, const VmasLidarDesc* lidars, int32_t n) 
   return 0;
 }
 
+// the lane-compacted cast is taken: when pinned (mode 1), or - the library's choice - once the batch has more tiles than half
+// the CUs AND the sensor set's LDS leaves a CU at least two resident tiles (measured on navigation's 8 x 12 rays x 7 targets,
+// 46 KB; larger sets keep the plain kernel until they have been measured)
+static bool lidar_compact_on(const VmasWorld* w) {
+  return w->lc.ok && (w->lc.mode == 1 || (w->lc.mode == -1 && 2 * blocks_of(w->batch) > w->n_cu && w->lc.lds <= 64 * 1024));
+}
+
 int vmas_world_set_lidar_compact(VmasWorld* w, int32_t mode) {
   if (!w) return fail("vmas_world_set_lidar_compact: null world");
   if (mode < -1 || mode > 1) return fail("vmas_world_set_lidar_compact: mode %d (-1 library's choice, 0 never, 1 whenever the sensor set qualifies)", mode);
@@ -2905,7 +2912,7 @@ int vmas_world_set_lidar_compact(VmasWorld* w, int32_t mode) {
 }
 
 int vmas_world_get_lidar_compact(VmasWorld* w) {
-  return (w && w->lc.ok && (w->lc.mode == 1 || (w->lc.mode == -1 && 2 * blocks_of(w->batch) > w->n_cu))) ? 1 : 0;
+  return (w && lidar_compact_on(w)) ? 1 : 0;
 }
 
 int vmas_world_set_queries(VmasWorld* w, const VmasQuery* queries, int32_t n) {
@@ -2948,7 +2955,7 @@ int vmas_world_cast_rays(VmasWorld* w, const float* state, int64_t ld, float* ou
   if (w->n_lidars <= 0) return fail("vmas_world_cast_rays: no sensors registered (vmas_world_set_lidars)");
   // sphere-only sensor sets: the lane-compacted cast - the library's choice once the batch has more tiles than half the CUs
   // (at 8 192 environments = 128 tiles the plain kernel's shorter chain still wins: 9.1 us against 10.0)
-  if (w->lc.ok && (w->lc.mode == 1 || (w->lc.mode == -1 && 2 * blocks_of(w->batch) > w->n_cu))) {
+  if (lidar_compact_on(w)) {
     const VmasWorld::LidarCompact& LC = w->lc;
     if (LC.lds > 64 * 1024) {
       static std::atomic<size_t> set_for_dev[64];
