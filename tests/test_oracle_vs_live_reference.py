@@ -82,3 +82,45 @@ def test_oracle_matches_live_reference_large_batch(scenario, kw, B, steps):
         assert stats["needed_sens"] == 0
     else:
         assert stats["needed_sens"] <= 1e-4 * stats["values"]
+
+
+@pytest.mark.parametrize("crowd", [1.0, 0.25, 0.05])
+def test_oracle_lidar_matches_live_reference_on_crowded_rotated_worlds(crowd):
+    """World.cast_rays (core.py:1662-1786, ray - sphere core.py:1414-1490) of navigation n_agents=8 at 1024 environments on
+    states the fixtures do not hold: positions scaled towards the origin (crowd 0.25: many agents within range of each
+    other; 0.05: agents OVERLAP, so sensors sit inside other agents' spheres and the measured distance goes negative) and
+    every agent rotated at random (the sensor's angles rotate with it, sensors.py:118).  The oracle's cast must be the
+    reference's within 1e-5 - the states the lane-compacted HIP cast is pinned on through the plain kernel."""
+    from oracle import ref
+    from oracle.oracle import Oracle
+    from vectorizedmultiagentsimulator_amd.spec import spec_from_world
+
+    B = 1024
+    torch.manual_seed(3)
+    env = ref.make_env("navigation", num_envs=B, device="cpu", seed=3, n_agents=8)
+    w = env.world
+    g = torch.Generator().manual_seed(7)
+    for a in w.agents:
+        a.set_pos(a.state.pos * crowd, batch_index=None)
+        a.set_rot((torch.rand(B, 1, generator=g) * 2 - 1) * 3.0, batch_index=None)
+    spec = spec_from_world(w)
+    o = Oracle(spec)
+    ents = list(w.entities)
+    L = spec.lidars
+    assert len(L) == 8
+    got = o.cast_rays(pack_state(w), batch=B, threads=8)
+    k, worst, below_zero = 0, 0.0, 0
+    for agent in w.agents:
+        for sensor in agent.sensors:
+            if not hasattr(sensor, "_angles"):
+                continue
+            m = w.cast_rays(agent, sensor._angles + agent.state.rot, max_range=sensor._max_range, entity_filter=sensor.entity_filter)
+            assert ents.index(agent) == L[k].entity
+            want = m.T.numpy()
+            below_zero += int((want < 0).sum())
+            worst = max(worst, compare_state(got[k, : want.shape[0], :B], want, f"navigation crowd={crowd} sensor {k}", atol=1e-5, rtol=1e-5))
+            k += 1
+    assert k == 8
+    if crowd <= 0.05:
+        assert below_zero > 0, "the crowded case is meant to put sensors inside spheres"
+    print(f"navigation lidar, crowd {crowd}: max |oracle - reference| = {worst:.2e}, {below_zero} negative distances")
