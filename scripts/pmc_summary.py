@@ -42,15 +42,37 @@ try:
         dur[short(r["Name"])] = (float(r["AverageNs"]), int(r["Calls"]), float(r["MinNs"]), float(r["MaxNs"]), float(r["StdDev"]))
 except Exception as e:  # noqa: BLE001
     print("no kernel stats:", e)
+# per-dispatch view of the kernel trace: medians, and the same over the LAST HALF of a kernel's calls - the profiler's mean
+# over a short run is taken before the clocks of a fresh process are up (profiles/README.md) and rates the kernel too low
+per_dispatch = {}
+for f in glob.glob(f"{work}/trace/**/*kernel_trace.csv", recursive=True):
+    rows = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        k = short(r["Kernel_Name"])
+        if any(o in k for o in OURS):
+            rows[k].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+    for k, v in rows.items():
+        v.sort()
+        d = [e - b for b, e in v]
+        per = [v[i + 1][0] - v[i][0] for i in range(len(v) - 1)]
+        med = lambda x: sorted(x)[len(x) // 2] if x else float("nan")
+        per_dispatch[k] = (med(d), med(d[len(d) // 2:]), med(per), med(per[len(per) // 2:]), (v[-1][1] - v[0][0]) / 1e6)
 print(f"# {cmd}")
 print(f"# envs {envs}, algorithmic bytes/env-step {bpe:g}, flop/env-step {fpe:g} (SURVEY.md section 8d)")
-for k in sorted(acc, key=lambda k: -dur.get(k, (0,))[0]):
-    c = {n: sum(v) / len(v) for n, v in acc[k].items()}
-    g = meta[k]
-    print(f"\n== {k}\n   grid {g[0]} threads, block {g[1]}, LDS {g[2]} B, VGPR {g[3]}, SGPR {g[4]}")
+for k in sorted(set(acc) | set(per_dispatch), key=lambda k: -dur.get(k, (0,))[0]):
+    c = {n: sum(v) / len(v) for n, v in acc[k].items()} if k in acc else {}
+    if k in meta:
+        g = meta[k]
+        print(f"\n== {k}\n   grid {g[0]} threads, block {g[1]}, LDS {g[2]} B, VGPR {g[3]}, SGPR {g[4]}")
+    else:
+        print(f"\n== {k}\n   (kernel trace only: no counter pass saw it)")
     if k in dur:
         avg, calls, mn, mx, sd = dur[k]
         print(f"   duration (kernel trace): avg {avg / 1e3:.2f} us over {calls} calls (min {mn / 1e3:.2f}, max {mx / 1e3:.2f}, sd {sd / 1e3:.2f})")
+    if k in per_dispatch:
+        m, m2, pm, pm2, span = per_dispatch[k]
+        print(f"   per dispatch: duration median {m / 1e3:.2f} us (last half of the calls {m2 / 1e3:.2f}), launch-to-launch median "
+              f"{pm / 1e3:.2f} us (last half {pm2 / 1e3:.2f}); first to last call {span:.1f} ms")
     waves = c.get("SQ_WAVES", 0)
     for n in sorted(c):
         per_wave = f"  per wave {c[n] / waves:.1f}" if waves and n.startswith("SQ_") and n != "SQ_WAVES" else ""
@@ -63,6 +85,9 @@ for k in sorted(acc, key=lambda k: -dur.get(k, (0,))[0]):
         gbs, gfs = bpe * envs / t / 1e9, fpe * envs / t / 1e9
         print(f"   achieved (algorithmic)  {gbs:.0f} GB/s = {gbs / 8000:.3f} of HBM peak | {gfs:.0f} GFLOP/s = {gfs / 157300:.3f} of fp32 vector peak")
         assert gbs / 8000 <= 1.0 and gfs / 157300 <= 1.0, f"{k}: a fraction above the roof - wrong bytes / flop per environment for this kernel"
+        if k in per_dispatch:  # the same by the median duration of the last half of the calls (the clocks are up by then)
+            t2 = per_dispatch[k][1] * 1e-9
+            print(f"   by the last half's median duration: {bpe * envs / t2 / 1e9:.0f} GB/s = {bpe * envs / t2 / 8e12:.3f} of HBM peak")
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             print(f"   traffic / algorithmic   {traffic / (bpe * envs):.3f}")
     elif k in dur:
