@@ -37,4 +37,16 @@ json.dump({"num_envs": 32768, "bytes_per_launch": (f * FETCH_CAL + w * WRITE_CAL
           open('gpurun_out/prof/latest_traffic.json','w'))
 print(open('gpurun_out/prof/latest_traffic.json').read())
 PY
+# the kernel trace per dispatch: medians over the whole run and over its last half (the profiler's mean over a run that starts
+# with the clock warm-up of a fresh process rates the kernel too low: profiles/README.md)
+python - <<'PY' | tee gpurun_out/prof/per_dispatch_medians.txt
+import csv, glob
+for f in glob.glob('gpurun_out/prof/trace/**/*kernel_trace.csv', recursive=True):
+    v = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp'])) for r in csv.DictReader(open(f)) if 'step_kernel' in r['Kernel_Name'])
+    if len(v) < 4: continue
+    d = [e - b for b, e in v]; per = [v[i + 1][0] - v[i][0] for i in range(len(v) - 1)]
+    med = lambda x: sorted(x)[len(x) // 2]
+    print(f"step kernel, {len(v)} dispatches over {(v[-1][1] - v[0][0]) / 1e6:.1f} ms: duration median {med(d) / 1e3:.2f} us "
+          f"(last half {med(d[len(d) // 2:]) / 1e3:.2f}), launch-to-launch median {med(per) / 1e3:.2f} us (last half {med(per[len(per) // 2:]) / 1e3:.2f})")
+PY
 find $OUT -name "*.csv" -size +3M -delete
