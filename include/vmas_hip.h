@@ -278,6 +278,9 @@ int64_t vmas_world_step_bytes_per_env(const VmasWorld* w);
 
 const char* vmas_last_error(void);
 int vmas_abi_version(void);
+/* A digest of the sources the loaded library was built from (part of the key of the run-time specialisations' on-disk
+ * cache: a code object compiled for another build of the library is never handed to this one). */
+const char* vmas_build_id(void);
 
 #ifdef __cplusplus
 }

@@ -297,6 +297,7 @@ EXPORTED_SYMBOLS = (
     "vmas_world_step_bytes_per_env",
     "vmas_last_error",
     "vmas_abi_version",
+    "vmas_build_id",
     # include/vmas_env_hip.h
     "vmas_env_ingest_actions",
     "vmas_balance_post_step",
@@ -390,6 +391,8 @@ def load_library() -> C.CDLL:
     lib.vmas_last_error.restype = C.c_char_p
     lib.vmas_abi_version.argtypes = []
     lib.vmas_abi_version.restype = C.c_int
+    lib.vmas_build_id.argtypes = []
+    lib.vmas_build_id.restype = C.c_char_p
     if lib.vmas_abi_version() != ABI_VERSION:
         raise VmasHipLibraryMissing(
             f"{LIB_PATH} has ABI version {lib.vmas_abi_version()}, expected {ABI_VERSION}: rebuild it"

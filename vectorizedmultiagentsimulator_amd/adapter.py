@@ -18,9 +18,14 @@ What stays dynamic (SURVEY.md 8b "inputs that are mutable between steps")
     every step.  The STATIC description (mass - ``debug/het_mass.py:50-53`` redraws it at every reset -,
     drag / friction / gravity / speed limits, ``collision_filter`` - ``joint_passage.py:614-622`` filters on
     data its reset rewrites -, movable / rotatable / collide flags, shape dimensions) is watched:
-    every step compares a cheap fingerprint of those attributes (setters ``core.py:634-636, 696-706,
-    720-722``), and the first step after any ``World.reset`` (``core.py:1234``) re-extracts the whole
-    spec - collidability matrix included - and rebuilds the native world iff it differs.
+    writes to those attributes (setters ``core.py:634-636, 696-706, 720-722`` and the private names behind them) set a
+    dirty flag on the handle through a ``__setattr__`` hook on the classes of the attached world, its entities and
+    their shapes; a step then costs two integer comparisons unless something was written (round 3 rebuilt a
+    fingerprint of ~25 attributes per entity on every step: 26 us for ``balance``, 67 us for ``football`` - several
+    times the kernel).  After a ``World.reset`` (``core.py:1234``) the whole spec - collidability matrix included - is
+    re-extracted iff the flag is set or some ``collision_filter`` is a closure / callable object, i.e. can depend on
+    data the scenario's ``reset_world_at`` rewrites; the native world is rebuilt iff the spec differs.
+    Not seen: a closure's captured data changing WITHOUT a ``World.reset`` - call ``handle.refresh()`` after such a write.
 
 ``grad_enabled`` worlds are refused (the kernels have no backward), as is a CPU device:
 there is no fallback path.
@@ -43,6 +48,33 @@ def _default_backend(spec: WorldSpec, batch: int, device, state, agent_ft):
 
 _FIELDS = ("pos", "vel", "rot", "ang_vel", "force", "torque")
 _MARK = "_vmas_amd_attached"
+_OWNER = "_vmas_amd_owner"
+# private names behind everything spec_from_world reads from a world, an entity or a shape (one set for the three kinds)
+_WATCH = frozenset((
+    "_drag", "_linear_friction", "_angular_friction", "_gravity", "_substeps", "_sub_dt", "_x_semidim", "_y_semidim",
+    "_collision_force", "_joint_force", "_contact_margin", "_torque_constraint_force", "_joints",
+    "_mass", "_max_speed", "_v_range", "_movable", "_rotatable", "_collide", "_collision_filter", "_shape",
+    "_max_f", "_f_range", "_max_t", "_t_range", "_radius", "_length", "_width", "hollow", "_hollow", "_dt",
+))
+
+
+def _patch_setattr(cls) -> None:
+    """A write to a watched attribute of an object that belongs to an attached world marks that world's handle dirty.  The
+    hook goes on the object's class (once; subclasses of a hooked class inherit it) and does nothing for unattached
+    instances beyond one dictionary probe on watched names."""
+    cur = cls.__setattr__
+    if getattr(cur, "_vmas_amd", False):
+        return
+
+    def hook(self, name, value, _orig=cur):
+        _orig(self, name, value)
+        if name in _WATCH:
+            owner = self.__dict__.get(_OWNER)
+            if owner is not None:
+                owner._dirty = True
+
+    hook._vmas_amd = True
+    cls.__setattr__ = hook
 
 
 def _patch_state_class(cls) -> None:
@@ -97,9 +129,9 @@ class AttachedWorld:
         self.specialize = bool(specialize)  # a step kernel compiled for this world (specialize.py), also after a refresh()
         if self.specialize and hasattr(self.backend, "specialize"):
             self.backend.specialize()
-        self._fp = self._fingerprint()
         self._check_spec = False  # set by World.reset: the scenario's reset_world_at that follows may change statics
         self.refreshes = 0        # how many times the static description was found changed (tests, diagnostics)
+        self._watch()
         world.step = self.step
         self._orig_reset = world.reset
 
@@ -164,56 +196,60 @@ class AttachedWorld:
         return jfr, eg
 
     # ---- mutable static inputs ---------------------------------------------------------
-    def _fingerprint(self):
-        """The attributes of the static description that have public setters or are written by in-tree scenarios, as
-        one comparable tuple (no device sync: tensors are identified by object and version)."""
+    def _watch(self):
+        """(Re)arm the change detection on the world as it is now: owner marks on the world, its entities and their shapes
+        (their classes hooked once), the tensor-valued attributes identified by object and version, and whether any
+        collision filter can depend on data a reset rewrites."""
         w = self.world
+        objs = [w] + list(w.entities) + [e.shape for e in w.entities]
+        for o in objs:
+            _patch_setattr(type(o))
+            o.__dict__[_OWNER] = self
+        self._marked = objs
 
-        def key(x):
-            if x is None or isinstance(x, (bool, int, float, str)):
-                return x
-            if isinstance(x, torch.Tensor):
-                if x.dim() >= 2:  # per-environment values (entity.gravity [B, 2], wind_flocking.py:372 rebinds it every
-                    return ("per_env", tuple(x.shape))  # step): a dynamic input, re-read by every step anyway
-                return ("T", id(x), x._version, tuple(x.shape))
-            if isinstance(x, (tuple, list)):
-                return tuple(key(v) for v in x)
-            return ("O", id(x))
+        def volatile(f):  # a closure, a bound method or a callable object: may read data reset_world_at rewrites
+            return getattr(f, "__closure__", None) is not None or not hasattr(f, "__code__")
 
-        fp = [key(getattr(w, a, None)) for a in ("_drag", "_linear_friction", "_angular_friction", "_gravity", "_substeps",
-                                                  "_sub_dt", "_x_semidim", "_y_semidim", "_collision_force", "_joint_force",
-                                                  "_contact_margin", "_torque_constraint_force")]
-        fp.append(len(getattr(w, "_joints", {})))
-        for e in w.entities:
-            sh = e.shape
-            fp.append((key(e.mass), key(e.drag), key(e.linear_friction), key(e.angular_friction), key(e.gravity),
-                       key(e.max_speed), key(e.v_range), bool(e.movable), bool(e.rotatable), bool(getattr(e, "_collide", True)),
-                       id(e.collision_filter), type(sh).__name__, key(getattr(sh, "_radius", None)),
-                       key(getattr(sh, "_length", None)), key(getattr(sh, "_width", None)), key(getattr(sh, "_hollow", None)),
-                       key(getattr(e, "max_f", None)), key(getattr(e, "f_range", None)), key(getattr(e, "max_t", None)),
-                       key(getattr(e, "t_range", None))))
-        return tuple(fp)
+        self._volatile_filters = any(volatile(e.collision_filter) for e in w.entities)
+        # the step itself: with no per-environment inputs (joint rotations, tensor gravities) it is one pre-marshalled
+        # foreign call (backend.HipWorld.make_stepper)
+        spec = self.spec
+        self._per_env = any(j.per_env_fixed_rotation for j in spec.joints) or any(e.per_env_gravity for e in spec.entities)
+        mk = getattr(self.backend, "make_stepper", None)
+        self._fast_step = mk(self.exact_broad_phase) if (mk is not None and not self._per_env) else None
+        self._mini = self._mini_fingerprint()
+        self._dirty = False
+
+    def _mini_fingerprint(self):
+        """What a ``__setattr__`` hook cannot see: in-place writes to the world's gravity tensor, joints added to the dict."""
+        w = self.world
+        g = getattr(w, "_gravity", None)
+        return (id(g), getattr(g, "_version", 0), len(getattr(w, "_joints", ())))
 
     def _sync_static(self):
         """Rebuild the native world iff the live world's static description is no longer the one it was built from."""
-        fp = self._fingerprint()
-        if not self._check_spec and fp == self._fp:
+        check, self._check_spec = self._check_spec, False
+        if not self._dirty and not (check and self._volatile_filters) and self._mini_fingerprint() == self._mini:
             return
-        self._fp, self._check_spec = fp, False
         spec = spec_from_world(self.world)
         if spec != self.spec:
             self.refresh(spec)
+        else:
+            self._watch()  # (a shape object may have been replaced by an equal one: mark the new one)
 
     # ---- the replaced seam ----------------------------------------------------------
     def step(self):
         """World.step() (core.py:1972-2015) on the native path."""
         w = self.world
         self._sync_static()
-        jfr, eg = self._per_env_inputs()
-        if self.exact_broad_phase:
-            self.backend.step_exact(joint_fixed_rot=jfr, entity_gravity=eg)
+        if self._fast_step is not None:
+            self._fast_step()
         else:
-            self.backend.step(joint_fixed_rot=jfr, entity_gravity=eg)
+            jfr, eg = self._per_env_inputs() if self._per_env else (None, None)
+            if self.exact_broad_phase:
+                self.backend.step_exact(joint_fixed_rot=jfr, entity_gravity=eg)
+            else:
+                self.backend.step(joint_fixed_rot=jfr, entity_gravity=eg)
         if w._dim_c > 0:  # _update_comm_state core.py:2910-2913
             for agent in w._agents:
                 if not agent.silent:
@@ -230,7 +266,7 @@ class AttachedWorld:
         self.backend = self._factory(self.spec, self.batch, self.device, self.state, self.agent_ft)
         if self.specialize and hasattr(self.backend, "specialize"):
             self.backend.specialize()
-        self._fp = self._fingerprint()
+        self._watch()
         self.refreshes += 1
 
     # ---- sensors -----------------------------------------------------------------------
@@ -266,6 +302,8 @@ class AttachedWorld:
             st.__dict__[_MARK] = False
         for sensor, orig in self._orig_measures:
             sensor.measure = orig
+        for o in self._marked:  # (the class hooks stay: they do nothing for objects without an owner)
+            o.__dict__.pop(_OWNER, None)
         self.backend.close()
 
 

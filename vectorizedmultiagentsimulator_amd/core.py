@@ -751,14 +751,41 @@ class World:
             hint = getattr(self, "epilogue_hint", None)  # (post_kind, n_packages), set by scenarios with a fused post-step
             if hint is not None and not self._lanes_per_env:
                 self._backend.reserve_epilogue(*hint)
+            req = getattr(self, "_specialize_request", None)
+            if req is not None:
+                # a static change (mass setter, add_joint, sensors ...) rebuilt the backend: the specialisation asked for
+                # belongs to the world, not to one backend object - re-applied to the new schedule here (from the cache, or
+                # compiled if the request allowed compiling); `backend.specialized` tells whether it took
+                self._apply_specialize(*req)
         return self._backend
 
-    def specialize(self, cache_dir: Optional[str] = None, cached_only: bool = False) -> bool:
-        """A world-specialised step kernel for this world as it is now (specialize.py): compiled once, cached on disk."""
-        be = self._get_backend()
+    def _apply_specialize(self, cache_dir, cached_only: bool, strict: bool) -> bool:
+        import warnings
+
+        from .specialize import SpecializeError
+
+        be = self._backend
         hint = getattr(self, "epilogue_hint", None)  # (epilogues the planner reserves LDS for; else the scenario's fused_post)
-        return be.specialize(post=hint[0] if hint is not None else getattr(self, "fused_post", 0), cache_dir=cache_dir,
-                             cached_only=cached_only)
+        try:
+            return be.specialize(post=hint[0] if hint is not None else getattr(self, "fused_post", 0), cache_dir=cache_dir,
+                                 cached_only=cached_only)
+        except (SpecializeError, OSError) as e:
+            if strict:
+                raise
+            # the specialisation is an optional fast path: a cache entry the library refuses, an unreadable header, a failing
+            # compiler ... must not break make_env - the world keeps the interpreter (same results bit for bit)
+            warnings.warn(f"world-specialised kernel not used, the world runs the schedule interpreter: {e}", RuntimeWarning)
+            return False
+
+    def specialize(self, cache_dir: Optional[str] = None, cached_only: bool = False, strict: Optional[bool] = None) -> bool:
+        """A world-specialised step kernel for this world as it is now (specialize.py): compiled once, cached on disk.  The
+        request stays with the world: a backend rebuilt after a static change is specialised again.  ``strict`` (default:
+        whenever compiling is allowed): errors raise; otherwise they warn and the world keeps the interpreter."""
+        strict = (not cached_only) if strict is None else strict
+        self._specialize_request = None  # (applied explicitly below; _get_backend must not apply it a second time)
+        self._get_backend()
+        self._specialize_request = (cache_dir, cached_only, strict)
+        return self._apply_specialize(cache_dir, cached_only, strict)
 
     # ---- reference API ---------------------------------------------------------------
     batch_dim = property(lambda s: s._batch_dim)

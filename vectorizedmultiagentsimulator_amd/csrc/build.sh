@@ -31,5 +31,11 @@ for unit in vmas_hip vmas_env vmas_compact; do
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-"$HIPCC" --offload-arch=gfx950 -fPIC -shared -o "$OUT" "${objs[@]}"
+# the build id (vmas_build_id): a digest of everything the library is built from, in a translation unit of its own - part of
+# the key of the run-time specialisations' on-disk cache (specialize.py)
+BUILD_ID=$( (echo "$FLAGS"; "$HIPCC" --version | head -2; cat vmas_hip.hip vmas_env.hip vmas_compact.hip *.h ../../include/*.h) | sha256sum | cut -c1-32)
+printf 'extern "C" { extern const char vmas_build_id_string[]; const char vmas_build_id_string[] = "%s"; }\n' "$BUILD_ID" > "$OBJ/build_id.$BUILD_ID.cpp"
+g++ -O1 -fPIC -c "$OBJ/build_id.$BUILD_ID.cpp" -o "$OBJ/build_id.$BUILD_ID.o"
+"$HIPCC" --offload-arch=gfx950 -fPIC -shared -o "$OUT" "${objs[@]}" "$OBJ/build_id.$BUILD_ID.o"
+rm -f "$OBJ/build_id.$BUILD_ID.cpp"
 echo "built $(pwd)/$OUT"

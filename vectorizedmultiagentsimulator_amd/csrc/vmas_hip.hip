@@ -1062,6 +1062,9 @@ struct VmasWorld {
     hipEvent_t copied = nullptr;   // fires when h_count holds the count as of `tiles_at_copy`
     bool pending = false;
     int in_window = 0, backoff = 0;
+    int forced = -1;  // >= 0: the kernel of the step being enqueued was chosen by the caller (vmas_world_step_n over several
+                      // queues decides ONCE per step, before its sub-range launches: every part of a step runs the same kernel,
+                      // and the backoff counts steps, not launches)
     long tiles = 0, tiles_at_copy = 0, tiles_seen = 0;
     unsigned long long count_seen = 0;
     long switches = 0;
@@ -2005,14 +2008,26 @@ static int compact_adapt_tick(VmasWorld* w, hipStream_t s, int n_steps) {
   return 0;
 }
 
+// The adaptive choice for ONE step (VmasWorld::CompactAdapt): 0 = the interpreter's turn (the tiles were overflowing; counts the
+// backoff down by one STEP), 1 = the compacted kernel.  Called once per step - by launch_physics for a whole-batch launch, by
+// vmas_world_step_n before the sub-range launches of a step split over several queues.
+static int compact_pick_step(VmasWorld* w) {
+  if (w->adapt.backoff > 0) {
+    --w->adapt.backoff;
+    return 0;
+  }
+  return 1;
+}
+
 static int launch_physics(VmasWorld* w, Sched* S, float* state, float* aft, long ld, const DevStepArgs& a, hipStream_t s,
                           int batch = -1, long pad = -1) {
   if (batch < 0) { batch = w->batch; pad = ld; }
   if (compact_on(w) && !a.joint_fixed_rot && !ABLATE(a)) {
     const bool adaptive = w->compact_mode == -1 && w->adapt.d_count != nullptr;
-    if (adaptive && w->adapt.backoff > 0) {
-      --w->adapt.backoff;  // (the tiles were overflowing: the interpreter's turn, see VmasWorld::CompactAdapt)
-    } else {
+    bool interpreter_turn;
+    if (adaptive && w->adapt.forced >= 0) interpreter_turn = w->adapt.forced == 0;  // (chosen for the whole step by the caller)
+    else interpreter_turn = adaptive && compact_pick_step(w) == 0;
+    if (!interpreter_turn) {
       DevStepArgs ac = a;
       if (adaptive) ac.contacts = w->adapt.d_count;
       if (adaptive) w->adapt.tiles += (long)blocks_of(batch) * w->base.substeps * (a.n_steps > 1 ? a.n_steps : 1);
@@ -2066,6 +2081,9 @@ static int queues_for(const VmasWorld* w, int n_steps) {
 extern "C" {
 
 int vmas_abi_version(void) { return VMAS_ABI_VERSION; }
+// a digest of the sources this library was built from (csrc/build.sh writes it into its own small translation unit)
+extern "C" const char vmas_build_id_string[];
+const char* vmas_build_id(void) { return vmas_build_id_string; }
 const char* vmas_last_error(void) { return g_err; }
 
 int vmas_world_create(const VmasWorldDesc* d, int32_t batch, int32_t device_id, VmasWorld** out) {
@@ -2284,10 +2302,13 @@ int vmas_world_load_spec(VmasWorld* w, const char* code_object_path) {
                              (uint32_t)D.nA, (uint32_t)D.off_af, (uint32_t)D.row_tr, (uint32_t)(D.trig_mask & 0xffffffffu),
                              (uint32_t)(D.trig_mask >> 32), (uint32_t)(D.box_mask & 0xffffffffu), (uint32_t)(D.box_mask >> 32),
                              (uint32_t)D.trig_in_args};
-  if (got.size() != 25 + S->h_blob.size() || memcmp(got.data(), meta, sizeof(meta)) != 0 || got[23] != (uint32_t)D.substeps ||
-      memcmp(got.data() + 25, S->h_blob.data(), S->h_blob.size() * sizeof(uint32_t)) != 0)
+  if (got.size() != 26 + S->h_blob.size() || memcmp(got.data(), meta, sizeof(meta)) != 0 || got[23] != (uint32_t)D.substeps ||
+      memcmp(got.data() + 26, S->h_blob.data(), S->h_blob.size() * sizeof(uint32_t)) != 0)
     return fail("vmas_world_load_spec: %s was generated from another schedule (world, batch geometry or library version)",
                 code_object_path);
+  if (got[25] != kLayoutHash)
+    return fail("vmas_world_load_spec: %s was compiled against other kernel-argument layouts than this library (headers on disk "
+                "out of step with the built libvmas_hip.so: rebuild it)", code_object_path);
   Sched::Rt rt;
   rt.post = (int)got[24];
   char name[64];
@@ -2766,11 +2787,15 @@ int vmas_world_step_n(VmasWorld* w, float* state, float* agent_ft, int64_t ld, i
       for (int q = 0; q < nq - 1; ++q) HIP_TRY(hipStreamWaitEvent(w->side[q], w->ev_fork, 0));
       for (int i = i0; i < i1 && !rc; ++i) {
         float* ft = agent_ft ? agent_ft + (int64_t)i * ft_step_stride : nullptr;
+        // one kernel for the whole step, whichever queue a part of it runs on (the two football kernels are not bitwise
+        // equal in dense contact: halves on different kernels would make the bits depend on the queue split)
+        if (w->compact_mode == -1 && w->adapt.d_count != nullptr && compact_on(w)) w->adapt.forced = compact_pick_step(w);
         for (int q = 0; q < nq && !rc; ++q) {
           const int lo = first_env(q), hi = q + 1 == nq ? w->batch : first_env(q + 1);
           rc = step_impl(w, state, ft, ld, nullptr, q == 0 ? (void*)s : (void*)w->side[q - 1], 1, 0, nullptr, ENV_NONE, 0, 0,
                          lo, hi - lo);
         }
+        w->adapt.forced = -1;
       }
       for (int q = 0; q < nq - 1; ++q) {  // (joined even after a failed launch: the caller's stream stays ordered)
         HIP_TRY(hipEventRecord(w->ev_join[q], w->side[q]));

@@ -98,6 +98,16 @@ struct DevEnv {
 };
 struct NoEnv {};
 
+// What a code object compiled at run time (specialize.py) must agree with the library on besides the schedule: the layout of
+// the kernel arguments.  Both sides compute this from THEIR headers - the library when it was built, the specialisation when
+// it is compiled - and vmas_world_load_spec refuses a module whose word differs (a library out of step with the headers on
+// disk would otherwise pass the word-for-word schedule check and read its arguments through the wrong offsets).
+constexpr uint32_t kLayoutHash =
+    (uint32_t)sizeof(DevWorld) * 0x9E3779B1u ^ (uint32_t)sizeof(DevEnv) * 0x85EBCA77u ^ (uint32_t)sizeof(DevStepArgs) * 0xC2B2AE3Du ^
+    (uint32_t)__builtin_offsetof(DevWorld, blob) * 0x27D4EB2Fu ^ (uint32_t)__builtin_offsetof(DevEnv, ingest) * 0x165667B1u ^
+    (uint32_t)__builtin_offsetof(DevEnv, balance) * 0xD3A2646Cu ^ (uint32_t)sizeof(VmasActionSlot) * 0xFD7046C5u ^
+    (uint32_t)VMAS_ABI_VERSION * 0xB55A4F09u;
+
 // Profiling knobs (env VMAS_ABLATE / VMAS_ENV_ABLATE) exist only in -DVMAS_PROFILE builds (scripts/gpu_ablate.sh): in the
 // product build they are the literal 0, so their tests - and the scalar register that carried them through every loop -
 // are compiled out.
