@@ -1,36 +1,49 @@
 #!/usr/bin/env python
-"""bench.py - BASELINE.json's metric on the MI355X-native hot path.
+"""bench.py - BASELINE.json's metric on the MI355X-native hot path, one JSON line per run.
 
-metric : env-steps/sec (batch x substeps) on `balance`, 32768 envs per GPU, n_agents=4
-step   : ONE World.step() (core.py:1972-2015) over the whole batch = one fused kernel launch; state and the
-         pre-generated agent forces are resident in HBM before the timed region starts.  This is the north-star
-         hot path and what `value` reports.  The same line carries, as a peer field, `env_step`: the rate through
-         make_env('balance').step() (SURVEY.md 8d's definition: action ingest + World.step + reward / observation /
-         done, ONE launch) with its own roofline.
-timing : W warm-up steps, then exactly K steps between barrier+synchronize pairs; HIP events recorded on the launch
-         stream right inside the two fences bracket the same K launches.  `ms_per_step` and `value` come from the
-         events (MAX over ranks): with K = 20 the wall clock around a 0.2 ms region is mostly the cost of the fences
-         themselves; the wall-clock figures are kept beside them (`wall`).
-multi-GPU: `--gpus N` with no WORLD_SIZE in the environment re-executes itself under torch.distributed.run with N
-         ranks (one per GPU, backend nccl = RCCL); under a launcher it reads RANK/LOCAL_RANK/WORLD_SIZE.  The batch
-         is sharded by environment (weak scaling: 32768 envs per GPU), NO collective on the step path; the only
-         exchange of the pipeline - the end-of-rollout all-gather of obs/rew/done - is timed
-         separately (`rollout_gather`) and is not part of `value`.
-roofline: achieved = algorithmic bytes per launch (384 B/env x envs) / average launch duration from
-         the HIP events; achieved GFLOP/s beside it (1.7 kflop per env-step) and which bound binds.
-cpu_baseline: the REFERENCE itself (VMAS, `kind: "reference"`): its World.step (core.py:1972) and its
-         Environment.step (environment.py:325) on the host cores, device="cpu", torch threads = all cores, same
-         initial state and actions, bounded to ~10 s each; rank 0, N=1 only.  The reference is imported from
-         /root/reference when present, else from its byte-compiled build oracle/_ref (made by
-         __graft_entry__.build()).  `cpu_port` = the C oracle with OpenMP (a scalar port, the conservative baseline).
-
-Episodes are 100 steps long (actions ~ U(-1,1) * u_multiplier, reference law environment.py:536-548): every 100
-steps the post-reset state is restored by a device-to-device copy inside the timed region.
+usage  : python bench.py [--config balance|transport|transport_2pkg|navigation|football] [--gpus N] [--strong|--weak]
+                         [--steps K] [--warmup W]            (no flags: config 2 - balance, 32768 envs, n_agents=4 - on 1 GPU)
+metric : env-steps/sec (batch x substeps) on the configuration's scenario (SURVEY.md 8d's table: cfg 2 balance 32768 envs,
+         cfg 3 transport 16384 (+ the n_packages=2 box-box variant), cfg 4 navigation n_agents=8 65536, cfg 5 football 5v5 131072)
+step   : ONE World.step() (core.py:1972-2015) over the whole batch = one fused kernel launch; state and the pre-generated
+         agent forces are resident in HBM before the timed region starts.  This is the north-star hot path and what `value`
+         reports.  The same line carries `environment_step`: SURVEY.md 8d's own definition of the metric - the rate through
+         make_env(...).step() (action ingest + World.step + reward / observation / done, ONE launch, driven from Python with
+         fresh output tensors every step) - with its own roofline, the GPU-bound form (`bound`: caller-owned action tensors,
+         one foreign call per step) and the K-steps-per-launch form (`rollout`) beside it.
+timing : W warm-up steps, then exactly K steps between barrier+synchronize pairs; HIP events recorded on the launch stream
+         right inside the two fences bracket the same K launches.  `ms_per_step` and `value` come from the events (MAX over
+         ranks): with K = 20 the wall clock around a 0.2 ms region is mostly the cost of the fences themselves; the
+         wall-clock figures are kept beside them (`wall`).  The window is timed `--repeats` times; `value` = the median.
+inputs : SURVEY.md 8d's protocol - per step and policy agent u ~ U(-u_range, u_range), pre-generated on the host with
+         torch.Generator().manual_seed(1234 + rank) (the law of Environment.get_random_action, environment.py:536-548);
+         episodes are 100 steps long: every 100 steps the post-reset state is restored by a device-to-device copy inside
+         the timed region.  World.step's agent forces are what Environment._set_action + process_action made of those
+         actions (recorded from one real episode, scripted agents included).
+multi-GPU: `--gpus N` with no WORLD_SIZE in the environment re-executes itself under torch.distributed.run with N ranks
+         (one per GPU, backend nccl = RCCL); under a launcher it reads RANK/LOCAL_RANK/WORLD_SIZE.  The batch is sharded by
+         environment - `--weak` (default for balance: the configuration's batch PER GPU) or `--strong` (default for the
+         configurations BASELINE.json quotes as "sharded across 8": the configuration's batch in total) - NO collective on
+         the step path; the pipeline's only exchange, the end-of-rollout all-gather, is timed on the REAL
+         sharded rollout (`sharded_rollout`: Environment.rollout writing K steps per launch straight into the buffer that
+         ONE all_gather_into_tensor sends) and on the three BASELINE shapes (`rollout_gather`); neither is part of `value`.
+roofline: achieved = algorithmic bytes per launch (24 E + 12 A read, 24 E_dyn written per environment) /
+         average launch duration from the HIP events; achieved GFLOP/s beside it and which bound binds.  `traffic` (HBM bytes
+         by the PMC counters) cannot be measured inside this process: null here, per launch in profiles/r04_*_pmc_summary.txt.
+cpu_baseline: the REFERENCE itself (VMAS, `kind: "reference"`): its Environment.step (environment.py:325) on the host
+         cores, device="cpu", torch threads = the fastest count on this host, same initial state and actions, bounded to
+         ~10 s; `value` = its World.step (core.py:1972) share of those steps (timed inside the same calls).  Rank 0, N=1
+         only; configurations above 32768 environments are timed on the first 32768 (the reference's rate is flat in the
+         batch there).  The reference is imported from /root/reference when present, else from its
+         byte-compiled build oracle/_ref (made by __graft_entry__.build()).  `cpu_port` = the C oracle with OpenMP.
+attached_reference: the drop-in boundary itself - attach(vmas.make_env(..., device="cuda")): the reference's
+         own Environment on the GPU with its World.step rebound to the native kernel.
 """
 from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import socket
 import sys
@@ -40,28 +53,46 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 EPISODE = 100
-HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
 FP32_PEAK_GFLOPS = 157286.4  # 256 CU x 4 SIMD x 32 lanes x 2 flop x 2.4 GHz (vector fp32, no MFMA)
-FLOP_PER_ENV_STEP = 1700.0   # balance n_agents=4, SURVEY.md section 8d
-POST_BYTES_PER_ENV = 273     # obs 4 x 16 x 4 + rew 4 x 4 + done 1
+
+# the configurations, their algorithmic flop per env-step and the bytes a fused post-step adds
+CONFIGS = {
+    "balance": dict(cfg=2, scenario="balance", envs=32768, kwargs=dict(n_agents=4), flop=1700.0, post_bytes=273, scaling="weak"),
+    "transport": dict(cfg=3, scenario="transport", envs=16384, kwargs={}, flop=800.0, post_bytes=193, scaling="weak"),
+    "transport_2pkg": dict(cfg=3, scenario="transport", envs=16384, kwargs=dict(n_packages=2), flop=4700.0, post_bytes=305,
+                           scaling="weak"),
+    "navigation": dict(cfg=4, scenario="navigation", envs=65536, kwargs=dict(n_agents=8), flop=1800.0, post_bytes=609,
+                       env_flop=28800.0, scaling="strong"),
+    "football": dict(cfg=5, scenario="football", envs=131072,
+                     kwargs=dict(n_blue_agents=5, n_red_agents=5, ai_red_agents=False), flop=11900.0, post_bytes=3561,
+                     scaling="strong"),
+}
+GATHER_SHAPES = {"balance": (4, 16), "transport": (4, 11), "transport_2pkg": (4, 18), "navigation": (8, 18), "football": (10, 88)}
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="balance", choices=sorted(CONFIGS))
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10000)
     ap.add_argument("--warmup", type=int, default=500)
+    ap.add_argument("--strong", action="store_true", help="N GPUs share the configuration's batch (default for navigation / football)")
+    ap.add_argument("--weak", action="store_true", help="every GPU steps the configuration's batch (default for balance / transport)")
     ap.add_argument("--clock-warmup", type=float, default=0.25,
                     help="seconds of untimed launches before the W warm-up steps (the GPU's clocks ramp up: see bench.py)")
     ap.add_argument("--repeats", type=int, default=5,
                     help="the K-step window is timed this many times (each between its own fences); `value` = the median window")
-    ap.add_argument("--num-envs", type=int, default=32768, help="environments PER GPU")
-    ap.add_argument("--n-agents", type=int, default=4)
+    ap.add_argument("--num-envs", type=int, default=0, help="environments PER GPU (0 = the configuration's)")
+    ap.add_argument("--n-agents", type=int, default=0, help="balance / navigation: agents (0 = the configuration's)")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per environment (0 = library default)")
     ap.add_argument("--queues", type=int, default=0, help="HIP queues of vmas_world_step_n (0 = library's choice, 1..4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-fused", action="store_true", help="skip the secondary measurements (env_step, persistent rollout)")
-    ap.add_argument("--no-gather", action="store_true", help="skip the rollout all-gather timing (N > 1)")
+    ap.add_argument("--no-fused", action="store_true", help="skip the secondary measurements (environment_step, persistent rollout)")
+    ap.add_argument("--no-gather", action="store_true", help="skip the rollout all-gather timings (N > 1)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="default run (balance, 1 GPU) only: skip the short lines of the other configurations")
+    ap.add_argument("--no-attached", action="store_true", help="skip the attached_reference leg")
     ap.add_argument("--fused", action="store_true",
                     help="time vmas_world_rollout (persistent launch, state resident in LDS) instead of one launch per step")
     ap.add_argument("--dry-run", action="store_true",
@@ -91,34 +122,39 @@ def maybe_spawn(args):
     os.execv(sys.executable, cmd)
 
 
-def build_world(num_envs, device, n_agents, lanes, seed):
-    import torch
-    from vectorizedmultiagentsimulator_amd.scenarios.balance import Scenario
-
-    torch.manual_seed(seed)
-    sc = Scenario()
-    w = sc.env_make_world(num_envs, device, n_agents=n_agents, lanes_per_env=lanes)
-    sc.env_reset_world_at(None)
-    return sc, w
+def config_kwargs(name, n_agents=0):
+    kw = dict(CONFIGS[name]["kwargs"])
+    if n_agents and "n_agents" in kw:
+        kw["n_agents"] = n_agents
+    return kw
 
 
-def make_actions(n_steps, n_agents, num_envs, seed):
-    """[n_steps, A, B, 2] ~ U(-1, 1) on the host (the reference's get_random_action law, u_range = 1)."""
+def make_actions(env, n_steps, seed):
+    """[n_steps, A, B, size] ~ U(-u_range, u_range) on the host (the reference's get_random_action law, environment.py:536-548)."""
     import torch
 
     g = torch.Generator(device="cpu").manual_seed(seed)
-    return torch.rand(n_steps, n_agents, num_envs, 2, generator=g) * 2 - 1
+    A, B = len(env.agents), env.num_envs
+    size = env.agents[0].action_size
+    assert all(a.action_size == size for a in env.agents)
+    u = torch.rand(n_steps, A, B, size, generator=g) * 2 - 1
+    rng = torch.tensor([[float(x) for x in (a.action.u_range if isinstance(a.action.u_range, (list, tuple)) else [a.action.u_range] * size)]
+                        for a in env.agents])
+    return u * rng[None, :, None, :]
 
 
-def pack_forces(w, actions, device):
-    """[n_steps, A, 3, ld] packed agent forces: u * u_multiplier (what Environment._set_action + Holonomic produce)."""
+def record_episode_forces(env, acts_dev):
+    """[EPISODE, A_all, 3, ld]: the agent-force rows Environment._set_action + process_action (scripted agents included)
+    leave for World.step, step by step, over one real episode from the current state; the state is restored afterwards."""
     import torch
 
-    n_steps, A = actions.shape[0], len(w.agents)
-    f = torch.zeros(n_steps, max(A, 1), 3, w._ld)
-    for i, a in enumerate(w.agents):
-        f[:, i, 0:2, : w.batch_dim] = actions[:, i].transpose(1, 2) * float(a.u_range) * float(a.u_multiplier)
-    return f.to(device)
+    snap = env.get_state()
+    rows = []
+    for k in range(acts_dev.shape[0]):
+        env.step(list(acts_dev[k].unbind(0)))
+        rows.append(env.world._packed_agent_ft().clone())
+    env.set_state(snap)
+    return torch.stack(rows).contiguous()
 
 
 # ------------------------------------------------------------------------------------------------ CPU baselines
@@ -127,7 +163,7 @@ def cpu_port(w, forces_cpu, state0_cpu, budget_s=6.0):
     from oracle.oracle import Oracle
 
     o = Oracle(w.spec)
-    B = w.batch_dim
+    B = state0_cpu.shape[-1]
     ncpu = os.cpu_count() or 1
     best = (0.0, 1)  # the thread count that is actually fastest on this host; 3 steps per candidate
     for th in sorted({1, 8, 16, 32, 64, 128, ncpu}):
@@ -153,18 +189,18 @@ def cpu_port(w, forces_cpu, state0_cpu, budget_s=6.0):
         if el > budget_s or n >= 2000:
             break
     return {"value": B * n * w.substeps / el, "unit": "env-steps/s", "cores": threads, "kind": "port",
-            "sample": f"{n} World.step() of balance x {B} envs (same state/forces as the GPU run), {el:.1f} s, C oracle "
-                      f"with OpenMP over environments"}
+            "sample": f"{n} World.step() x {B} envs (same state/forces as the GPU run), {el:.1f} s, C oracle with OpenMP over environments"}
 
 
-def cpu_reference(w, actions, state0_cpu, n_agents, budget_s=10.0):
-    """The reference's own World.step and Environment.step on the host cores (device="cpu")."""
+def cpu_reference(name, kw, w, actions, state0_cpu, budget_s=10.0, max_envs=32768):
+    """The reference's own Environment.step - and, inside it, its World.step - on the host cores (device="cpu")."""
     import torch
     from oracle import ref
 
-    B = w.batch_dim
+    B = min(w.batch_dim, max_envs)
     ncpu = os.cpu_count() or 1
-    env = ref.make_env("balance", num_envs=B, device="cpu", seed=0, continuous_actions=True, n_agents=n_agents)
+    sc = CONFIGS[name]["scenario"]
+    env = ref.make_env(sc, num_envs=B, device="cpu", seed=0, continuous_actions=True, **kw)
     world = env.world
     assert [e.name for e in world.entities] == [e.name for e in w.entities], "entity order differs from the reference's"
     st0 = torch.from_numpy(state0_cpu)
@@ -176,17 +212,22 @@ def cpu_reference(w, actions, state0_cpu, n_agents, budget_s=10.0):
             e.set_rot(st0[i, 4:5, :B].T.clone(), batch_index=None)
             e.set_ang_vel(st0[i, 5:6, :B].T.clone(), batch_index=None)
 
-    def world_step(k):
-        for i, a in enumerate(world.agents):  # what _set_action + Holonomic.process_action leave in the state
-            a.state.force = actions[k % EPISODE, i] * a.u_range * a.u_multiplier
-        world.step()
+    in_world = [0.0]
+    orig_step = world.step
+
+    def timed_world_step():
+        t0 = time.perf_counter()
+        orig_step()
+        in_world[0] += time.perf_counter() - t0
+
+    world.step = timed_world_step
 
     def env_step(k):
-        env.step([actions[k % EPISODE, i] * a.u_range for i, a in enumerate(env.agents)])
+        env.step([actions[k % EPISODE, i, :B] for i in range(len(env.agents))])
 
     # torch's intra-op thread count that is actually fastest on this host: World.step is ~2800 small aten calls per step,
     # and os.cpu_count() threads (the survey's plan) can be pathological - 256 threads measured 58 s per step on a pool
-    # box against 50 ms with 8.  Probed in ascending order on World.step, stopping once a count is clearly slower.
+    # box against 50 ms with 8.  Probed in ascending order, stopping once a count is clearly slower.
     probed, best = {}, (float("inf"), 1)
     with torch.no_grad():
         for th in sorted({4, 8, 16, 32, 64, min(ncpu, 128), ncpu}):
@@ -194,40 +235,39 @@ def cpu_reference(w, actions, state0_cpu, n_agents, budget_s=10.0):
                 continue
             torch.set_num_threads(th)
             restore()
-            world_step(0)
+            env_step(0)
             t0 = time.perf_counter()
-            world_step(1)
+            env_step(1)
             dt = time.perf_counter() - t0
             probed[th] = round(dt * 1e3, 2)
             if dt < best[0]:
                 best = (dt, th)
             elif dt > 1.3 * best[0]:
                 break
-    threads = best[1]
-    torch.set_num_threads(threads)
-    out = {}
-    with torch.no_grad():
-        for name, fn in (("world_step", world_step), ("env_step", env_step)):
-            restore()
-            for k in range(2):
-                fn(k)
-            restore()
-            n, t0 = 0, time.perf_counter()
-            while True:
-                fn(n)
-                n += 1
-                el = time.perf_counter() - t0
-                if el > budget_s or n >= EPISODE:
-                    break
-            out[name] = {"value": B * n * w.substeps / el, "ms_per_step": el / n * 1e3, "steps": n, "seconds": el}
+        threads = best[1]
+        torch.set_num_threads(threads)
+        restore()
+        for k in range(2):
+            env_step(k)
+        restore()
+        in_world[0] = 0.0
+        n, t0 = 0, time.perf_counter()
+        while True:
+            env_step(n)
+            n += 1
+            el = time.perf_counter() - t0
+            if (el > budget_s and n >= 2) or n >= EPISODE:
+                break
+    sub = w.substeps
     return {
-        "value": out["world_step"]["value"], "unit": "env-steps/s", "cores": threads, "kind": "reference",
-        "torch_threads": torch.get_num_threads(), "host_cpus": ncpu,
-        "ms_per_world_step_by_threads": probed,
-        "sample": f"{out['world_step']['steps']} World.step() (vmas/simulator/core.py:1972) of the reference's balance "
-                  f"n_agents={n_agents} x {B} envs on device='cpu', same initial state and actions as the GPU run, "
-                  f"{out['world_step']['seconds']:.1f} s ({out['world_step']['ms_per_step']:.1f} ms/step); 2 warm-up steps",
-        "env_step": {**out["env_step"], "unit": "env-steps/s",
+        "value": B * n * sub / in_world[0], "unit": "env-steps/s", "cores": threads, "kind": "reference",
+        "torch_threads": torch.get_num_threads(), "host_cpus": ncpu, "envs": B,
+        "ms_per_env_step_by_threads": probed,
+        "sample": f"{n} Environment.step() (vmas/simulator/environment/environment.py:325) of the reference's {sc} {kw} x {B} envs on "
+                  f"device='cpu', same initial state and actions as the GPU run, {el:.1f} s ({el / n * 1e3:.1f} ms/step), of which "
+                  f"{in_world[0]:.1f} s inside World.step (core.py:1972; {in_world[0] / n * 1e3:.1f} ms/step = `value`); 2 warm-up steps",
+        "env_step": {"value": B * n * sub / el, "ms_per_step": el / n * 1e3, "steps": n, "seconds": el, "unit": "env-steps/s",
+                     "world_step_share": in_world[0] / el,
                      "note": "the reference's Environment.step (environment.py:325): ingest + World.step + reward/obs/done"},
         "reference_from": ref.root(),
     }
@@ -236,11 +276,10 @@ def cpu_reference(w, actions, state0_cpu, n_agents, budget_s=10.0):
 # ------------------------------------------------------------------------------------------------ gather
 def time_rollout_gather(dist, shard_cls, packed_cls, rank, world_size, device, per_gpu_envs, t_steps=100,
                         max_chunk_bytes=2 << 30, shrink=1):
-    """End-of-rollout all-gather, the ONLY collective of the pipeline, for the shapes of BASELINE configs
-    2 / 4 / 5: every rank's rollout chunk is ONE packed buffer [b, T, W] (environment axis first: observations, rewards,
-    done of a step side by side, shard.PackedRollout) and the exchange ONE all_gather_into_tensor per chunk, straight into
-    the global buffer - no copies around it.  Chunks of steps keep the gathered buffer below ``max_chunk_bytes`` (config 5:
-    46 GB per 100-step rollout on 8 GPUs)."""
+    """End-of-rollout all-gather for the shapes of BASELINE configs 2 / 4 / 5 on synthetic buffers: every
+    rank's rollout chunk is ONE packed buffer and the exchange ONE all_gather_into_tensor per chunk, straight into the
+    global buffer.  Chunks of steps keep the gathered buffer below ``max_chunk_bytes`` (config 5: 46 GB per 100-step
+    rollout on 8 GPUs).  (`sharded_rollout` times the same collective on a real rollout.)"""
     import torch
 
     shapes = {  # name: (envs per GPU, agents, obs dim)
@@ -276,11 +315,360 @@ def time_rollout_gather(dist, shard_cls, packed_cls, rank, world_size, device, p
     return out
 
 
+def sharded_rollout_leg(env, shard, acts_dev, snapshot, dist, device, t_steps=EPISODE, max_chunk_bytes=2 << 30):
+    """The pipeline SURVEY.md 8e describes, for real: this rank's shard of the batch is rolled out K steps per launch
+    (Environment.rollout, pre-computed actions) with the kernel storing straight into the buffer that ONE
+    all_gather_into_tensor then sends (shard.NativeRollout) - chunk after chunk until `t_steps` steps are done.  Times, MAX
+    over ranks: the rollout launches and the collectives by HIP events on the stream both run on, and the wall clock of
+    the whole pipeline."""
+    import torch
+    from vectorizedmultiagentsimulator_amd.rollout import collect_native
+    from vectorizedmultiagentsimulator_amd.shard import NativeRollout, max_over_ranks
+
+    if not (env._one_launch and getattr(env._post, "rollout_ok", True)):
+        return {"skipped": "this configuration's Environment.step is not one launch per step on this shard size "
+                           "(navigation above one tile per CU: its collision penalties reduce over the batch per step)"}
+    ws = shard.world_size
+    per_step = sum(math.prod(s) * torch.empty((), dtype=d).element_size() for _, s, d in env.rollout_fields(1))
+    tc = max(1, min(t_steps, max_chunk_bytes // max(per_step * ws, 1)))
+    while t_steps % tc:
+        tc -= 1
+    nr = NativeRollout.for_env(shard, env, tc)
+    acts = [acts_dev[:tc, i].contiguous() for i in range(acts_dev.shape[1])]
+
+    def pipeline():
+        env.set_state(snapshot)
+        t_roll = t_gath = 0.0
+        pend = []
+        for _ in range(t_steps // tc):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            ev[0].record()
+            collect_native(env, acts, shard, into=nr)
+            ev[1].record()
+            g = nr.gather()
+            ev[2].record()
+            pend.append(ev)
+        torch.cuda.synchronize()
+        for e in pend:
+            t_roll += e[0].elapsed_time(e[1]) * 1e-3
+            t_gath += e[1].elapsed_time(e[2]) * 1e-3
+        return t_roll, t_gath, g
+
+    pipeline()  # warm-up: communicator, the gathered buffer, one-time costs
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    t_roll, t_gath, g = pipeline()
+    wall = time.perf_counter() - t0
+    R = next(iter(g.values()))
+    ranks_in_result = len(R) if isinstance(R, list) else R.shape[0]
+    mine = t_roll / t_steps * 1e6
+    per_rank = [mine]
+    if dist is not None:
+        t = torch.tensor([mine], dtype=torch.float64, device=device)
+        allr = [torch.zeros_like(t) for _ in range(ws)]
+        dist.all_gather(allr, t)
+        per_rank = [float(x.item()) for x in allr]
+    t_roll, t_gath, wall = (max_over_ranks(x, device) for x in (t_roll, t_gath, wall))
+    gathered = nr.nbytes * ws * (t_steps // tc)  # bytes of the gathered buffers over the whole rollout
+    return {
+        "steps": t_steps, "steps_per_launch": tc, "envs_per_gpu": env.num_envs, "ranks_in_result": ranks_in_result,
+        "rollout_us_per_step": t_roll / t_steps * 1e6, "per_rank_rollout_us_per_step": per_rank,
+        "gather_ms_per_100_steps": t_gath * 1e3 * 100 / t_steps, "collectives": t_steps // tc,
+        "gathered_GB_per_100_steps": gathered * 100 / t_steps / 1e9,
+        "GBps_received_per_gpu": (gathered * (ws - 1) / ws / t_gath / 1e9) if (ws > 1 and t_gath > 0) else None,
+        "pipeline_wall_ms_per_100_steps": wall * 1e3 * 100 / t_steps,
+        "value": ws * env.num_envs * env.world.substeps * t_steps / wall, "unit": "env-steps/s",
+        "note": "Environment.rollout (K Environment.step per launch, pre-computed actions) storing into shard.NativeRollout, "
+                "then ONE all_gather_into_tensor of that buffer per chunk; value = all ranks' env-steps / pipeline wall time",
+    }
+
+
 def _sync(device):
     import torch
 
     if torch.device(device).type == "cuda":
         torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------------------------------------------ attached reference
+def attached_reference_leg(name, kw, B, device, n=300):
+    """attach(vmas.make_env(..., device='cuda')) - the reference's own Environment / Scenario / World objects on the GPU, its
+    World.step (and Lidar.measure) rebound to the native kernels: us per world.step() call (host enqueue and GPU), and the
+    reference's full Environment.step around it."""
+    import torch
+    from oracle import ref  # (locates the reference package - /root/reference or its byte-compiled build; it is the HOST here)
+    from vectorizedmultiagentsimulator_amd.adapter import attach
+
+    sc = CONFIGS[name]["scenario"]
+    env = ref.make_env(sc, num_envs=B, device=str(device), seed=0, continuous_actions=True, **kw)
+    h = attach(env, specialize=None)
+    world = env.world
+    acts = [env.get_random_action(a) for a in env.agents]
+    with torch.no_grad():
+        for _ in range(5):
+            env.step(acts)
+        torch.cuda.synchronize()
+        # (a) world.step alone: the rebound seam, forces as the last env.step left them
+        t_w = time.perf_counter()
+        while time.perf_counter() - t_w < 0.2:
+            for _ in range(50):
+                world.step()
+            torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(n):
+            world.step()
+        t1 = time.perf_counter()
+        e1.record()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        gpu_us = e0.elapsed_time(e1) / n * 1e3
+        # (b) the reference's Environment.step with the native World.step inside
+        m = max(10, n // 10)
+        for _ in range(3):
+            env.step(acts)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        for _ in range(m):
+            env.step(acts)
+        torch.cuda.synchronize()
+        t4 = time.perf_counter()
+    out = {
+        "world_step_us": (t2 - t0) / n * 1e6, "world_step_host_enqueue_us": (t1 - t0) / n * 1e6, "world_step_gpu_us": gpu_us,
+        "env_step_us": (t4 - t3) / m * 1e6, "steps": n, "env_steps": m, "envs": B,
+        "kernel": "world-specialised (from the on-disk cache)" if h.backend.specialized else "schedule interpreter",
+        "exact_broad_phase": bool(h.exact_broad_phase), "refreshes": h.refreshes,
+        "value": B * world.substeps / ((t2 - t0) / n), "unit": "env-steps/s",
+        "note": "attach(vmas.make_env(..., device='cuda')): the reference's World.step rebound to vmas_world_step; host enqueue = "
+                "Python time per world.step() call (static-change detection + one foreign call), env_step = the reference's own "
+                "Environment.step (its tensor-op ingest / reward / observation on the GPU) around it",
+    }
+    h.detach()
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ one configuration
+def measure(name, args, device, shard, dist, rank, world_size, brief=False):
+    """Everything bench.py measures on one configuration; `brief`: the short form the default run appends for the other
+    configurations (physics + Environment.step, fewer steps, no CPU legs)."""
+    import torch
+    from vectorizedmultiagentsimulator_amd.environment import make_env
+    from vectorizedmultiagentsimulator_amd.shard import max_over_ranks
+
+    cfg = CONFIGS[name]
+    kw = config_kwargs(name, args.n_agents)
+    B = shard.local_envs
+    steps = args.steps if not brief else min(args.steps, 300)
+    warmup = args.warmup if not brief else min(args.warmup, 50)
+    repeats = max(1, args.repeats if not brief else 3)
+    env = make_env(cfg["scenario"], num_envs=B, device=device, seed=shard.seed(0), validate_actions=False, **kw)
+    w = env.world
+    be = w._get_backend()
+    if args.lanes:
+        be.set_lanes_per_env(args.lanes)
+    be.set_queues(args.queues)
+    snapshot = env.get_state()
+    actions = make_actions(env, EPISODE, 1234 + rank)  # host
+    acts_dev = actions.to(device)
+    forces = record_episode_forces(env, acts_dev)
+    state0 = w._packed_state().clone()
+    stream = torch.cuda.current_stream()
+    sub = w.substeps
+
+    def run(n_steps, start=0, fused=args.fused):
+        done = 0
+        while done < n_steps:
+            k = (start + done) % EPISODE
+            if k == 0:
+                w._state.copy_(state0)
+            chunk = min(EPISODE - k, n_steps - done)
+            (be.rollout if fused else be.step_n)(chunk, forces[k: k + chunk])
+            done += chunk
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(fn, n):
+        """K steps between fences: (HIP-event seconds, wall seconds), each MAX over ranks, and this rank's own events."""
+        fence()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        fn(n)
+        ev1.record(stream)
+        fence()
+        wall = time.perf_counter() - t0
+        own = ev0.elapsed_time(ev1) * 1e-3
+        return max_over_ranks(own, device), max_over_ranks(wall, device), own
+
+    def rate(n, seconds):
+        return world_size * B * sub * n / seconds
+
+    def clock_warm(fn):
+        t_clock = time.perf_counter()
+        while time.perf_counter() - t_clock < args.clock_warmup:
+            fn()
+            torch.cuda.synchronize()
+
+    bytes_per_env = be.step_bytes_per_env()
+    # ---- secondary legs first: they also bring the GPU to its steady clocks before the headline region
+    persistent = env_leg = sharded = None
+    if not args.no_fused and not args.fused:
+        if not brief:
+            try:
+                run(EPISODE, fused=True)
+                ev_s, wall_s, _ = timed(lambda n: run(n, fused=True), steps)
+                persistent = {"value": rate(steps, ev_s), "unit": "env-steps/s", "us_per_step": ev_s / steps * 1e6,
+                              "note": "vmas_world_rollout: identical results bit for bit, state stays in LDS between steps "
+                                      "(scripted / pre-computed forces only); NOT the headline value"}
+            except Exception as e:  # noqa: BLE001 (a secondary leg never breaks the line)
+                persistent = {"error": repr(e)}
+        try:
+            env.set_state(snapshot)
+            step_acts = [list(acts_dev[k].unbind(0)) for k in range(EPISODE)]  # per step: the agents' [B, size] tensors (views)
+
+            def env_steps(n, start=0):
+                for i in range(n):
+                    k = (start + i) % EPISODE
+                    if k == 0:
+                        env.set_state(snapshot)
+                    env.step(step_acts[k])
+
+            clock_warm(lambda: env_steps(EPISODE))
+            env_steps(300 if not brief else 100)  # (the first few hundred steps carry one-time costs)
+            n_env = max(min(steps, 2000), 200) if not brief else 200
+            wins = sorted((timed(env_steps, n_env) for _ in range(3 if not brief else 1)), key=lambda x: x[1])
+            ev_s, wall_s, _ = wins[len(wins) // 2]
+            per_env = bytes_per_env + cfg["post_bytes"]
+            env_leg = {
+                "metric": "env-steps/s through Environment.step() (SURVEY.md 8d's definition of BASELINE.json's metric)",
+                "value": rate(n_env, wall_s), "unit": "env-steps/s",
+                "us_per_step": wall_s / n_env * 1e6, "gpu_us_per_step": ev_s / n_env * 1e6, "steps": n_env,
+                "launches_per_step": 1 if env._one_launch else None,
+                "roofline": {"bound": "hbm", "achieved": per_env * B / (ev_s / n_env) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": per_env * B / (ev_s / n_env) / 1e9 / HBM_PEAK_GBS, "bytes_per_env": per_env,
+                             "traffic": None},
+                "note": f"make_env('{cfg['scenario']}').step() driven from Python, fresh random actions and fresh output tensors every "
+                        "step: action ingest (prologue) + World.step + reward/observation/done/info (epilogue) in ONE kernel "
+                        "launch (vmas_world_step_env); value from the wall clock (host included), roofline from HIP events",
+            }
+            if env._one_launch:
+                env.set_state(snapshot)
+                held = [a.clone() for a in step_acts[0]]
+                env.bind(held)  # caller-owned action tensors, static outputs: one foreign call per step
+
+                def env_steps_bound(n):
+                    for _ in range(n):
+                        env.step_bound()
+
+                env_steps_bound(100)
+                ev_b, wall_b, _ = timed(env_steps_bound, n_env)
+                env_leg["bound"] = {
+                    "value": rate(n_env, wall_b), "us_per_step": wall_b / n_env * 1e6, "gpu_us_per_step": ev_b / n_env * 1e6,
+                    "note": "Environment.bind(actions) + step_bound(): the same step on caller-owned action tensors (one random "
+                            "action held) and static output buffers - a single foreign call per step, no host-side tensor work"}
+                if getattr(env._post, "rollout_ok", True):
+                    env.set_state(snapshot)
+                    per_step_out = sum(math.prod(s_) * torch.empty((), dtype=d_).element_size() for _, s_, d_ in env.rollout_fields(1))
+                    K = max(1, min(EPISODE if not brief else 50, (16 << 30) // per_step_out))  # (<= 16 GB of outputs per launch)
+                    racts = [acts_dev[:K, i].contiguous() for i in range(acts_dev.shape[1])]
+                    env.rollout(racts)
+                    reps = 5 if not brief else 2
+
+                    def rollouts(n):
+                        for _ in range(n):
+                            env.rollout(racts)
+
+                    ev_r, wall_r, _ = timed(rollouts, reps)
+                    env_leg["rollout"] = {
+                        "value": rate(reps * K, ev_r), "us_per_step": ev_r / (reps * K) * 1e6, "steps_per_launch": K,
+                        "note": "Environment.rollout: K Environment.step() per launch (vmas_world_rollout_env), pre-computed "
+                                "actions, bitwise the K single steps; HIP events"}
+            if not brief and (world_size > 1 or os.environ.get("VMAS_BENCH_SHARDED")) and not args.no_gather:
+                try:
+                    sharded = sharded_rollout_leg(env, shard, acts_dev, snapshot, dist, device)
+                except Exception as e:  # noqa: BLE001
+                    sharded = {"error": repr(e)}
+        except Exception as e:  # noqa: BLE001 never let a secondary leg break the bench line
+            env_leg = {"error": repr(e)}
+        env.set_state(snapshot)
+
+    # ---- the same K launches on ONE queue (what rocprofv3's per-kernel durations describe); then the headline
+    single = None
+    if not args.fused and not brief and be.queues(min(EPISODE, steps)) > 1:
+        be.set_queues(1)
+        run(warmup)
+        ev_1, wall_1, _ = timed(lambda n: run(n, start=warmup), steps)
+        single = {"value": rate(steps, ev_1), "unit": "env-steps/s", "us_per_step": ev_1 / steps * 1e6,
+                  "roofline_frac": bytes_per_env * B / (ev_1 / steps) / 1e9 / HBM_PEAK_GBS,
+                  "note": "vmas_world_set_queues(1): one launch per step on one HIP queue; its time per step is the "
+                          "kernel's launch-to-launch time and agrees with rocprofv3's per-kernel duration + launch gap"}
+        be.set_queues(args.queues)
+    # ---- headline: W warm-up steps, then exactly K World.step launches between fences - R times over (every window is a
+    #      complete measurement by the contract; `value` is the MEDIAN window, min / max beside it).  In front of the W
+    #      steps, untimed: `clock_warmup_s` seconds of the same launches - a process that has just been set up finds the
+    #      GPU's clocks ramping (the first ~0.1 s of kernels reads up to several times slow: profiles/README.md), and with
+    #      the driver's small K every window would fall inside that ramp.
+    clock_warm(lambda: run(EPISODE))
+    run(warmup)
+    windows = [timed(lambda n: run(n, start=warmup), steps) for _ in range(repeats)]
+    order = sorted(range(len(windows)), key=lambda i: windows[i][0])
+    ev_s, wall_s, own_s = windows[order[len(order) // 2]]
+    kernel_s = ev_s / steps
+    n_queues = 1 if args.fused else be.queues(min(EPISODE, steps))
+    per_rank_us = [own_s / steps * 1e6]
+    if dist is not None:
+        mine = torch.tensor([own_s], dtype=torch.float64, device=device)
+        allr = [torch.zeros_like(mine) for _ in range(world_size)]
+        dist.all_gather(allr, mine)
+        per_rank_us = [float(x.item()) / steps * 1e6 for x in allr]
+    if be.compact:
+        kernel = "step_kernel_compact (lane-compacted step for dense sphere worlds, csrc/vmas_compact.h)"
+        kernel_short = "step_kernel_compact"
+    elif be.specialized:
+        kernel = ("step_kernel_spec: the world-specialised form of the step kernel (schedule as compile-time tables, generated from "
+                  "the library's planner; bitwise the interpreter's results)")
+        kernel_short = "step_kernel_spec"
+    else:
+        kernel, kernel_short = "step_kernel (interpreter of the schedule)", "step_kernel"
+    ach = bytes_per_env * B / kernel_s / 1e9
+    gflops = cfg["flop"] * B / kernel_s / 1e9
+    res = {
+        "name": name, "cfg": cfg["cfg"], "scenario": cfg["scenario"], "kwargs": kw, "envs_per_gpu": B, "substeps": sub,
+        "steps": steps, "warmup": warmup, "ev_s": ev_s, "wall_s": wall_s, "kernel_s": kernel_s, "windows": windows,
+        "per_rank_us": per_rank_us, "n_queues": n_queues, "kernel": kernel, "kernel_short": kernel_short,
+        "bytes_per_env": bytes_per_env, "ach": ach, "gflops": gflops, "lanes": be.lanes_per_env,
+        "value": rate(steps, ev_s), "wall_value": rate(steps, wall_s),
+        "single": single, "env_leg": env_leg, "persistent": persistent, "sharded": sharded,
+        "env": env, "w": w, "be": be, "actions": actions, "forces": forces, "state0": state0,
+    }
+    return res
+
+
+def brief_line(r):
+    """The short form of one configuration's measurements (default run: the configurations other than the headline's)."""
+    out = {
+        "workload": f"{r['scenario']} {r['kwargs']}, {r['envs_per_gpu']} envs, World.step() physics only",
+        "value": r["value"], "unit": "env-steps/s", "us_per_step": r["kernel_s"] * 1e6, "steps": r["steps"],
+        "kernel": r["kernel_short"], "queues": r["n_queues"], "lanes_per_env": r["lanes"],
+        "roofline": {"bound": "hbm", "achieved": r["ach"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r["ach"] / HBM_PEAK_GBS,
+                     "bytes_per_env": r["bytes_per_env"], "gflops": r["gflops"], "traffic": None},
+    }
+    if r["env_leg"] is not None:
+        e = r["env_leg"]
+        out["environment_step"] = {k: e[k] for k in ("value", "us_per_step", "gpu_us_per_step", "launches_per_step", "error") if k in e}
+        if "roofline" in e:
+            out["environment_step"]["roofline_frac"] = e["roofline"]["frac"]
+        for k in ("bound", "rollout"):
+            if k in e:
+                out["environment_step"][k + "_us_per_step"] = e[k].get("gpu_us_per_step", e[k].get("us_per_step"))
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ main
@@ -294,8 +682,10 @@ def main():
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     if world_size != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world_size} ranks")
-    from vectorizedmultiagentsimulator_amd.shard import EnvShard, PackedRollout, max_over_ranks
+    from vectorizedmultiagentsimulator_amd.shard import EnvShard, PackedRollout
 
+    cfg = CONFIGS[args.config]
+    scaling = "strong" if args.strong else ("weak" if args.weak else cfg["scaling"])
     dist = None
     if args.dry_run:
         device = torch.device("cpu")
@@ -318,253 +708,146 @@ def main():
         dist.all_reduce(t)  # every rank really is in the group
         assert int(t.item()) == world_size == ranks_seen
 
-    # weak scaling: the global batch is world_size x num_envs, sharded by environment; every rank steps its own
-    # contiguous block, no collective on the step path
-    shard = EnvShard(world_size * args.num_envs, rank, world_size)
-    assert shard.local_envs == args.num_envs
+    # the global batch, sharded by environment: every rank steps its own contiguous block, no collective on the step path
+    per_gpu = args.num_envs or (cfg["envs"] if scaling == "weak" else -(-cfg["envs"] // world_size))
+    global_envs = per_gpu * world_size if (scaling == "weak" or args.num_envs) else cfg["envs"]
+    shard = EnvShard(global_envs, rank, world_size)
 
     gather = None
     if world_size > 1 and not args.no_gather:
         gather = time_rollout_gather(dist, EnvShard, PackedRollout, rank, world_size, device,
-                                     args.num_envs if not args.dry_run else 64, t_steps=100 if not args.dry_run else 4,
+                                     32768 if not args.dry_run else 64, t_steps=100 if not args.dry_run else 4,
                                      shrink=512 if args.dry_run else 1)
 
     if args.dry_run:
         if rank == 0:
-            print(json.dumps({"metric": "env-steps/sec (batch x substeps) on 'balance'", "value": None, "dry_run": True,
-                              "n_gpus": world_size, "ranks_seen": ranks_seen, "backend": "gloo",
-                              "shard": [shard.lo, shard.hi], "rollout_gather": gather}), flush=True)
+            print(json.dumps({"metric": f"env-steps/sec (batch x substeps) on '{cfg['scenario']}'", "value": None, "dry_run": True,
+                              "n_gpus": world_size, "ranks_seen": ranks_seen, "backend": "gloo", "scaling": scaling,
+                              "shard": [shard.lo, shard.hi], "global_envs": global_envs, "rollout_gather": gather}), flush=True)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
         return
 
-    sc, w = build_world(shard.local_envs, device, args.n_agents, args.lanes, seed=shard.seed(0))
-    be = w._get_backend()
-    be.set_queues(args.queues)
-    state0 = w._state.clone()
-    actions = make_actions(EPISODE, args.n_agents, args.num_envs, 1234 + rank)
-    forces = pack_forces(w, actions, device)
-    stream = torch.cuda.current_stream()
+    r = measure(args.config, args, device, shard, dist, rank, world_size)
+    B, steps, kernel_s, n_queues = r["envs_per_gpu"], r["steps"], r["kernel_s"], r["n_queues"]
+    windows = r["windows"]
+    kw = r["kwargs"]
 
-    def run(n_steps, start=0, fused=args.fused):
-        done = 0
-        while done < n_steps:
-            k = (start + done) % EPISODE
-            if k == 0:
-                w._state.copy_(state0)
-            chunk = min(EPISODE - k, n_steps - done)
-            (be.rollout if fused else be.step_n)(chunk, forces[k: k + chunk])
-            done += chunk
-
-    def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def timed(fn, n):
-        """K steps between fences: (HIP-event seconds, wall seconds), each MAX over ranks."""
-        fence()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        ev0.record(stream)
-        fn(n)
-        ev1.record(stream)
-        fence()
-        wall = time.perf_counter() - t0
-        own = ev0.elapsed_time(ev1) * 1e-3
-        return max_over_ranks(own, device), max_over_ranks(wall, device), own
-
-    # ---- secondary legs first: they also bring the GPU to its steady clocks before the headline region
-    persistent = env_leg = None
-    if not args.no_fused and not args.fused:
-        run(EPISODE, fused=True)
-        ev_s, wall_s, _ = timed(lambda n: run(n, fused=True), args.steps)
-        persistent = {
-            "value": world_size * args.num_envs * w.substeps * args.steps / ev_s, "unit": "env-steps/s",
-            "us_per_step": ev_s / args.steps * 1e6,
-            "note": "vmas_world_rollout: identical results bit for bit, state stays in LDS between steps (scripted / "
-                    "pre-computed forces only); NOT the headline value",
-        }
-        try:
-            from vectorizedmultiagentsimulator_amd.environment import make_env
-
-            env = make_env("balance", num_envs=args.num_envs, device=device, seed=0, validate_actions=False,
-                           n_agents=args.n_agents)
-            acts = [env.get_random_action(a) for a in env.agents]
-
-            def env_steps(n):
-                for _ in range(n):
-                    env.step(acts)
-
-            env_steps(400)  # (the first few hundred steps carry one-time costs)
-            n_env = max(min(args.steps, 2000), 200)
-            ev_s, wall_s, _ = timed(env_steps, n_env)
-            env.bind(acts)  # caller-owned action tensors, static outputs: one foreign call per step
-
-            def env_steps_bound(n):
-                for _ in range(n):
-                    env.step_bound()
-
-            env_steps_bound(100)
-            ev_b, wall_b, _ = timed(env_steps_bound, n_env)
-            per_env = be.step_bytes_per_env() + POST_BYTES_PER_ENV
-            env_leg = {
-                "value": world_size * args.num_envs * w.substeps * n_env / wall_s, "unit": "env-steps/s",
-                "us_per_step": wall_s / n_env * 1e6, "gpu_us_per_step": ev_s / n_env * 1e6, "steps": n_env,
-                "launches_per_step": 1 if env._one_launch else None,
-                "bound": {"value": world_size * args.num_envs * w.substeps * n_env / wall_b, "us_per_step": wall_b / n_env * 1e6,
-                          "gpu_us_per_step": ev_b / n_env * 1e6,
-                          "note": "Environment.bind(actions) + step_bound(): the same step on caller-owned action tensors and "
-                                  "static output buffers - a single foreign call per step, no host-side tensor work"},
-                "roofline": {"bound": "hbm", "achieved": per_env * args.num_envs / (ev_s / n_env) / 1e9,
-                             "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": per_env * args.num_envs / (ev_s / n_env) / 1e9 / HBM_PEAK_GBS,
-                             "bytes_per_env": per_env},
-                "note": "make_env('balance').step() driven from Python, fresh output tensors every step: action ingest "
-                        "(prologue) + World.step + reward/observation/done/info (epilogue) in ONE kernel launch "
-                        "(vmas_world_step_env); value from the wall clock (host included), roofline from HIP events",
-            }
-            del env
-        except Exception as e:  # never let a secondary leg break the bench line
-            env_leg = {"error": repr(e)}
-
-    # ---- the same K launches on ONE queue (what rocprofv3's per-kernel durations describe); then the headline
-    single = None
-    if not args.fused and be.queues(min(EPISODE, args.steps)) > 1:
-        be.set_queues(1)
-        run(args.warmup)
-        ev_1, wall_1, _ = timed(lambda n: run(n, start=args.warmup), args.steps)
-        single = {"value": world_size * args.num_envs * w.substeps * args.steps / ev_1, "unit": "env-steps/s",
-                  "us_per_step": ev_1 / args.steps * 1e6,
-                  "note": "vmas_world_set_queues(1): one launch per step on one HIP queue; its time per step is the "
-                          "kernel's launch-to-launch time and agrees with rocprofv3's per-kernel duration + launch gap"}
-        be.set_queues(args.queues)
-    # ---- headline: W warm-up steps, then exactly K World.step launches between fences - R times over (every window is a
-    #      complete measurement by the contract; `value` is the MEDIAN window, min / max beside it).  In front of the W
-    #      steps, untimed: `clock_warmup_s` seconds of the same launches - a process that has just been set up finds the
-    #      GPU's clocks ramping (the first ~0.1 s of kernels reads up to several times slow: profiles/README.md), and with
-    #      the driver's small K every window would fall inside that ramp.
-    t_clock = time.perf_counter()
-    while time.perf_counter() - t_clock < args.clock_warmup:
-        run(EPISODE)
-        torch.cuda.synchronize()
-    run(args.warmup)
-    windows = [timed(lambda n: run(n, start=args.warmup), args.steps) for _ in range(max(1, args.repeats))]
-    order = sorted(range(len(windows)), key=lambda i: windows[i][0])
-    ev_s, wall_s, _ = windows[order[len(order) // 2]]
-    kernel_s = ev_s / args.steps
-    n_queues = 1 if args.fused else be.queues(min(EPISODE, args.steps))
-    # every rank's own time per step (the headline takes the slowest rank, window by window)
-    per_rank_us = [ev_s / args.steps * 1e6]
-    if dist is not None:
-        mine = torch.tensor([windows[order[len(order) // 2]][2]], dtype=torch.float64, device=device)
-        allr = [torch.zeros_like(mine) for _ in range(world_size)]
-        dist.all_gather(allr, mine)
-        per_rank_us = [float(x.item()) / args.steps * 1e6 for x in allr]
+    # the other configurations, short (default run only: one GPU, the headline configuration)
+    others = None
+    if args.config == "balance" and world_size == 1 and not args.no_other_configs and not args.fused and not args.num_envs:
+        others = {}
+        for other in ("transport", "transport_2pkg", "navigation", "football"):
+            try:
+                o = measure(other, args, device, EnvShard(CONFIGS[other]["envs"], 0, 1), None, 0, 1, brief=True)
+                others[other] = brief_line(o)
+                del o
+            except Exception as e:  # noqa: BLE001
+                others[other] = {"error": repr(e)}
+            torch.cuda.empty_cache()
 
     if rank == 0:
-        bytes_per_env = be.step_bytes_per_env()
-        ach = bytes_per_env * args.num_envs / kernel_s / 1e9
-        gflops = FLOP_PER_ENV_STEP * args.num_envs / kernel_s / 1e9
+        bytes_per_env = r["bytes_per_env"]
+        gb_note = ("neither roof at this batch: one launch moves %.1f MB (%.1f us at 8 TB/s) and %.0f Mflop (%.2f us at fp32 peak); "
+                   "the launch is a ~3 us launch floor plus one tile's dependent chain (DESIGN.md section 3.1, profiles/r04_*). "
+                   "HBM is the nominal bound." % (bytes_per_env * B / 1e6, bytes_per_env * B / 8e12 * 1e6, cfg["flop"] * B / 1e6,
+                                                   cfg["flop"] * B / (FP32_PEAK_GFLOPS * 1e9) * 1e6))
         out = {
-            "metric": "env-steps/sec (batch x substeps) on 'balance'",
-            "value": world_size * args.num_envs * w.substeps * args.steps / ev_s,
+            "metric": f"env-steps/sec (batch x substeps) on '{cfg['scenario']}'",
+            "value": r["value"],
             "unit": "env-steps/s",
             "n_gpus": world_size,
             "ranks_seen": ranks_seen,
-            "steps": args.steps,
-            "warmup": args.warmup, "clock_warmup_s": args.clock_warmup,
+            "steps": steps,
+            "warmup": r["warmup"], "clock_warmup_s": args.clock_warmup,
             "ms_per_step": kernel_s * 1e3,
-            "repeats": {"windows": len(windows), "steps_per_window": args.steps,
-                        "ms_per_step_min": min(w_[0] for w_ in windows) / args.steps * 1e3,
+            "repeats": {"windows": len(windows), "steps_per_window": steps,
+                        "ms_per_step_min": min(w_[0] for w_ in windows) / steps * 1e3,
                         "ms_per_step_median": kernel_s * 1e3,
-                        "ms_per_step_max": max(w_[0] for w_ in windows) / args.steps * 1e3,
+                        "ms_per_step_max": max(w_[0] for w_ in windows) / steps * 1e3,
                         "note": "each window = exactly `steps` launches between barrier + synchronize fences; `value` and "
                                 "`ms_per_step` are the median window"},
-            "per_rank_us_per_step": per_rank_us,
+            "per_rank_us_per_step": r["per_rank_us"],
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "value_is": "World.step() physics (north-star hot path), timed with HIP events inside the fences; "
-                        "`env_step` = through Environment.step(); `wall` = the same K steps by the host clock",
-            "wall": {"ms_per_step": wall_s / args.steps * 1e3,
-                     "value": world_size * args.num_envs * w.substeps * args.steps / wall_s},
+            "value_is": "World.step() physics (north-star hot path), timed with HIP events inside the fences; `environment_step` = "
+                        "the same metric through Environment.step() (SURVEY.md 8d); `wall` = the same K steps by the host clock",
+            "wall": {"ms_per_step": r["wall_s"] / steps * 1e3, "value": r["wall_value"]},
             "config": {
-                "workload": f"balance n_agents={args.n_agents}, {args.num_envs} envs/GPU, World.step() physics only, "
-                            f"random actions, {EPISODE}-step episodes",
-                "num_envs_per_gpu": args.num_envs,
-                "global_envs": world_size * args.num_envs,
-                "substeps": w.substeps,
-                "lanes_per_env": be.lanes_per_env,
+                "workload": f"BASELINE config {cfg['cfg']}: {cfg['scenario']} {kw}, {B} envs/GPU ({shard.num_envs} in all), World.step() "
+                            f"physics only, fresh random actions every step (pre-generated), {EPISODE}-step episodes",
+                "baseline_config": cfg["cfg"], "scenario": cfg["scenario"], "scenario_kwargs": kw,
+                "num_envs_per_gpu": B,
+                "global_envs": shard.num_envs,
+                "substeps": r["substeps"],
+                "lanes_per_env": r["lanes"],
                 "launch": "persistent rollout (vmas_world_rollout)" if args.fused else (
                     "one launch per step" if n_queues == 1 else
                     f"one launch per step and per part of the batch: {n_queues} HIP queues, {n_queues} launches per "
                     f"World.step of the whole batch (vmas_world_step_n, environments are independent)"),
                 "queues": n_queues,
-                "kernel": ("step_kernel_spec<SpecBalance4>: the world-specialised form of the step kernel (schedule as "
-                           "compile-time tables, generated from the library's planner; bitwise the interpreter's results)")
-                if be.specialized else "step_kernel (interpreter of the schedule)",
+                "kernel": r["kernel"],
                 "parallelism": f"env-sharded x{world_size}",
             },
             "roofline": {
                 "bound": "hbm",
-                "achieved": ach,
+                "achieved": r["ach"],
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS,
+                "frac": r["ach"] / HBM_PEAK_GBS,
                 "traffic": None,
-                "kernel": "step_kernel_spec" if be.specialized else "step_kernel",
+                "traffic_note": "HBM bytes by the PMC counters need rocprofv3 around the process: per launch in "
+                                f"profiles/r04_{args.config}{B}_physics_pmc_summary.txt (scripts/gpu_evidence_r4.sh), not in this line",
+                "kernel": r["kernel_short"],
                 "kernel_us": kernel_s * 1e6,
                 "kernel_us_is": "time per World.step of the whole batch from the HIP events (region / K)" + (
-                    "" if n_queues == 1 else f"; {n_queues} launches of {args.num_envs // n_queues} environments each "
+                    "" if n_queues == 1 else f"; {n_queues} launches of {B // n_queues} environments each "
                     "overlap in it - rocprofv3's per-launch durations add up to more than this, see `single_queue`"),
-                "bytes_per_launch": bytes_per_env * args.num_envs // n_queues,
+                "bytes_per_env": bytes_per_env,
+                "bytes_per_launch": bytes_per_env * B // n_queues,
                 "launches_per_step": n_queues,
-                "gflops": gflops,
-                "gflops_frac_of_fp32_vector_peak": gflops / FP32_PEAK_GFLOPS,
-                "binds": "neither roof at this batch: one launch moves 12.6 MB (1.6 us at 8 TB/s) and 56 Mflop "
-                         "(0.4 us at fp32 peak); the launch is a ~3 us launch floor plus one tile's dependent chain "
-                         "(profiles/r02e_balance32768_physics_pmc_summary.txt, r02_balance32768_phase_trace.txt). At "
-                         "1 M environments the same kernel reaches 50 % of the HBM roof. HBM is the nominal bound.",
+                "gflops": r["gflops"],
+                "gflops_frac_of_fp32_vector_peak": r["gflops"] / FP32_PEAK_GFLOPS,
+                "binds": gb_note,
             },
         }
-        if single is not None:
-            single["roofline_frac"] = bytes_per_env * args.num_envs / (single["us_per_step"] * 1e-6) / 1e9 / HBM_PEAK_GBS
-            out["single_queue"] = single
-        if env_leg is not None:
-            out["env_step"] = env_leg
-        if persistent is not None:
-            out["persistent_rollout"] = persistent
+        if r["single"] is not None:
+            out["single_queue"] = r["single"]
+        if r["env_leg"] is not None:
+            out["environment_step"] = r["env_leg"]
+        if r["persistent"] is not None:
+            out["persistent_rollout"] = r["persistent"]
+        if r["sharded"] is not None:
+            out["sharded_rollout"] = r["sharded"]
         if gather is not None:
             out["rollout_gather"] = gather
-        tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
-        if os.path.exists(tpath):  # HBM bytes per launch from rocprofv3 PMC passes (scripts/gpu_prof.sh)
+        if others is not None:
+            out["other_configs"] = others
+        if world_size == 1 and not args.no_attached and not args.fused:
             try:
-                tr = json.load(open(tpath))
-                if tr.get("num_envs") == args.num_envs:
-                    out["roofline"]["traffic"] = tr["bytes_per_launch"]
-                    out["roofline"]["traffic_source"] = ("from profiles/latest_traffic.json (rocprofv3 PMC passes of this kernel, "
-                                                         "scripts/gpu_prof.sh) - NOT measured in this run")
-                    out["roofline"]["traffic_note"] = tr["note"]
-            except Exception:
-                pass
+                out["attached_reference"] = attached_reference_leg(args.config, kw, B, device)
+            except Exception as e:  # noqa: BLE001 (the reference is not importable here, or does not run on this device)
+                out["attached_reference"] = {"error": repr(e)[:500]}
         if world_size == 1 and not args.no_cpu_baseline:
-            st0, f_cpu = state0.cpu().numpy(), forces.cpu().numpy()
+            w = r["w"]
+            st0, f_cpu = r["state0"].cpu().numpy(), r["forces"].cpu().numpy()
             try:
-                out["cpu_baseline"] = cpu_reference(w, actions, st0, args.n_agents)
-            except Exception as e:  # the reference is not importable here: say so, keep the port
-                out["cpu_baseline_error"] = repr(e)
-            out["cpu_port"] = cpu_port(w, f_cpu, st0)
+                out["cpu_baseline"] = cpu_reference(args.config, kw, w, r["actions"], st0)
+            except Exception as e:  # noqa: BLE001 the reference is not importable here: say so, keep the port
+                out["cpu_baseline_error"] = repr(e)[:500]
+            nb = min(B, 32768)
+            out["cpu_port"] = cpu_port(w, f_cpu[:, :, :, :nb].copy(), st0[:, :, :nb].copy())
             if "cpu_baseline" not in out:
                 out["cpu_baseline"] = dict(out["cpu_port"])
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
             out["cpu_port"]["gpu_over_cpu"] = out["value"] / out["cpu_port"]["value"]
-            if env_leg and "value" in env_leg and "env_step" in out["cpu_baseline"]:
-                out["cpu_baseline"]["env_step"]["gpu_over_cpu"] = env_leg["value"] / out["cpu_baseline"]["env_step"]["value"]
+            e = r["env_leg"]
+            if e and "value" in e and "env_step" in out["cpu_baseline"]:
+                out["cpu_baseline"]["env_step"]["gpu_over_cpu"] = e["value"] / out["cpu_baseline"]["env_step"]["value"]
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

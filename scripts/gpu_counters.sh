@@ -1,10 +1,10 @@
 # rocprofv3 evidence for one command: kernel trace (durations) + PMC passes, each in its own run.
 #   [RATED=kernel-name-part] bash scripts/gpu_counters.sh TAG BYTES_PER_ENV FLOP_PER_ENV ENVS -- CMD...
 # writes gpurun_out/$EVIDENCE_DIR/TAG_kernel_stats.csv and TAG_pmc_summary.txt (copy to profiles/ to keep).  The bytes / flop
-# per environment rate ONE kernel family (RATED, default step_kernel); the others are listed without a roofline line.
+# per environment rate ONE kernel family (RATED = family[:physics|:env], default step_kernel_spec: scripts/pmc_summary.py); the others are listed without a roofline line.
 TAG=$1; BPE=$2; FPE=$3; ENVS=$4; shift 5
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/${EVIDENCE_DIR:-r03}; mkdir -p $OUT
+OUT=$R/gpurun_out/${EVIDENCE_DIR:-r04}; mkdir -p $OUT
 W=/tmp/cnt_$TAG; rm -rf $W; mkdir -p $W
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $W/trace -o t -- "$@" > $W/trace.log 2>&1
@@ -15,5 +15,5 @@ rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIV
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $W/p3 -o p -- "$@" > $W/p3.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $W/p4 -o p -- "$@" > $W/p4.log 2>&1
 cd $R
-python scripts/pmc_summary.py $W $OUT/${TAG}_kernel_stats.csv $BPE $FPE $ENVS "$*" ${RATED:-step_kernel} > $OUT/${TAG}_pmc_summary.txt 2>&1
+python scripts/pmc_summary.py $W $OUT/${TAG}_kernel_stats.csv $BPE $FPE $ENVS "$*" ${RATED:-step_kernel_spec} > $OUT/${TAG}_pmc_summary.txt 2>&1
 cat $OUT/${TAG}_pmc_summary.txt

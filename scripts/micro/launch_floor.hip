@@ -45,6 +45,16 @@ __global__ void k2(float* __restrict__ s, float* __restrict__ ft, long ld, int n
   for (int r = wv; r < n_out; r += nw) s[(long)(n_in - n_out + r) * ld + env] = lds[(n_in - n_out + r) * 64 + lane] + 1e-7f;
 }
 
+// shader clock against the constant 100 MHz counter: what frequency do kernels of this process run at (a profiler may pin
+// the device to a stable, lower power state - then its kernel durations cannot agree with a free-running process's)
+__global__ void clock_probe(unsigned long long* out, int iters) {
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  float x = (float)threadIdx.x;
+  for (int i = 0; i < iters; ++i) x = x * 1.000001f + 0.5f;
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; out[2] = (unsigned long long)x; }
+}
+
 int main(int argc, char** argv) {
   const int B = argc > 1 ? atoi(argv[1]) : 32768;
   const int nw = argc > 2 ? atoi(argv[2]) : 8;
@@ -93,5 +103,58 @@ int main(int argc, char** argv) {
   float ms;
   CK(hipEventElapsedTime(&ms, e0, e1));
   printf("%-44s %7.2f us/launch\n", "K2 as a 100-node HIP graph", ms * 1e3 / N);
+  // the batch cut in NQ parts on NQ streams, 100 steps each, captured as ONE graph (fork / join by events): what
+  // vmas_world_step_n over several queues would cost without the host's NQ enqueues per step; and the same eagerly
+  for (int NQ = 2; NQ <= 4; NQ += 2) {
+    hipStream_t sq[4]; sq[0] = st;
+    hipEvent_t fork, join[4];
+    CK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+    for (int q = 1; q < NQ; ++q) { CK(hipStreamCreate(&sq[q])); CK(hipEventCreateWithFlags(&join[q], hipEventDisableTiming)); }
+    auto first = [&](int q) { return tiles * q / NQ; };
+    auto enqueue = [&](int n_steps) {
+      CK(hipEventRecord(fork, st));
+      for (int q = 1; q < NQ; ++q) CK(hipStreamWaitEvent(sq[q], fork, 0));
+      for (int i = 0; i < n_steps; ++i)
+        for (int q = 0; q < NQ; ++q)
+          hipLaunchKernelGGL(k2<2>, dim3(first(q + 1) - first(q)), dim3(64 * nw), lds, sq[q], s + first(q) * 64, ft + first(q) * 64, ld, n_in, n_ft, n_out);
+      for (int q = 1; q < NQ; ++q) { CK(hipEventRecord(join[q], sq[q])); CK(hipStreamWaitEvent(st, join[q], 0)); }
+    };
+    hipGraph_t g2; hipGraphExec_t ge2;
+    CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    enqueue(100);
+    CK(hipStreamEndCapture(st, &g2));
+    CK(hipGraphInstantiate(&ge2, g2, nullptr, nullptr, 0));
+    CK(hipGraphLaunch(ge2, st)); CK(hipStreamSynchronize(st));
+    CK(hipEventRecord(e0, st));
+    for (int i = 0; i < N / 100; ++i) CK(hipGraphLaunch(ge2, st));
+    CK(hipEventRecord(e1, st));
+    CK(hipStreamSynchronize(st));
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("K2 in %d parts on %d streams, one %d-node graph   %7.2f us/step\n", NQ, NQ, 100 * NQ, ms * 1e3 / N);
+    for (int rep = 0; rep < 2; ++rep) {
+      CK(hipDeviceSynchronize());
+      CK(hipEventRecord(e0, st));
+      enqueue(N);
+      CK(hipEventRecord(e1, st));
+      CK(hipStreamSynchronize(st));
+      CK(hipEventElapsedTime(&ms, e0, e1));
+    }
+    printf("K2 in %d parts on %d streams, eager                %7.2f us/step\n", NQ, NQ, ms * 1e3 / N);
+  }
+  // two 64-environment tiles per block (1024 threads): half as many workgroups to dispatch
+  if (nw == 8) {
+    time("K0 empty, 256 blocks x 1024 threads", [&] { hipLaunchKernelGGL(k0, dim3(tiles / 2), dim3(1024), 2 * lds, st, s, ld); });
+    time("K0 empty, 1024 blocks x 256 threads", [&] { hipLaunchKernelGGL(k0, dim3(tiles * 2), dim3(256), lds / 2, st, s, ld); });
+  }
+  {
+    unsigned long long* d; CK(hipMalloc(&d, 64));
+    unsigned long long h[3];
+    for (int rep = 0; rep < 3; ++rep) {
+      hipLaunchKernelGGL(clock_probe, dim3(1), dim3(64), 0, st, d, 2000000);
+      CK(hipStreamSynchronize(st));
+      CK(hipMemcpy(h, d, 24, hipMemcpyDeviceToHost));
+      printf("clock probe: %llu shader cycles in %llu ticks of the 100 MHz counter -> %.0f MHz\n", h[0], h[1], (double)h[0] / ((double)h[1] / 100.0));
+    }
+  }
   return 0;
 }

@@ -2,9 +2,12 @@
 kernels), mean counters per dispatch and per wave, achieved GB/s and GFLOP/s against the MI355X peaks, and which
 resource binds.  usage: pmc_summary.py WORKDIR KERNEL_STATS_CSV BYTES_PER_ENV FLOP_PER_ENV ENVS "cmd" [RATED_KERNEL]
 
-Only the kernels whose name contains RATED_KERNEL (default "step_kernel": the physics step the per-environment figures
-belong to) get an achieved-GB/s / GFLOP/s line - the other kernels of a trace move other bytes (round 2 rated a physics
-kernel with LIDAR flops: "1.392 of peak").  A rated fraction above 1 is an error of the inputs and aborts.
+Only the kernel FAMILY named by RATED_KERNEL - the kernel's name up to its template arguments, compared exactly
+("step_kernel", "step_kernel_spec", "step_kernel_spec_multi", "step_kernel_compact", "lidar_compact_kernel", "vmas_rt_lean" ...; optionally ":physics" / ":env" behind it - a launch with or
+without Environment.step stages, told by its DevEnv / NoEnv argument; default "step_kernel_spec") - gets an achieved-GB/s / GFLOP/s / traffic-over-algorithmic line: the per-environment bytes and flop
+on the command line are that family's in that run.  Every other kernel of the trace is listed with its counters and NO
+rating (round 2 rated a physics kernel with LIDAR flops, round 3's substring match rated env-step kernels with physics
+bytes).  A rated fraction above 1 is an error of the inputs and aborts.
 
 Peaks (MI355X_MICROARCH.md): HBM 8.0 TB/s; fp32 vector 157.3 TFLOP/s (256 CU x 4 SIMD x 32 lanes x 2 flop x 2.4 GHz).
 FETCH_SIZE is doubled (gfx950 tallies 128-B requests at 64 B; calibrated in this library's own 4 B/lane row pattern,
@@ -16,9 +19,9 @@ import glob
 import sys
 
 work, stats_csv, bpe, fpe, envs, cmd = sys.argv[1], sys.argv[2], float(sys.argv[3]), float(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
-rated = sys.argv[7] if len(sys.argv) > 7 else "step_kernel"
+rated = sys.argv[7] if len(sys.argv) > 7 else "step_kernel_spec"
 OURS = ("step_kernel", "lidar_kernel", "lidar_compact_kernel", "collision_kernel", "post_kernel", "pair_mask_kernel", "ingest_kernel", "query_kernel", "reset_kernel",
-        "rollout")
+        "rollout", "vmas_rt_")
 
 
 def short(name):
@@ -26,20 +29,45 @@ def short(name):
     return n.split("(")[0]
 
 
+def family(name):
+    f = short(name).split("<")[0].strip().replace("compact::", "")
+    for suffix in ("_t0", "_t1"):  # run-time specialisations (specialize.py): vmas_rt_lean_t0, vmas_rt_multi_e1_o1_t0
+        if f.startswith("vmas_rt_") and f.endswith(suffix):
+            f = f[: -len(suffix)]
+    return f
+
+
+def variant(name):
+    """'env': the launch carries Environment.step stages (action ingest / a post-step epilogue: a DevEnv argument);
+    'physics': plain World.step."""
+    n = short(name)
+    if n.startswith("vmas_rt_multi_e"):
+        return "physics" if n.startswith("vmas_rt_multi_e0") else "env"
+    return "env" if "DevEnv" in name else "physics"
+
+
+def is_rated(name):
+    fam, _, var = rated.partition(":")
+    return family(name) == fam and (not var or variant(name) == var)
+
+
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 meta = {}
+full = {}  # short name -> full name (with the argument list: the Env type tells physics from env launches)
 for d in ("p1", "p2", "p3", "p4"):
     for f in glob.glob(f"{work}/{d}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
             if not any(o in k for o in OURS):
                 continue
+            full[k] = r["Kernel_Name"]
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
             meta[k] = (r["Grid_Size"], r["Workgroup_Size"], r["LDS_Block_Size"], r["VGPR_Count"], r["SGPR_Count"])
 dur = {}
 try:
     for r in csv.DictReader(open(stats_csv)):
         dur[short(r["Name"])] = (float(r["AverageNs"]), int(r["Calls"]), float(r["MinNs"]), float(r["MaxNs"]), float(r["StdDev"]))
+        full.setdefault(short(r["Name"]), r["Name"])
 except Exception as e:  # noqa: BLE001
     print("no kernel stats:", e)
 # per-dispatch view of the kernel trace: medians, and the same over the LAST HALF of a kernel's calls - the profiler's mean
@@ -50,6 +78,7 @@ for f in glob.glob(f"{work}/trace/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = short(r["Kernel_Name"])
         if any(o in k for o in OURS):
+            full.setdefault(k, r["Kernel_Name"])
             rows[k].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
     for k, v in rows.items():
         v.sort()
@@ -80,18 +109,18 @@ for k in sorted(set(acc) | set(per_dispatch), key=lambda k: -dur.get(k, (0,))[0]
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         traffic = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
         print(f"   HBM traffic per launch  {traffic / 1e6:.2f} MB (FETCH x2 + WRITE)")
-    if k in dur and rated in k:
+    if k in dur and is_rated(full.get(k, k)):
         t = dur[k][0] * 1e-9
         gbs, gfs = bpe * envs / t / 1e9, fpe * envs / t / 1e9
         print(f"   achieved (algorithmic)  {gbs:.0f} GB/s = {gbs / 8000:.3f} of HBM peak | {gfs:.0f} GFLOP/s = {gfs / 157300:.3f} of fp32 vector peak")
         assert gbs / 8000 <= 1.0 and gfs / 157300 <= 1.0, f"{k}: a fraction above the roof - wrong bytes / flop per environment for this kernel"
         if k in per_dispatch:  # the same by the median duration of the last half of the calls (the clocks are up by then)
             t2 = per_dispatch[k][1] * 1e-9
-            print(f"   by the last half's median duration: {bpe * envs / t2 / 1e9:.0f} GB/s = {bpe * envs / t2 / 8e12:.3f} of HBM peak")
+            print(f"   by the last half's median duration ({t2 * 1e6:.2f} us): {bpe * envs / t2 / 1e9:.0f} GB/s = {bpe * envs / t2 / 8e12:.3f} of HBM peak  <- the sustained figure")
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             print(f"   traffic / algorithmic   {traffic / (bpe * envs):.3f}")
     elif k in dur:
-        print("   (not rated: the per-environment bytes / flop given on the command line belong to another kernel)")
+        print(f"   (not rated: the per-environment bytes / flop of this run belong to the family {rated!r})")
     if waves and "SQ_WAVE_CYCLES" in c:
         wc = c["SQ_WAVE_CYCLES"]
         parts = []

@@ -107,7 +107,7 @@ class AttachedWorld:
     """Handle returned by ``attach``; ``detach()`` restores the reference behaviour."""
 
     def __init__(self, world, backend_factory: Callable = _default_backend, exact_broad_phase: Optional[bool] = None,
-                 specialize: bool = False):
+                 specialize: Optional[bool] = False):
         from .core import EXACT_AUTO_BELOW
 
         self.world = world
@@ -126,9 +126,10 @@ class AttachedWorld:
         self.agent_ft = torch.zeros(max(nA, 1), A.AGENT_FIELDS, self.ld, dtype=torch.float32, device=self.device)
         self._rehome()
         self.backend = self._factory(self.spec, self.batch, self.device, self.state, self.agent_ft)
-        self.specialize = bool(specialize)  # a step kernel compiled for this world (specialize.py), also after a refresh()
-        if self.specialize and hasattr(self.backend, "specialize"):
-            self.backend.specialize()
+        # a step kernel compiled for this world (specialize.py), also after a refresh(): True = compile it if the on-disk
+        # cache does not have it, None = take it from the cache if it is there (never compile, never fail), False = never
+        self.specialize = specialize
+        self._apply_specialize()
         self._check_spec = False  # set by World.reset: the scenario's reset_world_at that follows may change statics
         self.refreshes = 0        # how many times the static description was found changed (tests, diagnostics)
         self._watch()
@@ -141,6 +142,19 @@ class AttachedWorld:
 
         world.reset = reset
         self._patch_lidars()
+
+    def _apply_specialize(self):
+        if self.specialize is False or not hasattr(self.backend, "specialize"):
+            return
+        if self.specialize:
+            self.backend.specialize()
+            return
+        try:  # (None: an optional fast path - whatever goes wrong with a cache entry, the world keeps the interpreter)
+            self.backend.specialize(cached_only=True)
+        except Exception as e:  # noqa: BLE001
+            import warnings
+
+            warnings.warn(f"attach(): cached world-specialised kernel not used ({e}); the schedule interpreter runs", RuntimeWarning)
 
     # ---- state re-homing ---------------------------------------------------------
     def _rehome(self):
@@ -264,8 +278,7 @@ class AttachedWorld:
         self.spec = spec
         self.backend.close()
         self.backend = self._factory(self.spec, self.batch, self.device, self.state, self.agent_ft)
-        if self.specialize and hasattr(self.backend, "specialize"):
-            self.backend.specialize()
+        self._apply_specialize()
         self._watch()
         self.refreshes += 1
 
@@ -308,12 +321,13 @@ class AttachedWorld:
 
 
 def attach(env_or_world, backend_factory: Callable = _default_backend,
-           exact_broad_phase: Optional[bool] = None, specialize: bool = False) -> AttachedWorld:
+           exact_broad_phase: Optional[bool] = None, specialize: Optional[bool] = False) -> AttachedWorld:
     """Put a reference ``Environment`` (or ``World``) on the MI355X-native physics step.  ``exact_broad_phase``: the
     reference's batch-global ``.any()`` broad phase (core.py:2797-2801) exactly; None = below 1024 environments, where
-    it can matter (above, every pair that matters has SOME environment overlapping).  ``specialize``: compile (once, cached
-    on disk) a step kernel for this very world - any scenario the reference ships then runs at the speed of the built-in
-    BASELINE specialisations instead of the schedule interpreter's (specialize.py)."""
+    it can matter (above, every pair that matters has SOME environment overlapping).  ``specialize``: True = compile (once,
+    cached on disk) a step kernel for this very world - any scenario the reference ships then runs at the speed of the
+    built-in BASELINE specialisations instead of the schedule interpreter's (specialize.py); None = use it if the cache has
+    it, never compile; False = the interpreter."""
     world = getattr(env_or_world, "world", env_or_world)
     if getattr(env_or_world, "grad_enabled", False):
         raise NotImplementedError("grad_enabled=True needs the reference's autograd path; the HIP step has no backward")

@@ -352,7 +352,13 @@ class Environment:
         self._graph.replay()
         return self._static_out
 
-    def rollout(self, actions: List[Tensor]) -> Dict[str, Tensor]:
+    def rollout_fields(self, n_steps: int):
+        """(name, shape, dtype) of every per-step output ``rollout()`` writes for ``n_steps`` steps: what a caller-provided
+        ``out`` must hold (shard.PackedRollout lays these out in ONE buffer that is gathered across GPUs as it is)."""
+        assert self._one_launch, "rollout() needs a scenario whose Environment.step is one launch"
+        return self._post.rollout_fields(n_steps)
+
+    def rollout(self, actions: List[Tensor], out: Optional[Dict[str, Tensor]] = None) -> Dict[str, Tensor]:
         """K consecutive ``step()`` calls with given actions in ONE kernel launch.
 
         ``actions[i]`` = agent i's actions for all K steps, ``[K, num_envs, action_size]``.  Returns
@@ -360,14 +366,16 @@ class Environment:
         scenario's per-step info terms): entry k is what the k-th ``step()`` would have returned, bit for bit.  No
         resets in between (like K plain ``step()`` calls: ``done`` environments keep running until the caller
         resets them); the 64 environments of a tile stay in LDS for the whole rollout.  For the scenarios whose step
-        is one launch (balance, transport); others: loop over ``step()``."""
+        is one launch (balance, transport); others: loop over ``step()``.  ``out``: the per-step outputs are written
+        into the caller's tensors (names, shapes, dtypes of ``rollout_fields(K)``) instead of fresh ones - the kernel
+        stores straight into a rollout buffer, no copy between the rollout and whatever consumes it."""
         assert self._one_launch and getattr(self._post, "rollout_ok", True), \
             "rollout() needs a scenario whose Environment.step is one launch without a batch-wide reduction (balance, transport)"
         assert len(actions) == self.n_agents, f"Expecting actions for {self.n_agents}, got {len(actions)} actions"
         K = int(actions[0].shape[0])
         self._bound = None  # (the ingest slots and the post-step's buffer struct are re-pointed below: step_bound() re-binds)
         self._ingest.prepare_rollout(actions, K, self.validate_actions)
-        desc, buffers, out = self._post.prepare_rollout(K)
+        desc, buffers, out = self._post.prepare_rollout(K, out)
         self._launch.rollout(self._post.kind, desc, buffers, K)
         self._lidar_cache = None
         return out
@@ -395,14 +403,7 @@ class Environment:
         if b is None:  # first call, or a reset / step() / set_state since: pointers may have moved
             assert self._bound_actions is not None, "step_bound() needs bind(actions) first"
             self._ingest.prepare(self._bound_actions)
-            post = self._post
-            keep, post.static_outputs, post._out = post.static_outputs, True, None  # a set of output buffers of its own
-            if hasattr(post, "_terms"):
-                post._terms = None
-            try:
-                b = self._bound = post.prepare()
-            finally:
-                post.static_outputs = keep
+            b = self._bound = self._post.prepare(dedicated=True)  # a set of output buffers of its own
         self._launch(self._post.kind, b[0], b[1], False)
         self._lidar_cache = None
         fin = getattr(self._post, "finish", None)  # (tensor ops on the step's outputs: football's red rewards)

@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import sys
 from typing import List, Optional
 
 import torch
@@ -116,6 +117,7 @@ class ActionIngest:
         self._ft = w._packed_agent_ft()
         self._keep = None
         self._fast = None
+        self._slots = [self.args.agents[i] for i in range(len(env.agents))]  # (ctypes array indexing builds a wrapper per access)
 
     def prepare(self, actions: List[Tensor]):
         """Check the action tensors and point the slots at them (no launch)."""
@@ -124,17 +126,32 @@ class ActionIngest:
         fast = self._fast
         if fast is None:  # per agent: (action columns, dtype) - what a well-formed action tensor looks like
             dtype = torch.float32 if env.continuous_actions else torch.int64
-            fast = self._fast = [(env.get_agent_action_size(a), dtype) for a in env.agents]
+            fast = self._fast = [((env.num_envs, env.get_agent_action_size(a)), dtype, (env.get_agent_action_size(a), 1))
+                                 for a in env.agents]
         B, dev, cont = env.num_envs, env.device, env.continuous_actions
+        slots, prev = self._slots, self._keep
+        if prev is not None and len(prev) == len(actions):
+            same = True
+            for a, b in zip(actions, prev):
+                if a is not b:
+                    same = False
+                    break
+            if same:  # the very tensor objects of the last call (a policy writing into its own buffers): they were checked
+                for i, act in enumerate(actions):  # then; only the pointer is read again (`.data` can be re-pointed)
+                    if cont:
+                        slots[i].action = act.data_ptr()
+                    else:
+                        slots[i].action_index = act.data_ptr()
+                return
         for i, (agent, act) in enumerate(zip(env.agents, actions)):
-            want, dtype = fast[i]
-            if (type(act) is Tensor and act.dtype is dtype and act.dim() == 2 and act.shape[0] == B and act.shape[1] == want
-                    and act.is_contiguous() and act.device == dev):  # the usual case: nothing to convert
+            shape, dtype, strides = fast[i]
+            if (type(act) is Tensor and act.dtype is dtype and act.shape == shape and act.stride() == strides
+                    and act.device == dev):  # the usual case: nothing to convert ([B, size] contiguous, on the env's device)
                 held.append(act)
                 if cont:
-                    self.args.agents[i].action = act.data_ptr()
+                    slots[i].action = act.data_ptr()
                 else:
-                    self.args.agents[i].action_index = act.data_ptr()
+                    slots[i].action_index = act.data_ptr()
                 continue
             if not isinstance(act, Tensor):
                 act = torch.tensor(act, dtype=torch.float32, device=env.device)
@@ -309,6 +326,7 @@ class StepLauncher:
         self.fn = A.load_library().vmas_world_step_env
         self._be = None
         self._cd = self._cb = self._rd = self._rb = None
+        self._refs = {}
 
     def _bind(self):
         w = self.env.world
@@ -335,10 +353,20 @@ class StepLauncher:
             sa.entity_gravity = eg.data_ptr() if eg is not None else None
             sa.exact_broad_phase = 1 if self._exact else 0
             args = C.byref(sa)
-        if desc is not self._cd or buffers is not self._cb:  # (the structs persist: their references are built once)
-            self._cd, self._cb = desc, buffers
+        if desc is not self._cd:  # (the structs persist: their references are built once)
+            self._cd = desc
             self._rd = C.byref(desc) if desc is not None else None
-            self._rb = C.byref(buffers) if buffers is not None else None
+        if buffers is not self._cb:  # (a few buffer structs alternate - the post-step's output sets: one reference each)
+            self._cb = buffers
+            if buffers is None:
+                self._rb = None
+            else:
+                hit = self._refs.get(id(buffers))
+                if hit is None or hit[0] is not buffers:
+                    if len(self._refs) > 64:
+                        self._refs.clear()
+                    hit = self._refs[id(buffers)] = (buffers, C.byref(buffers))
+                self._rb = hit[1]
         rc = self.fn(self._h, self._st, self._ft, self._ld, args, self._ing, self._err if validate else None, kind,
                      self._rd, self._rb, _stream(self._dev))
         if rc != 0:
@@ -367,10 +395,47 @@ class StepLauncher:
             raise VmasHipError(A.last_error())
 
 
+_use_count = getattr(torch._C, "_storage_Use_Count", None)  # references on a storage: every tensor / view over it holds one
+_getrefcount = sys.getrefcount
+
+
+def _rcs(tensors):
+    """Python reference counts of the tensor objects (one function for the baseline and for every check: the same transient
+    references are counted both times)."""
+    return [_getrefcount(t) for t in tensors]
+
+
+class _OutSet:
+    """One step's output tensors, all views of ONE storage, with everything that is the same every time the set is used
+    built once: the buffer struct the kernel reads (pointers filled in), the per-agent lists / info dictionaries
+    ``Environment.step`` returns (as templates: a step hands out copies of the containers, the tensors themselves), and what
+    tells whether the caller still holds any of it - the storage's reference count (a view the caller made keeps the
+    storage alive) and the Python reference counts of the handed-out tensor objects.  A set whose counts are back at their
+    baselines is invisible to the caller and can be written again: to the caller every step returns fresh tensors, exactly
+    as in the reference, without an allocation or a view being made per step (three ``torch.empty`` + three ``unbind`` cost
+    the host ~15 us per step around an 11 us kernel)."""
+
+    __slots__ = ("base", "storage", "cdata", "uc0", "tensors", "rc0", "buffers", "ref", "v", "obs", "rew", "done", "infos",
+                 "extra", "nbytes", "pooled")
+
+    def seal(self):
+        """Baselines, taken when nothing but the set itself refers to its tensors (called by the pool, outside the frame
+        that built the set)."""
+        self.storage = self.base.untyped_storage()
+        self.cdata = self.storage._cdata
+        self.uc0 = _use_count(self.cdata) if _use_count is not None else -1
+        self.rc0 = _rcs(self.tensors)
+
+    def free(self) -> bool:
+        return _use_count is not None and _use_count(self.cdata) == self.uc0 and _rcs(self.tensors) == self.rc0
+
+
 class _Post:
     """Shared plumbing of the per-scenario post-step kernels."""
 
     kind = None  # A.POST_*: the post-step can also run as the epilogue of the physics kernel
+    POOL_MAX_SETS = 8
+    POOL_MAX_BYTES = 4 << 30
 
     def __init__(self, env):
         self.env = env
@@ -379,7 +444,9 @@ class _Post:
         self.dev = env.device
         self.n = len(env.agents)
         self.static_outputs = False
-        self._out = None
+        self._static_set = None
+        self._pool: List[_OutSet] = []
+        self._next = 0
 
     def persistent_tensors(self) -> List[Tensor]:
         """Scenario tensors the kernel reads AND writes (shaping terms ...)."""
@@ -391,28 +458,78 @@ class _Post:
         lim.max_steps = float(self.env.max_steps) if self.env.max_steps is not None else -1.0
         return lim
 
-    def _buffers(self, cls):
-        """The kernel's buffer struct, built once; per step only the pointers that change are rewritten."""
-        b = getattr(self, "_b", None)
-        if b is None:
-            b = self._b = cls()
-            b.limit = self._limit()
-        return b
+    # ---- output sets ----------------------------------------------------------------------------------------------
+    def _carve(self, fields):
+        """``fields``: (name, shape, dtype) -> (the one buffer, {name: view}); every view starts 256-byte aligned."""
+        offs, total = [], 0
+        for _, shape, dtype in fields:
+            n = math.prod(shape) * torch.empty((), dtype=dtype).element_size()
+            offs.append((total, n))
+            total += (n + 255) // 256 * 256
+        base = torch.empty(max(total, 256), dtype=torch.uint8, device=self.dev)
+        v = {}
+        for (name, shape, dtype), (off, n) in zip(fields, offs):
+            v[name] = base[off:off + n].view(dtype).view(shape)
+        return base, v
 
-    def _outputs(self, obs_dim: int):
-        if self._out is None or not self.static_outputs:
-            self._out = (
-                torch.empty(self.n, self.B, obs_dim, device=self.dev, dtype=torch.float32),
-                torch.empty(self.n, self.B, device=self.dev, dtype=torch.float32),
-                torch.empty(self.B, device=self.dev, dtype=torch.bool),
-            )
-        return self._out
+    def _new_set(self) -> _OutSet:
+        """Build one output set (tensors, buffer struct with its output pointers, result templates)."""
+        raise NotImplementedError
+
+    def _make(self, pooled: bool) -> _OutSet:
+        st = self._new_set()
+        st.pooled = pooled
+        st.nbytes = st.base.numel()
+        st.ref = C.byref(st.buffers)
+        st.seal()
+        return st
+
+    def _acquire(self, dedicated: bool = False) -> _OutSet:
+        """The set this step writes.  ``dedicated``: a fresh one that never enters the pool (step_bound's static outputs);
+        ``static_outputs`` (HIP-graph replay): always the same one."""
+        if dedicated:
+            return self._make(False)
+        if self.static_outputs:
+            if self._static_set is None:
+                self._static_set = self._make(False)
+            return self._static_set
+        pool = self._pool
+        n = len(pool)
+        for k in range(n):
+            st = pool[(self._next + k) % n]
+            if st.free():
+                self._next = (self._next + k + 1) % n
+                return st
+        st = self._make(True)
+        if n < self.POOL_MAX_SETS and (n + 1) * st.nbytes <= self.POOL_MAX_BYTES and _use_count is not None:
+            pool.append(st)
+            self._next = 0
+        return st  # (beyond the pool's size the set is simply the caller's: one allocation per step, as before)
 
     def _state(self):
         st = self.env.world._packed_state()
         return st.data_ptr(), st.shape[-1]
 
-    def prepare_rollout(self, n_steps: int):
+    @staticmethod
+    def _check_out(out, name, shape, dtype, dev):
+        t = out[name]
+        assert tuple(t.shape) == tuple(shape) and t.dtype == dtype and t.is_contiguous() and t.device == dev, (
+            f"rollout output {name!r}: expected a contiguous {dtype} tensor of shape {tuple(shape)} on {dev}, got "
+            f"{t.dtype} {tuple(t.shape)} on {t.device}")
+        return t
+
+    def _rollout_out(self, fields, out):
+        """The per-step outputs of a K-step launch: allocated here, or the caller's (``out``: a dict with exactly these
+        names, shapes and dtypes - e.g. views of one rollout buffer that is gathered across GPUs as it is, shard.PackedRollout)."""
+        if out is None:
+            return {name: torch.empty(shape, device=self.dev, dtype=dtype) for name, shape, dtype in fields}
+        return {name: self._check_out(out, name, shape, dtype, self.dev) for name, shape, dtype in fields}
+
+    def rollout_fields(self, n_steps: int):
+        """(name, shape, dtype) of every per-step output of ``prepare_rollout(n_steps)``."""
+        raise NotImplementedError
+
+    def prepare_rollout(self, n_steps: int, out=None):
         """(descriptor, buffers, outputs) for ``vmas_world_rollout_env``: every per-step output gets a leading
         ``n_steps`` axis ([K, n_agents, B, D] observations, [K, n_agents, B] rewards, [K, B] dones ...), the buffer
         struct points at step 0."""
@@ -438,34 +555,43 @@ class BalancePost(_Post):
     def persistent_tensors(self):
         return [self.env.scenario.global_shaping]
 
-    def prepare(self):
-        """(descriptor, buffers, what env.step returns) - outputs allocated, nothing launched."""
-        sc, n, B = self.env.scenario, self.n, self.B
-        if self._out is None or not self.static_outputs:
-            # three allocations per step: observations | rewards + the two info terms | done + on_the_ground
-            # (every torch call costs the host ~1.5 us and the step is host-bound around a 14 us kernel)
-            self._out = (torch.empty(n, B, 16, device=self.dev, dtype=torch.float32),
-                         torch.empty(n + 2, B, device=self.dev, dtype=torch.float32),
-                         torch.empty(2, B, device=self.dev, dtype=torch.bool))
-        obs, fl32, flags = self._out
-        rows = fl32.unbind(0)
-        done, sc.on_the_ground = flags.unbind(0)
-        sc.pos_rew, sc.ground_rew = rows[n], rows[n + 1]
-        b = self._buffers(A.BalanceBuffers)
-        b.global_shaping = sc.global_shaping.data_ptr()
-        p32, pfl = fl32.data_ptr(), flags.data_ptr()
-        b.obs, b.rew, b.done = obs.data_ptr(), p32, pfl
+    def _new_set(self):
+        n, B = self.n, self.B
+        st = _OutSet()
+        # observations | rewards + the two info terms | done + on_the_ground
+        st.base, v = self._carve([("obs", (n, B, 16), torch.float32), ("fl32", (n + 2, B), torch.float32),
+                                  ("flags", (2, B), torch.bool)])
+        rows = v["fl32"].unbind(0)
+        done, on_ground = v["flags"].unbind(0)
+        st.v = v
+        st.obs, st.rew, st.done = list(v["obs"].unbind(0)), list(rows[:n]), done
+        st.extra = (rows[n], rows[n + 1], on_ground)  # pos_rew, ground_rew, on_the_ground
+        st.infos = {"pos_rew": rows[n], "ground_rew": rows[n + 1]}
+        st.tensors = tuple(st.obs) + tuple(rows) + (done, on_ground)
+        b = st.buffers = A.BalanceBuffers()
+        b.limit = self._limit()
+        p32, pfl = v["fl32"].data_ptr(), v["flags"].data_ptr()
+        b.obs, b.rew, b.done = v["obs"].data_ptr(), p32, pfl
         b.pos_rew, b.ground_rew, b.on_the_ground = p32 + 4 * n * B, p32 + 4 * (n + 1) * B, pfl + B
-        info = {"pos_rew": sc.pos_rew, "ground_rew": sc.ground_rew}
-        return self.desc, b, (list(obs.unbind(0)), list(rows[:n]), done, [dict(info) for _ in range(n)])
+        return st
 
-    def prepare_rollout(self, n_steps: int):
-        sc, K = self.env.scenario, int(n_steps)
-        out = {
-            "obs": torch.empty(K, self.n, self.B, 16, device=self.dev), "rew": torch.empty(K, self.n, self.B, device=self.dev),
-            "done": torch.empty(K, self.B, device=self.dev, dtype=torch.bool),
-            "pos_rew": torch.empty(K, self.B, device=self.dev), "ground_rew": torch.empty(K, self.B, device=self.dev),
-        }
+    def prepare(self, dedicated: bool = False):
+        """(descriptor, buffers, what env.step returns) - nothing launched."""
+        sc = self.env.scenario
+        st = self._acquire(dedicated)
+        sc.pos_rew, sc.ground_rew, sc.on_the_ground = st.extra
+        st.buffers.global_shaping = sc.global_shaping.data_ptr()
+        info = st.infos
+        return self.desc, st.buffers, (list(st.obs), list(st.rew), st.done, [dict(info) for _ in range(self.n)])
+
+    def rollout_fields(self, n_steps: int):
+        K, n, B = int(n_steps), self.n, self.B
+        return [("obs", (K, n, B, 16), torch.float32), ("rew", (K, n, B), torch.float32), ("done", (K, B), torch.bool),
+                ("pos_rew", (K, B), torch.float32), ("ground_rew", (K, B), torch.float32)]
+
+    def prepare_rollout(self, n_steps: int, out=None):
+        sc = self.env.scenario
+        out = self._rollout_out(self.rollout_fields(n_steps), out)
         sc.on_the_ground = torch.empty(self.B, device=self.dev, dtype=torch.bool)
         sc.pos_rew, sc.ground_rew = out["pos_rew"][-1], out["ground_rew"][-1]  # scenario attributes: the last step's
         b = A.BalanceBuffers()
@@ -498,48 +624,65 @@ class TransportPost(_Post):
         d.shaping_factor = sc.shaping_factor
         self.desc = d
         self.P = P
+        self.D = 4 + 7 * P
         # the packages' persistent terms live in one [P, B] block each; the objects hold row views
         self.global_shaping = torch.stack([p.global_shaping for p in sc.packages]).contiguous()
         self.on_goal = torch.stack([p.on_goal for p in sc.packages]).contiguous()
+        self._gs_rows, self._og_rows = list(self.global_shaping.unbind(0)), list(self.on_goal.unbind(0))
+        self._gs_ptr, self._og_ptr = self.global_shaping.data_ptr(), self.on_goal.data_ptr()
         self._bind()
 
     def _bind(self):
         for i, p in enumerate(self.env.scenario.packages):
-            p.global_shaping = self.global_shaping[i]
-            p.on_goal = self.on_goal[i]
+            p.global_shaping = self._gs_rows[i]
+            p.on_goal = self._og_rows[i]
 
     kind = A.POST_TRANSPORT
 
     def persistent_tensors(self):
         return [self.global_shaping, self.on_goal]
 
-    def prepare(self):
-        sc = self.env.scenario
-        for i, p in enumerate(sc.packages):  # reset() may have rebound them
-            if p.global_shaping.data_ptr() != self.global_shaping[i].data_ptr():
-                self.global_shaping[i].copy_(p.global_shaping)
-                p.global_shaping = self.global_shaping[i]
-            if p.on_goal.data_ptr() != self.on_goal[i].data_ptr():
-                self.on_goal[i].copy_(p.on_goal)
-                p.on_goal = self.on_goal[i]
-        obs, rew, done = self._outputs(4 + 7 * self.P)
-        b = self._buffers(A.TransportBuffers)
-        b.global_shaping, b.on_goal = self.global_shaping.data_ptr(), self.on_goal.data_ptr()
-        b.obs, b.rew, b.done = obs.data_ptr(), rew.data_ptr(), done.data_ptr()
-        sc.rew = rew[0]
-        return self.desc, b, (list(obs.unbind(0)), list(rew.unbind(0)), done, [{} for _ in range(self.n)])
+    def _rebind(self):
+        for i, p in enumerate(self.env.scenario.packages):  # reset() may have rebound them
+            if p.global_shaping is not self._gs_rows[i]:
+                self._gs_rows[i].copy_(p.global_shaping)
+                p.global_shaping = self._gs_rows[i]
+            if p.on_goal is not self._og_rows[i]:
+                self._og_rows[i].copy_(p.on_goal)
+                p.on_goal = self._og_rows[i]
 
-    def prepare_rollout(self, n_steps: int):
-        K, D = int(n_steps), 4 + 7 * self.P
-        self.prepare()  # (re-binds the packages' persistent terms)
-        out = {
-            "obs": torch.empty(K, self.n, self.B, D, device=self.dev), "rew": torch.empty(K, self.n, self.B, device=self.dev),
-            "done": torch.empty(K, self.B, device=self.dev, dtype=torch.bool),
-        }
+    def _new_set(self):
+        n, B = self.n, self.B
+        st = _OutSet()
+        st.base, v = self._carve([("obs", (n, B, self.D), torch.float32), ("rew", (n, B), torch.float32), ("done", (B,), torch.bool)])
+        st.v = v
+        st.obs, st.rew, st.done = list(v["obs"].unbind(0)), list(v["rew"].unbind(0)), v["done"]
+        st.extra, st.infos = None, None
+        st.tensors = tuple(st.obs) + tuple(st.rew) + (st.done,)
+        b = st.buffers = A.TransportBuffers()
+        b.limit = self._limit()
+        b.global_shaping, b.on_goal = self._gs_ptr, self._og_ptr
+        b.obs, b.rew, b.done = v["obs"].data_ptr(), v["rew"].data_ptr(), v["done"].data_ptr()
+        return st
+
+    def prepare(self, dedicated: bool = False):
+        self._rebind()
+        st = self._acquire(dedicated)
+        self.env.scenario.rew = st.rew[0]
+        return self.desc, st.buffers, (list(st.obs), list(st.rew), st.done, [{} for _ in range(self.n)])
+
+    def rollout_fields(self, n_steps: int):
+        K = int(n_steps)
+        return [("obs", (K, self.n, self.B, self.D), torch.float32), ("rew", (K, self.n, self.B), torch.float32),
+                ("done", (K, self.B), torch.bool)]
+
+    def prepare_rollout(self, n_steps: int, out=None):
+        self._rebind()  # (re-binds the packages' persistent terms)
+        out = self._rollout_out(self.rollout_fields(n_steps), out)
         self.env.scenario.rew = out["rew"][-1, 0]
         b = A.TransportBuffers()
         b.limit = self._limit()
-        b.global_shaping, b.on_goal = self.global_shaping.data_ptr(), self.on_goal.data_ptr()
+        b.global_shaping, b.on_goal = self._gs_ptr, self._og_ptr
         b.obs, b.rew, b.done = out["obs"].data_ptr(), out["rew"].data_ptr(), out["done"].data_ptr()
         return self.desc, b, out
 
@@ -597,12 +740,9 @@ class NavigationPost(_Post):
         self.obs_dim = 4 + 2 * (self.n if sc.observe_all_goals else 1) + (d.n_rays if sc.collisions else 0)
         self.pos_shaping = torch.stack([a.pos_shaping for a in agents]).contiguous()
         self._shaping_rows = list(self.pos_shaping.unbind(0))
-        self._shaping_ptrs = [r.data_ptr() for r in self._shaping_rows]
         for a, row in zip(agents, self._shaping_rows):
             a.pos_shaping = row
-        self._buf = A.NavigationBuffers()
-        self._buf.pos_shaping = self.pos_shaping.data_ptr()
-        self._buf.limit = self._limit()
+        self._pair_index_ptr = None
         if sc.collisions:  # (i, j) -> index in the world's static pair list, for World.collides' global reduction
             spec = w.spec
             where = {}
@@ -610,7 +750,7 @@ class NavigationPost(_Post):
                 where[(p.a, p.b)] = where[(p.b, p.a)] = k
             table = [[where.get((a._index, b._index), -1) for b in agents] for a in agents]
             self.pair_index = torch.tensor(table, dtype=torch.int32, device=self.dev).contiguous()
-            self._buf.pair_index = self.pair_index.data_ptr()
+            self._pair_index_ptr = self.pair_index.data_ptr()
 
     def persistent_tensors(self):
         return [self.pos_shaping]
@@ -618,68 +758,80 @@ class NavigationPost(_Post):
     kind = A.POST_NAVIGATION  # as the epilogue of the physics kernel: LIDAR cast and collision reduction in the launch
     rollout_ok = True         # (instance attribute, see __init__: several steps per launch need a grid barrier per step)
 
-    def prepare_rollout(self, n_steps: int):
-        env, sc, K, n, B = self.env, self.env.scenario, int(n_steps), self.n, self.B
-        self._bind_outputs()  # (re-binds the agents' shaping rows after a reset)
-        out = {
-            "obs": torch.empty(K, n, B, self.obs_dim, device=self.dev), "rew": torch.empty(K, n, B, device=self.dev),
-            "done": torch.empty(K, B, device=self.dev, dtype=torch.bool),
-            "agent_pos_rew": torch.empty(K, n, B, device=self.dev), "pos_rew": torch.empty(K, B, device=self.dev),
-            "final_rew": torch.empty(K, B, device=self.dev), "agent_collisions": torch.empty(K, n, B, device=self.dev),
-        }
+    def _rebind_shaping(self):
+        for a, row in zip(self.env.world.agents, self._shaping_rows):  # reset() may have rebound it
+            if a.pos_shaping is not row:
+                row.copy_(a.pos_shaping)
+                a.pos_shaping = row
+
+    def rollout_fields(self, n_steps: int):
+        K, n, B = int(n_steps), self.n, self.B
+        f32 = torch.float32
+        return [("obs", (K, n, B, self.obs_dim), f32), ("rew", (K, n, B), f32), ("done", (K, B), torch.bool),
+                ("agent_pos_rew", (K, n, B), f32), ("pos_rew", (K, B), f32), ("final_rew", (K, B), f32),
+                ("agent_collisions", (K, n, B), f32)]
+
+    def prepare_rollout(self, n_steps: int, out=None):
+        env, sc = self.env, self.env.scenario
+        self._rebind_shaping()  # (re-binds the agents' shaping rows after a reset)
+        out = self._rollout_out(self.rollout_fields(n_steps), out)
         sc.pos_rew, sc.final_rew = out["pos_rew"][-1], out["final_rew"][-1]  # scenario / agent attributes: the last step's
         for i, a in enumerate(env.world.agents):
             a.pos_rew, a.agent_collision_rew = out["agent_pos_rew"][-1, i], out["agent_collisions"][-1, i]
         sc._lidar_cache = None
         b = A.NavigationBuffers()
         b.pos_shaping, b.limit = self.pos_shaping.data_ptr(), self._limit()
-        b.limit.steps = env.steps.data_ptr()
-        b.pair_index = self._buf.pair_index
+        b.pair_index = self._pair_index_ptr
         b.obs, b.rew, b.done = out["obs"].data_ptr(), out["rew"].data_ptr(), out["done"].data_ptr()
         b.agent_pos_rew, b.collision_rew = out["agent_pos_rew"].data_ptr(), out["agent_collisions"].data_ptr()
         b.pos_rew, b.final_rew = out["pos_rew"].data_ptr(), out["final_rew"].data_ptr()
         return self.desc, b, out
 
-    def _bind_outputs(self):
-        """Output tensors + the buffer struct's pointers (nothing launched)."""
-        env, sc, w = self.env, self.env.scenario, self.env.world
-        agents = w.agents
-        for a, row, ptr in zip(agents, self._shaping_rows, self._shaping_ptrs):  # reset() may have rebound it
-            if a.pos_shaping.data_ptr() != ptr:
-                row.copy_(a.pos_shaping)
-                a.pos_shaping = row
-        fresh = self._out is None or not self.static_outputs
-        obs, rew, done = self._outputs(self.obs_dim)
-        if fresh or getattr(self, "_terms", None) is None:
-            # one block: agent_pos_rew [n] | collision_rew [n] | pos_rew | final_rew
-            self._terms = torch.empty(2 * self.n + 2, self.B, device=self.dev)
-        t = self._terms
-        rows = t.unbind(0)
-        n = self.n
-        sc.pos_rew, sc.final_rew = rows[2 * n], rows[2 * n + 1]
-        for i, a in enumerate(agents):
-            a.pos_rew, a.agent_collision_rew = rows[i], rows[n + i]
-        b = self._buf
-        b.obs, b.rew, b.done = obs.data_ptr(), rew.data_ptr(), done.data_ptr()
-        p, row_bytes = t.data_ptr(), 4 * self.B
+    def _new_set(self):
+        n, B, sc = self.n, self.B, self.env.scenario
+        st = _OutSet()
+        # observations | rewards | agent_pos_rew [n] | collision_rew [n] | pos_rew | final_rew | done
+        st.base, v = self._carve([("obs", (n, B, self.obs_dim), torch.float32), ("rew", (n, B), torch.float32),
+                                  ("terms", (2 * n + 2, B), torch.float32), ("done", (B,), torch.bool)])
+        st.v = v
+        rows = v["terms"].unbind(0)
+        st.obs, st.rew, st.done = list(v["obs"].unbind(0)), list(v["rew"].unbind(0)), v["done"]
+        st.extra = rows
+        pos_rew, final_rew = rows[2 * n], rows[2 * n + 1]
+        st.infos = [{"pos_rew": pos_rew if sc.shared_rew else rows[i], "final_rew": final_rew, "agent_collisions": rows[n + i]}
+                    for i in range(n)]
+        st.tensors = tuple(st.obs) + tuple(st.rew) + tuple(rows) + (st.done,)
+        b = st.buffers = A.NavigationBuffers()
+        b.pos_shaping, b.limit = self.pos_shaping.data_ptr(), self._limit()
+        b.pair_index = self._pair_index_ptr
+        b.obs, b.rew, b.done = v["obs"].data_ptr(), v["rew"].data_ptr(), v["done"].data_ptr()
+        p, row_bytes = v["terms"].data_ptr(), 4 * B
         b.agent_pos_rew, b.collision_rew = p, p + n * row_bytes
         b.pos_rew, b.final_rew = p + 2 * n * row_bytes, p + (2 * n + 1) * row_bytes
-        b.limit.steps = env.steps.data_ptr()
-        infos = [{"pos_rew": sc.pos_rew if sc.shared_rew else a.pos_rew, "final_rew": sc.final_rew,
-                  "agent_collisions": a.agent_collision_rew} for a in env.agents]
-        return list(obs.unbind(0)), list(rew.unbind(0)), done, infos
+        return st
 
-    def prepare(self):
+    def _bind_outputs(self, dedicated: bool = False):
+        """The output set of this step, bound to the scenario's / agents' attributes (nothing launched)."""
+        sc, n = self.env.scenario, self.n
+        self._rebind_shaping()
+        st = self._acquire(dedicated)
+        rows = st.extra
+        sc.pos_rew, sc.final_rew = rows[2 * n], rows[2 * n + 1]
+        for i, a in enumerate(self.env.world.agents):
+            a.pos_rew, a.agent_collision_rew = rows[i], rows[n + i]
+        return st, (list(st.obs), list(st.rew), st.done, [dict(d) for d in st.infos])
+
+    def prepare(self, dedicated: bool = False):
         """(descriptor, buffers, what env.step returns) for the one-launch step (vmas_world_step_env)."""
-        result = self._bind_outputs()
+        st, result = self._bind_outputs(dedicated)
         self.env.scenario._lidar_cache = None  # (the sensors' measurements are made inside the launch, on the LDS tile)
-        self._buf.lidar = self._buf.pair_any = None
-        return self.desc, self._buf, result
+        st.buffers.lidar = st.buffers.pair_any = None
+        return self.desc, st.buffers, result
 
     def __call__(self):
         env, sc, w = self.env, self.env.scenario, self.env.world
-        result = self._bind_outputs()
-        b = self._buf
+        st, result = self._bind_outputs()
+        b = st.buffers
         main = torch.cuda.current_stream(self.dev)
         if sc.collisions:
             # the batch-global collision mask (a short latency-bound kernel) runs beside the LIDAR cast on a
@@ -697,8 +849,8 @@ class NavigationPost(_Post):
             main.wait_event(self._join)
             b.lidar, b.lidar_max_rays = lidar.data_ptr(), lidar.shape[1]
             b.pair_any = pair_any.data_ptr()
-        st = w._packed_state()
-        _check(self.lib.vmas_navigation_post_step(C.byref(self.desc), C.byref(b), self.B, st.data_ptr(), st.shape[-1],
+        state = w._packed_state()
+        _check(self.lib.vmas_navigation_post_step(C.byref(self.desc), C.byref(b), self.B, state.data_ptr(), state.shape[-1],
                                                   main.cuda_stream))
         return result
 
@@ -738,6 +890,7 @@ class FootballPost(_Post):
         for n, row in zip(names, self._shaping_rows):  # the ball's shaping terms live in one [4, B] block
             setattr(ball, n, row)
         self._shaping_names = names
+        self._blue = [a in sc.blue_agents for a in env.agents]
         # as the epilogue of the step kernel (one launch per Environment.step, K steps per launch in rollout()): worlds that
         # run the lane-compacted kernel (csrc/vmas_compact.h) - the default for football
         be = w._get_backend()
@@ -750,43 +903,54 @@ class FootballPost(_Post):
         ball = self.env.scenario.ball
         for n, row in zip(self._shaping_names, self._shaping_rows):  # reset() may have rebound them
             cur = getattr(ball, n)
-            if cur.data_ptr() != row.data_ptr():
+            if cur is not row:
                 row.copy_(cur)
                 setattr(ball, n, row)
 
-    def prepare(self):
-        """(descriptor, buffers, what env.step returns) - outputs allocated and bound to the scenario's attributes, nothing
-        launched.  ``finish(result)`` completes the infos once the step has been enqueued."""
-        env, sc, w = self.env, self.env.scenario, self.env.world
-        ball = sc.ball
-        self._rebind_shaping()
-        obs, rew, done = self._outputs(self.obs_dim)
-        if not self.static_outputs or getattr(self, "_terms", None) is None:
-            self._terms = (torch.empty(len(self.TERMS), self.B, device=self.dev),
-                           torch.empty(2, self.B, device=self.dev, dtype=torch.bool))
-        terms, touching = self._terms
-        b = self._buffers(A.FootballBuffers)
-        b.pos_shaping = self.pos_shaping.data_ptr()
-        b.obs, b.rew, b.done = obs.data_ptr(), rew.data_ptr(), done.data_ptr()
-        b.terms, b.touching = terms.data_ptr(), touching.data_ptr()
-        b.agent_ft = w._packed_agent_ft().data_ptr()
-        t = dict(zip(self.TERMS, terms.unbind(0)))
-        sc._sparse_reward_blue, sc._done = t["sparse_reward_blue"], done
-        ball.pos_rew_blue, ball.pos_rew_red = t["pos_rew_blue"], t["pos_rew_red"]
-        ball.pos_rew_agent_blue, ball.pos_rew_agent_red = t["pos_rew_agent_blue"], t["pos_rew_agent_red"]
-        sc.min_agent_dist_to_ball_blue, sc.min_agent_dist_to_ball_red = (
-            t["min_agent_dist_to_ball_blue"], t["min_agent_dist_to_ball_red"])
-        infos = []
-        for a in env.agents:
-            side = "blue" if a in sc.blue_agents else "red"
-            infos.append({
+    def _new_set(self):
+        n, B = self.n, self.B
+        st = _OutSet()
+        st.base, v = self._carve([("obs", (n, B, self.obs_dim), torch.float32), ("rew", (n, B), torch.float32),
+                                  ("terms", (len(self.TERMS), B), torch.float32), ("touching", (2, B), torch.bool),
+                                  ("done", (B,), torch.bool)])
+        st.v = v
+        st.obs, st.rew, st.done = list(v["obs"].unbind(0)), list(v["rew"].unbind(0)), v["done"]
+        terms, touching = v["terms"].unbind(0), v["touching"].unbind(0)
+        t = dict(zip(self.TERMS, terms))
+        st.extra = t
+        st.infos = []
+        for blue in self._blue:
+            side = "blue" if blue else "red"
+            st.infos.append({
                 "sparse_reward": t["sparse_reward_blue"],  # (red: negated in finish(), once the kernel has been enqueued)
                 "ball_goal_pos_rew": t[f"pos_rew_{side}"], "all_agent_ball_pos_rew": t[f"pos_rew_agent_{side}"],
                 "ball_pos": None, "dist_ball_to_goal": t[f"dist_ball_to_goal_{side}"],
                 "min_agent_dist_to_ball": t[f"min_agent_dist_to_ball_{side}"],
-                "touching_ball": touching[0 if side == "blue" else 1],
+                "touching_ball": touching[0 if blue else 1],
             })
-        return self.desc, b, (list(obs.unbind(0)), list(rew.unbind(0)), done, infos)
+        st.tensors = tuple(st.obs) + tuple(st.rew) + tuple(terms) + tuple(touching) + (st.done,)
+        b = st.buffers = A.FootballBuffers()
+        b.limit = self._limit()
+        b.pos_shaping = self.pos_shaping.data_ptr()
+        b.obs, b.rew, b.done = v["obs"].data_ptr(), v["rew"].data_ptr(), v["done"].data_ptr()
+        b.terms, b.touching = v["terms"].data_ptr(), v["touching"].data_ptr()
+        return st
+
+    def prepare(self, dedicated: bool = False):
+        """(descriptor, buffers, what env.step returns) - outputs bound to the scenario's attributes, nothing launched.
+        ``finish(result)`` completes the infos once the step has been enqueued."""
+        sc, w = self.env.scenario, self.env.world
+        ball = sc.ball
+        self._rebind_shaping()
+        st = self._acquire(dedicated)
+        st.buffers.agent_ft = w._packed_agent_ft().data_ptr()
+        t = st.extra
+        sc._sparse_reward_blue, sc._done = t["sparse_reward_blue"], st.done
+        ball.pos_rew_blue, ball.pos_rew_red = t["pos_rew_blue"], t["pos_rew_red"]
+        ball.pos_rew_agent_blue, ball.pos_rew_agent_red = t["pos_rew_agent_blue"], t["pos_rew_agent_red"]
+        sc.min_agent_dist_to_ball_blue, sc.min_agent_dist_to_ball_red = (
+            t["min_agent_dist_to_ball_blue"], t["min_agent_dist_to_ball_red"])
+        return self.desc, st.buffers, (list(st.obs), list(st.rew), st.done, [dict(d) for d in st.infos])
 
     def finish(self, result):
         """The parts of the infos that are tensor ops on the step's outputs (stream-ordered behind the launch)."""
@@ -794,23 +958,23 @@ class FootballPost(_Post):
         ball = sc.ball
         ball_pos = ball.state.pos if self.static_outputs else ball.state.pos.clone()  # (not a live view of the state)
         sparse_red = None
-        for a, info in zip(env.agents, result[3]):
+        for blue, info in zip(self._blue, result[3]):
             info["ball_pos"] = ball_pos
-            if a not in sc.blue_agents:
+            if not blue:
                 if sparse_red is None:
                     sparse_red = sc._sparse_reward_red = -sc._sparse_reward_blue
                 info["sparse_reward"] = sparse_red
         return result
 
-    def prepare_rollout(self, n_steps: int):
-        env, sc, K, n, B = self.env, self.env.scenario, int(n_steps), self.n, self.B
+    def rollout_fields(self, n_steps: int):
+        K, n, B = int(n_steps), self.n, self.B
+        return [("obs", (K, n, B, self.obs_dim), torch.float32), ("rew", (K, n, B), torch.float32), ("done", (K, B), torch.bool),
+                ("terms", (K, len(self.TERMS), B), torch.float32), ("touching_ball", (K, 2, B), torch.bool)]
+
+    def prepare_rollout(self, n_steps: int, out=None):
+        env, sc = self.env, self.env.scenario
         self._rebind_shaping()
-        out = {
-            "obs": torch.empty(K, n, B, self.obs_dim, device=self.dev), "rew": torch.empty(K, n, B, device=self.dev),
-            "done": torch.empty(K, B, device=self.dev, dtype=torch.bool),
-            "terms": torch.empty(K, len(self.TERMS), B, device=self.dev),
-            "touching_ball": torch.empty(K, 2, B, device=self.dev, dtype=torch.bool),
-        }
+        out = dict(self._rollout_out(self.rollout_fields(n_steps), out))
         b = A.FootballBuffers()
         b.limit = self._limit()
         b.pos_shaping = self.pos_shaping.data_ptr()

@@ -12,7 +12,7 @@ from typing import Callable, Dict, List, Optional
 import torch
 from torch import Tensor
 
-from .shard import EnvShard, PackedRollout, RolloutGather
+from .shard import EnvShard, NativeRollout, PackedRollout, RolloutGather
 
 
 def collect(env, policy: Callable[[List[Tensor]], List[Tensor]], n_steps: int,
@@ -61,3 +61,15 @@ def collect_packed(env, policy: Callable[[List[Tensor]], List[Tensor]], n_steps:
         if auto_reset:
             obs = env.reset_where(dones)
     return pr
+
+
+def collect_native(env, actions: List[Tensor], shard: EnvShard, into: Optional[NativeRollout] = None) -> NativeRollout:
+    """K steps with PRE-COMPUTED actions (``actions[i]``: agent i's ``[K, b, action_size]``) as ONE kernel launch
+    (``Environment.rollout``) whose per-step outputs are stored straight into the buffer the end-of-rollout gather sends:
+    ``.fields`` are this shard's ``obs [K, A, b, D]`` / ``rew [K, A, b]`` / ``done [K, b]`` (+ info terms), ``.gather()`` the
+    rollouts of all ranks with ONE collective and no copy on either side (SURVEY.md 8e + 8f-3).  For the scenarios whose
+    step is one launch; ``into``: a buffer of an earlier call (same K) to write again."""
+    K = int(actions[0].shape[0])
+    nr = into if into is not None else NativeRollout.for_env(shard, env, K)
+    env.rollout(actions, out=nr.fields)
+    return nr

@@ -117,6 +117,100 @@ class PackedRollout:
         return self._views(full, sh.num_envs)
 
 
+class NativeRollout:
+    """One shard's K-step rollout in ONE byte buffer laid out as the step kernel writes it: the per-step outputs of
+    ``Environment.rollout`` (``env.rollout_fields(K)``: obs ``[K, A, b, D]``, rew ``[K, A, b]``, done ``[K, b]`` + the scenario's
+    info terms) side by side at 256-byte aligned offsets.  ``fields`` are typed views of the buffer: passed to
+    ``env.rollout(actions, out=nr.fields)`` the kernel's stores land in it directly - no copy between the fast rollout and
+    the collective - and ``gather()`` is ONE ``all_gather_into_tensor`` of the buffer (the pipeline's only
+    exchange).  Ranks own contiguous blocks of environments, so rank order IS environment order: the gathered tensors
+    carry it as a leading axis, ``obs [R, K, A, b, D]`` with global environment ``r * b + e`` - views of the gathered
+    buffer, nothing is moved (``env_major`` makes the flat ``[K, A, B, D]`` copy for consumers that insist on it).
+    Shards of unequal size: the offsets are those of the largest shard on every rank, a rank's tensors cover its own
+    ``local_envs`` and ``gather()`` returns a list of per-rank views instead of one stacked view."""
+
+    def __init__(self, shard: EnvShard, fields, device, env_axis: Optional[Dict[str, int]] = None,
+                 group: Optional[dist.ProcessGroup] = None):
+        """``fields``: (name, shape, dtype) for THIS rank's ``shard.local_envs`` environments (``env.rollout_fields(K)``);
+        ``env_axis[name]``: which axis of ``shape`` is the environment axis (default: axis 2 of a four-dimensional output -
+        ``[K, A, b, D]`` -, else the last - ``[K, b]``, ``[K, A, b]``: what the shipped scenarios write)."""
+        self.shard, self.group = shard, group
+        b, bmax = shard.local_envs, shard.max_local_envs
+        self.layout = []
+        off = 0
+        for name, shape, dtype in fields:
+            shape = tuple(int(x) for x in shape)
+            ax = (env_axis or {}).get(name)
+            if ax is None:
+                ax = 2 if len(shape) == 4 else len(shape) - 1
+            assert shape[ax] == b, f"{name}: axis {ax} of {shape} is not the shard's {b} environments"
+            item = torch.empty((), dtype=dtype).element_size()
+            full = shape[:ax] + (bmax,) + shape[ax + 1:]
+            n_full = item
+            for x in full:
+                n_full *= x
+            self.layout.append((name, shape, dtype, ax, off, item))
+            off += (n_full + 255) // 256 * 256
+        self.nbytes = max(off, 256)
+        self.local = torch.zeros(self.nbytes, dtype=torch.uint8, device=device)
+        self.fields: Dict[str, torch.Tensor] = {}
+        for name, shape, dtype, ax, o, item in self.layout:
+            n = item
+            for x in shape:
+                n *= x
+            self.fields[name] = self.local[o:o + n].view(dtype).view(shape)
+        self._full: Optional[torch.Tensor] = None
+
+    @classmethod
+    def for_env(cls, shard: EnvShard, env, n_steps: int, group: Optional[dist.ProcessGroup] = None) -> "NativeRollout":
+        assert env.num_envs == shard.local_envs, f"the environment has {env.num_envs} envs, the shard {shard.local_envs}"
+        return cls(shard, env.rollout_fields(n_steps), env.device, group=group)
+
+    def _rank_fields(self, buf: torch.Tensor, r: int) -> Dict[str, torch.Tensor]:
+        sh = self.shard
+        lo, hi = shard_range(sh.num_envs, r, sh.world_size)
+        out = {}
+        for name, shape, dtype, ax, o, item in self.layout:
+            shp = shape[:ax] + (hi - lo,) + shape[ax + 1:]
+            n = item
+            for x in shp:
+                n *= x
+            out[name] = buf[o:o + n].view(dtype).view(shp)
+        return out
+
+    def gather(self):
+        """Every rank's rollout on every rank - ONE collective on the caller's stream, its output buffer re-used by the next
+        call.  Equal shards: ``{name: tensor [R, *shape]}`` (views of the gathered buffer); unequal: ``{name: [R tensors]}``."""
+        sh = self.shard
+        R = sh.world_size
+        if R == 1:
+            return {k: v.unsqueeze(0) for k, v in self.fields.items()}
+        if self._full is None:
+            self._full = torch.empty(R * self.nbytes, dtype=torch.uint8, device=self.local.device)
+        dist.all_gather_into_tensor(self._full, self.local, group=self.group)
+        rows = self._full.view(R, self.nbytes)
+        if sh.num_envs % R == 0:
+            out = {}
+            for name, shape, dtype, ax, o, item in self.layout:
+                n = item
+                for x in shape:
+                    n *= x
+                out[name] = rows[:, o:o + n].view(dtype).view((R,) + shape)  # (256-byte aligned ranges: re-typed in place)
+            return out
+        per_rank = [self._rank_fields(rows[r], r) for r in range(R)]
+        return {name: [pr[name] for pr in per_rank] for name in self.fields}
+
+    def env_major(self, gathered, name: str) -> torch.Tensor:
+        """``gathered[name]`` with the global environment axis in the field's own position (``obs [K, A, B, D]``): the one
+        copy, for consumers that want the reference's flat batch."""
+        ax = next(l[3] for l in self.layout if l[0] == name)
+        g = gathered[name]
+        if isinstance(g, list):
+            return torch.cat(g, dim=ax)
+        x = g.movedim(0, ax)  # [..., R, b, ...]
+        return x.reshape(x.shape[:ax] + (x.shape[ax] * x.shape[ax + 1],) + x.shape[ax + 2:])
+
+
 class RolloutGather:
     """All-gather of per-shard rollout buffers whose environment axis is ``env_dim`` (any set of tensors).
 
