@@ -45,7 +45,7 @@ cat $OUT/${TAG}_bench_q1_under_profiler.jsonl
 tail -12 $OUT/${TAG}_launch_floor.txt
 # host side of Environment.step
 python scripts/prof_env_host.py balance 32768 > $OUT/${TAG}_env_step_host_profile.txt 2>&1; head -12 $OUT/${TAG}_env_step_host_profile.txt
-if [[ " $* " != *" quick "* ]]; then
+if [[ " $* " != *" quick "* && " $* " != *" no-shard-counters "* ]]; then
 # counters of the latency-regime shards and the one-launch balance step (next-round items 2 and 3)
 ACTIONS=zero RATED=step_kernel_spec_multi:env bash scripts/gpu_counters.sh ${TAG}_navigation8192_env_step 1480 30000 8192 -- python $S/bench_bound.py navigation 8192 > /dev/null 2>&1
 FORCES=random RATED=step_kernel_compact:physics bash scripts/gpu_counters.sh ${TAG}_football16384_physics_compact 948 11900 16384 -- python $S/bench_world.py football 16384 300 > /dev/null 2>&1
