@@ -200,9 +200,16 @@ int vmas_world_load_spec(VmasWorld* w, const char* code_object_path);
 
 /* The lane-compacted step kernel (csrc/vmas_compact.h) for worlds whose pairs are all sphere-sphere or line-sphere and
  * that have no joints: broad phase per (environment, pair) with every lane busy, narrow phase over the tile's CONTACTS
- * packed across environments and pairs, results added by the owners in the reference's order (core.py:2176-2199) - bit
- * for bit the results of the other kernels.  mode -1 (default): used when the world is dense (>= 64 pairs: football), 0:
- * never, 1: whenever the world qualifies.  vmas_world_get_compact: 1 if plain steps of this world run it. */
+ * packed across environments and pairs, results added by the owners in the reference's order (core.py:2176-2199).  Its
+ * results are bit for bit those of the other kernels wherever an entity has at most two simultaneous contacts; with three
+ * or more they can differ from the interpreter's in the last bit of the summed force (the interpreter adds an entity's
+ * contacts segment by segment, this kernel term by term in the reference's pair order; both are within the 1e-5 contract
+ * of the reference - tests/test_compact_gpu.py pins each against the oracle on dense-contact states).
+ * mode -1 (default): used when the world is dense (>= 64 pairs: football) - and left for the interpreter while the
+ * measured contact density says the interpreter is faster, a choice that depends on the states alone (reruns repeat it
+ * bit for bit, but a rollout can switch kernels in its course: pin one with 0 / 1 where bitwise equality between runs
+ * of DIFFERENT protocols matters); 0: never, 1: whenever the world qualifies.  vmas_world_get_compact: 1 if plain steps
+ * of this world run it. */
 int vmas_world_set_compact(VmasWorld* w, int32_t mode);
 int vmas_world_get_compact(VmasWorld* w);
 

@@ -217,11 +217,15 @@ class StepRecorder:
         )
 
 
-def rollout_env(name, scenario, B, steps, every, start=0, seed=0, toward=None, **kw):
+def rollout_env(name, scenario, B, steps, every, start=0, seed=0, toward=None, tweak=None, **kw):
     """Seeded random actions; with ``toward=<entity name>`` the first two action
-    components are biased toward that entity so that contacts actually happen."""
+    components are biased toward that entity so that contacts actually happen.  ``tweak(env)``: static attributes of
+    the scenario's own world set through the reference's attributes before the rollout (features no in-tree scenario
+    switches on: angular friction, force / torque limits)."""
     torch.manual_seed(seed)
     env = vmas.make_env(scenario, num_envs=B, device="cpu", seed=seed, continuous_actions=True, **kw)
+    if tweak is not None:
+        tweak(env)
     rec = StepRecorder(env.world, every=every, start=start)
     g = torch.Generator().manual_seed(1234)
     ents = {e.name: e for e in env.world.entities}
@@ -351,7 +355,33 @@ def rollout_band(name, B=4, seed=3):
     rec.save(name)
 
 
+def _tweak_angular_friction(env):
+    """`wheel` (agents pushing a heavy rotatable line, wheel.py:24-49) with the world's angular friction on
+    (core.py:2089-2102: no in-tree scenario sets it) and a stronger linear one on the agents."""
+    env.world._angular_friction = 0.02
+    env.world._linear_friction = 0.01
+    for e in env.world.entities:
+        if e.name == "line":
+            e._angular_friction = 0.05  # (the entity's own coefficient takes precedence, core.py:2089)
+
+
+def _tweak_force_torque_limits(env):
+    """`diff_drive` (debug scenario: rotating agents driven through force AND torque, dynamics/diff_drive.py) with the
+    agents' max_f / f_range / max_t / t_range set (core.py:2018-2041: no in-tree scenario sets any of them), low
+    enough that the clamps bind on a good part of the steps."""
+    for i, a in enumerate(env.world.agents):
+        a._max_f = 0.6 + 0.2 * i
+        a._f_range = 0.5
+        a._max_t = 0.004
+        a._t_range = 0.003 + 0.002 * i
+
+
 FIXTURES = {
+    # in-tree scenarios with the features none of them switches on (set on the scenario's own world) ------------
+    "wheel_angular_friction": lambda: rollout_env("wheel_angular_friction", "wheel", 8, 80, 5, toward="line",
+                                                  tweak=_tweak_angular_friction),
+    "diff_drive_force_torque_limits": lambda: rollout_env("diff_drive_force_torque_limits", "diff_drive", 8, 60, 4,
+                                                          tweak=_tweak_force_torque_limits),
     # the batch-global broad phase decides (exact-mode semantics pinned; fails without it) ---
     "band_4env": lambda: rollout_band("band_4env"),
     # the five BASELINE.json configs (small batch versions) ------------------

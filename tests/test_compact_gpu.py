@@ -226,3 +226,70 @@ def test_the_library_leaves_the_compacted_kernel_when_its_contact_lists_overflow
     got = envs[0].world._state[:nE, :, :B].cpu().numpy()
     err = np.abs(got - s0)
     assert (err <= 1e-5 + 1e-5 * np.abs(s0)).all(), f"max err {err.max():.3g}"
+
+
+def _contacts_per_entity(spec, state, B):
+    """[E, B] how many of an entity's pairs are in contact (within the distance below which the penalty force is non-zero,
+    core.py:2836) - sphere-sphere and line-sphere pairs, the worlds this kernel serves."""
+    E = spec.entities
+    pos = state[:, 0:2, :B]
+    rot = state[:, 4, :B]
+    n = np.zeros((len(E), B), np.int32)
+    LMD = 4.0 / 600.0
+    for p in spec.pairs:
+        a, b = p.a, p.b
+        if p.type == 0:
+            d = np.hypot(pos[a, 0] - pos[b, 0], pos[a, 1] - pos[b, 1]) - (E[a].radius + E[b].radius)
+        else:  # a = line, b = sphere: distance of the centre to the segment
+            c, s_ = np.cos(rot[a]), np.sin(rot[a])
+            dx, dy = pos[b, 0] - pos[a, 0], pos[b, 1] - pos[a, 1]
+            t = np.clip(dx * c + dy * s_, -E[a].length / 2, E[a].length / 2)
+            d = np.hypot(dx - t * c, dy - t * s_) - (E[b].radius + LMD)
+        hit = d < 0
+        n[a] += hit
+        n[b] += hit
+    return n
+
+
+@pytest.mark.parametrize("mode", [1, 0], ids=["compacted", "interpreter"])
+def test_each_football_kernel_holds_the_contract_against_the_oracle_in_dense_contact(mode):
+    """The two football kernels are not bitwise equal to each other where an entity has three or more simultaneous contacts
+    (include/vmas_hip.h, vmas_world_set_compact) - so EACH is pinned against the oracle there: 4096 environments driven
+    into the walls by one held action for 600 steps (bodies stacked against walls and each other), then one step of the
+    pinned kernel against the oracle's step of the same state, every environment, |err| <= 1e-5 (abs + rel) with NO
+    sensitivity allowance."""
+    from oracle.oracle import Oracle
+    from vectorizedmultiagentsimulator_amd.environment import make_env
+
+    kw = dict(n_blue_agents=5, n_red_agents=5, ai_red_agents=False)
+    B = 4096
+    env = make_env("football", num_envs=B, device="cuda:0", seed=4, validate_actions=False, **kw)
+    acts = [env.get_random_action(a) for a in env.agents]
+    for _ in range(20):
+        env.step([a.clone() for a in acts])
+    be = env.world._get_backend()
+    be.set_compact(0)  # (the approach to the dense state on ONE kernel, whichever is under test afterwards)
+    be.step_n(600)     # the last action held
+    spec = env.world.spec
+    nE, nA = spec.n_entities, spec.n_agents
+    worst = 0.0
+    for rep in range(3):  # three consecutive steps, each teacher-forced from the device state
+        s0 = env.world._state[:nE, :, :B].cpu().numpy().copy()
+        f0 = env.world._agent_ft[:nA, :, :B].cpu().numpy().copy()
+        if rep == 0:
+            cnt = _contacts_per_entity(spec, s0, B)
+            dense_envs = int((cnt.max(axis=0) >= 3).sum())
+            print(f"dense-contact state: {dense_envs} of {B} environments have an entity with >= 3 contacts, max {int(cnt.max())}")
+            assert dense_envs >= B // 20, f"only {dense_envs} environments reached three simultaneous contacts on one entity"
+        want = s0.copy()
+        Oracle(spec).step(want, f0.copy(), threads=16)
+        be.set_compact(mode)
+        assert be.compact == bool(mode)
+        be.step()
+        got = env.world._state[:nE, :, :B].cpu().numpy()
+        assert np.isfinite(got).all()
+        err = np.abs(got - want)
+        worst = max(worst, float(err.max()))
+        bad = err > 1e-5 + 1e-5 * np.abs(want)
+        assert not bad.any(), f"step {rep}: {int(bad.sum())} values beyond 1e-5 (max err {err.max():.3g})"
+    print(f"max |{'compacted' if mode else 'interpreter'} - oracle| over three dense-contact steps: {worst:.3g}")

@@ -66,6 +66,28 @@ def _worker(rank, world, port, num_envs, q):
         got = torch.stack([full[k][peer.lo:peer.hi].double().sum() for k in ("obs", "rew", "done")])
         ok &= torch.allclose(got, sums[1 - rank], rtol=1e-12, atol=1e-9)
         ok &= torch.isfinite(full["obs"]).all().item()
+        # the fast path: K steps in ONE launch (Environment.rollout) storing straight into the buffer the gather sends
+        from vectorizedmultiagentsimulator_amd.rollout import collect_native
+
+        K = 6
+        acts = [(torch.rand(K, sh.local_envs, 2, device=dev, generator=g) * 2 - 1) * 0.8 for _ in env.agents]
+        snap = env.get_state()
+        want = env.rollout([a.clone() for a in acts])
+        want = {k: v.clone() for k, v in want.items()}
+        env.set_state(snap)
+        nr = collect_native(env, acts, sh)
+        gn = nr.gather()
+        torch.cuda.synchronize()
+        for k in ("obs", "rew", "done", "pos_rew"):
+            mine_k = gn[k][rank]
+            ok &= torch.equal(mine_k, want[k])
+        flat = nr.env_major(gn, "obs")
+        ok &= flat.shape == (K, 4, num_envs, 16) and torch.equal(flat[:, :, sh.lo:sh.hi], want["obs"])
+        mine = torch.stack([want[k].double().sum() for k in ("obs", "rew")])
+        sums = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(sums, mine)
+        got = torch.stack([gn[k][1 - rank].double().sum() for k in ("obs", "rew")])
+        ok &= torch.allclose(got, sums[1 - rank], rtol=1e-12, atol=1e-9)
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
@@ -101,3 +123,17 @@ def test_bench_two_gpus_end_to_end():
     assert set(d["rollout_gather"]) == {"balance_cfg2", "navigation_cfg4", "football_cfg5"}
     assert all(v["collectives_per_chunk"] == 1 and v["GBps_received_per_gpu"] > 0 for v in d["rollout_gather"].values())
     assert d["value"] > 1e9
+    sr = d["sharded_rollout"]
+    assert sr["ranks_in_result"] == 2 and len(sr["per_rank_rollout_us_per_step"]) == 2 and sr["GBps_received_per_gpu"] > 0
+
+
+def test_bench_two_gpus_strong_scaling_config():
+    """`--config navigation --gpus 2`: BASELINE config 4 sharded (strong scaling: 65 536 environments in all)."""
+    _need_two()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "navigation", "--steps", "50",
+                          "--warmup", "10", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["global_envs"] == 65536
+    assert d["config"]["num_envs_per_gpu"] == 32768 and len(d["per_rank_us_per_step"]) == 2

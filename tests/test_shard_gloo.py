@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from vectorizedmultiagentsimulator_amd.shard import EnvShard, PackedRollout, RolloutGather, max_over_ranks, shard_range
+from vectorizedmultiagentsimulator_amd.shard import EnvShard, NativeRollout, PackedRollout, RolloutGather, max_over_ranks, shard_range
 
 
 def test_shard_ranges_partition_the_batch():
@@ -64,6 +64,30 @@ def _worker(rank, world, port, num_envs, q):
         ok &= torch.equal(g["done"].movedim(0, 1) > 0.5, (genv[None, :] + t[:, None]) % 3 == 0)
         if num_envs % world == 0:  # equal shards: the results are views of the gathered buffer (no copy behind the collective)
             ok &= g["obs"].untyped_storage().data_ptr() == pr._full.untyped_storage().data_ptr()
+        # the native form: the layout the K-step rollout kernel writes ([K, A, b, D] ...), one byte buffer per rank, ONE
+        # collective; the gathered tensors carry the rank as a leading axis (rank order IS environment order)
+        b = sh.local_envs
+        fields = [("obs", (T, A, b, D), torch.float32), ("rew", (T, A, b), torch.float32), ("done", (T, b), torch.bool),
+                  ("pos_rew", (T, b), torch.float32)]
+        nr = NativeRollout(sh, fields, "cpu")
+        nr.fields["obs"].copy_(obs.movedim(1, 2)); nr.fields["rew"].copy_(rew.movedim(1, 2)); nr.fields["done"].copy_(done)
+        nr.fields["pos_rew"].copy_(rew[:, :, 0])
+        calls = []
+        dist.all_gather_into_tensor = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        try:
+            gn = nr.gather()
+        finally:
+            dist.all_gather_into_tensor = orig
+        ok &= len(calls) == 1
+        ok &= torch.equal(nr.env_major(gn, "obs"), want_obs.movedim(1, 2)) and nr.env_major(gn, "obs").shape == (T, A, num_envs, D)
+        ok &= torch.equal(nr.env_major(gn, "rew"), (t[:, None, None] - genv[None, :, None] + torch.arange(A)[None, None, :]).movedim(1, 2))
+        ok &= torch.equal(nr.env_major(gn, "done"), (genv[None, :] + t[:, None]) % 3 == 0) and nr.env_major(gn, "done").dtype == torch.bool
+        ok &= torch.equal(nr.env_major(gn, "pos_rew"), t[:, None] - genv[None, :])
+        if num_envs % world == 0:  # equal shards: [R, *shape] views of the gathered buffer
+            ok &= gn["obs"].shape == (world, T, A, b, D) and gn["obs"].untyped_storage().data_ptr() == nr._full.untyped_storage().data_ptr()
+            ok &= torch.equal(gn["obs"][rank], nr.fields["obs"])
+        else:
+            ok &= isinstance(gn["obs"], list) and [x.shape[2] for x in gn["obs"]] == [shard_range(num_envs, r, world)[1] - shard_range(num_envs, r, world)[0] for r in range(world)]
         slowest = max_over_ranks(float(rank + 1), "cpu")
         ok &= slowest == float(world)
         q.put((rank, bool(ok), sh.seed(0)))
