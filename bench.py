@@ -441,7 +441,7 @@ def attached_reference_leg(name, kw, B, device, n=300):
         "env_step_us": (t4 - t3) / m * 1e6, "steps": n, "env_steps": m, "envs": B,
         "kernel": "world-specialised (from the on-disk cache)" if h.backend.specialized else "schedule interpreter",
         "exact_broad_phase": bool(h.exact_broad_phase), "refreshes": h.refreshes,
-        "value": B * world.substeps / ((t2 - t0) / n), "unit": "env-steps/s",
+        "value": B * int(getattr(world, "_substeps", 1)) / ((t2 - t0) / n), "unit": "env-steps/s",
         "note": "attach(vmas.make_env(..., device='cuda')): the reference's World.step rebound to vmas_world_step; host enqueue = "
                 "Python time per world.step() call (static-change detection + one foreign call), env_step = the reference's own "
                 "Environment.step (its tensor-op ingest / reward / observation on the GPU) around it",

@@ -39,7 +39,10 @@
 
 namespace compact {
 
-constexpr int CAP = 1024;                 // contact slots per tile and round
+#ifndef VMAS_COMPACT_CAP
+#define VMAS_COMPACT_CAP 1024
+#endif
+constexpr int CAP = VMAS_COMPACT_CAP;     // contact slots per tile and round
 constexpr int OWN_MAX = 4;                // dynamic entities one wave can own
 constexpr int LIST_MAX = 64;              // pairs one entity can be in (its list lives in one register, one entry per lane)
 constexpr int HW_MAX = LIST_MAX / 32;     // 32-bit words of an entity's "pairs with contacts" mask

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(512) void navigation_post_kernel(const VmasNavigati
   auto vel = [&](int a) { return V(rows[(a * 6 + 2) * 64 + C.lane], rows[(a * 6 + 3) * 64 + C.lane]); };
   auto goal = [&](int a) { return V(rows[(a * 6 + 4) * 64 + C.lane], rows[(a * 6 + 5) * 64 + C.lane]); };
 
-  auto rays = [&](int a, int s) {
+  auto rays = [&](int a, int s, int, int) {
     if (s > 0)  // (the wave's first agent had its rays put in the opening burst)
       burst<16>(n_rays, [&](int r) { return o.lidar[((long)a * n_rays + r) * ld + C.e]; },
                 [&](int r, float v) { T.put(4 + 2 * n_goal + r, d.lidar_range - v); });

@@ -539,9 +539,20 @@ VD void navigation_post_body(const TileCtx& C, const VmasNavigationDesc& d, cons
     }
   }
 
+  // With at least twice as many waves as agents (16 waves per tile at the shard sizes where a tile has a CU to itself) the
+  // waves beyond the first A would idle through the observation writer - the longest single piece of the epilogue: wave w
+  // then serves agent w % A and writes every `nparts`-th 512-byte piece of its block (the few columns that are not rays are
+  // recomputed by every part into its own scratch: cheaper than a hand-over between waves); part 0 stores the rewards.
+  const int nparts = (std::is_same<Tile, ObsGather>::value && C.nw >= 2 * A) ? C.nw / A : 1;
 #pragma unroll
   for (int s = 0; s < kNavMaxOwn; ++s) {
-    const int a = C.wave + s * C.nw;
+    int a = C.wave + s * C.nw, part = 0;
+    if (nparts > 1) {
+      if (s > 0) break;
+      a = C.wave % A;
+      part = C.wave / A;
+      if (part >= nparts) break;
+    }
     if (a >= A) break;
     const v2 p = pos(a);
     // pairwise penalties navigation.py:218-229: a pair counts only if World.collides(a, b) holds
@@ -555,7 +566,7 @@ VD void navigation_post_body(const TileCtx& C, const VmasNavigationDesc& d, cons
         if (distance <= d.min_collision_distance) col += d.agent_collision_penalty;
       }
     }
-    if (C.live) {
+    if (C.live && part == 0) {
       const float partial = (d.shared_rew ? pos_rew : my_pos_rew[s]) + final_rew;
       if (!FUSED || !d.collisions) {
         o.collision_rew[(long)a * batch + C.env] = col;
@@ -571,7 +582,7 @@ VD void navigation_post_body(const TileCtx& C, const VmasNavigationDesc& d, cons
     } else {
       T.put(4, p - goal(a));
     }
-    rays(a, s);
+    rays(a, s, part, nparts);
     if constexpr (std::is_same<Tile, ObsTile>::value) T.flush(o.obs + ((long)a * batch + C.b0) * T.dim, C.n_rows);
   }
 }
@@ -838,7 +849,7 @@ VD void navigation_post_tile(const TileCtx& C, const VmasNavigationDesc& d, cons
   stamp(9);
   // agent a's 64 x D block of the observation matrix (navigation.py:244-263) as one contiguous run: every lane gathers two
   // consecutive elements (one if D is odd) - the columns the body just put into `own`, the rays from `measured`
-  auto rays = [&](int a, int) {
+  auto rays = [&](int a, int, int part, int nparts) {
     wave_lds_fence();
     float* out = o.obs + ((long)a * batch + C.b0) * D;
     const int total = C.n_rows * D;
@@ -849,12 +860,12 @@ VD void navigation_post_tile(const TileCtx& C, const VmasNavigationDesc& d, cons
       return src[env];
     };
     if ((D & 1) == 0) {  // (every block starts 8-byte aligned: 64 * D * 4 bytes per tile, batch * D * 4 per agent)
-      for (int i = 2 * C.lane; i < total; i += 128) {
+      for (int i = 2 * C.lane + 128 * part; i < total; i += 128 * nparts) {
         const int env = (int)(((float)i + 0.5f) * inv_d), k = i - env * D;
         *(float2*)(out + i) = make_float2(elem(env, k), elem(env, k + 1));
       }
     } else {
-      for (int i = C.lane; i < total; i += 64) {
+      for (int i = C.lane + 64 * part; i < total; i += 64 * nparts) {
         const int env = (int)(((float)i + 0.5f) * inv_d);
         out[i] = elem(env, i - env * D);
       }

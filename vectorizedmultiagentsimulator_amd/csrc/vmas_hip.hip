@@ -2437,7 +2437,7 @@ int vmas_world_step_env_check(VmasWorld* w, int32_t post_kind, const void* post_
   if (nav_epilogue_plan(w, d, &fixed, &per_wave)) return -1;
   Sched* S;
   if (get_sched(w, w->lanes, &S)) return -1;
-  if (env_extra_lds(w, &S, fixed, per_wave, d->n_agents, &extra)) return -1;
+  if (env_extra_lds(w, &S, fixed, per_wave, 1 << 20, &extra)) return -1;  // (every wave has its columns: see navigation_post_body)
   if (d->n_agents > kNavMaxOwn * S->nw)
     return fail("vmas_world_step_env: %d agents on %d waves per tile (at most %d agents per wave)", d->n_agents, S->nw, kNavMaxOwn);
   return 0;
@@ -2542,7 +2542,7 @@ static int step_env_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld
                   "(World.collides): several steps per launch need every tile resident at once (%d tiles, %d CUs) and a stream "
                   "that is not being captured", blocks_of(w->batch), w->n_cu);
     if (step_impl(w, state, agent_ft, ld, args, stream, n_steps, 0, &env, ENV_NAVIGATION, nav_fixed, nav_per_wave, 0, -1,
-                  d->n_agents))
+                  1 << 20))  // (the per-wave columns for EVERY wave: with >= 2 waves per agent they share its block's writing)
       return -1;
     if (grid_sync) w->nav_seq += (uint32_t)n_steps;  // (only a launch that was made has arrived at its barriers)
     if (d->collisions && !grid_sync) {

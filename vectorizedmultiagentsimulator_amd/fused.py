@@ -427,7 +427,9 @@ class _OutSet:
         self.rc0 = _rcs(self.tensors)
 
     def free(self) -> bool:
-        return _use_count is not None and _use_count(self.cdata) == self.uc0 and _rcs(self.tensors) == self.rc0
+        if _use_count is None or _use_count(self.cdata) != self.uc0:
+            return False
+        return _rcs(self.tensors) == self.rc0
 
 
 class _Post:
@@ -446,7 +448,6 @@ class _Post:
         self.static_outputs = False
         self._static_set = None
         self._pool: List[_OutSet] = []
-        self._next = 0
 
     def persistent_tensors(self) -> List[Tensor]:
         """Scenario tensors the kernel reads AND writes (shaping terms ...)."""
@@ -494,16 +495,13 @@ class _Post:
                 self._static_set = self._make(False)
             return self._static_set
         pool = self._pool
-        n = len(pool)
-        for k in range(n):
-            st = pool[(self._next + k) % n]
-            if st.free():
-                self._next = (self._next + k + 1) % n
+        for st in pool:  # (always from the front: a caller that keeps one step's results alternates between the first two
+            if st.free():  #  sets however large the pool once grew - the working set stays small and warm in the caches)
                 return st
         st = self._make(True)
+        n = len(pool)
         if n < self.POOL_MAX_SETS and (n + 1) * st.nbytes <= self.POOL_MAX_BYTES and _use_count is not None:
             pool.append(st)
-            self._next = 0
         return st  # (beyond the pool's size the set is simply the caller's: one allocation per step, as before)
 
     def _state(self):
