@@ -12,7 +12,8 @@ step   : ONE World.step() (core.py:1972-2015) over the whole batch = one fused k
          fresh output tensors every step) - with its own roofline, the GPU-bound form (`bound`: caller-owned action tensors,
          one foreign call per step) and the K-steps-per-launch form (`rollout`) beside it.
 timing : W warm-up steps, then exactly K steps between barrier+synchronize pairs; HIP events recorded on the launch stream
-         right inside the two fences bracket the same K launches.  `ms_per_step` and `value` come from the events (MAX over
+         right inside the two fences bracket the same K launches (behind a ~100 us untimed spin kernel that lets the host
+         queue them up: the events time K back-to-back steps, not the host's first-launch latency on an idle GPU).  `ms_per_step` and `value` come from the events (MAX over
          ranks): with K = 20 the wall clock around a 0.2 ms region is mostly the cost of the fences themselves; the
          wall-clock figures are kept beside them (`wall`).  The window is timed `--repeats` times; `value` = the median.
 inputs : SURVEY.md 8d's protocol - per step and policy agent u ~ U(-u_range, u_range), pre-generated on the host with
@@ -81,6 +82,9 @@ def parse_args():
     ap.add_argument("--weak", action="store_true", help="every GPU steps the configuration's batch (default for balance / transport)")
     ap.add_argument("--clock-warmup", type=float, default=0.25,
                     help="seconds of untimed launches before the W warm-up steps (the GPU's clocks ramp up: see bench.py)")
+    ap.add_argument("--gate-us", type=float, default=100.0,
+                    help="untimed spin kernel in front of every timed window (microseconds; 0 = none): the K launches are "
+                         "queued behind it, so the HIP events hold K back-to-back steps and not the host's first-launch latency")
     ap.add_argument("--repeats", type=int, default=5,
                     help="the K-step window is timed this many times (each between its own fences); `value` = the median window")
     ap.add_argument("--num-envs", type=int, default=0, help="environments PER GPU (0 = the configuration's)")
@@ -494,11 +498,33 @@ def measure(name, args, device, shard, dist, rank, world_size, brief=False):
             dist.barrier()
         torch.cuda.synchronize()
 
+    gate_cycles = 0
+    if args.gate_us > 0:  # calibrate torch's spin kernel (its unit differs between builds) to ~gate_us microseconds
+        try:
+            torch.cuda._sleep(1000)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            torch.cuda._sleep(100000)
+            e1.record()
+            torch.cuda.synchronize()
+            per_cycle_us = max(e0.elapsed_time(e1) * 1e3 / 100000, 1e-6)
+            gate_cycles = max(1, int(args.gate_us / per_cycle_us))
+        except Exception:  # noqa: BLE001 (no spin kernel in this build: the events then include the first launch's latency)
+            gate_cycles = 0
+
     def timed(fn, n):
-        """K steps between fences: (HIP-event seconds, wall seconds), each MAX over ranks, and this rank's own events."""
+        """K steps between fences: (HIP-event seconds, wall seconds), each MAX over ranks, and this rank's own events.
+        Behind the opening fence the stream is first held by a short spin kernel (`gate`, ~100 us, untimed): the host
+        enqueues the start event and the first launches while it spins, so the HIP events bracket K steps that run back
+        to back - without it the events also contain the host's latency between recording the start event on an idle
+        GPU and getting the first launch to it (~9 us: 0.45 us per step at the driver's K = 20, nothing at K = 10000).
+        The wall clock (`wall`) keeps everything."""
         fence()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
+        if gate_cycles:
+            torch.cuda._sleep(gate_cycles)
         ev0.record(stream)
         fn(n)
         ev1.record(stream)
@@ -760,7 +786,7 @@ def main():
             "n_gpus": world_size,
             "ranks_seen": ranks_seen,
             "steps": steps,
-            "warmup": r["warmup"], "clock_warmup_s": args.clock_warmup,
+            "warmup": r["warmup"], "clock_warmup_s": args.clock_warmup, "gate_us": args.gate_us,
             "ms_per_step": kernel_s * 1e3,
             "repeats": {"windows": len(windows), "steps_per_window": steps,
                         "ms_per_step_min": min(w_[0] for w_ in windows) / steps * 1e3,

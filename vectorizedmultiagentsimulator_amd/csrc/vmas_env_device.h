@@ -674,28 +674,27 @@ VD void navigation_post_tile(const TileCtx& C, const VmasNavigationDesc& d, cons
   const ObsGather T{own_cols + C.lane, D};
   if (d.collisions) {  // World.collides' reduction over the batch (core.py:2797-2801), this tile's share: into LDS words
                        // now, into the world's mask by one lane of the tile behind the LIDAR barrier
+    uint32_t seen = 0u;
     for (int k = C.wave; k < nav.n_pairs; k += C.nw) {
       const DevMaskPair P = st_pairs[k];
       const float* sa = col + P.a * 6 * 64;
       const float* sb = col + P.b * 6 * 64;
       const bool hit = C.live && norm2(sa[0] - sb[0], sa[64] - sb[64]) <= P.bound_sum;
-      if (__any(hit) && C.lane == 0) atomicOr((uint32_t*)&misc[1 + (k >> 5)], 1u << (k & 31));
-    }
-    if (grid_sync) {  // publish and arrive now, wait behind the LIDAR units: ONE thread does both, so that the arrival
-                      // is ordered behind the bits without a second block barrier
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        uint32_t seen = 0u;
-        for (int w_ = 0; w_ < words; ++w_) {
-          const uint32_t b = (uint32_t)misc[1 + w_];
-          if (b != 0u) seen |= __hip_atomic_fetch_or(slot + w_, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        // (no release fence: at agent scope it writes the XCD's whole L2 back - 5 us of this thread's time, measured.  The
-        //  bits travel in agent-scope atomics only: it is enough that they have been PERFORMED - their old values are
-        //  back - before the arrival is sent)
-        asm volatile("s_waitcnt vmcnt(0)" ::"v"(seen) : "memory");
-        __hip_atomic_fetch_add(nav.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__any(hit) && C.lane == 0) {
+        // grid-barrier form: the bit goes to the launch's mask slot AT ONCE, by the wave that found it - its round trip to
+        // the memory side runs beside the other waves' pairs instead of in front of the tile's arrival (one thread used to
+        // publish the tile's words behind a block barrier: a microsecond on the arrival path of every tile)
+        if (grid_sync) seen |= __hip_atomic_fetch_or(slot + (k >> 5), 1u << (k & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else atomicOr((uint32_t*)&misc[1 + (k >> 5)], 1u << (k & 31));
       }
+    }
+    if (grid_sync) {  // arrive now, wait behind the LIDAR units.  (No release fence: at agent scope it writes the XCD's
+                      // whole L2 back - 5 us, measured.  The bits travel in agent-scope atomics only: it is enough that every
+                      // wave's have been PERFORMED - their old values are back - before the block barrier behind which ONE
+                      // thread sends the tile's arrival)
+      asm volatile("s_waitcnt vmcnt(0)" ::"v"(seen) : "memory");
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_fetch_add(nav.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   stamp(7);
