@@ -40,7 +40,7 @@
 namespace compact {
 
 #ifndef VMAS_COMPACT_CAP
-#define VMAS_COMPACT_CAP 1024
+#define VMAS_COMPACT_CAP 256
 #endif
 constexpr int CAP = VMAS_COMPACT_CAP;     // contact slots per tile and round
 constexpr int OWN_MAX = 4;                // dynamic entities one wave can own
@@ -135,7 +135,10 @@ __global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld
   extern __shared__ float lds[];
   const int lane = threadIdx.x & (TILE - 1);
   const int wv = sgpr(threadIdx.x >> 6);
-  const int nw = args_in.nw;  // (= blockDim.x / 64, from the explicit arguments: see DevStepArgs)
+  // (measured in round 4: the waves per tile as an explicit kernel argument instead of this load from the implicit ones
+  //  changes nothing at 16 384 environments - 16.05 us either way - and tips the register allocation of the football
+  //  forms, 100+ scalar registers spilled to vector lanes, into a scratch frame: the K-step rollout ran 12 x slower)
+  const int nw = sgpr(blockDim.x >> 6);
   const int nA = W.nA;
 #ifdef VMAS_TRACE  // profiling build only (scripts/trace_compact.py): per-wave s_memtime stamps and phase sums
   unsigned long long tr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tr_t = 0;
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld
     const unsigned long long any_mask = P.dyn_mask | P.static_mask;
     const uint4* bsrc = (const uint4*)P.blob;
     uint4* bdst = (uint4*)(lds + P.off_tab);
-    const int n4 = P.blob_words >> 2, nt = nw * TILE;
+    const int n4 = P.blob_words >> 2, nt = blockDim.x;
     for (int e0 = wv; e0 < W.nE || e0 == wv; e0 += LB * nw) {
       float v[LB][6];
       float4 tc[LB];
@@ -296,9 +299,9 @@ __global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld
     }
     for (int i = (int)threadIdx.x + 2 * nt; i < n4; i += nt) bdst[i] = bsrc[i];  // (blobs beyond 32 bytes per thread)
     const int n_zero = 4 + P.n_owned * P.hw;
-    for (int i = threadIdx.x; i < n_zero; i += nw * TILE) dyn[i] = 0u;
+    for (int i = threadIdx.x; i < n_zero; i += blockDim.x) dyn[i] = 0u;
     if (args.sync != nullptr)
-      for (int i = threadIdx.x; i < P.mask_words; i += nw * TILE) xmask[i] = 0u;
+      for (int i = threadIdx.x; i < P.mask_words; i += blockDim.x) xmask[i] = 0u;
   }
   [[maybe_unused]] float fb_prev[4] = {0.f, 0.f, 0.f, 0.f};
   [[maybe_unused]] float post_steps = 0.f;
@@ -585,7 +588,7 @@ __global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld
       if (rounds) {
         __syncthreads();  // (every wave has read the count)
         if (threadIdx.x == 0) cnt[0] = 0u;
-        for (int i = threadIdx.x; i < P.n_owned * P.hw; i += nw * TILE) hit[i] = 0u;
+        for (int i = threadIdx.x; i < P.n_owned * P.hw; i += blockDim.x) hit[i] = 0u;
         broad_phase(true);  // every pair's mask, zeros included (the first pass stored those with contacts only)
         __syncthreads();
         hi = 0;
@@ -753,7 +756,7 @@ __global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld
           const int in_dead = (int)((const float*)xmask - (const float*)ballots) / kSlab;
           slab = wv < in_dead ? (float*)ballots + wv * kSlab : lds + E.scratch_off + (wv - in_dead) * kSlab;
         }
-        football_post_tile(TileCtx(batch, nw), E.football.d, E.football.o, batch,
+        football_post_tile(TileCtx(batch), E.football.d, E.football.o, batch,
                            [&](int slot, int k) { return k < 4 ? rows[(slot * 6 + k) * ROWF] : af[(slot * 3 + (k - 4)) * ROWF]; },
                            slab, kFootballStageChunk, fb_prev, post_steps, stp);
       }

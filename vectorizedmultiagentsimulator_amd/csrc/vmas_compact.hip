@@ -58,10 +58,8 @@ static int launch_own(int own, size_t lds, int device, dim3 grid, dim3 block, hi
 }
 
 int vmas_compact_launch(int env_kind, int own, int nw, size_t lds, int device, const DevWorld& W, const compact::DevCompact& P,
-                        float* state, float* agent_ft, long ld, int batch, int padded, const DevStepArgs& args_in, const DevEnv* env,
+                        float* state, float* agent_ft, long ld, int batch, int padded, const DevStepArgs& args, const DevEnv* env,
                         hipStream_t s) {
-  DevStepArgs args = args_in;
-  args.nw = nw;  // (the kernel reads the waves per tile from here, not from blockDim)
   const dim3 grid((batch + TILE - 1) / TILE), block(TILE * nw);
   if (env_kind == ENV_NONE) return launch_own<ENV_NONE>(own, lds, device, grid, block, s, W, P, state, agent_ft, ld, batch, padded, args, NoEnv{});
   if (!env) return vmas::host_fail("vmas_compact_launch: null environment arguments");

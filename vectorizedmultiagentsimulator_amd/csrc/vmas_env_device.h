@@ -594,7 +594,8 @@ struct NavWorld {
   const float2* angles_cs;
   const DevMaskPair* pairs;
   uint32_t* mask;  // [(n_pairs + 31) / 32] words, zero when the launch starts
-  uint32_t* sync;  // grid-barrier form (NULL: off): arrivals | timeout flag | two mask slots (launch parity)
+  uint32_t* sync;  // grid-barrier form (NULL: off): unused | timeout flag | ring of four slots of [pair words][tile groups] 64-bit
+                   // words: arrival bits of the group's tiles (low half) | the OR of their pair bits (high half)
   uint32_t seq;    // this launch's barrier number
   int32_t n_pairs;
   uint32_t* gave_up;  // host-mapped word set when the barrier gives up waiting (read by the host at the world's next call)
@@ -662,7 +663,7 @@ VD void navigation_post_tile(const TileCtx& C, const VmasNavigationDesc& d, cons
   // is stored without the penalties and navigation_collision_kernel, launched behind this kernel, adds them.
   const bool grid_sync = nav.sync != nullptr;
   const uint32_t seq = nav.seq + (uint32_t)stp;  // ring of four mask slots: slot seq + 2 is cleared behind barrier seq
-  uint32_t* slot = grid_sync ? nav.sync + 2 + (seq & 3u) * (uint32_t)words : nav.mask;
+  const int groups = ((int)gridDim.x + 31) >> 5;  // tiles in groups of 32: one arrival bit per tile in a word's low half
   const int R = d.collisions ? A * d.n_rays : 0;
   const float* stage = (const float*)(misc + 2 * VMAS_ENV_MAX_AGENTS) + 2;  // staged by navigation_prologue_tile
   const float2* st_cs = (const float2*)stage;
@@ -674,27 +675,27 @@ VD void navigation_post_tile(const TileCtx& C, const VmasNavigationDesc& d, cons
   const ObsGather T{own_cols + C.lane, D};
   if (d.collisions) {  // World.collides' reduction over the batch (core.py:2797-2801), this tile's share: into LDS words
                        // now, into the world's mask by one lane of the tile behind the LIDAR barrier
-    uint32_t seen = 0u;
     for (int k = C.wave; k < nav.n_pairs; k += C.nw) {
       const DevMaskPair P = st_pairs[k];
       const float* sa = col + P.a * 6 * 64;
       const float* sb = col + P.b * 6 * 64;
       const bool hit = C.live && norm2(sa[0] - sb[0], sa[64] - sb[64]) <= P.bound_sum;
-      if (__any(hit) && C.lane == 0) {
-        // grid-barrier form: the bit goes to the launch's mask slot AT ONCE, by the wave that found it - its round trip to
-        // the memory side runs beside the other waves' pairs instead of in front of the tile's arrival (one thread used to
-        // publish the tile's words behind a block barrier: a microsecond on the arrival path of every tile)
-        if (grid_sync) seen |= __hip_atomic_fetch_or(slot + (k >> 5), 1u << (k & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else atomicOr((uint32_t*)&misc[1 + (k >> 5)], 1u << (k & 31));
-      }
+      if (__any(hit) && C.lane == 0) atomicOr((uint32_t*)&misc[1 + (k >> 5)], 1u << (k & 31));
     }
-    if (grid_sync) {  // arrive now, wait behind the LIDAR units.  (No release fence: at agent scope it writes the XCD's
-                      // whole L2 back - 5 us, measured.  The bits travel in agent-scope atomics only: it is enough that every
-                      // wave's have been PERFORMED - their old values are back - before the block barrier behind which ONE
-                      // thread sends the tile's arrival)
-      asm volatile("s_waitcnt vmcnt(0)" ::"v"(seen) : "memory");
+    if (grid_sync) {
+      // Publish AND arrive with ONE agent-scope atomic per mask word, no reply awaited: word (plane p, tile group g) of this
+      // barrier's slot holds, in its low half, one arrival bit per tile of the group and, in its high half, the OR of those
+      // tiles' pair bits 32 p .. 32 p + 31 - a tile ORs both in with a single 64-bit atomic, so whoever sees a tile's
+      // arrival bit sees its pair bits.  (An agent-scope atomic is a round trip to the memory side, ~2.6 us by this
+      // kernel's own stamps: the earlier form - OR the bits, wait for the reply, then bump an arrival counter - put one
+      // such round trip on every tile's arrival path, and seven more, one per pair word read back, behind the barrier.)
       __syncthreads();
-      if (threadIdx.x == 0) __hip_atomic_fetch_add(nav.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((int)threadIdx.x < words) {
+        const int g = (int)blockIdx.x >> 5;
+        unsigned long long* W64 = (unsigned long long*)(nav.sync + 2) + (size_t)(seq & 3u) * words * groups;
+        const unsigned long long v = ((unsigned long long)(uint32_t)misc[1 + threadIdx.x] << 32) | (1ull << (blockIdx.x & 31));
+        __hip_atomic_fetch_or(W64 + threadIdx.x * groups + g, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
   }
   stamp(7);
@@ -805,32 +806,47 @@ VD void navigation_post_tile(const TileCtx& C, const VmasNavigationDesc& d, cons
     }
     stamp(8);
     if (grid_sync) {
-      if (threadIdx.x == 0) {
-        const uint32_t target = (seq + 1u) * gridDim.x;  // arrivals are never reset: every launch of this world has this grid
+      uint32_t* gmask = (uint32_t*)&misc[1];  // (LDS) the batch's pair words, once every tile has arrived
+      if (C.wave == 0) {
+        // wave 0 polls: lane l reads word l of the slot (words x groups <= 64: host-checked), all lanes in one round trip
+        unsigned long long* W64 = (unsigned long long*)(nav.sync + 2) + (size_t)(seq & 3u) * words * groups;
+        const int n = words * groups;
+        const int g = C.lane % groups;
+        const int in_group = (int)gridDim.x - 32 * g;
+        const uint32_t full = in_group >= 32 ? 0xffffffffu : ((1u << in_group) - 1u);
+        unsigned long long v = 0ull;
         int spins = 0;
-        while ((int32_t)(__hip_atomic_load(nav.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-          __builtin_amdgcn_s_sleep(8);
+        for (;;) {
+          if (C.lane < n) v = __hip_atomic_load(W64 + C.lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (__all(C.lane >= n || ((uint32_t)v & full) == full)) break;
+          __builtin_amdgcn_s_sleep(4);
           if (++spins > (1 << 18)) {  // the grid is not co-resident (it should be): flag it and go on, never hang
-            __hip_atomic_fetch_or(nav.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (nav.gave_up) __hip_atomic_fetch_or(nav.gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (C.lane == 0) {
+              __hip_atomic_fetch_or(nav.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (nav.gave_up) __hip_atomic_fetch_or(nav.gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             break;
           }
         }
-        if (blockIdx.x == 0)  // every tile has arrived at barrier seq, i.e. is done reading the slots up to seq - 1; the one
-                              // of seq - 2 = seq + 2 (mod 4) is cleared here - no tile writes it before it has passed
-                              // barrier seq + 1, which this thread has yet to join
-          for (int w_ = 0; w_ < words; ++w_)
-            __hip_atomic_store(nav.sync + 2 + ((seq + 2u) & 3u) * (uint32_t)words + w_, 0u, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+        // the pair words of the whole batch: OR over the groups of each plane (lane p * groups + g holds plane p, group g)
+        uint32_t hi = C.lane < n ? (uint32_t)(v >> 32) : 0u;
+        for (int off = 1; off < groups; off <<= 1) {
+          const uint32_t o = (uint32_t)__shfl_down((int)hi, off);
+          if ((C.lane % groups) + off < groups) hi |= o;
+        }
+        if (C.lane < n && (C.lane % groups) == 0) gmask[C.lane / groups] = hi;
+        if (blockIdx.x == 0 && C.lane < n)  // every tile has arrived at barrier seq, i.e. is done with the slots up to seq - 1;
+                                            // the one of seq - 2 = seq + 2 (mod 4) is cleared here - no tile writes it before it
+                                            // has passed barrier seq + 1, which this wave has yet to join
+          __hip_atomic_store((unsigned long long*)(nav.sync + 2) + (size_t)((seq + 2u) & 3u) * words * groups + C.lane, 0ull,
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       __syncthreads();
       if ((int)threadIdx.x < A) {  // bit j of collide_with[a]: World.collides(agent a, agent j)
         uint32_t m = 0;
         for (int j = 0; j < A; ++j) {
           const int pi = st_pair_index[threadIdx.x * A + j];
-          if (j != (int)threadIdx.x && pi >= 0 &&
-              ((__hip_atomic_load(slot + (pi >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (pi & 31)) & 1u))
-            m |= 1u << j;
+          if (j != (int)threadIdx.x && pi >= 0 && ((gmask[pi >> 5] >> (pi & 31)) & 1u)) m |= 1u << j;
         }
         collide_with[threadIdx.x] = m;
       }

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
   extern __shared__ float lds[];
   const int lane = threadIdx.x & (TILE - 1);
   const int wv = sgpr(threadIdx.x >> 6);
-  const int nw = args_in.nw;  // (= blockDim.x / 64, from the explicit arguments: see DevStepArgs)
+  const int nw = sgpr(blockDim.x >> 6);
   const int nE = W.nE, nA = W.nA;
   const long env = (long)blockIdx.x * TILE + lane;
   const bool live = PLAIN == 3 || env < batch;  // guards every store and every load from a buffer that is not padded to ld
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
     if (wv == 0) post_steps = (E.transport.o.limit.steps != nullptr && live) ? E.transport.o.limit.steps[env] : 0.f;
   }
   if constexpr (ENV == ENV_NAVIGATION) {
-    const TileCtx C(batch, nw);
+    const TileCtx C(batch);
     navigation_prologue_tile(C, E.navigation.d, E.navigation.o, E.navigation.w, batch, lds + E.scratch_off);  // (published by the load barrier)
     if (wv == 0) post_steps = load_steps(E.navigation.o.limit, C);
   }
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
     const uint4* src = (const uint4*)W.blob;
     uint4* dst = (uint4*)blob;
     const int n4 = W.blob_words >> 2;  // (the host pads the blob to a multiple of four words)
-    const int nt = nw * TILE;
+    const int nt = blockDim.x;
     for (int i0 = threadIdx.x; i0 < n4; i0 += 4 * nt) {
       const int i1 = i0 + nt, i2 = i0 + 2 * nt, i3 = i0 + 3 * nt;
       const uint4 a = src[i0], b = src[i1 < n4 ? i1 : i0], c = src[i2 < n4 ? i2 : i0], d = src[i3 < n4 ? i3 : i0];
@@ -607,13 +607,13 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
 #else
     unsigned long long* nav_tr = nullptr;
 #endif
-    navigation_post_tile(TileCtx(batch, nw), E.navigation.d, E.navigation.o, E.navigation.w, batch, lds, lds + E.scratch_off,
+    navigation_post_tile(TileCtx(batch), E.navigation.d, E.navigation.o, E.navigation.w, batch, lds, lds + E.scratch_off,
                          post_steps, nav_tr, stp, stp + 1 == n_steps);
     if (stp + 1 < n_steps) __syncthreads();  // the next step's prologue rewrites the agent-force rows
   }
   if constexpr (ENV == ENV_BALANCE || ENV == ENV_TRANSPORT) {
     if (stp + 1 == n_steps) __syncthreads();  // (earlier steps: the substep loop ended with a barrier)
-    const TileCtx C(batch, nw);
+    const TileCtx C(batch);
     if constexpr (ENV == ENV_BALANCE)
       if (!(ABLATE(E) & 4))  // profiling (VMAS_ENV_ABLATE): 1 queries off, 2 observations off, 4 epilogue off, 8 prologue off
       {
@@ -1073,7 +1073,7 @@ struct VmasWorld {
   uint32_t* d_nav_mask = nullptr;  // navigation epilogue: World.collides' pair bits of the post-step state: two masks that
   int nav_flip = 0;                //   eager launches alternate between (nav_flip: the one the next launch fills; it is zero)
                                    //   and a third for captured launches
-  uint32_t* d_nav_sync = nullptr;  // its grid-barrier form: arrivals | timeout flag | ring of four mask slots
+  uint32_t* d_nav_sync = nullptr;  // its grid-barrier form: unused | timeout flag | ring of four slots of 64-bit arrival-and-pair-bit words
   uint32_t nav_seq = 0;
   std::vector<DevLidar> h_lidars;  // host copy of the registered sensors (argument checks of the navigation epilogue)
   std::vector<DevTarget> h_targets;
@@ -1627,10 +1627,8 @@ static int launch_spec(VmasWorld* w, Sched* S, float* state, float* aft, long ld
 }
 
 template <int LEVEL, int ENV, class EnvArgs>
-static int launch_level(VmasWorld* w, Sched* S, float* state, float* aft, long ld, const DevStepArgs& a_in,
+static int launch_level(VmasWorld* w, Sched* S, float* state, float* aft, long ld, const DevStepArgs& a,
                         const EnvArgs& env, size_t extra_lds, hipStream_t s, int batch, long pad) {
-  DevStepArgs a = a_in;
-  a.nw = S->nw;  // (the kernels read the waves per tile from here, not from blockDim)
   // `batch` environments starting at `state` / `aft` (a sub-range of the world's batch when the step is split over two
   // queues); `pad` = columns of the planes that exist from there on (ld minus the range's first environment)
   const size_t lds = S->lds_bytes + extra_lds;
@@ -2175,8 +2173,11 @@ int vmas_world_create(const VmasWorldDesc* d, int32_t batch, int32_t device_id, 
     HIP_TRY(hipMalloc((void**)&w->d_exact_mask, (mw ? mw : 1) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void**)&w->d_nav_mask, (3 * mw + 1) * sizeof(uint32_t)));
     HIP_TRY(hipMemset(w->d_nav_mask, 0, (3 * mw + 1) * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void**)&w->d_nav_sync, (2 + 4 * mw) * sizeof(uint32_t)));
-    HIP_TRY(hipMemset(w->d_nav_sync, 0, (2 + 4 * mw) * sizeof(uint32_t)));
+    // navigation epilogue's grid barrier: unused | timeout flag | ring of four slots of [pair words][tile groups of 32] 64-bit
+    // words (arrival bits | pair bits: navigation_post_tile); tile groups for the largest grid that uses it (one tile per CU)
+    const size_t nav_groups = 16;  // (grids of up to 512 tiles: the barrier form is used at one tile per CU at most)
+    HIP_TRY(hipMalloc((void**)&w->d_nav_sync, (2 + 4 * mw * nav_groups * 2 + 2) * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(w->d_nav_sync, 0, (2 + 4 * mw * nav_groups * 2 + 2) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void**)&w->adapt.d_count, sizeof(unsigned long long)));
     HIP_TRY(hipMemset(w->adapt.d_count, 0, sizeof(unsigned long long)));
     HIP_TRY(hipHostMalloc((void**)&w->adapt.h_count, 64, hipHostMallocDefault));
@@ -2528,7 +2529,9 @@ static int step_env_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld
       hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
       if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
       capturing = cap != hipStreamCaptureStatusNone;
-      grid_sync = !capturing && blocks_of(w->batch) <= w->n_cu;
+      // (one wave polls the barrier's words, a lane each: pair words x tile groups <= 64)
+      grid_sync = !capturing && blocks_of(w->batch) <= w->n_cu && blocks_of(w->batch) <= 512 &&
+                  ((w->n_pairs + 31) / 32) * ((blocks_of(w->batch) + 31) / 32) <= 64;
     }
     // the second-kernel form: the tiles OR into one of two masks (zero by now), the collision kernel reads it, and the NEXT
     // eager launch - which fills the other mask - zeroes it.  A captured launch cannot alternate (a replay repeats its

@@ -70,8 +70,6 @@ struct DevStepArgs {
   const float* entity_gravity;
   int32_t first_substep, n_substeps;
   int32_t n_steps;    // > 1: persistent rollout, the tile stays in LDS between steps
-  int32_t nw;         // waves per tile of this launch (= blockDim.x / 64: read from here, the block size is a load from the
-                      // implicit kernel arguments with a wait of its own at the top of the kernel)
   long ft_stride;     // floats between the agent-force slabs of consecutive steps
   unsigned long long* contacts;  // compacted kernel: device counter, + the contacts of every (tile, substep) (NULL: not counted)
   unsigned long long* trace;  // profiling only (env VMAS_TRACE): per-wave s_memtime stamps
