@@ -378,7 +378,6 @@ __global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld
       if (args.sync != nullptr) {
         // World.collides' batch-global rule (core.py:2797-2801) for this substep by the whole grid: see step_kernel
         const uint32_t seq = args.seq0 + (uint32_t)it;
-        uint32_t* slot = args.sync + 4 + (seq & 3u) * (uint32_t)args.mask_words;
         for (int p = wv; p < nP; p += nw) {  // (descriptors from the LDS tables, not from global memory)
           const uint32_t q = (uint32_t)sgpr((int)tab[P.t_pairs + p * PAIR_W]);
           const float* A = tile + (int)(q & 0xffffu);
@@ -387,36 +386,19 @@ __global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld
           if (__any(h) && lane == 0) atomicOr(&xmask[p >> 5], 1u << (p & 31));
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-          uint32_t seen = 0u;
-          for (int w_ = 0; w_ < args.mask_words; ++w_) {
-            const uint32_t b = xmask[w_];
-            if (b != 0u) seen |= __hip_atomic_fetch_or(slot + w_, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            xmask[w_] = 0u;
-          }
-          const uint32_t target = (seq + 1u) * gridDim.x;
-          // (no release fence: at agent scope it writes the XCD's whole L2 back - microseconds.  The tile's bits travel in
-          //  agent-scope atomics only, so it is enough that they have been PERFORMED - their old values are back - before
-          //  the arrival is sent)
-          asm volatile("s_waitcnt vmcnt(0)" ::"v"(seen) : "memory");
-          __hip_atomic_fetch_add(args.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          int spins = 0;
-          while ((int32_t)(__hip_atomic_load(args.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-            __builtin_amdgcn_s_sleep(8);
-            if (++spins > (1 << 18)) {
-              __hip_atomic_fetch_or(args.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              if (args.gave_up) __hip_atomic_fetch_or(args.gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-              break;
-            }
-          }
-          if (blockIdx.x == 0) {
-            uint32_t* nxt = args.sync + 4 + ((seq + 2u) & 3u) * (uint32_t)args.mask_words;
-            for (int w_ = 0; w_ < args.mask_words; ++w_)
-              __hip_atomic_store(nxt + w_, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
+        {  // one atomic per pair word = this tile's arrival + its bits; wave 0 collects the batch's words into LDS
+          const int groups = ((int)gridDim.x + 31) >> 5;
+          unsigned long long* base = (unsigned long long*)(args.sync + 4);
+          const size_t stride = (size_t)args.mask_words * groups;
+          uint32_t* gmask = xmask + ((P.mask_words + 3) & ~3);
+          grid_bits_publish(base + (seq & 3u) * stride, args.mask_words, xmask);
+          if ((int)threadIdx.x < args.mask_words) xmask[threadIdx.x] = 0u;  // (re-armed for the next substep by the thread that published it)
+          if (wv == 0)
+            grid_bits_collect(base + (seq & 3u) * stride, base + ((seq + 2u) & 3u) * stride, args.mask_words, gmask, args.sync + 1,
+                              args.gave_up);
+          __syncthreads();
+          pmask = gmask;  // (LDS)
         }
-        __syncthreads();
-        pmask = slot;
       }
 
       // ---- the owners' running sums (registers: they survive the rounds of an overflowing tile)

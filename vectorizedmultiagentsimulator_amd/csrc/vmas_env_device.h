@@ -503,11 +503,14 @@ struct ObsGather {
   VD void put(int k, v2 v) const { own[k * kNavMeasuredStride] = v.x; own[(k + 1) * kNavMeasuredStride] = v.y; }
 };
 
-template <bool FUSED, class Tile, class Pos, class Vel, class Goal, class Rays>
+struct NavNoMid { VD void operator()() const {} };
+template <bool FUSED, class Tile, class Pos, class Vel, class Goal, class Rays, class Mid = NavNoMid>
 VD void navigation_post_body(const TileCtx& C, const VmasNavigationDesc& d, const VmasNavigationBuffers& o, int batch,
                              const float* per_agent, const uint32_t* collide_with, Tile T, float steps_in,
                              Pos pos, Vel vel, Goal goal, Rays rays /* (agent, slot): its LIDAR part into T */,
-                             float* new_shaping = nullptr /* [kNavMaxOwn] out: the shaping of this wave's agents */) {
+                             float* new_shaping = nullptr /* [kNavMaxOwn] out: the shaping of this wave's agents */,
+                             Mid mid = Mid() /* runs between the observations and the collision penalties: the fused
+                                                epilogue collects the batch's World.collides bits there (collide_with) */) {
   const int A = d.n_agents;
   // agent_reward of every agent (navigation.py:232-242, 206-216), recomputed by every wave: the shared
   // terms need all of them; the wave that owns agent a stores a's terms
@@ -544,18 +547,40 @@ VD void navigation_post_body(const TileCtx& C, const VmasNavigationDesc& d, cons
   // then serves agent w % A and writes every `nparts`-th 512-byte piece of its block (the few columns that are not rays are
   // recomputed by every part into its own scratch: cheaper than a hand-over between waves); part 0 stores the rewards.
   const int nparts = (std::is_same<Tile, ObsGather>::value && C.nw >= 2 * A) ? C.nw / A : 1;
-#pragma unroll
-  for (int s = 0; s < kNavMaxOwn; ++s) {
-    int a = C.wave + s * C.nw, part = 0;
+  auto mine = [&](int s, int& a, int& part) {  // this wave's s-th agent (and which part of its block): false = no more
+    a = C.wave + s * C.nw;
+    part = 0;
     if (nparts > 1) {
-      if (s > 0) break;
+      if (s > 0) return false;
       a = C.wave % A;
       part = C.wave / A;
-      if (part >= nparts) break;
+      if (part >= nparts) return false;
     }
-    if (a >= A) break;
+    return a < A;
+  };
+  // ---- observations navigation.py:244-263 first: nothing in them depends on the other tiles
+#pragma unroll
+  for (int s = 0; s < kNavMaxOwn; ++s) {
+    int a, part;
+    if (!mine(s, a, part)) break;
     const v2 p = pos(a);
-    // pairwise penalties navigation.py:218-229: a pair counts only if World.collides(a, b) holds
+    T.put(0, p); T.put(2, vel(a));
+    if (d.observe_all_goals) {
+      for (int g = 0; g < A; ++g) T.put(4 + 2 * g, p - goal(g));
+    } else {
+      T.put(4, p - goal(a));
+    }
+    rays(a, s, part, nparts);
+    if constexpr (std::is_same<Tile, ObsTile>::value) T.flush(o.obs + ((long)a * batch + C.b0) * T.dim, C.n_rows);
+  }
+  mid();
+  // ---- pairwise penalties navigation.py:218-229 (a pair counts only if World.collides(a, b) holds) and the rewards
+#pragma unroll
+  for (int s = 0; s < kNavMaxOwn; ++s) {
+    int a, part;
+    if (!mine(s, a, part)) break;
+    if (part != 0) break;
+    const v2 p = pos(a);
     float col = 0.f;
     if (!FUSED && d.collisions) {
       uint32_t m = __builtin_amdgcn_readfirstlane(collide_with[a]);
@@ -566,7 +591,7 @@ VD void navigation_post_body(const TileCtx& C, const VmasNavigationDesc& d, cons
         if (distance <= d.min_collision_distance) col += d.agent_collision_penalty;
       }
     }
-    if (C.live && part == 0) {
+    if (C.live) {
       const float partial = (d.shared_rew ? pos_rew : my_pos_rew[s]) + final_rew;
       if (!FUSED || !d.collisions) {
         o.collision_rew[(long)a * batch + C.env] = col;
@@ -575,17 +600,66 @@ VD void navigation_post_body(const TileCtx& C, const VmasNavigationDesc& d, cons
         o.rew[(long)a * batch + C.env] = partial;  // + its collision penalties: navigation_collision_kernel
       }
     }
-    // observation navigation.py:244-263
-    T.put(0, p); T.put(2, vel(a));
-    if (d.observe_all_goals) {
-      for (int g = 0; g < A; ++g) T.put(4 + 2 * g, p - goal(g));
-    } else {
-      T.put(4, p - goal(a));
-    }
-    rays(a, s, part, nparts);
-    if constexpr (std::is_same<Tile, ObsTile>::value) T.flush(o.obs + ((long)a * batch + C.b0) * T.dim, C.n_rows);
   }
 }
+
+// ---- grid-wide exchange of pair bits (World.collides' batch-global `.any()`, core.py:2797-2801) inside one launch whose
+// tiles are all resident.  `slot`: this barrier's [tile groups][words] 64-bit words, zero when the first tile gets here; a
+// word's low half holds one arrival bit per tile of its group of 32, its high half the OR of those tiles' pair bits.
+//   publish (threads < words, behind a block barrier that completed `bits`): ONE agent-scope atomic OR per word carries the
+//           tile's arrival bit AND its pair bits - whoever sees the arrival sees the bits, and nobody waits for a reply;
+//   collect (wave 0, any time later): lane w polls the `groups` words of pair word w - independent loads, one round trip per
+//           poll - until every tile's arrival bit is there, and leaves the batch's pair word w in bits[w] (LDS).
+// An agent-scope atomic is a round trip to the memory side of ~2.6 us (this library's own stamps): the earlier protocol -
+// OR the bits, wait for the reply, bump an arrival counter, poll it, then read the words back with one atomic load per use
+// - put three to nine of them in a row on every tile's path.  `spin_limit` bounds the wait: a grid that is not co-resident
+// (it should be) is flagged in `flag` / `gave_up` instead of hanging.  Returns false if the wait gave up.
+VD void grid_bits_publish(unsigned long long* slot, int words, const uint32_t* bits) {
+  if ((int)threadIdx.x < words) {
+    const int g = (int)blockIdx.x >> 5;
+    const unsigned long long v = ((unsigned long long)bits[threadIdx.x] << 32) | (1ull << (blockIdx.x & 31));
+    __hip_atomic_fetch_or(slot + (size_t)g * words + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+VD bool grid_bits_collect(const unsigned long long* slot, unsigned long long* clear_slot /* block 0 zeroes it (may be NULL) */,
+                          int words, uint32_t* bits /* LDS out */, uint32_t* flag, uint32_t* gave_up) {
+  const int lane = threadIdx.x & 63;
+  const int groups = ((int)gridDim.x + 31) >> 5;
+  bool ok = true;
+  for (int w0 = 0; w0 < words; w0 += 64) {  // (64 pair words = 2048 pairs per pass)
+    const int w = w0 + lane;
+    uint32_t mask = 0u;
+    int spins = 0;
+    for (;;) {
+      bool arrived = true;
+      mask = 0u;
+      if (w < words)
+        for (int g = 0; g < groups; ++g) {
+          const unsigned long long v = __hip_atomic_load(slot + (size_t)g * words + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const int in_group = (int)gridDim.x - 32 * g;
+          const uint32_t full = in_group >= 32 ? 0xffffffffu : ((1u << in_group) - 1u);
+          arrived = arrived && (((uint32_t)v & full) == full);
+          mask |= (uint32_t)(v >> 32);
+        }
+      if (__all(arrived)) break;
+      __builtin_amdgcn_s_sleep(4);
+      if (++spins > (1 << 18)) {
+        if (lane == 0) {
+          if (flag) __hip_atomic_fetch_or(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (gave_up) __hip_atomic_fetch_or(gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        ok = false;
+        break;
+      }
+    }
+    if (w < words) bits[w] = mask;
+    if (blockIdx.x == 0 && clear_slot != nullptr && w < words)
+      for (int g = 0; g < groups; ++g)
+        __hip_atomic_store(clear_slot + (size_t)g * words + w, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return ok;
+}
+__host__ __device__ inline size_t grid_bits_slot_words64(int words, int max_tiles) { return (size_t)words * ((max_tiles + 31) / 32); }
 
 // What the fused epilogue needs from the world besides the tile: its registered sensors (sensor a = agent a) and its
 // static pair list with the mask words the tiles OR their bits into.
@@ -682,20 +756,9 @@ VD void navigation_post_tile(const TileCtx& C, const VmasNavigationDesc& d, cons
       const bool hit = C.live && norm2(sa[0] - sb[0], sa[64] - sb[64]) <= P.bound_sum;
       if (__any(hit) && C.lane == 0) atomicOr((uint32_t*)&misc[1 + (k >> 5)], 1u << (k & 31));
     }
-    if (grid_sync) {
-      // Publish AND arrive with ONE agent-scope atomic per mask word, no reply awaited: word (plane p, tile group g) of this
-      // barrier's slot holds, in its low half, one arrival bit per tile of the group and, in its high half, the OR of those
-      // tiles' pair bits 32 p .. 32 p + 31 - a tile ORs both in with a single 64-bit atomic, so whoever sees a tile's
-      // arrival bit sees its pair bits.  (An agent-scope atomic is a round trip to the memory side, ~2.6 us by this
-      // kernel's own stamps: the earlier form - OR the bits, wait for the reply, then bump an arrival counter - put one
-      // such round trip on every tile's arrival path, and seven more, one per pair word read back, behind the barrier.)
+    if (grid_sync) {  // publish and arrive now (one atomic per word, no reply awaited), collect behind the LIDAR units
       __syncthreads();
-      if ((int)threadIdx.x < words) {
-        const int g = (int)blockIdx.x >> 5;
-        unsigned long long* W64 = (unsigned long long*)(nav.sync + 2) + (size_t)(seq & 3u) * words * groups;
-        const unsigned long long v = ((unsigned long long)(uint32_t)misc[1 + threadIdx.x] << 32) | (1ull << (blockIdx.x & 31));
-        __hip_atomic_fetch_or(W64 + threadIdx.x * groups + g, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+      grid_bits_publish((unsigned long long*)(nav.sync + 2) + (size_t)(seq & 3u) * words * groups, words, (const uint32_t*)&misc[1]);
     }
   }
   stamp(7);
@@ -805,54 +868,8 @@ VD void navigation_post_tile(const TileCtx& C, const VmasNavigationDesc& d, cons
       }
     }
     stamp(8);
-    if (grid_sync) {
-      uint32_t* gmask = (uint32_t*)&misc[1];  // (LDS) the batch's pair words, once every tile has arrived
-      if (C.wave == 0) {
-        // wave 0 polls: lane l reads word l of the slot (words x groups <= 64: host-checked), all lanes in one round trip
-        unsigned long long* W64 = (unsigned long long*)(nav.sync + 2) + (size_t)(seq & 3u) * words * groups;
-        const int n = words * groups;
-        const int g = C.lane % groups;
-        const int in_group = (int)gridDim.x - 32 * g;
-        const uint32_t full = in_group >= 32 ? 0xffffffffu : ((1u << in_group) - 1u);
-        unsigned long long v = 0ull;
-        int spins = 0;
-        for (;;) {
-          if (C.lane < n) v = __hip_atomic_load(W64 + C.lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (__all(C.lane >= n || ((uint32_t)v & full) == full)) break;
-          __builtin_amdgcn_s_sleep(4);
-          if (++spins > (1 << 18)) {  // the grid is not co-resident (it should be): flag it and go on, never hang
-            if (C.lane == 0) {
-              __hip_atomic_fetch_or(nav.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              if (nav.gave_up) __hip_atomic_fetch_or(nav.gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-            break;
-          }
-        }
-        // the pair words of the whole batch: OR over the groups of each plane (lane p * groups + g holds plane p, group g)
-        uint32_t hi = C.lane < n ? (uint32_t)(v >> 32) : 0u;
-        for (int off = 1; off < groups; off <<= 1) {
-          const uint32_t o = (uint32_t)__shfl_down((int)hi, off);
-          if ((C.lane % groups) + off < groups) hi |= o;
-        }
-        if (C.lane < n && (C.lane % groups) == 0) gmask[C.lane / groups] = hi;
-        if (blockIdx.x == 0 && C.lane < n)  // every tile has arrived at barrier seq, i.e. is done with the slots up to seq - 1;
-                                            // the one of seq - 2 = seq + 2 (mod 4) is cleared here - no tile writes it before it
-                                            // has passed barrier seq + 1, which this wave has yet to join
-          __hip_atomic_store((unsigned long long*)(nav.sync + 2) + (size_t)((seq + 2u) & 3u) * words * groups + C.lane, 0ull,
-                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      __syncthreads();
-      if ((int)threadIdx.x < A) {  // bit j of collide_with[a]: World.collides(agent a, agent j)
-        uint32_t m = 0;
-        for (int j = 0; j < A; ++j) {
-          const int pi = st_pair_index[threadIdx.x * A + j];
-          if (j != (int)threadIdx.x && pi >= 0 && ((gmask[pi >> 5] >> (pi & 31)) & 1u)) m |= 1u << j;
-        }
-        collide_with[threadIdx.x] = m;
-      }
-      __syncthreads();
-    } else {
-      __syncthreads();
+    __syncthreads();  // every item's atomic max has landed: the observation writer reads `measured`
+    if (!grid_sync) {
       if (blockIdx.x == 0 && nav.mask_clear != nullptr && (int)threadIdx.x < words) nav.mask_clear[threadIdx.x] = 0u;
       // (the mask only grows during a step: a stale read is harmless - and a thousand tiles hammering one word is not)
       if ((int)threadIdx.x < words) {
@@ -861,6 +878,32 @@ VD void navigation_post_tile(const TileCtx& C, const VmasNavigationDesc& d, cons
       }
     }
   }
+  // grid-barrier form: the batch's World.collides bits are collected BEHIND the observation writer (navigation_post_body
+  // calls this between the observations and the collision penalties): the tile arrived in front of the LIDAR units, the
+  // round trips of the barrier - an atomic to the memory side and a poll back, ~2.6 us each - run beside the LIDAR units
+  // and the observation blocks, and only the rewards wait for them
+  auto collect = [&]() {
+    if (!(grid_sync && d.collisions && d.n_rays > 0 && !(ablate & 1))) return;
+    uint32_t* gmask = (uint32_t*)&misc[1];  // (LDS) the batch's pair words, once every tile has arrived
+    if (C.wave == 0) {
+      // every tile that has arrived at barrier seq is done with the slots up to seq - 1; the one of seq - 2 = seq + 2
+      // (mod 4) is cleared by block 0 here - no tile writes it before it has passed barrier seq + 1, which this wave has
+      // yet to join
+      unsigned long long* base = (unsigned long long*)(nav.sync + 2);
+      grid_bits_collect(base + (size_t)(seq & 3u) * words * groups, base + (size_t)((seq + 2u) & 3u) * words * groups, words,
+                        gmask, nav.sync + 1, nav.gave_up);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < A) {  // bit j of collide_with[a]: World.collides(agent a, agent j)
+      uint32_t m = 0;
+      for (int j = 0; j < A; ++j) {
+        const int pi = st_pair_index[threadIdx.x * A + j];
+        if (j != (int)threadIdx.x && pi >= 0 && ((gmask[pi >> 5] >> (pi & 31)) & 1u)) m |= 1u << j;
+      }
+      collide_with[threadIdx.x] = m;
+    }
+    __syncthreads();
+  };
   stamp(9);
   // agent a's 64 x D block of the observation matrix (navigation.py:244-263) as one contiguous run: every lane gathers two
   // consecutive elements (one if D is odd) - the columns the body just put into `own`, the rays from `measured`
@@ -890,7 +933,7 @@ VD void navigation_post_tile(const TileCtx& C, const VmasNavigationDesc& d, cons
   float shaping_out[kNavMaxOwn] = {};
   if (ablate & 2) {}
   else if (grid_sync && d.collisions)
-    navigation_post_body<false>(C, d, o, batch, per_agent, collide_with, T, steps_in, pos, vel, goal, rays, shaping_out);
+    navigation_post_body<false>(C, d, o, batch, per_agent, collide_with, T, steps_in, pos, vel, goal, rays, shaping_out, collect);
   else
     navigation_post_body<true>(C, d, o, batch, per_agent, nullptr, T, steps_in, pos, vel, goal, rays, shaping_out);
   stamp(10);

@@ -281,7 +281,6 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
         // every tile ORs the pairs some environment of it overlaps into the substep's mask slot, all tiles meet at a
         // grid-wide barrier (the grid is at most one tile per CU, so every tile is resident), then read the mask.
         const uint32_t seq = args.seq0 + (uint32_t)it;
-        uint32_t* slot = args.sync + 4 + (seq & 3u) * (uint32_t)args.mask_words;
         for (int p = wv; p < args.n_mpairs; p += nw) {
           const DevMaskPair P = args.mpairs[p];
           const float* A = tile + sgpr(P.a) * 6 * ROWF;
@@ -290,36 +289,21 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
           if (__any(hit) && lane == 0) atomicOr(&xmask[p >> 5], 1u << (p & 31));  // (LDS)
         }
         __syncthreads();
-        if (threadIdx.x == 0) {  // ONE thread publishes the tile's bits and arrives: its release orders the arrival behind them
-          uint32_t seen = 0u;
-          for (int w_ = 0; w_ < args.mask_words; ++w_) {
-            const uint32_t b = xmask[w_];
-            if (b != 0u) seen |= __hip_atomic_fetch_or(slot + w_, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            xmask[w_] = 0u;  // (re-armed for the next substep: nobody touches it before the barrier below)
-          }
-          const uint32_t target = (seq + 1u) * gridDim.x;  // arrivals are never reset: every launch of this world has this grid
-          // (no release fence: at agent scope it writes the XCD's whole L2 back - microseconds.  The tile's bits travel in
-          //  agent-scope atomics only, so it is enough that they have been PERFORMED - their old values are back - before
-          //  the arrival is sent)
-          asm volatile("s_waitcnt vmcnt(0)" ::"v"(seen) : "memory");
-          __hip_atomic_fetch_add(args.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          int spins = 0;
-          while ((int32_t)(__hip_atomic_load(args.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-            __builtin_amdgcn_s_sleep(8);
-            if (++spins > (1 << 18)) {  // the grid is not co-resident (it should be): flag it and go on, never hang
-              __hip_atomic_fetch_or(args.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              if (args.gave_up) __hip_atomic_fetch_or(args.gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-              break;
-            }
-          }
-          if (blockIdx.x == 0) {  // every tile is past substep seq-1: the slot used two substeps ago is free, clear it for seq+2
-            uint32_t* nxt = args.sync + 4 + ((seq + 2u) & 3u) * (uint32_t)args.mask_words;
-            for (int w_ = 0; w_ < args.mask_words; ++w_)
-              __hip_atomic_store(nxt + w_, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
+        // one atomic per pair word carries this tile's arrival and its bits; wave 0 collects the batch's words into LDS
+        // (grid_bits_publish / grid_bits_collect, vmas_env_device.h): the items read the mask from there
+        {
+          const int groups = ((int)gridDim.x + 31) >> 5;
+          unsigned long long* base = (unsigned long long*)(args.sync + 4);
+          const size_t stride = (size_t)args.mask_words * groups;
+          uint32_t* gmask = xmask + ((args.mask_words + 3) & ~3);
+          grid_bits_publish(base + (seq & 3u) * stride, args.mask_words, xmask);
+          if ((int)threadIdx.x < args.mask_words) xmask[threadIdx.x] = 0u;  // (re-armed for the next substep by the thread that published it)
+          if (wv == 0)
+            grid_bits_collect(base + (seq & 3u) * stride, base + ((seq + 2u) & 3u) * stride, args.mask_words, gmask, args.sync + 1,
+                              args.gave_up);
+          __syncthreads();
+          args.pair_mask = gmask;  // (LDS)
         }
-        __syncthreads();
-        args.pair_mask = slot;
       }
     }
     // ================= phase B: gather forces per (entity, segment)
@@ -1473,7 +1457,8 @@ static int build_sched(VmasWorld* w, int nw, Sched& S) {
   S.dw.off_blob = row_bad * ROWF;  // (row_bad: the first row after the partial sums)
   S.dw.fired_recs = w->fired_recs;
   // + work counters, fired words (2 parities x 2), the tile's pair bits of the in-kernel exact broad phase (whole quads)
-  S.lds_bytes = ((size_t)row_bad * ROWF + S.dw.blob_words + 4 + 4 + ((((size_t)w->n_pairs + 31) / 32 + 3) & ~(size_t)3)) * sizeof(float);
+  // (... | work counters [4] | fired words [4] | this tile's pair words | the batch's pair words: in-kernel exact broad phase)
+  S.lds_bytes = ((size_t)row_bad * ROWF + S.dw.blob_words + 4 + 4 + 2 * ((((size_t)w->n_pairs + 31) / 32 + 3) & ~(size_t)3)) * sizeof(float);
   if (knob("VMAS_DEBUG_SCHED")) fprintf(stderr, "[sched nw=%d] %d segments, LDS %zu B per tile\n", nw, (int)segs.size(), S.lds_bytes);
   return 0;
 }
@@ -1923,7 +1908,7 @@ static int build_compact(VmasWorld* w) {
   for (const VmasPairDesc& P : w->pairs)
     if (P.type == VMAS_PAIR_LS && (E[P.a].flags & VMAS_F_ROTATABLE)) D.has_torque = 1;
   size_t dyn_words = 4 + (size_t)((D.n_owned * hw + 1) & ~1) + 2 * (size_t)nP + (size_t)((nP + 1) & ~1) + CAP;
-  dyn_words += 2 * (size_t)CAP + (D.has_torque ? (size_t)CAP : 0) + (((size_t)D.mask_words + 3) & ~(size_t)3);
+  dyn_words += 2 * (size_t)CAP + (D.has_torque ? (size_t)CAP : 0) + 2 * (((size_t)D.mask_words + 3) & ~(size_t)3);  // (xmask, gmask)
   C.lds_bytes = ((size_t)dyn_at + dyn_words) * sizeof(float);
   if (knob("VMAS_DEBUG_SCHED"))
     fprintf(stderr, "[compact nw=%d] rows %d, tables %d words, per-substep scratch %zu words, LDS %zu B per tile\n", nw, rows,
@@ -2168,8 +2153,9 @@ int vmas_world_create(const VmasWorldDesc* d, int32_t batch, int32_t device_id, 
   if (!host_only) HIP_TRY(upload(&w->d_mpairs, mp));
   if (!host_only) {  // exact broad phase: barrier word + four mask slots (in-kernel form), one mask (launch-per-substep form)
     const size_t mw = (size_t)(d->n_pairs + 31) / 32;
-    HIP_TRY(hipMalloc((void**)&w->d_sync, (4 + 4 * mw) * sizeof(uint32_t)));
-    HIP_TRY(hipMemset(w->d_sync, 0, (4 + 4 * mw) * sizeof(uint32_t)));
+    // (unused | gave-up flag | pad, then a ring of four slots of [16 tile groups][pair words] 64-bit words: grid_bits_publish)
+    HIP_TRY(hipMalloc((void**)&w->d_sync, (4 + 4 * mw * 16 * 2 + 2) * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(w->d_sync, 0, (4 + 4 * mw * 16 * 2 + 2) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void**)&w->d_exact_mask, (mw ? mw : 1) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void**)&w->d_nav_mask, (3 * mw + 1) * sizeof(uint32_t)));
     HIP_TRY(hipMemset(w->d_nav_mask, 0, (3 * mw + 1) * sizeof(uint32_t)));
@@ -2639,7 +2625,7 @@ static int step_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld, co
     // capture the launch-per-substep form is used, which keeps no state on the host)
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
-    if (blocks_of(w->batch) <= w->n_cu && cap == hipStreamCaptureStatusNone) {  // every tile resident at once: mask +
+    if (blocks_of(w->batch) <= w->n_cu && blocks_of(w->batch) <= 512 && cap == hipStreamCaptureStatusNone) {  // every tile resident at once: mask +
                                                                                 // grid barrier inside the step kernel
       a.sync = w->d_sync; a.mpairs = w->d_mpairs; a.n_mpairs = w->n_pairs; a.mask_words = mask_words;
       a.seq0 = w->sync_seq;

@@ -59,8 +59,9 @@ struct DevStepArgs {
   const uint32_t* pair_mask;
   // in-kernel exact broad phase (vmas_world_step with exact_broad_phase on a grid of at most one tile per CU): the
   // batch-global `.any()` of World.collides (core.py:2797-2801) evaluated at the top of every substep by all tiles
-  // together - bits ORed into a ring of mask slots with device-scope atomics, then a grid-wide barrier on `sync[0]`
-  uint32_t* sync;              // [0] arrivals (monotonic), [1] gave-up flag, [4 + slot * mask_words ...] four mask slots
+  // together - ONE device-scope 64-bit atomic per tile and pair word carries the tile's arrival bit and its pair bits into
+  // the substep's slot (grid_bits_publish / grid_bits_collect, vmas_env_device.h); the batch's words are then read from LDS
+  uint32_t* sync;              // [1] gave-up flag; from word 4: ring of four slots of [tile groups][mask_words] 64-bit words
   const DevMaskPair* mpairs;   // the world's static pairs with their bounding-circle sums
   uint32_t seq0;               // barrier sequence number of this launch's first substep
   uint32_t* gave_up;           // host-mapped word: set (system scope) when a grid barrier gave up waiting; the host reads it
@@ -118,11 +119,11 @@ constexpr uint32_t kLayoutHash =
 #endif
 
 __device__ __forceinline__ int sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
-// One word of the pair mask.  A device-scope atomic load: the in-kernel exact broad phase fills the mask of the running
-// substep from every tile of the grid (atomic ORs), and its slots are re-used within one launch.
-__device__ __forceinline__ uint32_t mask_word(const uint32_t* mask, int w) {
-  return __hip_atomic_load(mask + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+// One word of the pair mask: the caller's recorded mask (global memory, read-only during the launch) or the copy of the
+// batch's words the in-kernel exact broad phase leaves in LDS behind its grid barrier (grid_bits_collect) - a plain load
+// either way (until round 4 the exact form was read straight from the grid's slots, an agent-scope atomic load - a round
+// trip to the memory side - in front of every item).
+__device__ __forceinline__ uint32_t mask_word(const uint32_t* mask, int w) { return mask[w]; }
 // A pair may be skipped only on a FINITE squared distance beyond its bound: a NaN or an infinite operand must reach the
 // narrow phase, where the reference's own arithmetic decides (inf * 0, cos(inf) ... = NaN poisons the pair however far
 // apart the shapes are).  Together with the NaN checks on the cos rows of Lines and Boxes this is why no separate
