@@ -1,6 +1,6 @@
 # Round 4's evidence in one GPU call (summaries land in gpurun_out/r04/, copy what is to be judged into profiles/):
 #   bash scripts/gpu_evidence_r4.sh [skip-tests] [quick]
-TAG=r04
+TAG=${TAG:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 cd $R
@@ -52,6 +52,12 @@ FORCES=random RATED=step_kernel_compact:physics bash scripts/gpu_counters.sh ${T
 RATED=step_kernel_spec_multi:env bash scripts/gpu_counters.sh ${TAG}_balance32768_env_step 657 2000 32768 -- python $S/bench_bound.py balance 32768 > /dev/null 2>&1
 grep -h "sustained\|traffic / alg\|share of wave" $OUT/${TAG}_navigation8192_env_step_pmc_summary.txt $OUT/${TAG}_football16384_physics_compact_pmc_summary.txt $OUT/${TAG}_balance32768_env_step_pmc_summary.txt
 fi
+# rollout rates and per-phase traces
+{ python $S/bench_rollout_env.py balance 32768 100; python $S/bench_rollout_env.py transport 16384 100; python $S/bench_rollout_env.py navigation 8192 50; REPS=5 python $S/bench_rollout_env.py football 131072 50; python $S/bench_rollout_env.py football 16384 50; } 2>&1 | grep "^{" > $OUT/${TAG}_env_rollout_rates.jsonl; cat $OUT/${TAG}_env_rollout_rates.jsonl
+python $S/trace_compact.py football 16384 2>&1 | grep -v amdgpu > $OUT/${TAG}_football16384_compact_phase_trace.txt; cat $OUT/${TAG}_football16384_compact_phase_trace.txt
+VMAS_TRACE=2 python $S/trace_nav.py 8192 2>&1 | grep -v amdgpu > $OUT/${TAG}_navigation8192_env_step_phase_trace.txt
+python $S/trace_env.py balance 32768 2>&1 | grep -v amdgpu > $OUT/${TAG}_balance32768_env_step_phase_trace.txt; cat $OUT/${TAG}_balance32768_env_step_phase_trace.txt
+[ -n "${FLAGS_AB:-}" ] || exit 0
 # runtime flags A/B (kernel arguments in device memory, direct dispatch): the same driver-style command
 for FL in "HIP_FORCE_DEV_KERNARG=0" "HIP_FORCE_DEV_KERNARG=1" "DEBUG_HIP_KERNARG_COPY_OPT=0" "GPU_MAX_HW_QUEUES=8"; do
   env $FL python bench.py --no-cpu-baseline --no-other-configs --no-attached --steps 2000 --warmup 200 2>/dev/null | python -c "
