@@ -71,3 +71,49 @@ def test_the_planner_lands_on_a_geometry_with_a_builtin_specialisation(name, kw,
     for B in batches:
         _, meta, _ = _planned(name, B, **kw)
         assert meta[23] >= 0, f"{name} at {B} environments is planned at {meta[0]} waves per tile (sharing mode {meta[1]}): no built-in specialisation serves that geometry"
+
+
+def _race_worker(src, cache_dir, fake, q):
+    from vectorizedmultiagentsimulator_amd import specialize as S2
+
+    try:
+        q.put(("ok", S2.code_object(src, cache_dir=cache_dir, hipcc=fake)))
+    except Exception as e:  # noqa: BLE001
+        q.put(("err", repr(e)))
+
+
+def test_ranks_racing_on_a_cold_cache_compile_once_and_all_get_the_file(tmp_path):
+    """One rank per GPU, each `make_env(..., specialize=True)` on a cold cache: every process must come back with the same
+    whole file, and the lock must keep all but one from compiling (round 3 staged every compile under one shared temporary
+    name: a second rank's rename could find it gone, or a half-written file could pass the size check)."""
+    import multiprocessing as mp
+    import stat
+
+    fake = tmp_path / "fake_hipcc"
+    log = tmp_path / "invocations.log"
+    # a stand-in compiler: slow enough for the ranks to overlap, writes its output in two halves
+    fake.write_text(f"""#!/usr/bin/env python3
+import sys, time
+out = sys.argv[sys.argv.index('-o') + 1]
+open({str(log)!r}, 'a').write('x\\n')
+with open(out, 'wb') as f:
+    f.write(b'A' * 5000); f.flush(); time.sleep(0.5); f.write(b'B' * 5000)
+""")
+    fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
+    cache = tmp_path / "cache"
+    src = "// not a real kernel: the stand-in compiler does not read it\n"
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_race_worker, args=(src, str(cache), str(fake), q)) for _ in range(4)]
+    for p_ in procs:
+        p_.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p_ in procs:
+        p_.join(timeout=60)
+    assert all(kind == "ok" for kind, _ in res), res
+    paths = {p_ for _, p_ in res}
+    assert len(paths) == 1
+    path = paths.pop()
+    assert open(path, "rb").read() == b"A" * 5000 + b"B" * 5000, "a reader saw a half-written code object"
+    assert log.read_text().count("x") == 1, "the lock should have let ONE process compile"
+    assert sorted(os.listdir(cache)) == [os.path.basename(path)], "temporary / lock files left behind"

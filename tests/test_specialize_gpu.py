@@ -4,6 +4,8 @@ config 1's world), transport with two packages (box-box), jointed worlds (joint_
 ranges (give_way), a rotating line (wheel), and one attached reference scenario.  (Schedules of more than 40 item records -
 football, waterfall - are refused: unrolled they outgrow the instruction cache.)  Code objects come from the on-disk cache when
 __graft_entry__.build() (or an earlier test) made them, else hipcc compiles them here (~10 s each)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -166,3 +168,31 @@ def test_make_env_takes_a_cached_specialisation_and_never_compiles_by_default(tm
     monkeypatch.setattr(S, "CACHE", str(tmp_path))
     miss = make_env("balance", num_envs=4096, device="cuda:0", seed=3, n_agents=3, validate_actions=False)
     assert not miss.world._get_backend().specialized and not any(tmp_path.iterdir())
+
+
+def test_a_corrupt_cache_entry_never_breaks_make_env(tmp_path, monkeypatch):
+    """make_env(specialize=None) is an optional fast path: a cache entry the library refuses (truncated by a crash, foreign
+    bytes under the name) warns, is dropped and leaves the world on the interpreter - same results; with specialize=True the
+    same entry is replaced by a fresh compile on the next request."""
+    import warnings
+
+    from vectorizedmultiagentsimulator_amd import specialize as S
+    from vectorizedmultiagentsimulator_amd.environment import make_env
+
+    monkeypatch.setattr(S, "CACHE", str(tmp_path))
+    probe = make_env("balance", num_envs=4096, device="cuda:0", seed=3, n_agents=3, validate_actions=False, specialize=False)
+    be = probe.world._get_backend()
+    meta, words = S.schedule(be._h)
+    src = S.render(meta, words, int(be.spec.substeps), 1)
+    bad = S.cache_path(src, str(tmp_path))
+    with open(bad, "wb") as f:
+        f.write(b"not a code object" * 100)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        env = make_env("balance", num_envs=4096, device="cuda:0", seed=3, n_agents=3, validate_actions=False)
+    assert not env.world._get_backend().specialized
+    assert any("world-specialised kernel not used" in str(w.message) for w in caught), [str(w.message) for w in caught]
+    assert not os.path.exists(bad), "the refused entry should have been dropped"
+    acts = [env.get_random_action(a) for a in env.agents]
+    ra, rb = env.step(acts), probe.step([a.clone() for a in acts])
+    assert all(torch.equal(x, y) for x, y in zip(ra[0], rb[0]))
