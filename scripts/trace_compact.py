@@ -31,9 +31,15 @@ t = buf.reshape(tiles, 16, 16).astype(np.int64)
 nw = int((t[:, :, 0] > 0).sum(axis=1).max())
 t = t[:, :nw]
 t0 = t[:, :, 0].min()
-print(f"{name} {B} (held {hold} steps): tiles {tiles}, waves/tile {nw}; kernel span {t[:, :, 3].max() - t0} ticks (s_memtime, 100 MHz: x10 ns)")
+print(f"{name} {B} (held {hold} steps): tiles {tiles}, waves/tile {nw}; kernel span {t[:, :, 3].max() - t0} ticks (s_memtime)")
+start = t[:, :, 0] - t0
+print("wave start after the grid's first wave (ticks): mean %.0f | median %.0f | max %.0f; last wave of a tile after its first: mean %.0f" % (
+    start.mean(), np.median(start), start.max(), (t[:, :, 0].max(axis=1) - t[:, :, 0].min(axis=1)).mean()))
 print("per wave means (ticks): load %.0f | load barrier %.0f | total %.0f" % (
     (t[:, :, 1] - t[:, :, 0]).mean(), (t[:, :, 2] - t[:, :, 1]).mean(), (t[:, :, 3] - t[:, :, 0]).mean()))
+if (t[:, :, 12] > 0).all():
+    print("  inside load: start -> every load of the first batch requested %.0f | -> entity rows in LDS (waits for the loads, sincos of the lines) %.0f | -> agent rows, blob, zeroing %.0f" % (
+        (t[:, :, 12] - t[:, :, 0]).mean(), (t[:, :, 13] - t[:, :, 12]).mean(), (t[:, :, 1] - t[:, :, 13]).mean()))
 names = ["prologue+integrate", "A broad", "A barrier", "B narrow", "B barrier", "C add contacts", "contacts N", "rounds"]
 for k, nm in enumerate(names):
     v = t[:, :, 4 + k]

@@ -36,6 +36,7 @@ for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
 BUILD_ID=$( (echo "$FLAGS"; "$HIPCC" --version | head -2; cat vmas_hip.hip vmas_env.hip vmas_compact.hip *.h ../../include/*.h) | sha256sum | cut -c1-32)
 printf 'extern "C" { extern const char vmas_build_id_string[]; const char vmas_build_id_string[] = "%s"; }\n' "$BUILD_ID" > "$OBJ/build_id.$BUILD_ID.cpp"
 g++ -O1 -fPIC -c "$OBJ/build_id.$BUILD_ID.cpp" -o "$OBJ/build_id.$BUILD_ID.o"
-"$HIPCC" --offload-arch=gfx950 -fPIC -shared -o "$OUT" "${objs[@]}" "$OBJ/build_id.$BUILD_ID.o"
+# (-z defs: a symbol one unit declares and no unit defines fails HERE, not at dlopen on the GPU box)
+"$HIPCC" --offload-arch=gfx950 -fPIC -shared -Wl,-z,defs -o "$OUT" "${objs[@]}" "$OBJ/build_id.$BUILD_ID.o"
 rm -f "$OBJ/build_id.$BUILD_ID.cpp"
 echo "built $(pwd)/$OUT"

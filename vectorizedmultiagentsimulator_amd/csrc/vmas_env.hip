@@ -203,9 +203,9 @@ __global__ __launch_bounds__(256) void navigation_collision_kernel(const VmasNav
 
 // ------------------------------------------------------------------------------------ football
 // stand-alone form of football_post_tile (vmas_env_device.h).  LDS: rows[(n + 1) * 6][64] (pos, vel, force of every agent
-// and of the ball) | chunk tiles [nw][64][33]
+// and of the ball) | the tile's observation array [64][D + 2] (one pass per agent: its 64 * D floats leave as one run)
 __global__ __launch_bounds__(512) void football_post_kernel(const VmasFootballDesc d, const VmasFootballBuffers o, int batch,
-                                                            const float* __restrict__ state, long ld) {
+                                                            const float* __restrict__ state, long ld, int stp) {
   extern __shared__ float lds[];
   const TileCtx C(batch);
   const int n = d.n_blue + d.n_red;
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(512) void football_post_kernel(const VmasFootballDe
   float steps_in = C.wave == 0 ? load_steps(o.limit, C) : 0.f;
   __syncthreads();
   football_post_tile(C, d, o, batch, [&](int slot, int k) { return rows[(slot * 6 + k) * 64 + C.lane]; },
-                     lds + (n + 1) * 6 * 64 + C.wave * 64 * (kChunk + 1), kChunk, prev, steps_in, 0);
+                     lds + (n + 1) * 6 * 64, -64, prev, steps_in, stp);  // (stp: the step's slab of every per-step output)
 }
 
 int check_launch(const char* what) {
@@ -283,6 +283,21 @@ int check_navigation_args(const VmasNavigationDesc* d, const VmasNavigationBuffe
       return host_fail("vmas_navigation_post_step: every registered sensor must have n_rays rays (lidar_max_rays != n_rays)");
   }
   return 0;
+}
+
+// football's post-step (vmas_football_post_step; vmas_hip.hip: step `stp` of a rollout whose steps are two launches each)
+int launch_football_post(const VmasFootballDesc* d, const VmasFootballBuffers* o, int32_t batch, const float* state, int64_t ld,
+                         int stp, void* stream) {
+  if (!d || !o || !state) return host_fail("vmas_football_post_step: null argument");
+  if (batch <= 0 || ld < batch) return host_fail("vmas_football_post_step: bad batch / ld");
+  if (d->n_blue < 1 || d->n_red < 1 || d->n_blue + d->n_red + 1 > VMAS_ENV_MAX_AGENTS || d->agent0 < 0)
+    return host_fail("vmas_football_post_step: team sizes out of range");
+  if (!o->pos_shaping || !o->obs || !o->rew || !o->terms || !o->touching || !o->done || !o->agent_ft)
+    return host_fail("vmas_football_post_step: null buffer");
+  const int nw = 8;
+  const int n_others = (d->observe_adversaries ? std::max(d->n_red, d->n_blue) : 0) + (d->observe_teammates ? std::max(d->n_blue, d->n_red) - 1 : 0);
+  const size_t lds = ((size_t)(d->n_blue + d->n_red + 1) * 6 * 64 + football_shared_slab_floats(64, 16 + 8 * n_others)) * sizeof(float);
+  LAUNCH_POST(football_post_kernel, nw, lds, "vmas_football_post_step", *d, *o, batch, state, (long)ld, stp);
 }
 
 // behind a step kernel with the navigation epilogue, same stream (navigation_collision_kernel)
@@ -509,15 +524,7 @@ int vmas_navigation_post_step(const VmasNavigationDesc* d, const VmasNavigationB
 
 int vmas_football_post_step(const VmasFootballDesc* d, const VmasFootballBuffers* o, int32_t batch, const float* state,
                             int64_t ld, void* stream) {
-  if (!d || !o || !state) return host_fail("vmas_football_post_step: null argument");
-  if (batch <= 0 || ld < batch) return host_fail("vmas_football_post_step: bad batch / ld");
-  if (d->n_blue < 1 || d->n_red < 1 || d->n_blue + d->n_red + 1 > VMAS_ENV_MAX_AGENTS || d->agent0 < 0)
-    return host_fail("vmas_football_post_step: team sizes out of range");
-  if (!o->pos_shaping || !o->obs || !o->rew || !o->terms || !o->touching || !o->done || !o->agent_ft)
-    return host_fail("vmas_football_post_step: null buffer");
-  const int nw = 4;
-  const size_t lds = ((size_t)(d->n_blue + d->n_red + 1) * 6 * 64 + (size_t)nw * 64 * (kChunk + 1)) * sizeof(float);
-  LAUNCH_POST(football_post_kernel, nw, lds, "vmas_football_post_step", *d, *o, batch, state, (long)ld);
+  return vmas::launch_football_post(d, o, batch, state, ld, 0, stream);
 }
 
 }  // extern "C"

@@ -1084,16 +1084,24 @@ VD void run_script(const VmasAgentScript& S, const float* E, long stride, long e
 // (slot = blue agents, red agents, ball; k = px py vx vy fx fy): the stand-alone kernel (vmas_env.hip) stages them from
 // HBM, the compact step kernel (vmas_compact.h) reads its own tile - the post-step as the physics kernel's epilogue.
 // An observation is 16 + 8 * (observed others) floats - 88 for 5 v 5, 3.5 KB per environment and step over the ten
-// agents: a streaming writer.  `slab`: THIS wave's chunk tile [64][chunk + 1] (chunk = 16 or 32 columns) - the wave
-// transposes its agent's observation `chunk` columns at a time, so that the lanes of one store instruction cover whole
-// 64-byte (chunk 16) or 128-byte (32) pieces of the rows; NULL: no staging, every lane stores its own row 16 bytes at a
-// time (one L2 request per lane and store: the L2's request rate bounds that form - 22 requests per row of 88 floats
-// where six would do).  `prev`: the four shaping terms of this lane
+// agents: a streaming writer, and HOW a store instruction's lanes cover the tensor decides the rate HBM takes it at
+// (scripts/micro/store_pattern.hip, 461 MB at 131 072 environments: every lane its own row 16 bytes at a time 3.6 TB/s,
+// 64- or 128-byte pieces of the rows 3.1-3.2 TB/s, the rows as they lie - 1 024 contiguous bytes per instruction - 5.85 TB/s).
+// For one agent the rows of a tile are ONE contiguous run of 64 * D floats, so:
+//   chunk < 0: `slab` is the TILE's [R = -chunk][D + 2] array.  All waves take the agents one after the other: each wave
+//     computes 8-column groups (the own/ball columns are two, every observed other is one) for the R rows of the pass -
+//     lanes outside the pass do not write -, block barrier, the block's threads store the pass's run of R * D floats as
+//     it lies (R a multiple of 4: whole 128-byte lines), block barrier.  EVERY wave of the tile must call.
+//   chunk > 0: `slab` is THIS wave's [64][chunk + 1] tile (chunk = 16 or 32 columns) - the wave transposes its agent's
+//     observation `chunk` columns at a time; the lanes of a store cover 64- or 128-byte pieces of the rows.  No block
+//     barrier: the latency regime's form (16 waves per tile, one agent per wave, nothing to wait for).
+//   slab == NULL: no staging, every lane stores its own row 16 bytes at a time.
+// `prev`: the four shaping terms of this lane
 // (in: before, out: after this step), `steps_in`: wave 0's Environment.steps (in/out), `stp`: step of a multi-step
-// launch (every per-step output is offset by stp slabs).  No block barrier inside.
-constexpr int kChunk = 32;               // the stand-alone kernel's chunk
-constexpr int kFootballStageChunk = 16;  // the step kernel's: 64-byte pieces, a quarter of the LDS
-__host__ __device__ inline size_t football_scratch_floats(int nw) { return (size_t)nw * 64 * (kChunk + 1); }
+// launch (every per-step output is offset by stp slabs).
+constexpr int kChunk = 32;               // (chunk > 0 forms: the widest chunk)
+constexpr int kFootballStageChunk = 16;  // the step kernel's per-wave form: 64-byte pieces, a quarter of the LDS
+__host__ __device__ inline size_t football_shared_slab_floats(int rows, int D) { return (size_t)rows * (D + 2); }
 
 template <class Get>
 VD void football_post_tile(const TileCtx& C, const VmasFootballDesc& d, const VmasFootballBuffers& o_in, int batch, Get G,
@@ -1145,7 +1153,15 @@ VD void football_post_tile(const TileCtx& C, const VmasFootballDesc& d, const Vm
     }
   }
   if (C.wave == 0) {
-    const bool done = apply_step_limit(o.limit, C, steps_in, blue_score || red_score);
+    // (the address of this lane's `steps` word is the prologue's too: remade here from an opaque lane number, or the step
+    //  kernel carries it - two registers - through the whole physics, and spills it where the kernel is at its register cap)
+    TileCtx Cs = C;
+    {
+      int l = C.lane;
+      asm volatile("" : "+v"(l));
+      Cs.env = C.b0 + l;
+    }
+    const bool done = apply_step_limit(o.limit, Cs, steps_in, blue_score || red_score);
     if (C.live) {
       o.terms[C.env] = sparse_blue;
       o.done[C.env] = done ? 1 : 0;
@@ -1154,9 +1170,68 @@ VD void football_post_tile(const TileCtx& C, const VmasFootballDesc& d, const Vm
   }
   const float rew_team[2] = {sparse_blue + dense[0], (0.f - sparse_blue) + dense[1]};
 
-  // ---- observation football.py:1221-1460, agents wave, wave + nw, ...; red agents see everything mirrored in
-  //      x.  Written chunk by chunk - the 16 own/ball columns, then the observed others chunk / 8 at a time -
-  //      through the wave's LDS tile; a chunk leaves as float4 stores.
+  // ---- observation football.py:1221-1460; red agents see everything mirrored in x.  The three forms of the header:
+  //      the tile's waves on one agent at a time through the shared array (contiguous runs) ...
+  if (slab != nullptr && chunk < 0) {
+    const int R = -chunk, tid = C.wave * 64 + C.lane, nthreads = C.nw * 64;
+    for (int a = 0; a < n; ++a) {
+      const bool blue = a < d.n_blue;
+      const float sx = blue ? 1.f : -1.f;
+      auto M = [&](v2 v) { return V(v.x * sx, v.y); };
+      const v2 goal = V(blue ? d.goal_x : -d.goal_x, 0.f);
+      const int n_adv = blue ? n_adv_b : n_adv_r;
+      const int mate0 = blue ? 0 : d.n_blue, n_team = blue ? d.n_blue : d.n_red;
+      const int n_others = n_adv + (d.observe_teammates ? n_team - 1 : 0);
+      const int D = 16 + 8 * n_others, S = D + 2, w4 = D >> 2, n_groups = D >> 3;
+      const float inv = 1.f / (float)w4;
+      float* out = o.obs + ((long)a * batch + C.b0) * D;
+      for (int r0 = 0; r0 < C.n_rows; r0 += R) {
+        const int r = C.lane - r0;
+        if (r >= 0 && r < R) {
+          const v2 pos = P2(a, 0), vel = P2(a, 2);
+          for (int g = C.wave; g < n_groups; g += C.nw) {
+            v2 q0, q1, q2, q3;
+            if (g == 0) {
+              q0 = M(P2(a, 4)); q1 = M(pos - bpos); q2 = M(vel - bvel); q3 = M(bpos - goal);
+            } else if (g == 1) {
+              q0 = M(bvel); q1 = M(bforce); q2 = M(pos - goal); q3 = M(vel);
+            } else {
+              const int j = g - 2;
+              int other;
+              if (j < n_adv) {
+                other = (blue ? d.n_blue : 0) + j;  // the other team, in order
+              } else {
+                other = mate0 + (j - n_adv);
+                if (other >= a) other += 1;         // my team, skipping myself
+              }
+              const v2 opos = P2(other, 0), ovel = P2(other, 2);
+              q0 = M(pos - opos); q1 = M(vel - ovel); q2 = M(ovel); q3 = M(P2(other, 4));
+            }
+            float2* dst = (float2*)(slab + r * S + 8 * g);  // (8-byte aligned: S and the slab's offset are even)
+            dst[0] = make_float2(q0.x, q0.y); dst[1] = make_float2(q1.x, q1.y);
+            dst[2] = make_float2(q2.x, q2.y); dst[3] = make_float2(q3.x, q3.y);
+          }
+        }
+        __syncthreads();
+        const int rows = C.n_rows - r0 < R ? C.n_rows - r0 : R, total4 = rows * w4;
+        float4* run = (float4*)(out + (long)r0 * D);
+        for (int i = tid; i < total4; i += nthreads) {
+          int rr = (int)((float)i * inv);
+          int c4 = i - rr * w4;
+          if (c4 >= w4) { c4 -= w4; rr += 1; }
+          if (c4 < 0) { c4 += w4; rr -= 1; }
+          const float2* src = (const float2*)(slab + rr * S + 4 * c4);
+          const float2 lo = src[0], hi = src[1];
+          run[i] = make_float4(lo.x, lo.y, hi.x, hi.y);
+        }
+        __syncthreads();
+      }
+      if (a % C.nw == C.wave && C.live) o.rew[(long)a * batch + C.env] = rew_team[blue ? 0 : 1];
+    }
+    return;
+  }
+  // ... or agents wave, wave + nw, ...: chunk by chunk - the 16 own/ball columns, then the observed others chunk / 8 at a
+  // time - through the wave's LDS tile (a chunk leaves as float4 stores), or every lane its own row
   for (int a = C.wave; a < n; a += C.nw) {
     const bool blue = a < d.n_blue;
     const float sx = blue ? 1.f : -1.f;
