@@ -31,10 +31,11 @@ int vmas_debug_schedule(VmasWorld* w, uint32_t* words, int64_t capacity, int32_t
  * vmas_world_exact_status): the next launch on the world must fail loudly.  For the test of exactly that. */
 int vmas_debug_force_gave_up(VmasWorld* w);
 
-/* football's Environment.step (vmas_world_step_env / vmas_world_rollout_env with VMAS_POST_FOOTBALL) has two forms with the
- * same device functions - one launch (the post-step as the compacted step kernel's epilogue: the latency regime) and two
- * launches per step (step kernel, then the stand-alone post-step kernel: beyond two tiles per CU).  form = 0 / 1 forces one,
- * -1 gives the choice back to the library.  For the test that pins one against the other bit for bit. */
+/* football's Environment.step / rollout (vmas_world_step_env / vmas_world_rollout_env with VMAS_POST_FOOTBALL) has two forms
+ * with the same device functions: 0 one launch (the post-step as the compacted step kernel's epilogue: every K-step rollout,
+ * single steps up to one tile per CU), 1 two launches per step (step kernel, then the stand-alone post-step kernel: single
+ * steps beyond).  form = 0 / 1 forces one, -1 gives the choice back to the library.  For the test that pins them against each
+ * other bit for bit. */
 int vmas_debug_football_form(VmasWorld* w, int32_t form);
 
 /* The adaptive choice between the lane-compacted step kernel and the interpreter (vmas_world_set_compact(-1), the default):

@@ -44,3 +44,6 @@ names = ["prologue+integrate", "A broad", "A barrier", "B narrow", "B barrier", 
 for k, nm in enumerate(names):
     v = t[:, :, 4 + k]
     print("  %-20s mean %9.1f  max %9d" % (nm, v.mean(), v.max()))
+print("by wave index (mean over tiles): prologue+integrate | A broad | A barrier | C add contacts")
+for wv in range(nw):
+    print("  wave %2d  %8.0f %8.0f %8.0f %8.0f" % (wv, t[:, wv, 4].mean(), t[:, wv, 5].mean(), t[:, wv, 6].mean(), t[:, wv, 9].mean()))

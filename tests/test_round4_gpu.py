@@ -94,34 +94,45 @@ def test_rollout_into_the_gather_buffer_is_the_plain_rollout(name, kw, B):
 
 @pytest.mark.parametrize("kw,B", [(dict(n_blue_agents=5, n_red_agents=5, ai_red_agents=False), 3000),
                                   (dict(n_blue_agents=3, n_red_agents=2, ai_red_agents=False), 1000)])
-def test_football_step_as_two_launches_is_bitwise_the_one_launch_step(kw, B):
-    """football's Environment.step / rollout have two forms (one launch with the post-step as the step kernel's epilogue: up to
-    two tiles per CU; step kernel + stand-alone post-step kernel beyond): the same device functions, so the same bits -
-    observations (written by three different store patterns), rewards, done, info terms, shaping terms, steps, state."""
+def test_football_forms_are_bitwise_each_other(kw, B):
+    """football's Environment.step / rollout have two forms (include/vmas_debug_hip.h: one launch with the post-step as the step
+    kernel's epilogue - rollouts, single steps up to one tile per CU; step kernel + stand-alone post-step kernel - single steps
+    beyond) and the library's own choice between them: the same device functions, so the same bits - observations (three
+    different store patterns), rewards, done, info terms, shaping terms, steps, state."""
     import ctypes as C
 
-    a, b = _pair("football", dict(kw, max_steps=9), B)  # (the step limit is applied inside both forms)
-    for env, form in ((a, 0), (b, 1)):
+    from vectorizedmultiagentsimulator_amd.environment import make_env
+
+    envs = [make_env("football", num_envs=B, device="cuda:0", seed=3, validate_actions=False, max_steps=9, **kw) for _ in range(3)]
+    for form, env in zip((0, 1, -1), envs):  # (max_steps: the step limit is applied inside every form)
+        env.set_state([t.clone() for t in envs[0].get_state()])
         be = env.world._get_backend()
         be.lib.vmas_debug_football_form.argtypes = [C.c_void_p, C.c_int32]
         assert be.lib.vmas_debug_football_form(be._h, form) == 0
+    a = envs[0]
     g = torch.Generator(device="cuda:0").manual_seed(5)
     for k in range(6):
         acts = [(torch.rand(B, 2, device="cuda:0", generator=g) * 2 - 1) * 0.9 for _ in a.agents]
-        ra, rb = a.step(acts), b.step([u.clone() for u in acts])
-        assert all(eq(x, y) for x, y in zip(ra[0], rb[0])), f"observations, step {k}"
-        assert all(eq(x, y) for x, y in zip(ra[1], rb[1])) and eq(ra[2], rb[2])
-        for da, db in zip(ra[3], rb[3]):
-            assert all(eq(da[k_], db[k_]) for k_ in da if torch.is_tensor(da[k_]))
-        assert eq(a.world._state, b.world._state) and eq(a.steps, b.steps)
-    K = 5
-    roll = [(torch.rand(K, B, 2, device="cuda:0", generator=g) * 2 - 1) * 0.8 for _ in a.agents]
-    wa, wb = a.rollout(roll), b.rollout([u.clone() for u in roll])
-    for name_ in wa:
-        assert eq(wa[name_], wb[name_]), name_
-    assert bool(wa["done"].any()), "the step limit should have ended episodes inside the rollout"
-    assert eq(a.world._state, b.world._state) and eq(a.steps, b.steps)
-    assert eq(a.scenario.ball.pos_shaping_blue, b.scenario.ball.pos_shaping_blue)
+        ra = a.step(acts)
+        for b in envs[1:]:
+            rb = b.step([u.clone() for u in acts])
+            assert all(eq(x, y) for x, y in zip(ra[0], rb[0])), f"observations, step {k}"
+            assert all(eq(x, y) for x, y in zip(ra[1], rb[1])) and eq(ra[2], rb[2])
+            for da, db in zip(ra[3], rb[3]):
+                assert all(eq(da[k_], db[k_]) for k_ in da if torch.is_tensor(da[k_]))
+            assert eq(a.world._state, b.world._state) and eq(a.steps, b.steps)
+    for K in (5, 2):
+        roll = [(torch.rand(K, B, 2, device="cuda:0", generator=g) * 2 - 1) * 0.8 for _ in a.agents]
+        wa = a.rollout(roll)
+        for form, b in enumerate(envs[1:], 1):
+            wb = b.rollout([u.clone() for u in roll])
+            for name_ in wa:
+                assert eq(wa[name_], wb[name_]), (name_, form, K)
+            assert eq(a.world._state, b.world._state) and eq(a.steps, b.steps), (form, K)
+            assert eq(a.world._agent_ft, b.world._agent_ft), (form, K)
+            assert eq(a.scenario.ball.pos_shaping_blue, b.scenario.ball.pos_shaping_blue)
+        if K == 5:
+            assert bool(wa["done"].any()), "the step limit should have ended episodes inside the rollout"
 
 
 @pytest.mark.reference

@@ -78,8 +78,8 @@ struct DevCompact {
   int32_t off_tab;              // the blob copy
   int32_t t_owned, t_lists, t_units, t_pairs, t_pairhm, t_waves, t_entoff, t_bounds;  // word offsets inside the blob
   int32_t n_owned, n_pairs, hw;
-  int32_t off_dyn;              // per-substep scratch: cnt[4] | hit[n_owned][hw] | xmask | gmask | ballots[n_pairs] (u64) |
-                                // base[n_pairs] | keys[CAP] | contacts[CAP] (fx, fy) | [torques[CAP] if has_torque]
+  int32_t off_dyn;              // per-substep scratch: cnt[4] | hit[n_owned][hw] | ballots[n_pairs] (u64) | base[n_pairs] |
+                                // keys[CAP] | contacts[CAP] (fx, fy) | [torques[CAP] if has_torque] | xmask[mask_words]
   int32_t has_torque;           // some pair exerts a torque (a rotatable line): the contacts carry a third number
   int32_t mask_words;
   const float4* trig_cache;     // [nE] {rotation, cos, sin, valid} of the static lines, made once from environment 0 (may be NULL)
@@ -160,15 +160,12 @@ __global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld
   uint32_t* dyn = (uint32_t*)(lds + P.off_dyn);
   uint32_t* cnt = dyn;                                       // [0] contacts of this round
   uint32_t* hit = dyn + 4;                                   // [n_owned][hw]
-  uint32_t* xmask = hit + ((P.n_owned * P.hw + 1) & ~1);     // [mask_words] this tile's pair bits | gmask: the batch's (each padded to 4 words)
-  unsigned long long* ballots = (unsigned long long*)(xmask + 2 * ((P.mask_words + 3) & ~3));
+  unsigned long long* ballots = (unsigned long long*)(hit + ((P.n_owned * P.hw + 1) & ~1));
   uint32_t* base = (uint32_t*)(ballots + P.n_pairs);
   uint32_t* keys = base + ((P.n_pairs + 1) & ~1);
   float2* contacts = (float2*)(keys + CAP);   // (8-byte aligned: every part in front of it has an even number of words)
   float* torques = (float*)(contacts + CAP);  // [CAP] only if P.has_torque
-  // (ballots ... torques are the LAST parts of the kernel's own LDS and dead between steps: football's epilogue stages its
-  //  observations there, running on into the dynamic LDS behind the kernel's own where the host added some)
-  const float* dead_end = torques + (P.has_torque ? CAP : 0);
+  uint32_t* xmask = (uint32_t*)(torques + (P.has_torque ? CAP : 0));
   const int nP = P.n_pairs;
 
   // tile offset of entity e's first row / of its cos row, from the masks in the kernel arguments
@@ -227,9 +224,12 @@ __global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld
         const float* src = state + (long)(on ? e : 0) * 6 * ld + env;
 #pragma unroll
         for (int f = 0; f < 6; ++f) v[j][f] = (((rows >> f) & 1) && lv) ? src[f * ld] : 0.f;
-        // (a scalar load with its own wait per entity - four in a row in front of the tile's first barrier.  Measured in round 4
-        //  as vector loads, all in flight together: 16 384 environments 16.38 -> 16.2 us, but 16 more vector registers took
-        //  the kernel from 6 to 5 waves per SIMD - 131 072 environments 65.3 -> 76.9 us: profiles/r04h_ab_*.jsonl)
+        // (a scalar load with its own wait per entity - four in a row in front of the tile's first barrier.  Measured in round 4,
+        //  same box, the previous build beside it: as vector loads, all in flight together, 16 384 environments 16.38 -> 16.2 us
+        //  but 16 more vector registers took the kernel from 6 to 5 waves per SIMD - 131 072 environments 65.3 -> 76.9 us
+        //  (profiles/r04h_ab_*.jsonl); as branch-free SCALAR loads in flight with the rows, no register more: 16.33 -> 16.34,
+        //  65.3 -> 65.6 (r04k_ab_*.jsonl) - the 7.4 k cycles between a wave's start and its last load request
+        //  (r04k_football16384_compact_phase_trace.txt) are not these loads)
         tc[j] = (is_line && !is_dyn && P.trig_cache != nullptr) ? P.trig_cache[e] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
       // (first batch only) the agent forces that are plain loads, and this thread's share of the blob
@@ -737,25 +737,18 @@ __global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld
       {
         const float* rows = tile + ent_off(E.football.d.agent0);  // (host-checked: the agents and the ball are consecutive
         const float* af = tile + P.off_af;                        //  dynamic entities, agent index = slot)
-        // observation staging, as the host found room (vmas_hip.hip, launch of ENV_FOOTBALL):
-        //   E.scratch_off <= -2: the TILE's [R = -E.scratch_off][D + 2] array from the ballots on (football_post_tile's
-        //     shared form: contiguous runs; the block barriers inside are uniform - every wave of the tile is here);
-        //   E.scratch_off >= 0: a [64][17] tile per wave - the first waves in the per-substep scratch from the ballots to the
-        //     contact list (ballots | base | keys | forces | torques: written before they are read in every substep, and the
-        //     next one is a barrier away), the others behind the kernel's own LDS;  -1: none
+        // observation staging (E.scratch_off >= 0: the host found room): a [64][17] tile per wave - the first waves in
+        // the per-substep scratch from the ballots to the contact list (ballots | base | keys | forces | torques: written
+        // before they are read in every substep, and the next one is a barrier away), the others behind the kernel's own LDS
         float* slab = nullptr;
-        int chunk = kFootballStageChunk;
-        if (E.scratch_off <= -2) {
-          slab = (float*)ballots;
-          chunk = E.scratch_off;
-        } else if (E.scratch_off >= 0) {
+        if (E.scratch_off >= 0) {
           constexpr int kSlab = 64 * (kFootballStageChunk + 1);
-          const int in_dead = (int)(dead_end - (const float*)ballots) / kSlab;
+          const int in_dead = (int)((const float*)xmask - (const float*)ballots) / kSlab;
           slab = wv < in_dead ? (float*)ballots + wv * kSlab : lds + E.scratch_off + (wv - in_dead) * kSlab;
         }
         football_post_tile(TileCtx(batch), E.football.d, E.football.o, batch,
                            [&](int slot, int k) { return k < 4 ? rows[(slot * 6 + k) * ROWF] : af[(slot * 3 + (k - 4)) * ROWF]; },
-                           slab, chunk, fb_prev, post_steps, stp);
+                           slab, kFootballStageChunk, fb_prev, post_steps, stp);
       }
       if (stp + 1 < n_steps) __syncthreads();  // the next step's prologue rewrites the agent-force rows
     }

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(512) void football_post_kernel(const VmasFootballDe
   for (int k = 0; k < 4; ++k) prev[k] = C.live ? o.pos_shaping[(long)k * batch + C.env] : 0.f;  // (every wave: all need the team rewards)
   float steps_in = C.wave == 0 ? load_steps(o.limit, C) : 0.f;
   __syncthreads();
-  football_post_tile(C, d, o, batch, [&](int slot, int k) { return rows[(slot * 6 + k) * 64 + C.lane]; },
+  football_post_tile<true>(C, d, o, batch, [&](int slot, int k) { return rows[(slot * 6 + k) * 64 + C.lane]; },
                      lds + (n + 1) * 6 * 64, -64, prev, steps_in, stp);  // (stp: the step's slab of every per-step output)
 }
 

@@ -1088,10 +1088,14 @@ VD void run_script(const VmasAgentScript& S, const float* E, long stride, long e
 // (scripts/micro/store_pattern.hip, 461 MB at 131 072 environments: every lane its own row 16 bytes at a time 3.6 TB/s,
 // 64- or 128-byte pieces of the rows 3.1-3.2 TB/s, the rows as they lie - 1 024 contiguous bytes per instruction - 5.85 TB/s).
 // For one agent the rows of a tile are ONE contiguous run of 64 * D floats, so:
-//   chunk < 0: `slab` is the TILE's [R = -chunk][D + 2] array.  All waves take the agents one after the other: each wave
-//     computes 8-column groups (the own/ball columns are two, every observed other is one) for the R rows of the pass -
-//     lanes outside the pass do not write -, block barrier, the block's threads store the pass's run of R * D floats as
-//     it lies (R a multiple of 4: whole 128-byte lines), block barrier.  EVERY wave of the tile must call.
+//   SHARED (chunk < 0; the stand-alone kernel): `slab` is the TILE's [R = -chunk][D + 2] array.  All waves take the agents
+//     one after the other: each wave computes 8-column groups (the own/ball columns are two, every observed other is one)
+//     for the R rows of the pass - lanes outside the pass do not write -, block barrier, the block's threads store the
+//     pass's run of R * D floats as it lies (R a multiple of 4: whole 128-byte lines), block barrier.  EVERY wave of the
+//     tile must call.  As the step kernel's epilogue this form was measured and dropped (profiles/r04h_football_
+//     observation_staging_ab.jsonl): a tile in a K-step launch is bound by its own chain, and 60 barriers per step lengthen it
+//     (131 072 environments: 210 us per step against 183; one step per launch 260 against 287 - but see vmas_hip.hip: two
+//     launches per step take 172).
 //   chunk > 0: `slab` is THIS wave's [64][chunk + 1] tile (chunk = 16 or 32 columns) - the wave transposes its agent's
 //     observation `chunk` columns at a time; the lanes of a store cover 64- or 128-byte pieces of the rows.  No block
 //     barrier: the latency regime's form (16 waves per tile, one agent per wave, nothing to wait for).
@@ -1103,7 +1107,7 @@ constexpr int kChunk = 32;               // (chunk > 0 forms: the widest chunk)
 constexpr int kFootballStageChunk = 16;  // the step kernel's per-wave form: 64-byte pieces, a quarter of the LDS
 __host__ __device__ inline size_t football_shared_slab_floats(int rows, int D) { return (size_t)rows * (D + 2); }
 
-template <class Get>
+template <bool SHARED = false, class Get>  // SHARED: the chunk < 0 form is compiled in (the stand-alone kernel; not the step kernel's epilogue)
 VD void football_post_tile(const TileCtx& C, const VmasFootballDesc& d, const VmasFootballBuffers& o_in, int batch, Get G,
                            float* slab, int chunk, float (&prev)[4], float& steps_in, int stp) {
   const int n = d.n_blue + d.n_red, ball = n;  // slot of the ball
@@ -1153,15 +1157,7 @@ VD void football_post_tile(const TileCtx& C, const VmasFootballDesc& d, const Vm
     }
   }
   if (C.wave == 0) {
-    // (the address of this lane's `steps` word is the prologue's too: remade here from an opaque lane number, or the step
-    //  kernel carries it - two registers - through the whole physics, and spills it where the kernel is at its register cap)
-    TileCtx Cs = C;
-    {
-      int l = C.lane;
-      asm volatile("" : "+v"(l));
-      Cs.env = C.b0 + l;
-    }
-    const bool done = apply_step_limit(o.limit, Cs, steps_in, blue_score || red_score);
+    const bool done = apply_step_limit(o.limit, C, steps_in, blue_score || red_score);
     if (C.live) {
       o.terms[C.env] = sparse_blue;
       o.done[C.env] = done ? 1 : 0;
@@ -1172,7 +1168,7 @@ VD void football_post_tile(const TileCtx& C, const VmasFootballDesc& d, const Vm
 
   // ---- observation football.py:1221-1460; red agents see everything mirrored in x.  The three forms of the header:
   //      the tile's waves on one agent at a time through the shared array (contiguous runs) ...
-  if (slab != nullptr && chunk < 0) {
+  if constexpr (SHARED) {
     const int R = -chunk, tid = C.wave * 64 + C.lane, nthreads = C.nw * 64;
     for (int a = 0; a < n; ++a) {
       const bool blue = a < d.n_blue;

@@ -1057,7 +1057,7 @@ struct VmasWorld {
   } adapt;
   uint32_t* d_exact_mask = nullptr;
   uint32_t* d_nav_mask = nullptr;  // navigation epilogue: World.collides' pair bits of the post-step state: two masks that
-  int football_form = -1;          // football's Environment.step: -1 the library's choice, 0 one launch, 1 two (vmas_debug_football_form)
+  int football_form = -1;          // football's Environment.step: -1 the library's choice, 0 one launch, 1 two per step (vmas_debug_football_form)
   int nav_flip = 0;                //   eager launches alternate between (nav_flip: the one the next launch fills; it is zero)
                                    //   and a third for captured launches
   uint32_t* d_nav_sync = nullptr;  // its grid-barrier form: unused | timeout flag | ring of four slots of 64-bit arrival-and-pair-bit words
@@ -1570,8 +1570,8 @@ static int select_config(VmasWorld* w) {
 }
 
 static inline int blocks_of(int batch) { return (batch + TILE - 1) / TILE; }
-// football's Environment.step: one launch (post-step as the epilogue) up to this many tiles per CU, two launches beyond
-constexpr int kFootballSplitTilesPerCu = 2;
+// football's Environment.step (one step per call): one launch (post-step as the epilogue) up to this many tiles per CU (step_env_impl)
+constexpr int kFootballOneLaunchTilesPerCu = 1;
 
 // Launch of a generated specialisation G (its schedule is word for word S's): the lean single World.step, the multi-step
 // form (several steps and / or substeps per launch) or the fused-environment forms.  0 ok, -1 error.
@@ -1828,6 +1828,17 @@ static int build_compact(VmasWorld* w) {
       load[best] += units[u].cost;
     }
   }
+  if (knob("VMAS_DEBUG_SCHED"))
+    for (int wv = 0; wv < nw; ++wv) {
+      float load = 0.f;
+      std::string what;
+      for (int u : of_wave[wv]) {
+        load += units[u].cost;
+        what += (units[u].type == VMAS_PAIR_LS ? " LS" : " SS") + std::to_string(units[u].n);
+      }
+      fprintf(stderr, "[compact nw=%d] wave %2d owns %d, units%s: cost %.0f\n", nw, wv,
+              (int)owned.size() > wv ? ((int)owned.size() - wv + nw - 1) / nw : 0, what.c_str(), load);
+    }
   std::vector<uint32_t> blob;
   auto align4 = [&]() { while (blob.size() % 4) blob.push_back(0); };
   D.t_owned = (int)blob.size();
@@ -1909,7 +1920,7 @@ static int build_compact(VmasWorld* w) {
   int dyn_at = D.off_tab + D.blob_words;
   dyn_at = (dyn_at + 3) & ~3;
   D.off_dyn = dyn_at;
-  // cnt[4] | hit | xmask | gmask | ballots (u64) | base | keys[CAP] | contacts[CAP] (float2) | torques[CAP] (worlds with rotatable lines)
+  // cnt[4] | hit | ballots (u64) | base | keys[CAP] | contacts[CAP] (float2) | torques[CAP] (worlds with rotatable lines) | xmask
   for (const VmasPairDesc& P : w->pairs)
     if (P.type == VMAS_PAIR_LS && (E[P.a].flags & VMAS_F_ROTATABLE)) D.has_torque = 1;
   size_t dyn_words = 4 + (size_t)((D.n_owned * hw + 1) & ~1) + 2 * (size_t)nP + (size_t)((nP + 1) & ~1) + CAP;
@@ -2568,19 +2579,26 @@ static int step_env_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld
       return fail("vmas_world_step_env: the football epilogue writes one [n_agents][batch][obs_dim] block (equal observation sizes)");
     if (!o->pos_shaping || !o->obs || !o->rew || !o->terms || !o->touching || !o->done)
       return fail("vmas_world_step_env: null football buffer");
-    // Two forms.  (a) ONE launch: the post-step as the compacted kernel's epilogue, K steps per launch - the latency regime's
-    // (every tile resident: 16 384 environments 25 us per rollout step against 16 + 12 as two launches).  (b) TWO launches
-    // per step from here - the step kernel with the ingest prologue, then the stand-alone post-step kernel: the throughput
-    // regime's.  The epilogue's registers on top of the physics' (119 against 80) leave the fused kernel four waves per SIMD
-    // = two tiles per CU where the physics alone has three, and a tile that is writing observations holds its LDS and
-    // registers while it does; measured at 131 072 environments (profiles/r04i_*): fused 277 us per Environment.step / 185
-    // per rollout step, split: see DESIGN.md section 6.  Same device functions either way: the same bits.
-    static const int env_knob = knob("VMAS_FOOTBALL_SPLIT") ? atoi(knob("VMAS_FOOTBALL_SPLIT")) : -1;  // (A/B: 0 fused, 1 split)
-    const int split_knob = w->football_form >= 0 ? w->football_form : env_knob;
+    // Two forms, the same device functions in both (the same bits: tests/test_round4_gpu.py).
+    // (0) ONE launch: the post-step as the compacted kernel's epilogue, K steps per launch.  Every K-step rollout, and single
+    //     steps up to one tile per CU.  Its limits as ONE step per launch beyond that: the epilogue's registers on top of the
+    //     physics' (119 against 80) leave the kernel four waves per SIMD = two tiles per CU where the physics alone has three;
+    //     every tile is in the same phase at the same time - all in the physics (instruction issue), then all storing
+    //     observations, a row per lane (3.6 TB/s of the 5.85 HBM takes contiguous runs at: scripts/micro/store_pattern.hip).
+    //     In a K-step launch the tiles drift apart and one tile's stores run beside another's contacts.
+    // (1) TWO launches per step: the step kernel with the ingest prologue (three tiles per CU), then the stand-alone post-step
+    //     kernel (a tile's rows as the contiguous runs they are).  Single steps beyond one tile per CU: 131 072 environments
+    //     245 -> 172-177 us per Environment.step, 65 536: 144 -> 123, 32 768: 71 -> 69 (profiles/r04j_football_forms_by_batch.jsonl;
+    //     16 384: 44 one launch, 48 two).  K-step rollouts stay with (0): 181 us per step at 131 072 against 195, 96 against
+    //     117 at 65 536.  Measured and dropped: (1) with the post-steps on a second queue beside the NEXT step's physics
+    //     (reading a snapshot of the agents' rows): 214 us per step at 131 072, 100 at 65 536 - the two kernels take the
+    //     chip from each other.
+    static const int env_knob = knob("VMAS_FOOTBALL_SPLIT") ? atoi(knob("VMAS_FOOTBALL_SPLIT")) : -1;  // (A/B, profile builds)
+    const int forced = w->football_form >= 0 ? w->football_form : env_knob;
     const bool fused_possible = compact_on(w) && !(args && args->joint_fixed_rot);
-    const bool split = split_knob >= 0 ? (split_knob == 1 || !fused_possible)
-                                       : (!fused_possible || blocks_of(w->batch) > kFootballSplitTilesPerCu * w->n_cu);
-    if (split) {
+    int form = forced >= 0 ? forced : (n_steps == 1 && blocks_of(w->batch) > kFootballOneLaunchTilesPerCu * w->n_cu ? 1 : 0);
+    if (form == 0 && !fused_possible) form = 1;
+    if (form != 0) {
       if (!o->agent_ft) return fail("vmas_world_step_env: football as two launches per step needs VmasFootballBuffers.agent_ft");
       if (ingest && ingest->n_scripts > 0 && n_steps > 1 && !compact_on(w))
         return fail("vmas_world_rollout_env: scripted agents read the state in HBM, which a multi-step launch does not refresh");
@@ -2700,50 +2718,19 @@ static int step_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld, co
     if (env_kind == ENV_FOOTBALL) {
       if (!cp) return fail("vmas_world_step_env: the football epilogue runs behind the compacted step kernel, which this world / "
                            "this launch does not use (vmas_world_set_compact, per-environment joint inputs)");
-      // observation staging (football_post_tile).  The per-substep scratch from the ballots on is dead by then and the last
-      // part of the kernel's own LDS (ballots, base, keys, contact forces, torques: vmas_compact.h), so a staging array that
-      // starts there runs on into whatever dynamic LDS is added behind.
+      // observation staging (football_post_tile): [64][17] floats per wave, the first waves' in the per-substep scratch
+      // that is dead by then (ballots, base, keys, contact forces, torques: vmas_compact.h).
+      const size_t slab = 64 * (kFootballStageChunk + 1);
       const compact::DevCompact& dc = w->cp.dc;
-      const size_t dead_words = 2 * (size_t)dc.n_pairs + (size_t)((dc.n_pairs + 1) & ~1) + (size_t)compact::CAP * (dc.has_torque ? 4 : 3);
-      const VmasFootballDesc& fd = env->football.d;
-      const int obs_dim = 16 + 8 * ((fd.observe_adversaries ? fd.n_red : 0) + (fd.observe_teammates ? fd.n_blue - 1 : 0));
+      const int in_dead = (int)((2 * (size_t)dc.n_pairs + (size_t)((dc.n_pairs + 1) & ~1) + (size_t)compact::CAP * (dc.has_torque ? 4 : 3)) / slab);
+      const size_t stage = w->cp.nw > in_dead ? (size_t)(w->cp.nw - in_dead) * slab * sizeof(float) : 0;
+      // Only in the latency regime (16 waves per tile: one tile per CU whatever its LDS).  With 8 waves per tile the
+      // 79 KB leave the CU two tiles on paper, but measured (131 072 environments, rollout): 657 us per step against 180
+      // without; half tiles ([32][17], a chunk in two passes, 61 KB per tile): 191 - 16 384 environments: 23.6 against 28.9.
       static const bool no_stage = knob("VMAS_FOOTBALL_NO_STAGE") != nullptr && knob("VMAS_FOOTBALL_NO_STAGE")[0] == '1';  // (A/B)
-      static const int forced_rows = knob("VMAS_FOOTBALL_STAGE_ROWS") ? atoi(knob("VMAS_FOOTBALL_STAGE_ROWS")) : 0;        // (A/B)
-      size_t stage = 0;
-      env->scratch_off = -1;
-      if (!no_stage && w->cp.nw >= 16 && forced_rows == 0) {
-        // (a) the latency regime (16 waves per tile: one tile per CU whatever its LDS): [64][17] floats per wave, one agent
-        // per wave, no barrier - the first waves' tiles in the dead scratch.  With 8 waves per tile the 79 KB leave the CU
-        // two tiles on paper, but measured (131 072 environments, rollout): 657 us per step against 180 without; half tiles
-        // ([32][17], a chunk in two passes, 61 KB per tile): 191 - 16 384 environments: 23.6 against 28.9.
-        const size_t slab = 64 * (kFootballStageChunk + 1);
-        const int in_dead = (int)(dead_words / slab);
-        stage = w->cp.nw > in_dead ? (size_t)(w->cp.nw - in_dead) * slab * sizeof(float) : 0;
-        if (w->cp.lds_bytes + stage <= 160 * 1024) env->scratch_off = (int32_t)(w->cp.lds_bytes / sizeof(float));
-        else stage = 0;
-      }
-      if (!no_stage && env->scratch_off == -1) {
-        // (b) the tile's waves on one agent at a time, R rows per pass through ONE [R][obs_dim + 2] array: the rows leave as
-        // the contiguous run they are (5.85 TB/s against the 3.6 of a row per lane: scripts/micro/store_pattern.hip).
-        // R: the most rows (a multiple of 4: whole 128-byte lines) that keep as many tiles on a CU as the kernel has alone
-        const size_t granule = 2048, cu = 160 * 1024;  // (an upper bound of the allocation granule: never a tile fewer)
-        auto tiles = [&](size_t bytes) { return cu / (((bytes + granule - 1) / granule) * granule); };
-        const size_t alone = tiles(w->cp.lds_bytes);
-        int rows = 0;
-        for (int r = 64; r >= 4 && rows == 0; r -= 4) {
-          const size_t need = football_shared_slab_floats(r, obs_dim);
-          const size_t extra = need > dead_words ? (need - dead_words) * sizeof(float) : 0;
-          if (tiles(w->cp.lds_bytes + extra) >= alone) { rows = r; stage = extra; }
-        }
-        if (forced_rows >= 4 && forced_rows <= 64 && forced_rows % 4 == 0) {
-          rows = forced_rows;
-          const size_t need = football_shared_slab_floats(rows, obs_dim);
-          stage = need > dead_words ? (need - dead_words) * sizeof(float) : 0;
-        }
-        if (rows >= 4 && w->cp.lds_bytes + stage <= cu) env->scratch_off = -rows;
-        else stage = 0;
-      }
-      return launch_compact(w, ENV_FOOTBALL, state, agent_ft, ld, a, env, stage, s, w->batch, ld);
+      const bool staged = !no_stage && w->cp.nw >= 16 && w->cp.lds_bytes + stage <= 160 * 1024;
+      env->scratch_off = staged ? (int32_t)(w->cp.lds_bytes / sizeof(float)) : -1;
+      return launch_compact(w, ENV_FOOTBALL, state, agent_ft, ld, a, env, staged ? stage : 0, s, w->batch, ld);
     }
     if (S->nw < 2 && env_kind != ENV_INGEST && env_kind != ENV_NAVIGATION)
       return fail("vmas_world_step_env: the fused epilogue needs at least 2 waves per tile");
@@ -2802,7 +2789,7 @@ int vmas_debug_compact_stats(VmasWorld* w, int64_t out[4]) {
 }
 
 int vmas_debug_football_form(VmasWorld* w, int32_t form) {
-  if (!w || form < -1 || form > 1) return fail("vmas_debug_football_form: form is -1 (the library's choice), 0 (one launch) or 1 (two)");
+  if (!w || form < -1 || form > 1) return fail("vmas_debug_football_form: form is -1 (the library's choice), 0 (one launch) or 1 (two per step)");
   w->football_form = form;
   return 0;
 }
