@@ -208,22 +208,36 @@ __global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld
   //      loop waits for each entity's rows in turn: 9 k of the kernel's 47 k cycles per wave in the first version).
   {
     constexpr int LB = 4;  // entities per wave and batch (4 x 8 waves >= football's 23 entities: one batch)
-    const unsigned long long any_mask = P.dyn_mask | P.static_mask;
+    // one word per entity from the planner's table (the blob in global memory: its LDS copy is made by this very phase):
+    // bit 0 in the tile, 1 dynamic, 2 line | tile row of its first row << 3 | tile row of its cos row << 13
+    const uint32_t* etab = P.blob + P.t_entoff;
+    const long env_ld = lv ? env : (long)batch - 1;  // (tail lanes of an unpadded plane read the last environment's column)
     const uint4* bsrc = (const uint4*)P.blob;
     uint4* bdst = (uint4*)(lds + P.off_tab);
     const int n4 = P.blob_words >> 2, nt = blockDim.x;
     for (int e0 = wv; e0 < W.nE || e0 == wv; e0 += LB * nw) {
       float v[LB][6];
       float4 tc[LB];
+      uint32_t desc[LB];
 #pragma unroll
       for (int j = 0; j < LB; ++j) {
         const int e = e0 + j * nw;
-        const bool on = e < W.nE && ((any_mask >> e) & 1ull);
-        const bool is_dyn = on && ((P.dyn_mask >> e) & 1ull), is_line = on && ((P.line_mask >> e) & 1ull);
-        const int rows = !on ? 0 : (is_dyn ? 0x3f : (0x03 | (is_line ? 0x10 : 0)));
-        const float* src = state + (long)(on ? e : 0) * 6 * ld + env;
+        const uint32_t d0 = etab[e < W.nE ? e : 0];
+        desc[j] = e < W.nE ? d0 : 0u;
+      }
 #pragma unroll
-        for (int f = 0; f < 6; ++f) v[j][f] = (((rows >> f) & 1) && lv) ? src[f * ld] : 0.f;
+      for (int j = 0; j < LB; ++j) {
+        const int e = e0 + j * nw;
+        const uint32_t d = desc[j];
+        const bool on = d & 1u, is_dyn = d & 2u, is_line = d & 4u;
+        const float* src = state + (long)(on ? e : 0) * 6 * ld + env_ld;
+#pragma unroll
+        for (int f = 0; f < 6; ++f) v[j][f] = 0.f;
+        if (on) {
+          v[j][0] = src[0]; v[j][1] = src[ld];
+          if (d & 6u) v[j][4] = src[4 * ld];
+          if (is_dyn) { v[j][2] = src[2 * ld]; v[j][3] = src[3 * ld]; v[j][5] = src[5 * ld]; }
+        }
         // (a scalar load with its own wait per entity - four in a row in front of the tile's first barrier.  Measured in round 4,
         //  same box, the previous build beside it: as vector loads, all in flight together, 16 384 environments 16.38 -> 16.2 us
         //  but 16 more vector registers took the kernel from 6 to 5 waves per SIMD - 131 072 environments 65.3 -> 76.9 us
@@ -256,10 +270,10 @@ __global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld
       // ---- stores (and the lines' cos / sin)
 #pragma unroll
       for (int j = 0; j < LB; ++j) {
-        const int e = e0 + j * nw;
-        if (!(e < W.nE && ((any_mask >> e) & 1ull))) continue;
-        const bool is_dyn = (P.dyn_mask >> e) & 1ull, is_line = (P.line_mask >> e) & 1ull;
-        float* dst = tile + ent_off(e);
+        const uint32_t d = desc[j];
+        if (!(d & 1u)) continue;
+        const bool is_dyn = d & 2u, is_line = d & 4u;
+        float* dst = tile + (int)((d >> 3) & 1023u) * ROWF;
         if (is_dyn) {
 #pragma unroll
           for (int f = 0; f < 6; ++f) dst[f * ROWF] = v[j][f];
@@ -276,7 +290,7 @@ __global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld
             cs = tc[j].y; sn = tc[j].z; cached = true;
           }
           if (!cached) sincosf(rot, &sn, &cs);
-          const int tr = trig_off(e);
+          const int tr = (int)((d >> 13) & 1023u) * ROWF;
           tile[tr] = cs;
           tile[tr + ROWF] = sn;
         }

@@ -1906,7 +1906,13 @@ static int build_compact(VmasWorld* w) {
   for (int wv = 0; wv < nw; ++wv) { blob.push_back((uint32_t)wave_range[wv].first); blob.push_back((uint32_t)wave_range[wv].second); }
   align4();
   D.t_entoff = (int)blob.size();
-  for (int e = 0; e < nE; ++e) blob.push_back((uint32_t)ent_off[e]);
+  for (int e = 0; e < 64; ++e) {  // the load phase's word per entity (vmas_compact.h): flags | first row << 3 | cos row << 13
+    uint32_t d = 0;
+    if (e < nE && ent_off[e] >= 0)
+      d = 1u | (dyn(e) ? 2u : 0u) | (tr_off[e] >= 0 ? 4u : 0u) | ((uint32_t)(ent_off[e] / ROWF) << 3) |
+          ((uint32_t)(tr_off[e] >= 0 ? tr_off[e] / ROWF : 0) << 13);
+    blob.push_back(d);
+  }
   align4();
   D.t_bounds = (int)blob.size();
   for (int p = 0; p < nP; ++p) blob.push_back(fbits(w->pairs[p].bound_sum));
