@@ -208,27 +208,28 @@ __global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld
   //      loop waits for each entity's rows in turn: 9 k of the kernel's 47 k cycles per wave in the first version).
   {
     constexpr int LB = 4;  // entities per wave and batch (4 x 8 waves >= football's 23 entities: one batch)
-    // one word per entity from the planner's table (the blob in global memory: its LDS copy is made by this very phase):
-    // bit 0 in the tile, 1 dynamic, 2 line | tile row of its first row << 3 | tile row of its cos row << 13
-    const uint32_t* etab = P.blob + P.t_entoff;
+    static_assert(LB == 4, "the load table holds four entities per (batch, wave): one uint4");
+    // the planner's load table (the blob in global memory: its LDS copy is made by this very phase): per (batch, wave) the
+    // LB entities the wave loads, one word each - bit 0 valid, 1 dynamic, 2 line | tile row of its first row << 3 | tile row
+    // of its cos row << 13 | entity << 23 - as ONE 16-byte scalar load
+    const uint4* etab = (const uint4*)(P.blob + P.t_entoff);
     const long env_ld = lv ? env : (long)batch - 1;  // (tail lanes of an unpadded plane read the last environment's column)
     const uint4* bsrc = (const uint4*)P.blob;
     uint4* bdst = (uint4*)(lds + P.off_tab);
     const int n4 = P.blob_words >> 2, nt = blockDim.x;
-    for (int e0 = wv; e0 < W.nE || e0 == wv; e0 += LB * nw) {
+    // One batch of LB entities per wave.  The first batch is code of its own, outside the loop of the later ones (worlds of
+    // more than LB * waves entities): inside a loop the compiler's wait insertion takes every register the previous
+    // iteration loaded into for still pending and puts a vmcnt(0) in front of each entity's address arithmetic - the four
+    // entities' loads went out one memory round trip after the other.
+    auto load_batch = [&](const int e0, const bool first) {
       float v[LB][6];
       float4 tc[LB];
-      uint32_t desc[LB];
+      const uint4 dq = etab[(e0 - wv) / LB + wv];  // (batch * nw + wave)
+      const uint32_t desc[LB] = {dq.x, dq.y, dq.z, dq.w};
 #pragma unroll
       for (int j = 0; j < LB; ++j) {
-        const int e = e0 + j * nw;
-        const uint32_t d0 = etab[e < W.nE ? e : 0];
-        desc[j] = e < W.nE ? d0 : 0u;
-      }
-#pragma unroll
-      for (int j = 0; j < LB; ++j) {
-        const int e = e0 + j * nw;
         const uint32_t d = desc[j];
+        const int e = (int)(d >> 23);
         const bool on = d & 1u, is_dyn = d & 2u, is_line = d & 4u;
         const float* src = state + (long)(on ? e : 0) * 6 * ld + env_ld;
 #pragma unroll
@@ -244,7 +245,9 @@ __global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld
         //  (profiles/r04h_ab_*.jsonl); as branch-free SCALAR loads in flight with the rows, no register more: 16.33 -> 16.34,
         //  65.3 -> 65.6 (r04k_ab_*.jsonl) - the 7.4 k cycles between a wave's start and its last load request
         //  (r04k_football16384_compact_phase_trace.txt) are not these loads)
-        tc[j] = (is_line && !is_dyn && P.trig_cache != nullptr) ? P.trig_cache[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+        // (branch-free, at an address that is always valid - the entity's entry, or the blob's first bytes: requested with the
+        //  rows, no wait of its own; whether it IS a cache entry is asked where it is used)
+        tc[j] = *((is_line && !is_dyn && P.trig_cache != nullptr) ? P.trig_cache + e : (const float4*)P.blob);
       }
       // (first batch only) the agent forces that are plain loads, and this thread's share of the blob
       auto plain_row = [&](int a) {
@@ -257,7 +260,6 @@ __global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld
         }
         return plain;
       };
-      const bool first = e0 == wv;
       const bool pa0 = first && plain_row(wv), pa1 = first && plain_row(wv + nw);
       const float* fs0 = agent_ft + (long)(pa0 ? wv : 0) * 3 * ld + env;
       const float* fs1 = agent_ft + (long)(pa1 ? wv + nw : 0) * 3 * ld + env;
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld
           const float rot = v[j][4];
           float sn, cs;
           bool cached = false;
-          if (!is_dyn && tc[j].w != 0.f && __all(__float_as_uint(rot) == __float_as_uint(tc[j].x) || !live)) {
+          if (!is_dyn && P.trig_cache != nullptr && tc[j].w != 0.f && __all(__float_as_uint(rot) == __float_as_uint(tc[j].x) || !live)) {
             cs = tc[j].y; sn = tc[j].z; cached = true;
           }
           if (!cached) sincosf(rot, &sn, &cs);
@@ -301,7 +303,9 @@ __global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld
         if (bi0 < n4) bdst[bi0] = bq0;
         if (bi1 < n4) bdst[bi1] = bq1;
       }
-    }
+    };
+    load_batch(wv, true);
+    for (int e0 = wv + LB * nw; e0 < W.nE; e0 += LB * nw) load_batch(e0, false);
     CSTAMP(13);  // (trace builds: the entity rows are in LDS)
     // agents beyond the first two per wave, and agents whose forces are made from actions / scripts (the ingest prologue)
     for (int a = wv; a < nA; a += nw) {

@@ -1906,12 +1906,19 @@ static int build_compact(VmasWorld* w) {
   for (int wv = 0; wv < nw; ++wv) { blob.push_back((uint32_t)wave_range[wv].first); blob.push_back((uint32_t)wave_range[wv].second); }
   align4();
   D.t_entoff = (int)blob.size();
-  for (int e = 0; e < 64; ++e) {  // the load phase's word per entity (vmas_compact.h): flags | first row << 3 | cos row << 13
-    uint32_t d = 0;
-    if (e < nE && ent_off[e] >= 0)
-      d = 1u | (dyn(e) ? 2u : 0u) | (tr_off[e] >= 0 ? 4u : 0u) | ((uint32_t)(ent_off[e] / ROWF) << 3) |
-          ((uint32_t)(tr_off[e] >= 0 ? tr_off[e] / ROWF : 0) << 13);
-    blob.push_back(d);
+  {  // the load phase's table (vmas_compact.h): per (batch, wave) the four entities wave + (4 * batch + j) * nw, one word each
+    // - flags | first row << 3 | cos row << 13 | entity << 23 - 16-byte aligned inside the blob (one scalar load per batch)
+    const int batches = (nE + 4 * nw - 1) / (4 * nw);
+    for (int b = 0; b < std::max(batches, 1); ++b)
+      for (int wv = 0; wv < nw; ++wv)
+        for (int j = 0; j < 4; ++j) {
+          const int e = wv + (4 * b + j) * nw;
+          uint32_t d = 0;
+          if (e < nE && ent_off[e] >= 0)
+            d = 1u | (dyn(e) ? 2u : 0u) | (tr_off[e] >= 0 ? 4u : 0u) | ((uint32_t)(ent_off[e] / ROWF) << 3) |
+                ((uint32_t)(tr_off[e] >= 0 ? tr_off[e] / ROWF : 0) << 13) | ((uint32_t)e << 23);
+          blob.push_back(d);
+        }
   }
   align4();
   D.t_bounds = (int)blob.size();
