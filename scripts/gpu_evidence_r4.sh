@@ -48,7 +48,7 @@ python scripts/prof_env_host.py balance 32768 > $OUT/${TAG}_env_step_host_profil
 if [[ " $* " != *" quick "* && " $* " != *" no-shard-counters "* ]]; then
 # counters of the latency-regime shards and the one-launch balance step (next-round items 2 and 3)
 ACTIONS=zero RATED=step_kernel_spec_multi:env bash scripts/gpu_counters.sh ${TAG}_navigation8192_env_step 1480 30000 8192 -- python $S/bench_bound.py navigation 8192 > /dev/null 2>&1
-FORCES=random RATED=step_kernel_compact:physics bash scripts/gpu_counters.sh ${TAG}_football16384_physics_compact 948 11900 16384 -- python $S/bench_world.py football 16384 300 > /dev/null 2>&1
+COMPACT=1 FORCES=random RATED=step_kernel_compact:physics bash scripts/gpu_counters.sh ${TAG}_football16384_physics_compact 948 11900 16384 -- python $S/bench_world.py football 16384 300 > /dev/null 2>&1
 RATED=step_kernel_spec_multi:env bash scripts/gpu_counters.sh ${TAG}_balance32768_env_step 657 2000 32768 -- python $S/bench_bound.py balance 32768 > /dev/null 2>&1
 grep -h "sustained\|traffic / alg\|share of wave" $OUT/${TAG}_navigation8192_env_step_pmc_summary.txt $OUT/${TAG}_football16384_physics_compact_pmc_summary.txt $OUT/${TAG}_balance32768_env_step_pmc_summary.txt
 fi
