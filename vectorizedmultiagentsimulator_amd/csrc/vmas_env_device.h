@@ -985,25 +985,6 @@ VD VmasActionSlot load_action_slot(const VmasActionSlot* p) {
   __builtin_memcpy(&s, r, sizeof(s));
   return s;
 }
-// (the same through a UNIFORM row and the 32-bit lane: `global_load v, v_lane, s[base]` - no 64-bit per-lane offset, the
-//  form the world-specialised kernel's load phase uses throughout: vmas_spec_kernel.h)
-VD void ingest_fetch_tile(const VmasActionSlot& S, long row_tile /* row0 + first environment of the tile */, unsigned lane, bool live,
-                          IngestRaw& r) {
-  r.u[0] = r.u[1] = r.u[2] = 0.f;
-  r.flat = 0;
-  if (!live) return;
-  if (S.action_index != nullptr) {
-    r.flat = as_global(S.action_index + row_tile)[lane];
-  } else if (S.action_size == 2 && ((uintptr_t)S.action & 7) == 0) {  // (rows of two floats: one 8-byte load)
-    typedef float vf2 __attribute__((ext_vector_type(2)));
-    const vf2 v = as_global((const vf2*)(S.action + row_tile * 2))[lane];
-    r.u[0] = v.x; r.u[1] = v.y;
-  } else {
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-      if (k < S.action_size) r.u[k] = as_global(S.action + row_tile * S.action_size)[lane * (unsigned)S.action_size + (unsigned)k];
-  }
-}
 VD void ingest_fetch(const VmasActionSlot& S, long env, bool live, long row0, IngestRaw& r) {
   r.u[0] = r.u[1] = r.u[2] = 0.f;
   r.flat = 0;
