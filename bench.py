@@ -455,6 +455,15 @@ def attached_reference_leg(name, kw, B, device, n=300):
 
 
 # ------------------------------------------------------------------------------------------------ one configuration
+def _library_build_id():
+    """Digest of the sources libvmas_hip.so was built from (vmas_build_id, csrc/build.sh): ties a line to a commit's kernels."""
+    try:
+        from vectorizedmultiagentsimulator_amd import _abi as A
+        return (A.load_library().vmas_build_id() or b"").decode()
+    except Exception:  # noqa: BLE001 - a line without the id is still a line
+        return None
+
+
 def measure(name, args, device, shard, dist, rank, world_size, brief=False):
     """Everything bench.py measures on one configuration; `brief`: the short form the default run appends for the other
     configurations (physics + Environment.step, fewer steps, no CPU legs)."""
@@ -800,6 +809,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            "library_build_id": _library_build_id(),
             "value_is": "World.step() physics (north-star hot path), timed with HIP events inside the fences; `environment_step` = "
                         "the same metric through Environment.step() (SURVEY.md 8d); `wall` = the same K steps by the host clock",
             "wall": {"ms_per_step": r["wall_s"] / steps * 1e3, "value": r["wall_value"]},
