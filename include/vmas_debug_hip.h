@@ -31,6 +31,14 @@ int vmas_debug_schedule(VmasWorld* w, uint32_t* words, int64_t capacity, int32_t
  * vmas_world_exact_status): the next launch on the world must fail loudly.  For the test of exactly that. */
 int vmas_debug_force_gave_up(VmasWorld* w);
 
+/* The plan of the lane-compacted step kernel (csrc/vmas_compact.h; works on planning worlds): the table blob as it is staged
+ * into LDS (`words`, may be NULL to query the size) and meta[16] = {waves per tile, owned entities per wave, LDS bytes per tile,
+ * blob words, pairs, owned entities, word offset of the load table, of the waves' unit ranges, of the unit records, dynamic /
+ * static-in-a-pair / line entity masks, tile row of the agent forces, of the first cos row, has_torque, entities}.  The load
+ * table: per (batch b, wave w) four words, word j for entity w + (4 b + j) * waves - bit 0 in the tile, 1 dynamic, 2 line |
+ * first tile row << 3 | cos row << 13 | entity << 23.  Fails for worlds the compacted kernel does not take. */
+int vmas_debug_compact_plan(VmasWorld* w, uint32_t* words, int64_t capacity, int64_t* meta /* [16] */);
+
 /* football's Environment.step / rollout (vmas_world_step_env / vmas_world_rollout_env with VMAS_POST_FOOTBALL) has two forms
  * with the same device functions: 0 one launch (the post-step as the compacted step kernel's epilogue: every K-step rollout,
  * single steps up to one tile per CU), 1 two launches per step (step kernel, then the stand-alone post-step kernel: single

@@ -286,6 +286,7 @@ EXPORTED_SYMBOLS = (
     "vmas_debug_schedule",
     "vmas_debug_force_gave_up",
     "vmas_debug_football_form",
+    "vmas_debug_compact_plan",
     "vmas_debug_compact_stats",
     "vmas_world_exact_status",
     "vmas_world_load_spec",

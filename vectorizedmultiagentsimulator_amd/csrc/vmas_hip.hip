@@ -1069,6 +1069,7 @@ struct VmasWorld {
     bool ok = false;
     compact::DevCompact dc{};
     uint32_t* d_blob = nullptr;
+    std::vector<uint32_t> h_blob;  // host copy of the tables (vmas_debug_compact_plan: the planner's tests run without a GPU)
     size_t lds_bytes = 0;
     int nw = 8, own = 1;
     float4* d_trig = nullptr;  // cos / sin of the static lines' rotations (environment 0), filled at the first launch
@@ -1943,6 +1944,7 @@ static int build_compact(VmasWorld* w) {
     fprintf(stderr, "[compact nw=%d] rows %d, tables %d words, per-substep scratch %zu words, LDS %zu B per tile\n", nw, rows,
             D.blob_words, dyn_words, C.lds_bytes);
   if (C.lds_bytes > 160 * 1024) return 0;
+  C.h_blob = blob;
   if (!w->host_only) {
     HIP_TRY(upload(&C.d_blob, blob));
     D.blob = C.d_blob;
@@ -2798,6 +2800,22 @@ int vmas_debug_compact_stats(VmasWorld* w, int64_t out[4]) {
   unsigned long long c = 0;
   HIP_TRY(hipMemcpy(&c, w->adapt.d_count, sizeof(c), hipMemcpyDeviceToHost));
   out[0] = (int64_t)c; out[1] = (int64_t)w->adapt.tiles; out[2] = (int64_t)w->adapt.switches; out[3] = (int64_t)w->adapt.backoff;
+  return 0;
+}
+
+int vmas_debug_compact_plan(VmasWorld* w, uint32_t* words, int64_t capacity, int64_t* meta /* [16] */) {
+  if (!w || !meta) return fail("vmas_debug_compact_plan: null argument");
+  const VmasWorld::CompactPlan& C = w->cp;
+  if (!C.ok) return fail("vmas_debug_compact_plan: this world has no plan for the lane-compacted kernel");
+  const compact::DevCompact& D = C.dc;
+  const int64_t m[16] = {C.nw, C.own, (int64_t)C.lds_bytes, (int64_t)C.h_blob.size(), D.n_pairs, D.n_owned, D.t_entoff, D.t_waves,
+                         D.t_units, (int64_t)D.dyn_mask, (int64_t)D.static_mask, (int64_t)D.line_mask, D.off_af, D.off_tr,
+                         D.has_torque, w->base.nE};
+  memcpy(meta, m, sizeof(m));
+  if (words) {
+    if (capacity < (int64_t)C.h_blob.size()) return fail("vmas_debug_compact_plan: %zu words, capacity %lld", C.h_blob.size(), (long long)capacity);
+    memcpy(words, C.h_blob.data(), C.h_blob.size() * sizeof(uint32_t));
+  }
   return 0;
 }
 
