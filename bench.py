@@ -196,8 +196,38 @@ def cpu_port(w, forces_cpu, state0_cpu, budget_s=6.0):
             "sample": f"{n} World.step() x {B} envs (same state/forces as the GPU run), {el:.1f} s, C oracle with OpenMP over environments"}
 
 
-def cpu_reference(name, kw, w, actions, state0_cpu, budget_s=10.0, max_envs=32768):
-    """The reference's own Environment.step - and, inside it, its World.step - on the host cores (device="cpu")."""
+def _pack_ref_state(world):
+    """[E, 6, B] of a reference world (pos.x pos.y vel.x vel.y rot ang_vel per entity: the packed layout, host side)."""
+    import torch
+
+    return torch.stack([torch.cat([e.state.pos, e.state.vel, e.state.rot, e.state.ang_vel], dim=-1).T for e in world.entities]).clone()
+
+
+def _pack_ref_ft(world):
+    import torch
+
+    return torch.stack([torch.cat([a.state.force, a.state.torque], dim=-1).T for a in world.agents]).clone()
+
+
+def _err_stats(got, want, tol=1e-5):
+    """max |got - want| over the values that are finite and of physical magnitude on both sides (a blown-up environment -
+    the reference itself reaches 1e24 in dense soups - is counted, not compared), and how many exceed tol abs + tol rel."""
+    import torch
+
+    got, want = got.double(), want.double()
+    sane = torch.isfinite(got) & torch.isfinite(want) & (want.abs() < 1e3) & (got.abs() < 1e3)
+    err = (got - want).abs()[sane]
+    beyond = int((err > tol + tol * want.abs()[sane]).sum())
+    return (float(err.max()) if err.numel() else 0.0), beyond, int(sane.numel() - sane.sum()), int(sane.sum())
+
+
+def cpu_reference(name, kw, w, actions, state0_cpu, budget_s=10.0, max_envs=32768, threads=None, parity=None):
+    """The reference's own Environment.step - and, inside it, its World.step - on the host cores (device="cpu").
+    ``parity`` (the GPU run's environment, its post-reset snapshot and device actions): the SAME reference steps are the
+    checker of the native path in this very run (BASELINE.md section 3 "parity in the same run") - every 10th step's
+    pre-step state and agent forces are kept (outside the timers), replayed as ONE native World.step each and compared
+    with what the reference's step made of them (teacher-forced); and the native environment is run free from the same
+    start with the same actions for as many steps as the reference made, its drift reported separately."""
     import torch
     from oracle import ref
 
@@ -217,12 +247,22 @@ def cpu_reference(name, kw, w, actions, state0_cpu, budget_s=10.0, max_envs=3276
             e.set_ang_vel(st0[i, 5:6, :B].T.clone(), batch_index=None)
 
     in_world = [0.0]
+    hook_s = [0.0]
+    samples, sample_now = [], [False]
     orig_step = world.step
 
     def timed_world_step():
+        if sample_now[0]:
+            th = time.perf_counter()
+            pre, ft = _pack_ref_state(world), _pack_ref_ft(world)
+            hook_s[0] += time.perf_counter() - th
         t0 = time.perf_counter()
         orig_step()
         in_world[0] += time.perf_counter() - t0
+        if sample_now[0]:
+            th = time.perf_counter()
+            samples.append((pre, ft, _pack_ref_state(world)))
+            hook_s[0] += time.perf_counter() - th
 
     world.step = timed_world_step
 
@@ -234,7 +274,7 @@ def cpu_reference(name, kw, w, actions, state0_cpu, budget_s=10.0, max_envs=3276
     # box against 50 ms with 8.  Probed in ascending order, stopping once a count is clearly slower.
     probed, best = {}, (float("inf"), 1)
     with torch.no_grad():
-        for th in sorted({4, 8, 16, 32, 64, min(ncpu, 128), ncpu}):
+        for th in (sorted({4, 8, 16, 32, 64, min(ncpu, 128), ncpu}) if threads is None else [threads]):
             if th > ncpu:
                 continue
             torch.set_num_threads(th)
@@ -254,16 +294,26 @@ def cpu_reference(name, kw, w, actions, state0_cpu, budget_s=10.0, max_envs=3276
         for k in range(2):
             env_step(k)
         restore()
-        in_world[0] = 0.0
+        in_world[0] = hook_s[0] = 0.0
         n, t0 = 0, time.perf_counter()
         while True:
+            sample_now[0] = parity is not None and n % 10 == 0
             env_step(n)
             n += 1
-            el = time.perf_counter() - t0
+            el = time.perf_counter() - t0 - hook_s[0]
             if (el > budget_s and n >= 2) or n >= EPISODE:
                 break
+        sample_now[0] = False
+        final_ref = _pack_ref_state(world)
     sub = w.substeps
+    par = None
+    if parity is not None:
+        try:
+            par = same_run_parity(parity, w, B, samples, final_ref, n)
+        except Exception as e:  # noqa: BLE001 (a parity leg that cannot run says so; it never breaks the line)
+            par = {"error": repr(e)[:300]}
     return {
+        "parity": par,
         "value": B * n * sub / in_world[0], "unit": "env-steps/s", "cores": threads, "kind": "reference",
         "torch_threads": torch.get_num_threads(), "host_cpus": ncpu, "envs": B,
         "ms_per_env_step_by_threads": probed,
@@ -274,6 +324,52 @@ def cpu_reference(name, kw, w, actions, state0_cpu, budget_s=10.0, max_envs=3276
                      "world_step_share": in_world[0] / el,
                      "note": "the reference's Environment.step (environment.py:325): ingest + World.step + reward/obs/done"},
         "reference_from": ref.root(),
+    }
+
+
+def same_run_parity(ctx, w, B, samples, final_ref, n_ref_steps):
+    """The native path checked against the reference steps that were just timed (see cpu_reference).  Teacher-forced: each
+    sampled pre-step state + agent forces -> ONE native World.step (the product's launch, the product's broad phase) ->
+    compared with the reference's post-step state.  Free-running: the native Environment from the same post-reset state
+    with the same actions, compared after the number of steps the reference made."""
+    import torch
+
+    genv, snapshot, acts_dev = ctx["env"], ctx["snapshot"], ctx["acts_dev"]
+    be = w._get_backend()
+    st, ft = w._packed_state(), w._packed_agent_ft()
+    nA = len(w.agents)
+    worst, beyond, blown, values = 0.0, 0, 0, 0
+    for pre, f, post in samples:
+        genv.set_state(snapshot)  # (columns beyond B: a sane state)
+        st[:, :, :B].copy_(pre.to(st.device))
+        ft[:nA, :, :B].copy_(f.to(st.device))
+        w.invalidate_queries()
+        if w.exact_broad_phase:
+            be.step_exact()
+        else:
+            be.step()
+        e, b, bl, v = _err_stats(st[:, :, :B].cpu(), post)
+        worst, beyond, blown, values = max(worst, e), beyond + b, blown + bl, values + v
+    # free-running: the native Environment.step (ingest + physics + post-step in one launch) from the same start
+    genv.set_state(snapshot)
+    for k in range(n_ref_steps):
+        genv.step(list(acts_dev[k % EPISODE].unbind(0)))
+    got = w._packed_state()[:, :, :B].cpu()
+    d = (got.double() - final_ref.double()).abs()
+    sane = torch.isfinite(d) & (final_ref.abs() < 1e3)
+    d = d[sane]
+    genv.set_state(snapshot)
+    return {
+        "teacher_forced_max_abs": worst, "values_beyond_1e-5": beyond, "values_compared": values, "blown_up_values_skipped": blown,
+        "teacher_forced_steps": len(samples), "envs": B,
+        "free_running_drift": {"steps": n_ref_steps, "max_abs": float(d.max()) if d.numel() else 0.0,
+                               "median_abs": float(d.median()) if d.numel() else 0.0,
+                               "frac_beyond_1e-3": float((d > 1e-3).double().mean()) if d.numel() else 0.0},
+        "note": "same run, same reference steps as `cpu_baseline`: every 10th reference World.step replayed as one native "
+                "World.step from the reference's pre-step state and forces (teacher-forced; tolerance 1e-5 abs + 1e-5 rel, "
+                "north_star); free_running = native Environment.step from the same start and actions, |state - reference's| after "
+                "`steps` steps (two fp32 implementations of a chaotic contact system: the reference against itself with "
+                "another thread count drifts alike, SURVEY.md App. C-2)",
     }
 
 
@@ -397,60 +493,89 @@ def _sync(device):
 
 
 # ------------------------------------------------------------------------------------------------ attached reference
-def attached_reference_leg(name, kw, B, device, n=300):
-    """attach(vmas.make_env(..., device='cuda')) - the reference's own Environment / Scenario / World objects on the GPU, its
-    World.step (and Lidar.measure) rebound to the native kernels: us per world.step() call (host enqueue and GPU), and the
-    reference's full Environment.step around it."""
+def attached_reference_leg(name, kw, B, device, n=300, brief=False):
+    """attach(vmas.make_env(..., device='cuda')) - the reference's own Environment / Scenario / World objects on the GPU.
+    `env_step_us`: the reference's ``env.step`` as `attach()` leaves it by default - for the four benchmark scenarios the
+    one-launch kernel (ingest prologue + World.step + reward/observation/done/info epilogue, attached_env.py) with the
+    reference's action asserts kept (one host sync per step); `env_step_no_validate_us`: the same with
+    ``validate_actions=False``; `env_step_unfused_us`: ``attach(fused=False)`` - only World.step (and Lidar.measure) rebound,
+    the reference's tensor-op ingest / reward / observation around it (what rounds 1-4 measured); `world_step_*`: the
+    rebound seam alone."""
     import torch
     from oracle import ref  # (locates the reference package - /root/reference or its byte-compiled build; it is the HOST here)
     from vectorizedmultiagentsimulator_amd.adapter import attach
 
     sc = CONFIGS[name]["scenario"]
     env = ref.make_env(sc, num_envs=B, device=str(device), seed=0, continuous_actions=True, **kw)
-    h = attach(env, specialize=None)
     world = env.world
-    acts = [env.get_random_action(a) for a in env.agents]
-    with torch.no_grad():
-        for _ in range(5):
-            env.step(acts)
+    # fresh random actions every step (a cycle of 25 pre-drawn sets: one held action drives every body into a wall and
+    # measures the dense-contact case only)
+    cycle = [[env.get_random_action(a) for a in env.agents] for _ in range(25)]
+    acts = cycle[0]
+    sub = int(getattr(world, "_substeps", 1))
+
+    def time_env_steps(m, warm=20):
+        for k in range(warm):
+            env.step(cycle[k % 25])
         torch.cuda.synchronize()
-        # (a) world.step alone: the rebound seam, forces as the last env.step left them
-        t_w = time.perf_counter()
-        while time.perf_counter() - t_w < 0.2:
-            for _ in range(50):
-                world.step()
-            torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         e0.record()
-        for _ in range(n):
-            world.step()
-        t1 = time.perf_counter()
+        for k in range(m):
+            env.step(cycle[k % 25])
         e1.record()
         torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        gpu_us = e0.elapsed_time(e1) / n * 1e3
-        # (b) the reference's Environment.step with the native World.step inside
-        m = max(10, n // 10)
-        for _ in range(3):
-            env.step(acts)
-        torch.cuda.synchronize()
-        t3 = time.perf_counter()
-        for _ in range(m):
-            env.step(acts)
-        torch.cuda.synchronize()
-        t4 = time.perf_counter()
-    out = {
-        "world_step_us": (t2 - t0) / n * 1e6, "world_step_host_enqueue_us": (t1 - t0) / n * 1e6, "world_step_gpu_us": gpu_us,
-        "env_step_us": (t4 - t3) / m * 1e6, "steps": n, "env_steps": m, "envs": B,
-        "kernel": "world-specialised (from the on-disk cache)" if h.backend.specialized else "schedule interpreter",
-        "exact_broad_phase": bool(h.exact_broad_phase), "refreshes": h.refreshes,
-        "value": B * int(getattr(world, "_substeps", 1)) / ((t2 - t0) / n), "unit": "env-steps/s",
-        "note": "attach(vmas.make_env(..., device='cuda')): the reference's World.step rebound to vmas_world_step; host enqueue = "
-                "Python time per world.step() call (static-change detection + one foreign call), env_step = the reference's own "
-                "Environment.step (its tensor-op ingest / reward / observation on the GPU) around it",
-    }
-    h.detach()
+        return (time.perf_counter() - t0) / m * 1e6, e0.elapsed_time(e1) / m * 1e3
+
+    out = {"envs": B}
+    with torch.no_grad():
+        # (1) the default attach: env.step itself is the kernel where a post-step kernel covers the configuration
+        h = attach(env, specialize=None)
+        out["fused"] = h.fused is not None
+        if h.fused is None:
+            out["fused_reason"] = h.fused_reason
+        else:
+            out["launches_per_env_step"] = 1 if h.fused.one_launch else (2 if h.fused.ingest_in_step else 3)
+        m = n if h.fused is not None else max(10, n // 10)
+        out["env_step_us"], out["env_step_gpu_us"] = time_env_steps(m)
+        out["kernel"] = "world-specialised" if h.backend.specialized else ("lane-compacted" if getattr(h.backend, "compact", False)
+                                                                          else "schedule interpreter")
+        out["exact_broad_phase"] = bool(h.exact_broad_phase)
+        if not brief:
+            # the rebound seam alone: forces as the last env.step left them
+            t_w = time.perf_counter()
+            while time.perf_counter() - t_w < 0.2:
+                for _ in range(50):
+                    world.step()
+                torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            e0.record()
+            for _ in range(n):
+                world.step()
+            t1 = time.perf_counter()
+            e1.record()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            out.update({"world_step_us": (t2 - t0) / n * 1e6, "world_step_host_enqueue_us": (t1 - t0) / n * 1e6,
+                        "world_step_gpu_us": e0.elapsed_time(e1) / n * 1e3, "steps": n})
+        out["refreshes"] = h.refreshes
+        h.detach()
+        if out["fused"]:
+            # (2) without the reference's action asserts (no host sync per step)
+            h = attach(env, specialize=None, validate_actions=False)
+            out["env_step_no_validate_us"], out["env_step_no_validate_gpu_us"] = time_env_steps(m)
+            h.detach()
+        if not brief:
+            # (3) only the seam rebound: the reference's own Environment.step around the native World.step
+            h = attach(env, specialize=None, fused=False)
+            out["env_step_unfused_us"], _ = time_env_steps(max(10, n // 10), warm=3)
+            h.detach()
+    out["value"] = B * sub / (out["env_step_us"] * 1e-6)
+    out["unit"] = "env-steps/s"
+    out["value_is"] = "env-steps/s through the REFERENCE's env.step after attach() (defaults: fused where covered, action asserts kept)"
+    if "env_step_no_validate_us" in out:
+        out["value_no_validate"] = B * sub / (out["env_step_no_validate_us"] * 1e-6)
     return out
 
 
@@ -681,9 +806,25 @@ def measure(name, args, device, shard, dist, rank, world_size, brief=False):
         "bytes_per_env": bytes_per_env, "ach": ach, "gflops": gflops, "lanes": be.lanes_per_env,
         "value": rate(steps, ev_s), "wall_value": rate(steps, wall_s),
         "single": single, "env_leg": env_leg, "persistent": persistent, "sharded": sharded,
-        "env": env, "w": w, "be": be, "actions": actions, "forces": forces, "state0": state0,
+        "env": env, "w": w, "be": be, "actions": actions, "forces": forces, "state0": state0, "snapshot": snapshot,
+        "acts_dev": acts_dev,
     }
     return res
+
+
+def binds_note(cfg, bytes_per_env, B, kernel_us):
+    """Which roof (if any) binds one World.step launch of this configuration: its traffic at 8 TB/s, its arithmetic at the fp32
+    vector peak, against the measured time and the ~2.6 us an empty launch takes (profiles/r04q_launch_floor.txt)."""
+    t_hbm = bytes_per_env * B / 8e12 * 1e6
+    t_flop = cfg["flop"] * B / (FP32_PEAK_GFLOPS * 1e9) * 1e6
+    if kernel_us < 3 * 2.6 and max(t_hbm, t_flop) < 0.5 * kernel_us:
+        which = "neither roof: launch floor (~2.6 us empty launch) plus one tile's dependent chain"
+    elif t_flop > t_hbm:
+        which = "closer to the fp32 vector roof than to HBM (transcendental-heavy contact arithmetic at quarter rate on top)"
+    else:
+        which = "HBM is the nearer roof"
+    return ("one launch moves %.1f MB (%.1f us at 8 TB/s) and %.0f Mflop (%.2f us at fp32 peak) in %.1f us: %s"
+            % (bytes_per_env * B / 1e6, t_hbm, cfg["flop"] * B / 1e6, t_flop, kernel_us, which))
 
 
 def brief_line(r):
@@ -693,7 +834,9 @@ def brief_line(r):
         "value": r["value"], "unit": "env-steps/s", "us_per_step": r["kernel_s"] * 1e6, "steps": r["steps"],
         "kernel": r["kernel_short"], "queues": r["n_queues"], "lanes_per_env": r["lanes"],
         "roofline": {"bound": "hbm", "achieved": r["ach"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r["ach"] / HBM_PEAK_GBS,
-                     "bytes_per_env": r["bytes_per_env"], "gflops": r["gflops"], "traffic": None},
+                     "bytes_per_env": r["bytes_per_env"], "gflops": r["gflops"], "traffic": None,
+                     "gflops_frac_of_fp32_vector_peak": r["gflops"] / FP32_PEAK_GFLOPS,
+                     "binds": binds_note(CONFIGS[r["name"]], r["bytes_per_env"], r["envs_per_gpu"], r["kernel_s"] * 1e6)},
     }
     if r["env_leg"] is not None:
         e = r["env_leg"]
@@ -773,21 +916,19 @@ def main():
     others = None
     if args.config == "balance" and world_size == 1 and not args.no_other_configs and not args.fused and not args.num_envs:
         others = {}
+        other_runs = {}
         for other in ("transport", "transport_2pkg", "navigation", "football"):
             try:
                 o = measure(other, args, device, EnvShard(CONFIGS[other]["envs"], 0, 1), None, 0, 1, brief=True)
                 others[other] = brief_line(o)
+                other_runs[other] = o
                 del o
             except Exception as e:  # noqa: BLE001
                 others[other] = {"error": repr(e)}
-            torch.cuda.empty_cache()
 
     if rank == 0:
         bytes_per_env = r["bytes_per_env"]
-        gb_note = ("neither roof at this batch: one launch moves %.1f MB (%.1f us at 8 TB/s) and %.0f Mflop (%.2f us at fp32 peak); "
-                   "the launch is a ~3 us launch floor plus one tile's dependent chain (DESIGN.md section 3.1, profiles/r04_*). "
-                   "HBM is the nominal bound." % (bytes_per_env * B / 1e6, bytes_per_env * B / 8e12 * 1e6, cfg["flop"] * B / 1e6,
-                                                   cfg["flop"] * B / (FP32_PEAK_GFLOPS * 1e9) * 1e6))
+        gb_note = binds_note(cfg, bytes_per_env, B, kernel_s * 1e6) + " (DESIGN.md section 3.1, profiles/r04q_launch_floor.txt). HBM is the nominal bound."
         out = {
             "metric": f"env-steps/sec (batch x substeps) on '{cfg['scenario']}'",
             "value": r["value"],
@@ -837,7 +978,7 @@ def main():
                 "frac": r["ach"] / HBM_PEAK_GBS,
                 "traffic": None,
                 "traffic_note": "HBM bytes by the PMC counters need rocprofv3 around the process: per launch in "
-                                f"profiles/r04_{args.config}{B}_physics_pmc_summary.txt (scripts/gpu_evidence_r4.sh), not in this line",
+                                f"profiles/r05_bench_q1_pmc_summary.txt (scripts/gpu_run.sh evidence), not in this line",
                 "kernel": r["kernel_short"],
                 "kernel_us": kernel_s * 1e6,
                 "kernel_us_is": "time per World.step of the whole batch from the HIP events (region / K)" + (
@@ -872,7 +1013,9 @@ def main():
             w = r["w"]
             st0, f_cpu = r["state0"].cpu().numpy(), r["forces"].cpu().numpy()
             try:
-                out["cpu_baseline"] = cpu_reference(args.config, kw, w, r["actions"], st0)
+                out["cpu_baseline"] = cpu_reference(args.config, kw, w, r["actions"], st0,
+                                                    parity={"env": r["env"], "snapshot": r["snapshot"], "acts_dev": r["acts_dev"]})
+                out["parity"] = out["cpu_baseline"].pop("parity")
             except Exception as e:  # noqa: BLE001 the reference is not importable here: say so, keep the port
                 out["cpu_baseline_error"] = repr(e)[:500]
             nb = min(B, 32768)
@@ -884,6 +1027,37 @@ def main():
             e = r["env_leg"]
             if e and "value" in e and "env_step" in out["cpu_baseline"]:
                 out["cpu_baseline"]["env_step"]["gpu_over_cpu"] = e["value"] / out["cpu_baseline"]["env_step"]["value"]
+            a = out.get("attached_reference")
+            if a and "value" in a and "env_step" in out["cpu_baseline"]:  # north_star's >= 50x THROUGH the reference's own API
+                a["over_cpu_reference_env_step"] = a["value"] / out["cpu_baseline"]["env_step"]["value"]
+        # the other configurations through the reference's own objects, each beside a short same-run CPU reference
+        if others is not None and world_size == 1 and not args.no_attached:
+            threads = out.get("cpu_baseline", {}).get("cores") if out.get("cpu_baseline", {}).get("kind") == "reference" else None
+            for other, o in other_runs.items():
+                line = others[other]
+                okw = o["kwargs"]
+                try:
+                    line["attached_reference"] = attached_reference_leg(other, okw, o["envs_per_gpu"], device, n=100, brief=True)
+                except Exception as e:  # noqa: BLE001
+                    line["attached_reference"] = {"error": repr(e)[:300]}
+                if args.no_cpu_baseline:
+                    continue
+                try:
+                    c = cpu_reference(other, okw, o["w"], o["actions"], o["state0"].cpu().numpy(), budget_s=3.0, max_envs=8192,
+                                      threads=threads, parity={"env": o["env"], "snapshot": o["snapshot"], "acts_dev": o["acts_dev"]})
+                    line["parity"] = c.pop("parity")
+                    line["cpu_reference"] = {"world_step_value": c["value"], "env_step_value": c["env_step"]["value"], "cores": c["cores"],
+                                             "envs": c["envs"], "steps": c["env_step"]["steps"], "unit": "env-steps/s"}
+                    line["gpu_over_cpu"] = line["value"] / c["value"]
+                    es = line.get("environment_step", {})
+                    if "value" in es:
+                        es["gpu_over_cpu"] = es["value"] / c["env_step"]["value"]
+                    a = line["attached_reference"]
+                    if "value" in a:
+                        a["over_cpu_reference_env_step"] = a["value"] / c["env_step"]["value"]
+                except Exception as e:  # noqa: BLE001
+                    line["cpu_reference"] = {"error": repr(e)[:300]}
+            other_runs.clear()
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

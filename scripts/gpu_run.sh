@@ -1,0 +1,95 @@
+# One parametrised GPU-call script (replaces the per-call gpu_r4*.sh of round 4):
+#   gpurun -- 'TAG=r05a bash scripts/gpu_run.sh STAGE [STAGE...]'
+# Everything lands in gpurun_out/$TAG/ (scratch); copy what is to be judged into profiles/.
+# Stages:
+#   tests-new        the attach(fused) tests + the tests touched this round (fast feedback)
+#   tests            the whole -m gpu suite + smoke()
+#   bench            bench.py default (every leg) + the driver-style invocation
+#   bench-configs    the full line of every other configuration
+#   attached         only the attached_reference legs of all five configurations
+#   ab LIB [LIB..] -- CMD...   A/B of libraries: CMD (a scripts/bench_*.py line printer) under each VMAS_HIP_LIB, twice, interleaved
+#   bw               bandwidth regime: balance at 262144 and 1048576 environments with kernel trace + counters
+#   counters-shards  counters of the latency-regime shards (navigation 8192 env step, football 16384 compact, balance env step)
+#   evidence         rocprofv3 of the bench command itself (one queue): kernel stats + PMC summary
+#   traces           per-phase traces (football compact, navigation env step, balance env step)
+TAG=${TAG:-r05}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
+cd $R
+S=$R/scripts
+export EVIDENCE_DIR=$TAG
+
+show_pytest() {  # the interesting lines of a pytest log
+  grep -E "^(FAILED|ERROR)|passed|failed|rc=|needed it|fixtures with any" "$1" | cut -c1-400 | head -40
+  grep -E "^E  +" "$1" | cut -c1-400 | head -60
+}
+
+while [ $# -gt 0 ]; do
+  STAGE=$1; shift
+  case $STAGE in
+  tests-new)
+    timeout 1500 python -m pytest tests/test_attached_env_gpu.py tests/test_adapter_reference.py tests/test_output_pool.py \
+      tests/test_env_fused_gpu.py tests/test_round4_gpu.py -m gpu -q --timeout=600 -p no:cacheprovider -x --tb=short > $OUT/pytest_new.log 2>&1
+    echo "pytest rc=$?" >> $OUT/pytest_new.log
+    show_pytest $OUT/pytest_new.log; tail -n 40 $OUT/pytest_new.log | cut -c1-300
+    ;;
+  tests)
+    rm -f gpurun_out/parity_allowance.jsonl
+    timeout 2400 python -m pytest tests -m gpu -q --timeout=600 -p no:cacheprovider -rs > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
+    show_pytest $OUT/pytest_gpu.log
+    cp gpurun_out/parity_allowance.jsonl $OUT/${TAG}_parity_allowance.jsonl 2>/dev/null
+    cp gpurun_out/broad_phase_full_size.jsonl $OUT/${TAG}_broad_phase_full_size.jsonl 2>/dev/null
+    python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+    ;;
+  bench)
+    ( time python bench.py > $OUT/${TAG}_bench_line_default.json 2> $OUT/bench_default.err ) 2>&1 | grep real
+    tail -3 $OUT/bench_default.err
+    python $S/show_line.py $OUT/${TAG}_bench_line_default.json
+    python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_bench_line_driver_style.json 2> $OUT/bench_driver_style.err
+    python $S/show_line.py $OUT/${TAG}_bench_line_driver_style.json brief
+    ;;
+  bench-configs)
+    for C_ in transport transport_2pkg navigation football; do
+      python bench.py --config $C_ > $OUT/${TAG}_bench_line_$C_.json 2> $OUT/bench_$C_.err; python $S/show_line.py $OUT/${TAG}_bench_line_$C_.json brief; tail -2 $OUT/bench_$C_.err
+    done
+    ;;
+  attached)
+    python $S/bench_attached.py > $OUT/${TAG}_attached_reference.jsonl 2> $OUT/attached.err; cat $OUT/${TAG}_attached_reference.jsonl | cut -c1-900; tail -5 $OUT/attached.err
+    ;;
+  ab)
+    LIBS=(); while [ $# -gt 0 ] && [ "$1" != "--" ]; do LIBS+=("$1"); shift; done; shift
+    CMD="$*"; set --
+    NAME=$(echo "${LIBS[*]:1}" | tr ' /' '__' | sed 's/libvmas_hip_//g; s/\.so//g')
+    AB=$OUT/${TAG}_ab_${NAME}.jsonl; : > $AB
+    for ROUND in 1 2; do for LIB in "${LIBS[@]}"; do
+      VMAS_HIP_LIB=$LIB bash -c "$CMD" 2>&1 | grep "^{" | sed "s/^{/{\"ab_library\": \"$LIB\", /" >> $AB
+    done; done
+    cut -c1-300 $AB
+    ;;
+  bw)
+    for B_ in 262144 1048576; do
+      { FORCES=random QUEUES=1 python $S/bench_world.py balance $B_ 300; FORCES=random python $S/bench_world.py balance $B_ 300; } 2>&1 | grep "^{" | tee -a $OUT/${TAG}_bandwidth_regime.jsonl
+      FORCES=random QUEUES=1 RATED=step_kernel_spec:physics bash $S/gpu_counters.sh ${TAG}_balance${B_}_physics 384 1700 $B_ -- python $S/bench_world.py balance $B_ 300 > /dev/null 2>&1
+      grep -h "sustained\|traffic / alg\|share of wave\|median" $OUT/${TAG}_balance${B_}_physics_pmc_summary.txt | head -12
+    done
+    scripts/micro/launch_floor 1048576 8 2>&1 | tail -8 | tee $OUT/${TAG}_launch_floor_1M.txt
+    ;;
+  counters-shards)
+    ACTIONS=zero RATED=step_kernel_spec_multi:env bash $S/gpu_counters.sh ${TAG}_navigation8192_env_step 1480 30000 8192 -- python $S/bench_bound.py navigation 8192 > /dev/null 2>&1
+    COMPACT=1 FORCES=random RATED=step_kernel_compact:physics bash $S/gpu_counters.sh ${TAG}_football16384_physics_compact 948 11900 16384 -- python $S/bench_world.py football 16384 300 > /dev/null 2>&1
+    RATED=step_kernel_spec_multi:env bash $S/gpu_counters.sh ${TAG}_balance32768_env_step 657 2000 32768 -- python $S/bench_bound.py balance 32768 > /dev/null 2>&1
+    grep -h "sustained\|traffic / alg\|share of wave" $OUT/${TAG}_navigation8192_env_step_pmc_summary.txt $OUT/${TAG}_football16384_physics_compact_pmc_summary.txt $OUT/${TAG}_balance32768_env_step_pmc_summary.txt
+    ;;
+  evidence)
+    BENCH="python $R/bench.py --no-cpu-baseline --no-fused --no-other-configs --no-attached --queues 1 --steps 2000 --warmup 200"
+    RATED=step_kernel_spec:physics bash $S/gpu_counters.sh ${TAG}_bench_q1 384 1700 32768 -- $BENCH > /dev/null 2>&1
+    grep -h "sustained\|traffic / alg\|share of wave\|median" $OUT/${TAG}_bench_q1_pmc_summary.txt | head
+    { echo "# scripts/micro/launch_floor (this round's box)"; scripts/micro/launch_floor 32768 8; } > $OUT/${TAG}_launch_floor.txt 2>&1; tail -6 $OUT/${TAG}_launch_floor.txt
+    ;;
+  traces)
+    python $S/trace_compact.py football 16384 2>&1 | grep -v amdgpu > $OUT/${TAG}_football16384_compact_phase_trace.txt; tail -20 $OUT/${TAG}_football16384_compact_phase_trace.txt
+    VMAS_TRACE=2 python $S/trace_nav.py 8192 2>&1 | grep -v amdgpu > $OUT/${TAG}_navigation8192_env_step_phase_trace.txt; tail -20 $OUT/${TAG}_navigation8192_env_step_phase_trace.txt
+    ;;
+  *) echo "unknown stage $STAGE";;
+  esac
+done

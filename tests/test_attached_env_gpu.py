@@ -1,0 +1,292 @@
+"""attach(vmas.make_env(..., device="cuda")) with the fused one-launch ``Environment.step`` (attached_env.py) beside an
+UNTOUCHED reference environment on the CPU - SURVEY.md 8b's boundary through the reference's own objects (VERDICT r4
+row g).  Teacher-forced: before every step the attached environment is given the CPU reference's state (entity state
+through the reference's setters, the scenario's shaping terms in place), both take the same actions, and what
+``env.step`` returns must agree - observations at 1e-5 abs+rel (north_star), rewards at that bound scaled by the
+magnitude of the shaping terms they are differences of (tests/test_env_fused_gpu.py), dones and flags exactly.  The
+configurations are those of the nine ``envstep_*`` fixtures.  The reference: oracle/_ref on the GPU box."""
+import ast
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import ENVSTEP_FIXTURES, GOLDEN_DIR
+
+pytestmark = [pytest.mark.gpu, pytest.mark.reference]
+
+ATOL, RTOL = 1e-5, 1e-5
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def vmas():
+    from oracle import ref
+
+    ref.import_vmas()
+    return ref
+
+
+def _cfg(fixture):
+    G = np.load(os.path.join(GOLDEN_DIR, fixture + ".npz"))
+    ms = int(G["max_steps"])
+    return fixture.split("_")[1], ast.literal_eval(str(G["kwargs"])), (None if ms < 0 else ms)
+
+
+SHAPING_SCALE = {"balance": 10.0, "transport": 10.0, "navigation": 1.0, "football": 2.0}
+
+
+def _terms(env, scenario):
+    """The scenario-side persistent tensors a step reads: (object, name) pairs."""
+    sc = env.scenario
+    if scenario == "balance":
+        return [(sc, "global_shaping")]
+    if scenario == "transport":
+        return [(p, n) for p in sc.packages for n in ("global_shaping", "on_goal")]
+    if scenario == "navigation":
+        return [(a, "pos_shaping") for a in env.world.agents]
+    return [(sc.ball, n) for n in ("pos_shaping_blue", "pos_shaping_red", "pos_shaping_agent_blue", "pos_shaping_agent_red")]
+
+
+def _force_state(ref, att, scenario):
+    """Teacher forcing: the CPU reference's state and shaping terms into the attached environment (in place)."""
+    for ea, eb in zip(ref.world.entities, att.world.entities):
+        eb.set_pos(ea.state.pos.to(DEV), batch_index=None)
+        eb.set_vel(ea.state.vel.to(DEV), batch_index=None)
+        eb.set_rot(ea.state.rot.to(DEV), batch_index=None)
+        eb.set_ang_vel(ea.state.ang_vel.to(DEV), batch_index=None)
+    for aa, ab in zip(ref.world.agents, att.world.agents):  # (football observes the previous step's agent forces)
+        if aa.state.force is not None:
+            ab.state.force = aa.state.force.to(DEV)
+        if aa.state.torque is not None:
+            ab.state.torque = aa.state.torque.to(DEV)
+    for (oa, n), (ob, _) in zip(_terms(ref, scenario), _terms(att, scenario)):
+        getattr(ob, n).copy_(getattr(oa, n).to(DEV))
+    att.steps.copy_(ref.steps.to(DEV))
+
+
+def _close(got, want, what, scale=1.0):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    assert got.shape == want.shape, f"{what}: shape {got.shape} vs {want.shape}"
+    err = np.abs(got - want)
+    bad = err > ATOL * scale + RTOL * np.abs(want)
+    assert not bad.any(), f"{what}: {bad.sum()} of {bad.size} off, max err {err.max():.3g} at {np.argwhere(bad)[:4].tolist()}"
+    return float(err.max()) if err.size else 0.0
+
+
+def _actions(env, g):
+    if env.continuous_actions:
+        return [(torch.rand(env.num_envs, a.action_size, generator=g) * 2 - 1) * a.action.u_range_tensor.cpu() for a in env.agents]
+    return [torch.randint(0, int(np.prod(a.discrete_action_nvec)), (env.num_envs, 1), generator=g) for a in env.agents]
+
+
+def _compare_step(out_ref, out_att, scenario, what):
+    o1, r1, d1, i1 = out_ref
+    o2, r2, d2, i2 = out_att
+    scale = SHAPING_SCALE[scenario]
+    assert isinstance(out_att, list) and isinstance(o2, list) and isinstance(r2, list) and isinstance(i2, list)
+    for k, (a, b) in enumerate(zip(o1, o2)):
+        _close(b.cpu().numpy(), a.numpy(), f"{what} obs[{k}]")
+    for k, (a, b) in enumerate(zip(r1, r2)):
+        _close(b.cpu().numpy(), a.numpy(), f"{what} rew[{k}]", scale=scale)
+    assert torch.equal(d1, d2.cpu()), f"{what} done: {(d1 != d2.cpu()).sum()} differ"
+    for k, (ia, ib) in enumerate(zip(i1, i2)):
+        assert set(ia) == set(ib), f"{what} info[{k}] keys {sorted(ia)} vs {sorted(ib)}"
+        for name in ia:
+            a, b = ia[name], ib[name].cpu()
+            if a.dtype == torch.bool:
+                assert torch.equal(a, b), f"{what} info[{k}][{name}]"
+            else:
+                _close(b.numpy(), a.numpy(), f"{what} info[{k}][{name}]", scale=scale)
+
+
+@pytest.mark.parametrize("fixture", ENVSTEP_FIXTURES)
+def test_attached_fused_env_step_equals_the_reference_teacher_forced(vmas, fixture):
+    from vectorizedmultiagentsimulator_amd.adapter import attach
+
+    scenario, kw, max_steps = _cfg(fixture)
+    B, T = 70, 40
+    ref = vmas.make_env(scenario, num_envs=B, device="cpu", seed=0, max_steps=max_steps, **kw)
+    att = vmas.make_env(scenario, num_envs=B, device=DEV, seed=0, max_steps=max_steps, **kw)
+    h = attach(att, fused=True)  # (True: a fallback to the reference's tensor-op step would fail the test, not pass it)
+    assert h.fused is not None and att.__dict__["step"] == h.fused.step and h.exact_broad_phase
+    g = torch.Generator().manual_seed(11)
+    n_done = 0
+    with torch.no_grad():
+        for t in range(T):
+            _force_state(ref, att, scenario)
+            acts = _actions(ref, g)
+            out_ref = ref.step([a.clone() for a in acts])
+            out_att = att.step([a.to(DEV) for a in acts])
+            _compare_step(out_ref, out_att, scenario, f"{fixture} t={t}")
+            assert torch.equal(att.steps.cpu(), ref.steps)
+            # the world the step left behind (what the NEXT reference-side call - reset_at, render, a query - would see)
+            for ea, eb in zip(ref.world.entities, att.world.entities):
+                _close(eb.state.pos.cpu().numpy(), ea.state.pos.numpy(), f"{fixture} t={t} {ea.name}.pos")
+                _close(eb.state.vel.cpu().numpy(), ea.state.vel.numpy(), f"{fixture} t={t} {ea.name}.vel")
+            n_done += int(out_ref[2].sum())
+            if t == 12:  # a partial reset through the reference's own reset_at: observations by its tensor ops on the views
+                ref.reset_at(3)
+                oa = att.reset_at(3)
+                assert len(oa) == len(att.agents) and oa[0].shape == out_att[0][0].shape[1:]
+            if t == 25:
+                ref.reset()
+                ob = att.reset()
+                assert len(ob) == len(att.agents) and ob[0].shape == out_att[0][0].shape
+    h.detach()
+    assert "step" not in att.__dict__
+    att.step([a.to(DEV) for a in _actions(att, g)])  # the reference's own Environment.step works again
+
+
+@pytest.mark.parametrize("scenario,kw", [("balance", dict(n_agents=4)), ("navigation", dict(n_agents=4)),
+                                         ("football", dict(n_blue_agents=3, n_red_agents=3, ai_red_agents=False))])
+def test_attached_fused_env_free_running_tracks_the_reference(vmas, scenario, kw):
+    """No teacher forcing: same start, same actions, 30 steps - the drift stays that of two fp32 implementations of a
+    chaotic system (the plumbing bound of tests/test_adapter_reference.py), rewards and dones follow."""
+    from vectorizedmultiagentsimulator_amd.adapter import attach
+
+    B = 130
+    ref = vmas.make_env(scenario, num_envs=B, device="cpu", seed=0, **kw)
+    att = vmas.make_env(scenario, num_envs=B, device=DEV, seed=0, **kw)
+    h = attach(att, fused=True)
+    _force_state(ref, att, scenario)
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for t in range(30):
+            acts = _actions(ref, g)
+            o1, r1, d1, _ = ref.step([a.clone() for a in acts])
+            o2, r2, d2, _ = att.step([a.to(DEV) for a in acts])
+            for a, b in zip(o1, o2):
+                assert torch.allclose(a, b.cpu(), atol=5e-3, rtol=1e-2), f"{scenario} obs diverged at step {t}: {(a - b.cpu()).abs().max()}"
+            assert (d1 == d2.cpu()).float().mean() > 0.98
+    h.detach()
+
+
+def test_attached_fused_dict_spaces_truncation_discrete_and_clamp(vmas):
+    from vectorizedmultiagentsimulator_amd.adapter import attach
+
+    B = 40
+    # dict spaces + terminated / truncated split
+    kw = dict(n_agents=3)
+    ref = vmas.make_env("balance", num_envs=B, device="cpu", seed=0, max_steps=4, dict_spaces=True, terminated_truncated=True, **kw)
+    att = vmas.make_env("balance", num_envs=B, device=DEV, seed=0, max_steps=4, dict_spaces=True, terminated_truncated=True, **kw)
+    h = attach(att, fused=True)
+    g = torch.Generator().manual_seed(2)
+    for t in range(6):
+        _force_state(ref, att, "balance")
+        acts = {a.name: u for a, u in zip(ref.agents, _actions(ref, g))}
+        o1, r1, te1, tr1, i1 = ref.step({k: v.clone() for k, v in acts.items()})
+        o2, r2, te2, tr2, i2 = att.step({k: v.to(DEV) for k, v in acts.items()})
+        assert list(o2) == list(o1) and list(r2) == list(r1) and list(i2) == list(i1)
+        for k in o1:
+            _close(o2[k].cpu().numpy(), o1[k].numpy(), f"dict obs {k} t={t}")
+            _close(r2[k].cpu().numpy(), r1[k].numpy(), f"dict rew {k} t={t}", scale=10.0)
+        assert torch.equal(te1, te2.cpu()) and torch.equal(tr1, tr2.cpu()), t
+        assert bool(tr1.all()) == (t >= 3)
+    h.detach()
+    # discrete actions, and clamped continuous ones out of range
+    for env_kw, bad_scale in ((dict(continuous_actions=False), None), (dict(clamp_actions=True), 3.0)):
+        ref = vmas.make_env("transport", num_envs=B, device="cpu", seed=0, **env_kw)
+        att = vmas.make_env("transport", num_envs=B, device=DEV, seed=0, **env_kw)
+        h = attach(att, fused=True)
+        for t in range(5):
+            _force_state(ref, att, "transport")
+            acts = _actions(ref, g)
+            if bad_scale:
+                acts = [a * bad_scale for a in acts]
+            out_ref = ref.step([a.clone() for a in acts])
+            out_att = att.step([a.to(DEV) for a in acts])
+            _compare_step(out_ref, out_att, "transport", f"transport {env_kw} t={t}")
+        h.detach()
+
+
+def test_attached_fused_validates_like_the_reference(vmas):
+    """environment.py:621,651-653: NaN / out-of-range actions raise BEFORE the world is touched; validate_actions=False
+    drops the check (and its host sync)."""
+    from vectorizedmultiagentsimulator_amd.adapter import attach
+
+    att = vmas.make_env("balance", num_envs=33, device=DEV, seed=0, n_agents=3)
+    h = attach(att, fused=True)
+    good = [att.get_random_action(a) for a in att.agents]
+    att.step(good)
+    before = h.state.clone()
+    steps = att.steps.clone()
+    bad = [a.clone() for a in good]
+    bad[1][5, 0] = float("nan")
+    with pytest.raises(AssertionError):
+        att.step(bad)
+    bad = [a.clone() for a in good]
+    bad[2][7, 1] = 1.5
+    with pytest.raises(AssertionError):
+        att.step(bad)
+    with pytest.raises(AssertionError):
+        att.step(good[:2])
+    assert torch.equal(h.state, before) and torch.equal(att.steps, steps), "a refused action must not touch the world"
+    att.step(good)  # and the environment goes on
+    h.detach()
+    h = attach(att, fused=True, validate_actions=False)
+    att.step(good)
+    h.detach()
+
+
+def test_attached_fused_outputs_are_fresh_and_scenario_attributes_follow(vmas):
+    from vectorizedmultiagentsimulator_amd.adapter import attach
+
+    att = vmas.make_env("balance", num_envs=130, device=DEV, seed=0, n_agents=4)
+    h = attach(att, fused=True)
+    acts = [att.get_random_action(a) for a in att.agents]
+    o1, r1, d1, i1 = att.step(acts)
+    keep = [x.clone() for x in o1]
+    o2, r2, _, _ = att.step(acts)
+    assert all(torch.equal(a, b) for a, b in zip(o1, keep)), "a later step must not overwrite returned observations"
+    assert o1[0].data_ptr() != o2[0].data_ptr()
+    sc = att.scenario
+    assert torch.equal(sc.ground_rew + sc.pos_rew, r2[0])  # the scenario's own attributes are the step's
+    # ... and its tensor-op methods see the same world: get_from_scenario by the reference's own code agrees with the kernel
+    obs = att.get_from_scenario(get_observations=True, get_rewards=False, get_infos=False, get_dones=True)
+    for a, b in zip(obs[0], o2):
+        assert torch.allclose(a, b, atol=1e-6, rtol=1e-6)
+    # a static change mid-episode rebuilds the native world AND the fused layer on it
+    att.world.agents[0].mass = 2.5
+    att.step(acts)
+    assert h.refreshes == 1 and h.fused._backend is h.backend
+    h.detach()
+
+
+def test_attach_falls_back_with_a_reason_where_no_kernel_covers_the_scenario(vmas):
+    from vectorizedmultiagentsimulator_amd.adapter import attach
+
+    att = vmas.make_env("waterfall", num_envs=16, device=DEV, seed=0)
+    h = attach(att)
+    assert h.fused is None and "no fused post-step kernel" in h.fused_reason and "step" not in att.__dict__
+    att.step([att.get_random_action(a) for a in att.agents])
+    h.detach()
+    with pytest.raises(NotImplementedError):
+        attach(att, fused=True)
+    att = vmas.make_env("football", num_envs=16, device=DEV, seed=0, n_blue_agents=2, n_red_agents=2)  # AgentPolicy opponents
+    h = attach(att)
+    assert h.fused is None and "ai_red_agents" in h.fused_reason
+    att.step([att.get_random_action(a) for a in att.agents])
+    h.detach()
+
+
+@pytest.mark.parametrize("scenario,kw,B", [("balance", dict(n_agents=4), 32768), ("navigation", dict(n_agents=8), 8192)])
+def test_attached_fused_at_benchmark_size_against_the_reference(vmas, scenario, kw, B):
+    """BASELINE sizes (per-environment broad phase above 1024 environments): one teacher-forced step against the CPU
+    reference of the same batch."""
+    from vectorizedmultiagentsimulator_amd.adapter import attach
+
+    ref = vmas.make_env(scenario, num_envs=B, device="cpu", seed=0, **kw)
+    att = vmas.make_env(scenario, num_envs=B, device=DEV, seed=0, **kw)
+    h = attach(att, fused=True, validate_actions=False)
+    assert h.fused.one_launch and not h.exact_broad_phase
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for t in range(3):
+            _force_state(ref, att, scenario)
+            acts = _actions(ref, g)
+            out_ref = ref.step([a.clone() for a in acts])
+            out_att = att.step([a.to(DEV) for a in acts])
+            _compare_step(out_ref, out_att, scenario, f"{scenario} {B} t={t}")
+    h.detach()

@@ -112,3 +112,45 @@ def test_static_and_dedicated_sets(post):
     s1, r1 = post.prepare()
     s2, r2 = post.prepare()
     assert s1 is s2 and not post._pool  # (HIP-graph replay: the captured pointers must not change)
+
+
+def test_an_autograd_graph_over_an_observation_keeps_its_set_busy(post):
+    """``policy(obs[i])`` saves the observation for backward() - a C++ handle on the SAME TensorImpl.  While the
+    graph is alive the set must not be written again, on any torch build: the TensorImpl use count is compared as well as
+    the Python reference count."""
+    if not F.POOLING:
+        pytest.skip("output pooling is off on this torch build: every step allocates")
+    w = torch.ones(5, requires_grad=True)
+    st, res = post.prepare()
+    res[0][1].fill_(2.0)
+    loss = (res[0][1] * w).sum()  # the graph saves obs[1]
+    del res
+    assert not st.free(), "an observation saved by an autograd graph must keep its set out of the pool"
+    for _ in range(6):  # later steps: other sets
+        st2, r2 = post.prepare()
+        assert st2 is not st
+        r2[0][1].fill_(7.0)
+        del r2
+    loss.backward()
+    assert torch.equal(w.grad, torch.full((5,), 14.0)), "backward() must see the observation as it was handed out"
+    del loss
+    assert st.free()
+
+
+def test_impl_use_count_is_a_witness_of_its_own(post):
+    """The TensorImpl count alone (Python counts equal) marks a set busy."""
+    if not F.POOLING:
+        pytest.skip("output pooling is off")
+    st, res = post.prepare()
+    del res
+    assert st.free()
+    st.ic0 = [c - 1 for c in st.ic0]  # as if a C++ handle existed that the Python count did not show
+    assert not st.free()
+
+
+def test_pooling_can_be_switched_off(post, monkeypatch):
+    monkeypatch.setattr(F, "POOLING", False)
+    a, ra = post.prepare()
+    del ra
+    b, rb = post.prepare()
+    assert a is not b and not post._pool, "with pooling off every step gets a set of its own"

@@ -107,13 +107,19 @@ class AttachedWorld:
     """Handle returned by ``attach``; ``detach()`` restores the reference behaviour."""
 
     def __init__(self, world, backend_factory: Callable = _default_backend, exact_broad_phase: Optional[bool] = None,
-                 specialize: Optional[bool] = False):
+                 specialize: Optional[bool] = False, epilogue=None, spec_post: int = 0):
         from .core import EXACT_AUTO_BELOW
 
         self.world = world
+        self._fast_step = None
         # None: the reference's exact batch-global broad phase below EXACT_AUTO_BELOW environments (core.World)
-        self.exact_broad_phase = (int(world.batch_dim) < EXACT_AUTO_BELOW) if exact_broad_phase is None else bool(exact_broad_phase)
+        self._exact = (int(world.batch_dim) < EXACT_AUTO_BELOW) if exact_broad_phase is None else bool(exact_broad_phase)
         self._factory = backend_factory
+        # the fused Environment.step (attached_env.py): the post-step epilogue this world's steps carry - (kind, n_packages)
+        # the library sizes its kernel geometry for, and the kind a run-time specialisation is compiled with
+        self._epilogue, self._spec_post = epilogue, int(spec_post)
+        self.fused = None          # attached_env.FusedEnvStep when env.step itself is the one-launch kernel
+        self.fused_reason = None   # ... and why not, when it is not
         self._orig_step = world.step
         self._orig_classes = {}
         self._orig_measures = []
@@ -125,11 +131,10 @@ class AttachedWorld:
         self.state = torch.zeros(nE, A.STATE_FIELDS, self.ld, dtype=torch.float32, device=self.device)
         self.agent_ft = torch.zeros(max(nA, 1), A.AGENT_FIELDS, self.ld, dtype=torch.float32, device=self.device)
         self._rehome()
-        self.backend = self._factory(self.spec, self.batch, self.device, self.state, self.agent_ft)
         # a step kernel compiled for this world (specialize.py), also after a refresh(): True = compile it if the on-disk
         # cache does not have it, None = take it from the cache if it is there (never compile, never fail), False = never
         self.specialize = specialize
-        self._apply_specialize()
+        self._new_backend()
         self._check_spec = False  # set by World.reset: the scenario's reset_world_at that follows may change statics
         self.refreshes = 0        # how many times the static description was found changed (tests, diagnostics)
         self._watch()
@@ -143,14 +148,31 @@ class AttachedWorld:
         world.reset = reset
         self._patch_lidars()
 
+    @property
+    def exact_broad_phase(self) -> bool:
+        return self._exact
+
+    @exact_broad_phase.setter
+    def exact_broad_phase(self, value):
+        """Takes effect at the next step (the pre-marshalled stepper is rebuilt for the new mode)."""
+        self._exact = bool(value)
+        if self._fast_step is not None:
+            self._fast_step = self.backend.make_stepper(self._exact)
+
+    def _new_backend(self):
+        self.backend = self._factory(self.spec, self.batch, self.device, self.state, self.agent_ft)
+        if self._epilogue is not None and hasattr(self.backend, "reserve_epilogue"):
+            self.backend.reserve_epilogue(*self._epilogue)
+        self._apply_specialize()
+
     def _apply_specialize(self):
         if self.specialize is False or not hasattr(self.backend, "specialize"):
             return
         if self.specialize:
-            self.backend.specialize()
+            self.backend.specialize(post=self._spec_post)
             return
         try:  # (None: an optional fast path - whatever goes wrong with a cache entry, the world keeps the interpreter)
-            self.backend.specialize(cached_only=True)
+            self.backend.specialize(post=self._spec_post, cached_only=True)
         except Exception as e:  # noqa: BLE001
             import warnings
 
@@ -215,6 +237,8 @@ class AttachedWorld:
         (their classes hooked once), the tensor-valued attributes identified by object and version, and whether any
         collision filter can depend on data a reset rewrites."""
         w = self.world
+        for o in getattr(self, "_marked", ()):  # (a shape object replaced since the last call must not keep marking this handle)
+            o.__dict__.pop(_OWNER, None)
         objs = [w] + list(w.entities) + [e.shape for e in w.entities]
         for o in objs:
             _patch_setattr(type(o))
@@ -230,15 +254,22 @@ class AttachedWorld:
         spec = self.spec
         self._per_env = any(j.per_env_fixed_rotation for j in spec.joints) or any(e.per_env_gravity for e in spec.entities)
         mk = getattr(self.backend, "make_stepper", None)
-        self._fast_step = mk(self.exact_broad_phase) if (mk is not None and not self._per_env) else None
+        self._fast_step = mk(self._exact) if (mk is not None and not self._per_env) else None
+        # tensor-valued statics (the world's gravity; an entity's gravity / speed range given as a tensor): an in-place write
+        # to one (``e.gravity[1] = ...``) goes through no setter - they are identified by object and version counter
+        ts = [getattr(w, "_gravity", None)]
+        for e in w.entities:
+            ts += [v for v in (e.__dict__.get("_gravity"), e.__dict__.get("_v_range"), e.__dict__.get("_mass")) if isinstance(v, torch.Tensor)]
+        self._watched_tensors = [t for t in ts if isinstance(t, torch.Tensor)]
         self._mini = self._mini_fingerprint()
         self._dirty = False
 
     def _mini_fingerprint(self):
-        """What a ``__setattr__`` hook cannot see: in-place writes to the world's gravity tensor, joints added to the dict."""
+        """What a ``__setattr__`` hook cannot see: in-place writes to tensor-valued statics, joints added to the dict,
+        entities added to the world."""
         w = self.world
-        g = getattr(w, "_gravity", None)
-        return (id(g), getattr(g, "_version", 0), len(getattr(w, "_joints", ())))
+        return (tuple((id(t), t._version) for t in self._watched_tensors), len(getattr(w, "_joints", ())),
+                len(getattr(w, "_landmarks", ())) + len(getattr(w, "_agents", ())), id(getattr(w, "_gravity", None)))
 
     def _sync_static(self):
         """Rebuild the native world iff the live world's static description is no longer the one it was built from."""
@@ -260,7 +291,7 @@ class AttachedWorld:
             self._fast_step()
         else:
             jfr, eg = self._per_env_inputs() if self._per_env else (None, None)
-            if self.exact_broad_phase:
+            if self._exact:
                 self.backend.step_exact(joint_fixed_rot=jfr, entity_gravity=eg)
             else:
                 self.backend.step(joint_fixed_rot=jfr, entity_gravity=eg)
@@ -277,8 +308,7 @@ class AttachedWorld:
             "entities were added to or removed from an attached world: detach() and attach() again")
         self.spec = spec
         self.backend.close()
-        self.backend = self._factory(self.spec, self.batch, self.device, self.state, self.agent_ft)
-        self._apply_specialize()
+        self._new_backend()
         self._watch()
         self.refreshes += 1
 
@@ -306,6 +336,9 @@ class AttachedWorld:
                 k += 1
 
     def detach(self):
+        if self.fused is not None:
+            self.fused.detach()
+            self.fused = None
         self.world.step = self._orig_step
         self.world.reset = self._orig_reset
         for st, cls in self._orig_classes.values():
@@ -321,14 +354,45 @@ class AttachedWorld:
 
 
 def attach(env_or_world, backend_factory: Callable = _default_backend,
-           exact_broad_phase: Optional[bool] = None, specialize: Optional[bool] = False) -> AttachedWorld:
+           exact_broad_phase: Optional[bool] = None, specialize: Optional[bool] = False,
+           fused: Optional[bool] = None, validate_actions: bool = True) -> AttachedWorld:
     """Put a reference ``Environment`` (or ``World``) on the MI355X-native physics step.  ``exact_broad_phase``: the
     reference's batch-global ``.any()`` broad phase (core.py:2797-2801) exactly; None = below 1024 environments, where
     it can matter (above, every pair that matters has SOME environment overlapping).  ``specialize``: True = compile (once,
     cached on disk) a step kernel for this very world - any scenario the reference ships then runs at the speed of the
     built-in BASELINE specialisations instead of the schedule interpreter's (specialize.py); None = use it if the cache has
-    it, never compile; False = the interpreter."""
+    it, never compile; False = the interpreter.
+
+    ``fused``: ``Environment.step`` ITSELF as one kernel launch (attached_env.py) - the reference's action ingest
+    (environment.py:616-749) as the step kernel's prologue, the scenario's reward / observation / done / info as its
+    epilogue - for the reference's balance, transport, navigation and football scenarios in the configurations the post-step
+    kernels cover.  None (default) = wherever that holds on a GPU environment, silently the reference's own
+    ``Environment.step`` around the native ``World.step`` otherwise (``handle.fused_reason`` says why); True = required;
+    False = never.  ``validate_actions``: the reference's NaN / range asserts (environment.py:621,651-653) - one small
+    kernel and ONE host sync in front of the step launch instead of two syncs per agent, same behaviour (a bad action
+    raises before the world is touched); False drops them for throughput runs."""
     world = getattr(env_or_world, "world", env_or_world)
     if getattr(env_or_world, "grad_enabled", False):
         raise NotImplementedError("grad_enabled=True needs the reference's autograd path; the HIP step has no backward")
-    return AttachedWorld(world, backend_factory, exact_broad_phase, specialize)
+    profile, reason = None, "fused=False"
+    if fused is not False:
+        from .attached_env import FusedEnvStep, plan_fuse
+
+        default_backend = backend_factory is _default_backend
+        profile, reason = plan_fuse(env_or_world) if default_backend else (None, "a custom backend_factory (no HIP library behind it)")
+        if profile is None and fused:
+            raise NotImplementedError(f"attach(fused=True): the one-launch Environment.step is not available - {reason}")
+    if profile is None:
+        h = AttachedWorld(world, backend_factory, exact_broad_phase, specialize)
+        h.fused_reason = reason
+        return h
+    h = AttachedWorld(world, backend_factory, exact_broad_phase, specialize, epilogue=profile.reserve(env_or_world),
+                      spec_post=profile.post_kind)
+    try:
+        h.fused = FusedEnvStep(env_or_world, h, profile, validate_actions)
+    except AssertionError as e:  # a world layout the post-step class refuses (entity order ...): the reference's Environment.step
+        h.fused_reason = f"the post-step kernel does not cover this world: {e}"
+        if fused:
+            h.detach()
+            raise NotImplementedError(f"attach(fused=True): {h.fused_reason}") from e
+    return h

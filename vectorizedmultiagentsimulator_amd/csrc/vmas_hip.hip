@@ -2307,9 +2307,13 @@ int vmas_world_load_spec(VmasWorld* w, const char* code_object_path) {
   if (get_sched(w, w->lanes, &S)) return -1;
   if (S->rt.mod) { (void)hipModuleUnload(S->rt.mod); S->rt = Sched::Rt{}; }
   hipModule_t mod = nullptr;
-  if (hipModuleLoad(&mod, code_object_path) != hipSuccess) {
+  const hipError_t load_rc = hipModuleLoad(&mod, code_object_path);
+  if (load_rc != hipSuccess) {
     (void)hipGetLastError();  // (the refusal is this call's result: not the next launch check's, whoever makes it)
-    return fail("vmas_world_load_spec: cannot load %s", code_object_path);
+    // (the caller keeps or drops its cached file by this wording: only the second case says anything about the FILE)
+    if (load_rc == hipErrorOutOfMemory || load_rc == hipErrorMemoryAllocation)
+      return fail("vmas_world_load_spec: cannot load %s: out of device memory", code_object_path);
+    return fail("vmas_world_load_spec: %s is not a loadable gfx950 code object (%s)", code_object_path, hipGetErrorString(load_rc));
   }
   struct Unload { hipModule_t m; ~Unload() { if (m) (void)hipModuleUnload(m); } } guard{mod};
   // the tables the module was generated from must be, word for word, the schedule this world runs
@@ -2550,9 +2554,9 @@ static int step_env_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld
       hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
       if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
       capturing = cap != hipStreamCaptureStatusNone;
-      // (one wave polls the barrier's words, a lane each: pair words x tile groups <= 64)
-      grid_sync = !capturing && blocks_of(w->batch) <= w->n_cu && blocks_of(w->batch) <= 512 &&
-                  ((w->n_pairs + 31) / 32) * ((blocks_of(w->batch) + 31) / 32) <= 64;
+      // (one wave polls the barrier's words: lane w loops over the tile groups of pair word w, 64 words per pass -
+      //  grid_bits_collect; d_nav_sync holds 16 groups = 512 tiles of every pair word)
+      grid_sync = !capturing && blocks_of(w->batch) <= w->n_cu && blocks_of(w->batch) <= 512;
     }
     // the second-kernel form: the tiles OR into one of two masks (zero by now), the collision kernel reads it, and the NEXT
     // eager launch - which fills the other mask - zeroes it.  A captured launch cannot alternate (a replay repeats its

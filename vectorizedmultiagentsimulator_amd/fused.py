@@ -132,12 +132,14 @@ class ActionIngest:
         slots, prev = self._slots, self._keep
         if prev is not None and len(prev) == len(actions):
             same = True
-            for a, b in zip(actions, prev):
-                if a is not b:
+            for a, b, f in zip(actions, prev, fast):
+                # the very tensor objects of the last call (a policy writing into its own buffers) - and still the layout they
+                # were checked with: `.data = ...`, resize_() or set_() re-point / re-shape a tensor without changing its identity
+                if a is not b or a.shape != f[0] or a.dtype is not f[1] or a.stride() != f[2]:
                     same = False
                     break
-            if same:  # the very tensor objects of the last call (a policy writing into its own buffers): they were checked
-                for i, act in enumerate(actions):  # then; only the pointer is read again (`.data` can be re-pointed)
+            if same:
+                for i, act in enumerate(actions):  # only the pointer is read again
                     if cont:
                         slots[i].action = act.data_ptr()
                     else:
@@ -395,8 +397,16 @@ class StepLauncher:
             raise VmasHipError(A.last_error())
 
 
+import os as _os
+
 _use_count = getattr(torch._C, "_storage_Use_Count", None)  # references on a storage: every tensor / view over it holds one
 _getrefcount = sys.getrefcount
+# The pool needs THREE witnesses that the caller holds nothing of a set: the storage's use count (views), the Python
+# reference counts of the handed-out tensor objects, and their TensorImpl use counts (a C++-only handle on the same
+# TensorImpl - an autograd SavedVariable of ``policy(obs[i])`` kept for a later backward() - need not show in the Python
+# count on every torch build).  Without any of them, or with VMAS_AMD_NO_OUTPUT_POOL=1, every step allocates its outputs.
+_impl_count = getattr(torch.Tensor, "_use_count", None)
+POOLING = (_use_count is not None and _impl_count is not None and not _os.environ.get("VMAS_AMD_NO_OUTPUT_POOL"))
 
 
 def _rcs(tensors):
@@ -415,7 +425,7 @@ class _OutSet:
     as in the reference, without an allocation or a view being made per step (three ``torch.empty`` + three ``unbind`` cost
     the host ~15 us per step around an 11 us kernel)."""
 
-    __slots__ = ("base", "storage", "cdata", "uc0", "tensors", "rc0", "buffers", "ref", "v", "obs", "rew", "done", "infos",
+    __slots__ = ("base", "storage", "cdata", "uc0", "tensors", "rc0", "ic0", "buffers", "ref", "v", "obs", "rew", "done", "infos",
                  "extra", "nbytes", "pooled")
 
     def seal(self):
@@ -425,11 +435,14 @@ class _OutSet:
         self.cdata = self.storage._cdata
         self.uc0 = _use_count(self.cdata) if _use_count is not None else -1
         self.rc0 = _rcs(self.tensors)
+        self.ic0 = [t._use_count() for t in self.tensors] if _impl_count is not None else None
 
     def free(self) -> bool:
-        if _use_count is None or _use_count(self.cdata) != self.uc0:
+        if not POOLING or _use_count(self.cdata) != self.uc0:
             return False
-        return _rcs(self.tensors) == self.rc0
+        if _rcs(self.tensors) != self.rc0:
+            return False
+        return [t._use_count() for t in self.tensors] == self.ic0
 
 
 class _Post:
@@ -500,7 +513,7 @@ class _Post:
                 return st
         st = self._make(True)
         n = len(pool)
-        if n < self.POOL_MAX_SETS and (n + 1) * st.nbytes <= self.POOL_MAX_BYTES and _use_count is not None:
+        if n < self.POOL_MAX_SETS and (n + 1) * st.nbytes <= self.POOL_MAX_BYTES and POOLING:
             pool.append(st)
         return st  # (beyond the pool's size the set is simply the caller's: one allocation per step, as before)
 
