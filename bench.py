@@ -29,8 +29,10 @@ multi-GPU: `--gpus N` with no WORLD_SIZE in the environment re-executes itself u
          sharded rollout (`sharded_rollout`: Environment.rollout writing K steps per launch straight into the buffer that
          ONE all_gather_into_tensor sends) and on the three BASELINE shapes (`rollout_gather`); neither is part of `value`.
 roofline: achieved = algorithmic bytes per launch (24 E + 12 A read, 24 E_dyn written per environment) /
-         average launch duration from the HIP events; achieved GFLOP/s beside it and which bound binds.  `traffic` (HBM bytes
-         by the PMC counters) cannot be measured inside this process: null here, per launch in profiles/r04_*_pmc_summary.txt.
+         average launch duration from the HIP events; achieved GFLOP/s beside it and which bound binds.  `traffic` = HBM bytes
+         per launch by the PMC counters: the same physics launches re-run (N = 1 only, two short child processes) under
+         `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` - separate passes, counters only, FETCH_SIZE doubled (gfx950) -
+         median per dispatch; null with the reason if rocprofv3 is not there (`--no-traffic` skips it).
 cpu_baseline: the REFERENCE itself (VMAS, `kind: "reference"`): its Environment.step (environment.py:325) on the host
          cores, device="cpu", torch threads = the fastest count on this host, same initial state and actions, bounded to
          ~10 s; `value` = its World.step (core.py:1972) share of those steps (timed inside the same calls).  Rank 0, N=1
@@ -99,6 +101,10 @@ def parse_args():
     ap.add_argument("--no-attached", action="store_true", help="skip the attached_reference leg")
     ap.add_argument("--fused", action="store_true",
                     help="time vmas_world_rollout (persistent launch, state resident in LDS) instead of one launch per step")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="skip `roofline.traffic` (HBM bytes per launch by the PMC counters: two short re-runs of the physics "
+                         "launches under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, N = 1 only)")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)  # (the re-run itself: launches only)
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU plumbing check (tests): ranks, sharding and the rollout gather over gloo, NO physics, value = null")
     return ap.parse_args()
@@ -579,6 +585,74 @@ def attached_reference_leg(name, kw, B, device, n=300, brief=False):
     return out
 
 
+# ------------------------------------------------------------------------------------------------ HBM traffic (PMC)
+def traffic_child(args, device):
+    """What the counter passes profile: the headline's own launches (same world, same queues, recorded forces), 200 of them."""
+    import torch
+    from vectorizedmultiagentsimulator_amd.environment import make_env
+
+    cfg = CONFIGS[args.config]
+    B = args.num_envs or cfg["envs"]
+    env = make_env(cfg["scenario"], num_envs=B, device=device, seed=0, validate_actions=False, **config_kwargs(args.config, args.n_agents))
+    be = env.world._get_backend()
+    if args.lanes:
+        be.set_lanes_per_env(args.lanes)
+    be.set_queues(args.queues)
+    acts = make_actions(env, 20, 1234).to(device)
+    forces = record_episode_forces(env, acts)
+    for _ in range(10):
+        be.step_n(20, forces)
+    torch.cuda.synchronize()
+
+
+def measure_traffic(args, n_launches_per_step, timeout_s=150):
+    """HBM bytes per launch of the dominant kernel by the PMC counters, collected as MI355X_MICROARCH.md prescribes:
+    FETCH_SIZE and WRITE_SIZE in separate `rocprofv3 --pmc` passes (they do not fit one), counters only (no trace domain
+    beside them), FETCH_SIZE doubled (gfx950 tallies 128-byte requests at 64 bytes; confirmed in this library's own access
+    pattern, profiles/r01_traffic_calibration.txt), both in KiB.  Returns (bytes per launch, details) or (None, why)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if prof is None:
+        return None, "rocprofv3 not found"
+    child = [sys.executable, os.path.abspath(__file__), "--traffic-child", "--config", args.config, "--queues", str(args.queues)]
+    if args.num_envs:
+        child += ["--num-envs", str(args.num_envs)]
+    if args.n_agents:
+        child += ["--n-agents", str(args.n_agents)]
+    if args.lanes:
+        child += ["--lanes", str(args.lanes)]
+    med = {}
+    kernel = None
+    env = dict(os.environ, TMPDIR="/tmp")
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+            try:
+                r = subprocess.run([prof, "--pmc", counter, "--output-format", "csv", "-d", tmp, "-o", "p", "--"] + child,
+                                   cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                return None, f"rocprofv3 --pmc {counter} timed out"
+            vals = {}
+            for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    name = row["Kernel_Name"]
+                    if row["Counter_Name"] == counter and ("step_kernel" in name or "vmas_rt_" in name):
+                        vals.setdefault(name, []).append(float(row["Counter_Value"]))
+            if not vals:
+                return None, f"no step-kernel dispatch in the {counter} pass (rc {r.returncode}): {r.stderr[-200:]}"
+            name = max(vals, key=lambda n: len(vals[n]))  # the kernel of the timed launches (the recording steps are other forms)
+            v = sorted(vals[name][len(vals[name]) // 2:])  # (the second half: past the first touches of the buffers)
+            med[counter] = v[len(v) // 2]
+            kernel = name.split("(")[0][-80:]
+    traffic = (2.0 * med["FETCH_SIZE"] + med["WRITE_SIZE"]) * 1024.0
+    return traffic, {"FETCH_SIZE_KiB_median": med["FETCH_SIZE"], "WRITE_SIZE_KiB_median": med["WRITE_SIZE"], "kernel": kernel,
+                     "formula": "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 per dispatch (gfx950: FETCH_SIZE counts 128-B requests as 64 B)"}
+
+
 # ------------------------------------------------------------------------------------------------ one configuration
 def _library_build_id():
     """Digest of the sources libvmas_hip.so was built from (vmas_build_id, csrc/build.sh): ties a line to a commit's kernels."""
@@ -898,13 +972,31 @@ def main():
                                      shrink=512 if args.dry_run else 1)
 
     if args.dry_run:
+        # the configuration's own rollout exchange: the chunking computed at FULL size (what an N-GPU run would do: chunks of
+        # steps that keep the gathered buffer below 2 GB), the collective itself executed on a buffer shrunk by 512
+        A_, D_ = GATHER_SHAPES[args.config]
+        step_bytes = per_gpu * (A_ * D_ + A_ + 1) * 4 * world_size
+        tc = max(1, min(EPISODE, (2 << 30) // step_bytes))
+        small = EnvShard(max(per_gpu // 512, 1) * world_size, rank, world_size)
+        pr = PackedRollout(small, min(tc, 4), A_, D_, device)
+        pr.views()["done"].fill_(float(rank))  # every rank's block carries its rank: the result must hold all of them, in order
+        res = pr.gather()
+        ranks_in_result = sorted({int(v) for v in res["done"][:, 0].tolist()}) if world_size > 1 else [0]
+        plan = {"envs_per_gpu": per_gpu, "global_envs": global_envs, "agents": A_, "obs_dim": D_, "bytes_per_step_all_ranks": step_bytes,
+                "steps_per_chunk": tc, "chunk_bytes": step_bytes * tc, "chunks_per_100_steps": -(-EPISODE // tc),
+                "collectives_per_chunk": 1, "ranks_in_result": len(ranks_in_result), "rank_order_kept": ranks_in_result == list(range(world_size))}
         if rank == 0:
             print(json.dumps({"metric": f"env-steps/sec (batch x substeps) on '{cfg['scenario']}'", "value": None, "dry_run": True,
                               "n_gpus": world_size, "ranks_seen": ranks_seen, "backend": "gloo", "scaling": scaling,
-                              "shard": [shard.lo, shard.hi], "global_envs": global_envs, "rollout_gather": gather}), flush=True)
+                              "shard": [shard.lo, shard.hi], "global_envs": global_envs, "sharding_plan": plan,
+                              "rollout_gather": gather}), flush=True)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
+        return
+
+    if args.traffic_child:
+        traffic_child(args, device)
         return
 
     r = measure(args.config, args, device, shard, dist, rank, world_size)
@@ -992,6 +1084,20 @@ def main():
                 "binds": gb_note,
             },
         }
+        if world_size == 1 and not args.no_traffic and not args.fused:
+            try:
+                traffic, detail = measure_traffic(args, n_queues)
+            except Exception as e:  # noqa: BLE001
+                traffic, detail = None, repr(e)[:300]
+            rf = out["roofline"]
+            rf["traffic"] = traffic
+            if traffic is not None:
+                rf["traffic_over_algorithmic"] = traffic / rf["bytes_per_launch"]
+                rf["traffic_note"] = ("HBM bytes per launch by the PMC counters: this command's own physics launches re-run under "
+                                      "`rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes), median per dispatch")
+                rf["traffic_detail"] = detail
+            else:
+                rf["traffic_note"] = f"not measured in this run ({detail}); per launch in profiles/r05*_pmc_summary.txt"
         if r["single"] is not None:
             out["single_queue"] = r["single"]
         if r["env_leg"] is not None:

@@ -29,7 +29,7 @@ while [ $# -gt 0 ]; do
   case $STAGE in
   tests-new)
     timeout 1500 python -m pytest tests/test_attached_env_gpu.py tests/test_adapter_reference.py tests/test_output_pool.py \
-      tests/test_env_fused_gpu.py tests/test_round4_gpu.py -m gpu -q --timeout=600 -p no:cacheprovider -x --tb=short > $OUT/pytest_new.log 2>&1
+      tests/test_env_fused_gpu.py tests/test_round4_gpu.py -m gpu -q --timeout=600 -p no:cacheprovider ${PYTEST_X:-} --tb=short > $OUT/pytest_new.log 2>&1
     echo "pytest rc=$?" >> $OUT/pytest_new.log
     show_pytest $OUT/pytest_new.log; tail -n 40 $OUT/pytest_new.log | cut -c1-300
     ;;

@@ -115,6 +115,13 @@ def compare_state(got: np.ndarray, want: np.ndarray, name: str, atol=1e-5, rtol=
     if stats is not None:
         stats["values"] = stats.get("values", 0) + int(err.size)
         stats["needed_sens"] = stats.get("needed_sens", 0) + int((err > lim).sum())
+        # the largest error among values of physical magnitude, and how many are not: a blown-up environment (the reference
+        # itself reaches 1e24 in the dense `soup_*` worlds) makes the plain maximum meaningless as a parity figure
+        with np.errstate(invalid="ignore"):
+            physical = np.isfinite(want) & np.isfinite(got) & (np.abs(want) < 1e3)
+        stats["blown_up"] = stats.get("blown_up", 0) + int(err.size - physical.sum())
+        if physical.any():
+            stats["worst_physical"] = max(stats.get("worst_physical", 0.0), float(err[physical].max()))
     if sens is not None:
         lim = lim + sens_mult * sens
     bad = err > lim

@@ -81,7 +81,8 @@ def _record_allowance(name, what, stats, worst):
         os.makedirs(out, exist_ok=True)
         with open(os.path.join(out, "parity_allowance.jsonl"), "a") as f:
             f.write(json.dumps({"fixture": name, "check": what, "values": stats["values"],
-                                "needed_allowance": stats["needed_sens"], "max_abs_err": worst}) + "\n")
+                                "needed_allowance": stats["needed_sens"], "max_abs_err": worst,
+                                "max_abs_err_physical": stats.get("worst_physical", 0.0), "blown_up_values": stats.get("blown_up", 0)}) + "\n")
     except OSError:
         pass
 

@@ -211,6 +211,32 @@ def test_bench_dry_run_spawns_its_ranks():
     assert set(d["rollout_gather"]) == {"balance_cfg2", "navigation_cfg4", "football_cfg5"}
 
 
+@pytest.mark.parametrize("config,per_gpu,agents,obs_dim", [("navigation", 8192, 8, 18), ("football", 16384, 10, 88)])
+def test_bench_dry_run_eight_ranks_strong_scaling_plan(config, per_gpu, agents, obs_dim):
+    """What the driver's 8-GPU run of BASELINE configs 4 / 5 does, minus the physics (no multi-GPU box is available to the
+    builder): `bench.py --gpus 8 --config C --strong` launches 8 ranks, shards the configuration's batch into contiguous
+    blocks of 8 192 / 16 384 environments, chunks the rollout so that a gathered buffer stays below 2 GB, and ONE
+    all_gather_into_tensor per chunk returns all eight ranks' blocks in rank = environment order."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--config", config, "--strong", "--dry-run",
+                          "--no-gather"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 8 and d["ranks_seen"] == 8 and d["scaling"] == "strong" and d["shard"] == [0, per_gpu]
+    plan = d["sharding_plan"]
+    assert plan["envs_per_gpu"] == per_gpu and plan["global_envs"] == 8 * per_gpu
+    assert plan["bytes_per_step_all_ranks"] == 8 * per_gpu * (agents * obs_dim + agents + 1) * 4
+    assert plan["chunk_bytes"] <= 2 << 30 and plan["steps_per_chunk"] >= 1
+    assert (plan["steps_per_chunk"] + 1) * plan["bytes_per_step_all_ranks"] > 2 << 30 or plan["steps_per_chunk"] == 100
+    assert plan["ranks_in_result"] == 8 and plan["rank_order_kept"] and plan["collectives_per_chunk"] == 1
+
+
 def test_bench_refuses_to_claim_more_gpus_than_it_sees():
     """`python bench.py --gpus 2` where fewer than two devices are visible (here: none) must fail loudly instead of
     printing an n_gpus=2 line."""

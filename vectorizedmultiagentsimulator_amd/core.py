@@ -39,6 +39,13 @@ ANGULAR_FRICTION = 0.0
 # ----------------------------------------------------------------------------------
 # shapes (core.py:84-203)
 # ----------------------------------------------------------------------------------
+def _positive(what: str, value) -> float:
+    """Shape dimensions must be positive numbers (the reference asserts the same, core.py:133-135, 143, 173)."""
+    if not value > 0:
+        raise AssertionError(f"a shape's {what} must be a positive number, got {value!r}")
+    return value
+
+
 class Shape:
     def moment_of_inertia(self, mass: float) -> float:
         raise NotImplementedError
@@ -52,9 +59,7 @@ class Shape:
 
 class Box(Shape):
     def __init__(self, length: float = 0.3, width: float = 0.1, hollow: bool = False):
-        assert length > 0, f"Length must be > 0, got {length}"
-        assert width > 0, f"Width must be > 0, got {length}"
-        self._length, self._width, self.hollow = length, width, hollow
+        self._length, self._width, self.hollow = _positive("length", length), _positive("width", width), hollow
 
     length = property(lambda self: self._length)
     width = property(lambda self: self._width)
@@ -71,8 +76,7 @@ class Box(Shape):
 
 class Sphere(Shape):
     def __init__(self, radius: float = 0.05):
-        assert radius > 0, f"Radius must be > 0, got {radius}"
-        self._radius = radius
+        self._radius = _positive("radius", radius)
 
     radius = property(lambda self: self._radius)
 
@@ -93,8 +97,7 @@ class Sphere(Shape):
 
 class Line(Shape):
     def __init__(self, length: float = 0.5):
-        assert length > 0, f"Length must be > 0, got {length}"
-        self._length, self._width = length, 2
+        self._length, self._width = _positive("length", length), 2
 
     length = property(lambda self: self._length)
     width = property(lambda self: self._width)

@@ -47,23 +47,6 @@ constexpr int OWN_MAX = 4;                // dynamic entities one wave can own
 constexpr int LIST_MAX = 64;              // pairs one entity can be in (its list lives in one register, one entry per lane)
 constexpr int HW_MAX = LIST_MAX / 32;     // 32-bit words of an entity's "pairs with contacts" mask
 constexpr int UNIT_PARTNERS = 6;          // partner spheres per broad-phase unit (register arrays of this size)
-// An experiment left compiled OUT: a unit costs ~1 500 cycles whatever its partners, so fewer,
-// longer units - runs of up to UNIT_CHUNKS * UNIT_PARTNERS partners, tested UNIT_PARTNERS at a time against ONE fetch of the
-// row entity - might pay.  Build with -DVMAS_COMPACT_UNIT_CHUNKS=2 (scripts/gpu_next_unit_chunks.sh) to measure it; with 1 the
-// kernel's code is what it was (checked: identical device .text).
-#ifndef VMAS_COMPACT_UNIT_CHUNKS
-#define VMAS_COMPACT_UNIT_CHUNKS 1
-#endif
-constexpr int UNIT_CHUNKS = VMAS_COMPACT_UNIT_CHUNKS;
-#if VMAS_COMPACT_UNIT_CHUNKS > 1
-#define VMAS_UNIT_CHUNK_LOOP for (int c0 = 0; c0 < n; c0 += UNIT_PARTNERS)
-#define VMAS_UNIT_C0 c0
-#define VMAS_UNIT_NC (n - c0 < UNIT_PARTNERS ? n - c0 : UNIT_PARTNERS)
-#else
-#define VMAS_UNIT_CHUNK_LOOP
-#define VMAS_UNIT_C0 0
-#define VMAS_UNIT_NC n
-#endif
 constexpr int WAVE_UNITS = 64;            // units per wave: a wave keeps its units' records in registers, one lane per unit
 
 // ---- descriptor records (32-bit words in the blob; all offsets are FLOAT offsets into the LDS tile)
@@ -559,18 +542,16 @@ __global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld
           const v2 pr = V(R[0], R[ROWF]);
           float cs = 0.f, sn = 0.f;
           if (type == VMAS_PAIR_LS) { cs = tile[(int)(h0 >> 16)]; sn = tile[(int)(h0 >> 16) + ROWF]; }
-          VMAS_UNIT_CHUNK_LOOP {
-          const int nc = VMAS_UNIT_NC;
           v2 ps[UNIT_PARTNERS];
 #pragma unroll
           for (int i = 0; i < UNIT_PARTNERS; ++i) {  // (slots beyond n repeat partner 0: always valid rows)
-            const float* S = S0 + (VMAS_UNIT_C0 + (i < nc ? i : 0)) * stride;
+            const float* S = S0 + (i < n ? i : 0) * stride;
             ps[i] = V(S[0], S[ROWF]);
           }
 #pragma unroll
           for (int i = 0; i < UNIT_PARTNERS; ++i) {
-            if (i >= nc) break;
-            const int pair = pair0 + VMAS_UNIT_C0 + i;
+            if (i >= n) break;
+            const int pair = pair0 + i;
             const float dx = pr.x - ps[i].x, dy = pr.y - ps[i].y;
             // One number per pair that must NOT lie in (threshold, +inf) for the pair to be in reach: the squared centre
             // distance (sphere-sphere), or the larger of the sphere's two gaps in the line's frame (eval_lsq) - beyond it the
@@ -596,7 +577,6 @@ __global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld
             } else if (b != 0ull) {
               take_slots(pair, b);
             }
-          }
           }
         }
       };

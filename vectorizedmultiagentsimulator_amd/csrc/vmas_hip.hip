@@ -1793,7 +1793,7 @@ static int build_compact(VmasWorld* w) {
     const VmasPairDesc& P0 = w->pairs[p];
     Unit U{P0.a, P0.type, 1, 0, ent_off[P0.b], p, pair_thr(P0), 0.f};
     int q = p + 1;
-    while (q < nP && U.n < UNIT_PARTNERS * UNIT_CHUNKS) {
+    while (q < nP && U.n < UNIT_PARTNERS) {
       const VmasPairDesc& Q = w->pairs[q];
       if (Q.a != P0.a || Q.type != P0.type || fbits(pair_thr(Q)) != fbits(U.thr)) break;
       const int step = (ent_off[Q.b] - ent_off[w->pairs[q - 1].b]) / ROWF;

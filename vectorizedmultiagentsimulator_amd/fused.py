@@ -715,7 +715,7 @@ class NavigationPost(_Post):
             return "too many agents"
         if len({a.shape.radius for a in agents}) != 1 or len({a.goal.shape.radius for a in agents}) != 1:
             return "non-uniform radii"
-        if sc.collisions and len({(s._angles.shape[0], s._max_range) for a in agents for s in a.sensors}) != 1:
+        if sc.collisions and len({(s._angles.shape[-1], s._max_range) for a in agents for s in a.sensors}) != 1:
             return "non-uniform sensors"
         return None
 
@@ -734,7 +734,7 @@ class NavigationPost(_Post):
         d.agent_collision_penalty, d.min_collision_distance = sc.agent_collision_penalty, sc.min_collision_distance
         if sc.collisions:
             s = agents[0].sensors[0]
-            d.n_rays, d.lidar_range = s._angles.shape[0], s._max_range
+            d.n_rays, d.lidar_range = s._angles.shape[-1], s._max_range
         self.desc = d
         self._side = None
         # as the physics kernel's epilogue only if the library says this world allows it (sensors as the epilogue casts
