@@ -503,8 +503,8 @@ def attached_reference_leg(name, kw, B, device, n=300, brief=False):
     """attach(vmas.make_env(..., device='cuda')) - the reference's own Environment / Scenario / World objects on the GPU.
     `env_step_us`: the reference's ``env.step`` as `attach()` leaves it by default - for the four benchmark scenarios the
     one-launch kernel (ingest prologue + World.step + reward/observation/done/info epilogue, attached_env.py) with the
-    reference's action asserts kept (one host sync per step); `env_step_no_validate_us`: the same with
-    ``validate_actions=False``; `env_step_unfused_us`: ``attach(fused=False)`` - only World.step (and Lidar.measure) rebound,
+    reference's action asserts kept (one stream synchronisation per step); `env_step_deferred_validate_us`: the asserts
+    deferred by one step (``validate_actions="deferred"``, no synchronisation); `env_step_no_validate_us`: none; `env_step_unfused_us`: ``attach(fused=False)`` - only World.step (and Lidar.measure) rebound,
     the reference's tensor-op ingest / reward / observation around it (what rounds 1-4 measured); `world_step_*`: the
     rebound seam alone."""
     import torch
@@ -568,7 +568,11 @@ def attached_reference_leg(name, kw, B, device, n=300, brief=False):
         out["refreshes"] = h.refreshes
         h.detach()
         if out["fused"]:
-            # (2) without the reference's action asserts (no host sync per step)
+            # (2) the asserts deferred by one step (the step launch flags a bad action, the next env.step raises: no sync) ...
+            h = attach(env, specialize=None, validate_actions="deferred")
+            out["env_step_deferred_validate_us"], out["env_step_deferred_validate_gpu_us"] = time_env_steps(m)
+            h.detach()
+            # ... and without them
             h = attach(env, specialize=None, validate_actions=False)
             out["env_step_no_validate_us"], out["env_step_no_validate_gpu_us"] = time_env_steps(m)
             h.detach()
@@ -582,6 +586,7 @@ def attached_reference_leg(name, kw, B, device, n=300, brief=False):
     out["value_is"] = "env-steps/s through the REFERENCE's env.step after attach() (defaults: fused where covered, action asserts kept)"
     if "env_step_no_validate_us" in out:
         out["value_no_validate"] = B * sub / (out["env_step_no_validate_us"] * 1e-6)
+        out["value_deferred_validate"] = B * sub / (out["env_step_deferred_validate_us"] * 1e-6)
     return out
 
 

@@ -74,6 +74,18 @@ typedef struct VmasIngestArgs {
 int vmas_env_ingest_actions(const VmasIngestArgs* args, int32_t batch, const float* state /* scripts only, else NULL */,
                             float* agent_ft, int64_t ld, uint32_t* err_flags, void* stream);
 
+/* The reference asserts on the host BEFORE it touches the world (environment.py:621,651-653) - two device-to-host
+ * round trips per agent there.  Here the flags are one word in pinned host memory the kernels OR into directly:
+ * `vmas_host_word_create` makes it (`*host`: the CPU's address, `*dev`: what to pass as `err_flags`), and
+ * `vmas_env_validate_actions` = vmas_env_ingest_actions + ONE stream synchronisation + read-and-clear of the word, in one
+ * call: returns the VMAS_ACTION_ERR_* flags (>= 0), or < 0 on an error of the call itself (vmas_last_error).  A caller
+ * that passes `dev` to vmas_world_step_env instead and looks at `*host` before its NEXT step learns of a bad action one
+ * step late, for nothing. */
+int vmas_host_word_create(int32_t device_id, uint32_t** host, uint32_t** dev);
+void vmas_host_word_destroy(uint32_t* host);
+int vmas_env_validate_actions(const VmasIngestArgs* args, int32_t batch, const float* state /* scripts only, else NULL */,
+                              float* agent_ft, int64_t ld, uint32_t* err_host, uint32_t* err_dev, void* stream);
+
 /* ---------------------------------------------------------------- step counter / time limit */
 typedef struct VmasStepLimit {
   float* steps;     /* [batch] Environment.steps (float, environment.py:107), incremented by 1; may be NULL */

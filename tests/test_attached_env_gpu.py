@@ -228,6 +228,26 @@ def test_attached_fused_validates_like_the_reference(vmas):
     h = attach(att, fused=True, validate_actions=False)
     att.step(good)
     h.detach()
+    # deferred: the step launch flags the bad action itself, the NEXT step (or check_actions) raises - no synchronisation
+    h = attach(att, fused=True, validate_actions="deferred")
+    att.step(good)
+    att.step(good)
+    h.fused.check_actions()  # nothing to report
+    bad = [a.clone() for a in good]
+    bad[0][3, 1] = float("nan")
+    att.step(bad)  # does not raise: the launch is asynchronous
+    torch.cuda.synchronize()
+    with pytest.raises(AssertionError, match="NaN"):
+        att.step(good)
+    att.reset()  # (the NaN went through one step of environment 3)
+    att.step(good)
+    bad = [a.clone() for a in good]
+    bad[1][0, 0] = -1.25
+    att.step(bad)
+    with pytest.raises(AssertionError, match="out of its range"):
+        h.fused.check_actions()
+    h.fused.check_actions()  # the flag was consumed
+    h.detach()
 
 
 def test_attached_fused_outputs_are_fresh_and_scenario_attributes_follow(vmas):

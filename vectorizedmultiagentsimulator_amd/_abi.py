@@ -302,6 +302,9 @@ EXPORTED_SYMBOLS = (
     "vmas_build_id",
     # include/vmas_env_hip.h
     "vmas_env_ingest_actions",
+    "vmas_host_word_create",
+    "vmas_host_word_destroy",
+    "vmas_env_validate_actions",
     "vmas_balance_post_step",
     "vmas_transport_post_step",
     "vmas_navigation_post_step",
@@ -373,6 +376,12 @@ def load_library() -> C.CDLL:
     lib.vmas_world_step_bytes_per_env.restype = i64
     lib.vmas_env_ingest_actions.argtypes = [C.POINTER(IngestArgs), i32, vp, vp, i64, vp, vp]
     lib.vmas_env_ingest_actions.restype = C.c_int
+    lib.vmas_host_word_create.argtypes = [i32, C.POINTER(vp), C.POINTER(vp)]
+    lib.vmas_host_word_create.restype = C.c_int
+    lib.vmas_host_word_destroy.argtypes = [vp]
+    lib.vmas_host_word_destroy.restype = None
+    lib.vmas_env_validate_actions.argtypes = [C.POINTER(IngestArgs), i32, vp, vp, i64, vp, vp, vp]
+    lib.vmas_env_validate_actions.restype = C.c_int
     for fn, d, b in ((lib.vmas_balance_post_step, BalanceDesc, BalanceBuffers),
                      (lib.vmas_transport_post_step, TransportDesc, TransportBuffers),
                      (lib.vmas_navigation_post_step, NavigationDesc, NavigationBuffers),

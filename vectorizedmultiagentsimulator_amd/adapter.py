@@ -355,7 +355,7 @@ class AttachedWorld:
 
 def attach(env_or_world, backend_factory: Callable = _default_backend,
            exact_broad_phase: Optional[bool] = None, specialize: Optional[bool] = False,
-           fused: Optional[bool] = None, validate_actions: bool = True) -> AttachedWorld:
+           fused: Optional[bool] = None, validate_actions=True) -> AttachedWorld:
     """Put a reference ``Environment`` (or ``World``) on the MI355X-native physics step.  ``exact_broad_phase``: the
     reference's batch-global ``.any()`` broad phase (core.py:2797-2801) exactly; None = below 1024 environments, where
     it can matter (above, every pair that matters has SOME environment overlapping).  ``specialize``: True = compile (once,
@@ -370,7 +370,9 @@ def attach(env_or_world, backend_factory: Callable = _default_backend,
     ``Environment.step`` around the native ``World.step`` otherwise (``handle.fused_reason`` says why); True = required;
     False = never.  ``validate_actions``: the reference's NaN / range asserts (environment.py:621,651-653) - one small
     kernel and ONE host sync in front of the step launch instead of two syncs per agent, same behaviour (a bad action
-    raises before the world is touched); False drops them for throughput runs."""
+    raises before the world is touched); "deferred": the step launch itself flags a bad action and the NEXT ``env.step``
+    (or ``handle.fused.check_actions()``) raises - no synchronisation at all, the world has stepped once with the bad
+    action by then; False drops the check."""
     world = getattr(env_or_world, "world", env_or_world)
     if getattr(env_or_world, "grad_enabled", False):
         raise NotImplementedError("grad_enabled=True needs the reference's autograd path; the HIP step has no backward")

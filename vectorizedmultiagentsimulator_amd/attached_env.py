@@ -289,7 +289,12 @@ class FusedEnvStep:
 
     def __init__(self, env, handle, profile: _Profile, validate_actions: bool = True):
         self.env, self.handle, self.profile = env, handle, profile
-        self.validate_actions = bool(validate_actions)
+        # True: the reference's asserts before the world is touched (one stream synchronisation per step); "deferred": the
+        # step launch itself flags a bad action and the NEXT env.step (or check_actions()) raises - no synchronisation;
+        # False: no check
+        assert validate_actions in (True, False, "deferred"), validate_actions
+        self.validate_actions = validate_actions is True
+        self.deferred = validate_actions == "deferred"
         self.dict_spaces = bool(getattr(env, "dict_spaces", False))
         self.split = bool(getattr(env, "terminated_truncated", False))
         self.names = [a.name for a in env.agents]
@@ -351,12 +356,15 @@ class FusedEnvStep:
         if env.steps is not self.steps:
             self._adopt_steps()
         ingest, post = self.ingest, self.post
+        deferred = self.deferred
+        if deferred:
+            ingest.pending()  # what an earlier step's launch found
         if self.one_launch:
             ingest.prepare(actions)
             if self.validate_actions:
                 ingest.validate()  # raises before the world is touched, like the reference's asserts
             desc, buffers, result = post.prepare()
-            self.launch(post.kind, desc, buffers, False)
+            self.launch(post.kind, desc, buffers, deferred)
             if self._finish is not None:
                 result = self._finish(result)
         else:
@@ -364,7 +372,7 @@ class FusedEnvStep:
                 ingest.prepare(actions)
                 if self.validate_actions:
                     ingest.validate()
-                self.launch(0, None, None, False)
+                self.launch(0, None, None, deferred)
             else:
                 ingest(actions, self.validate_actions)
                 h.step()
@@ -378,6 +386,11 @@ class FusedEnvStep:
             truncated = (self.steps >= ms) if ms is not None else torch.zeros_like(dones)
             return [obs, rews, dones, truncated, infos]
         return [obs, rews, dones, infos]
+
+    def check_actions(self):
+        """Deferred validation: wait for the steps enqueued so far and raise if one of them was given a bad action."""
+        torch.cuda.current_stream(self.view.device).synchronize()
+        self.ingest.pending()
 
     def detach(self):
         env = self.env

@@ -186,7 +186,7 @@ __global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld
         uint32_t bad = 0;
         ingest_slot(S, E.ingest.clamp, env, live, agent_ft, ld, f3, bad, act_row0);
         if (S.action_size < 3) f3[2] = from_tile ? tile[P.off_af + (a * 3 + 2) * ROWF] : (lv ? src[2 * ld] : 0.f);
-        if (E.err_flags != nullptr && bad != 0) atomicOr(E.err_flags, bad);
+        if (E.err_flags != nullptr && bad != 0) raise_action_error(E.err_flags, bad);
         return;
       }
       if (on && E.ingest.n_scripts > 0 && E.script_of_agent[a] >= 0) {  // driven by the state about to be stepped:

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void ingest_kernel(const VmasIngestArgs args, 
     const VmasAgentScript& S = args.scripts[blockIdx.y - args.n_agents];
     run_script(S, state + (long)S.entity * 6 * ld + (env < batch ? env : 0), ld, env, env < batch, agent_ft, ld, u);
   }
-  if (err != nullptr && bad != 0) atomicOr(err, bad);
+  if (err != nullptr && bad != 0) raise_action_error(err, bad);
 }
 
 // ------------------------------------------------------------------------------------ balance / transport
@@ -375,6 +375,42 @@ int vmas_env_ingest_actions(const VmasIngestArgs* args, int32_t batch, const flo
   hipLaunchKernelGGL(ingest_kernel, dim3((batch + 255) / 256, args->n_agents + args->n_scripts), dim3(256), 0,
                      (hipStream_t)stream, *args, batch, state, agent_ft, (long)ld, err_flags);
   return check_launch("vmas_env_ingest_actions");
+}
+
+int vmas_host_word_create(int32_t device_id, uint32_t** host, uint32_t** dev) {
+  if (!host || !dev) return host_fail("vmas_host_word_create: null argument");
+  if (hipSetDevice(device_id) != hipSuccess) return host_fail("vmas_host_word_create: hipSetDevice failed");
+  uint32_t* h = nullptr;
+  if (hipHostMalloc((void**)&h, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+    (void)hipGetLastError();
+    return host_fail("vmas_host_word_create: hipHostMalloc failed");
+  }
+  *h = 0u;
+  uint32_t* d = nullptr;
+  if (hipHostGetDevicePointer((void**)&d, h, 0) != hipSuccess || d == nullptr) {
+    (void)hipGetLastError();
+    (void)hipHostFree(h);
+    return host_fail("vmas_host_word_create: hipHostGetDevicePointer failed");
+  }
+  *host = h;
+  *dev = d;
+  return 0;
+}
+
+void vmas_host_word_destroy(uint32_t* host) {
+  if (host) (void)hipHostFree(host);
+}
+
+int vmas_env_validate_actions(const VmasIngestArgs* args, int32_t batch, const float* state, float* agent_ft, int64_t ld,
+                              uint32_t* err_host, uint32_t* err_dev, void* stream) {
+  if (!err_host || !err_dev) return host_fail("vmas_env_validate_actions: needs the flag word of vmas_host_word_create");
+  if (vmas_env_ingest_actions(args, batch, state, agent_ft, ld, err_dev, stream)) return -1;
+  if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) {
+    (void)hipGetLastError();
+    return host_fail("vmas_env_validate_actions: hipStreamSynchronize failed");
+  }
+  const uint32_t flags = __atomic_exchange_n(err_host, 0u, __ATOMIC_ACQ_REL);
+  return (int)(flags & 0x7fffffffu);
 }
 
 // ------------------------------------------------------------------------------------ masked reset

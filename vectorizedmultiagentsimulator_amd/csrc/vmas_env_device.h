@@ -955,6 +955,11 @@ VD void navigation_post_tile(const TileCtx& C, const VmasNavigationDesc& d, cons
   }
 }
 
+// VMAS_ACTION_ERR_* into the caller's flag word: system scope - the word may live in pinned host memory (vmas_host_word_create)
+VD void raise_action_error(uint32_t* err, uint32_t bad) {
+  __hip_atomic_fetch_or(err, bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ------------------------------------------------------------------------------------ action ingest
 // Environment._set_action (environment.py:616-749, continuous branch) + Holonomic(.WithRotation)
 // .process_action for ONE agent slot and this lane's environment: returns the (up to 3) scaled

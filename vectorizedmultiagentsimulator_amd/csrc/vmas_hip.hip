@@ -124,7 +124,7 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
         uint32_t bad = 0;
         ingest_slot(S, E.ingest.clamp, env, live, agent_ft, ld, f3, bad, act_row0);
         if (S.action_size < 3) f3[2] = lv ? src[2 * ld] : 0.f;  // Holonomic leaves the torque alone
-        if (E.err_flags != nullptr && bad != 0) atomicOr(E.err_flags, bad);
+        if (E.err_flags != nullptr && bad != 0) raise_action_error(E.err_flags, bad);
         return;
       }
       if (on && E.ingest.n_scripts > 0 && E.script_of_agent[a] >= 0) {  // scripted: driven by the state about to be stepped

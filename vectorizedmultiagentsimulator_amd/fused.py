@@ -113,7 +113,13 @@ class ActionIngest:
             s.u_out = u.data_ptr()
             agent.action.u = u
             self.u.append(u)
-        self.err = torch.zeros(1, device=env.device, dtype=torch.int32)
+        # the action-error flags: ONE word in pinned host memory the kernels OR into (include/vmas_env_hip.h,
+        # vmas_host_word_create): read here without a device-to-host copy
+        dev = torch.device(env.device)
+        h, d = C.c_void_p(), C.c_void_p()
+        _check(self.lib.vmas_host_word_create(dev.index if dev.index is not None else torch.cuda.current_device(), C.byref(h), C.byref(d)))
+        self._err_host_ptr, self.err_ptr = h.value, d.value
+        self._err_word = C.c_uint32.from_address(h.value)
         self._ft = w._packed_agent_ft()
         self._keep = None
         self._fast = None
@@ -210,23 +216,44 @@ class ActionIngest:
                                         else "Discrete action of an agent is out of range")
         self._keep = held
 
-    def check(self):
-        """The reference asserts on the host (environment.py:621,651-653): one sync, not 2 per agent."""
-        flags = int(self.err.item())
+    def __del__(self):
+        p, self._err_host_ptr = getattr(self, "_err_host_ptr", None), None
+        if p:
+            try:
+                self.lib.vmas_host_word_destroy(C.c_void_p(p))
+            except Exception:  # noqa: BLE001 (interpreter shutdown)
+                pass
+
+    @staticmethod
+    def _raise(flags: int):
+        """The reference's asserts (environment.py:621,651-653) for the flags a kernel raised."""
+        assert not (flags & A.ACTION_ERR_NAN), "actions contain NaN"
+        raise AssertionError("Physical actions of an agent are out of its range")
+
+    def pending(self):
+        """Deferred validation: flags a PREVIOUS launch raised (``err_ptr`` passed to the step launch itself), read from the
+        host word without any synchronisation - a bad action of step t raises at step t + 1 at the latest once step t's
+        kernel has run, for the price of one memory read."""
+        flags = self._err_word.value
         if flags:
-            self.err.zero_()
-            assert not (flags & A.ACTION_ERR_NAN), "actions contain NaN"
-            raise AssertionError("Physical actions of an agent are out of its range")
+            self._err_word.value = 0
+            self._raise(flags)
 
     def launch(self, validate: bool):
-        """The stand-alone ingest kernel on the prepared action tensors (+ the reference's asserts when ``validate``)."""
+        """The stand-alone ingest kernel on the prepared action tensors; ``validate``: + ONE stream synchronisation and the
+        reference's asserts on what it found (vmas_env_validate_actions)."""
         env = self.env
         ft = env.world._packed_agent_ft()
-        err = self.err.data_ptr() if validate else None
-        _check(self.lib.vmas_env_ingest_actions(C.byref(self.args), env.num_envs, env.world._packed_state().data_ptr(),
-                                                ft.data_ptr(), ft.shape[-1], err, _stream(env.device)))
         if validate:
-            self.check()
+            flags = self.lib.vmas_env_validate_actions(C.byref(self.args), env.num_envs, env.world._packed_state().data_ptr(),
+                                                       ft.data_ptr(), ft.shape[-1], self._err_host_ptr, self.err_ptr, _stream(env.device))
+            if flags < 0:
+                raise VmasHipError(A.last_error())
+            if flags:
+                self._raise(flags)
+            return
+        _check(self.lib.vmas_env_ingest_actions(C.byref(self.args), env.num_envs, env.world._packed_state().data_ptr(),
+                                                ft.data_ptr(), ft.shape[-1], None, _stream(env.device)))
 
     def validate(self):
         """``validate_actions`` on a path whose ingest is the physics kernel's prologue: the reference asserts BEFORE it
@@ -339,7 +366,7 @@ class StepLauncher:
         self._per_env = any(j.per_env_fixed_rotation for j in spec.joints) or any(e.per_env_gravity for e in spec.entities)
         self._exact = bool(w.exact_broad_phase)
         self._ing = C.byref(self.ingest.args)
-        self._err = C.c_void_p(self.ingest.err.data_ptr())
+        self._err = C.c_void_p(self.ingest.err_ptr)
         self._dev = self.env.device
 
     def __call__(self, kind: int, desc, buffers, validate: bool):
