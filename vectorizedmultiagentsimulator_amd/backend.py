@@ -28,7 +28,7 @@ def _round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
 
-_PARKED: list = []  # (lib, handle) of worlds released while a HIP-graph capture was in progress
+_PARKED: list = []  # releases (callables: a world, a pinned host word) deferred while a HIP-graph capture was in progress
 
 
 def _drain_parked():
@@ -40,8 +40,15 @@ def _drain_parked():
     except Exception:
         return
     while _PARKED:
-        lib, h = _PARKED.pop()
-        lib.vmas_world_destroy(h)
+        _PARKED.pop()()
+
+
+def release_later(free) -> None:
+    """Run ``free()`` (a hipFree / hipHostFree behind the C ABI) now, or - while any stream is being captured into a HIP graph,
+    where such a call invalidates the capture, and the garbage collector may run a ``__del__`` at any point - at the next
+    release that happens outside a capture."""
+    _PARKED.append(free)
+    _drain_parked()
 
 
 class HipWorld:
@@ -94,7 +101,8 @@ class HipWorld:
         next ``close()`` / constructor that runs outside one."""
         h, self._h = getattr(self, "_h", None), None
         if h:
-            _PARKED.append((self.lib, h))
+            lib = self.lib
+            _PARKED.append(lambda: lib.vmas_world_destroy(h))
         _drain_parked()
 
     def __del__(self):

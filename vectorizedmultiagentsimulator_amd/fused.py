@@ -219,8 +219,10 @@ class ActionIngest:
     def __del__(self):
         p, self._err_host_ptr = getattr(self, "_err_host_ptr", None), None
         if p:
-            try:
-                self.lib.vmas_host_word_destroy(C.c_void_p(p))
+            try:  # (hipHostFree is illegal while a stream is being captured: deferred like a world's release)
+                from .backend import release_later
+                lib = self.lib
+                release_later(lambda: lib.vmas_host_word_destroy(C.c_void_p(p)))
             except Exception:  # noqa: BLE001 (interpreter shutdown)
                 pass
 

@@ -160,6 +160,9 @@ class NativeRollout:
                 n *= x
             self.fields[name] = self.local[o:o + n].view(dtype).view(shape)
         self._full: Optional[torch.Tensor] = None
+        #: a single-rank group normally skips the collective (its result IS the local buffer); True makes the call anyway -
+        #: the one-GPU test boxes then run backend `nccl` (= RCCL) on the very buffer the step kernel stored into
+        self.force_collective = False
 
     @classmethod
     def for_env(cls, shard: EnvShard, env, n_steps: int, group: Optional[dist.ProcessGroup] = None) -> "NativeRollout":
@@ -183,7 +186,7 @@ class NativeRollout:
         call.  Equal shards: ``{name: tensor [R, *shape]}`` (views of the gathered buffer); unequal: ``{name: [R tensors]}``."""
         sh = self.shard
         R = sh.world_size
-        if R == 1:
+        if R == 1 and not self.force_collective:
             return {k: v.unsqueeze(0) for k, v in self.fields.items()}
         if self._full is None:
             self._full = torch.empty(R * self.nbytes, dtype=torch.uint8, device=self.local.device)
