@@ -564,7 +564,11 @@ def attached_reference_leg(name, kw, B, device, n=300, brief=False):
             torch.cuda.synchronize()
             t2 = time.perf_counter()
             out.update({"world_step_us": (t2 - t0) / n * 1e6, "world_step_host_enqueue_us": (t1 - t0) / n * 1e6,
-                        "world_step_gpu_us": e0.elapsed_time(e1) / n * 1e3, "steps": n})
+                        "world_step_gpu_us": e0.elapsed_time(e1) / n * 1e3, "steps": n,
+                        "world_step_protocol": "world.step() alone, the agent forces HELD as the last env.step left them: over the "
+                                               "300 calls every body is driven into a wall - the dense-contact case (football: "
+                                               "2-3x the random-action step, see `environment_step.bound` of the native line); "
+                                               "host_enqueue includes the queue's back-pressure once the GPU is the slower side"})
         out["refreshes"] = h.refreshes
         h.detach()
         if out["fused"]:

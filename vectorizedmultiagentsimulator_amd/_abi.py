@@ -11,6 +11,22 @@ import os
 from typing import Optional
 
 ABI_VERSION = 3
+
+
+def leading_dim(batch: int) -> int:
+    """``ld`` of the packed buffers for ``batch`` environments: the batch rounded up to whole 64-environment tiles, plus
+    ``LD_PAD_TILES`` tiles where that is a large power of two (see the constant)."""
+    ld = (int(batch) + 63) // 64 * 64
+    pad = int(os.environ.get("VMAS_LD_PAD", LD_PAD_TILES))
+    if pad and ld >= int(os.environ.get("VMAS_LD_FROM", LD_PAD_FROM)) and (ld & (ld - 1)) == 0:
+        ld += 64 * pad
+    return ld
+
+
+#: A tile reads its 6 E rows at a stride of ld * 4 bytes: with ld a large power of two (262 144 environments: 1 MiB, 1 M: 4 MiB)
+#: every row of a tile falls on the same HBM channel.  Measured (profiles/r05*_ld_pad*.jsonl): see DESIGN.md section 6 "Round 5".
+LD_PAD_TILES = 0
+LD_PAD_FROM = 1 << 16
 STATE_FIELDS = 6
 AGENT_FIELDS = 3
 

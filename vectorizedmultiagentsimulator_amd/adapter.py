@@ -124,7 +124,7 @@ class AttachedWorld:
         self._orig_classes = {}
         self._orig_measures = []
         self.batch = int(world.batch_dim)
-        self.ld = (self.batch + 63) // 64 * 64
+        self.ld = A.leading_dim(self.batch)
         self.device = torch.device(world.device)
         self.spec = spec_from_world(world)
         nE, nA = self.spec.n_entities, self.spec.n_agents

@@ -65,7 +65,7 @@ class HipWorld:
         if not torch.cuda.is_available():
             raise VmasHipError("HipWorld: no GPU visible (torch.cuda.is_available() is False)")
         self.device_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
-        self.ld = _round_up(self.batch, 64)
+        self.ld = A.leading_dim(self.batch)
         self.cdesc = spec.to_ctypes()
         handle = C.c_void_p()
         with torch.cuda.device(self.device_index):

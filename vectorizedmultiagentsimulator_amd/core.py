@@ -647,7 +647,7 @@ class World:
         self._contact_margin, self._torque_constraint_force = contact_margin, torque_constraint_force
         self._joints: Dict[frozenset, JointConstraint] = {}
         # packed storage + backend (built lazily once the entity list is known)
-        self._ld = (batch_dim + 63) // 64 * 64
+        self._ld = A.leading_dim(batch_dim)
         self._state: Optional[Tensor] = None
         self._agent_ft: Optional[Tensor] = None
         self._backend = None
