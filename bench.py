@@ -521,6 +521,7 @@ def attached_reference_leg(name, kw, B, device, n=300, brief=False):
     sub = int(getattr(world, "_substeps", 1))
 
     def time_env_steps(m, warm=20):
+        env.reset(seed=0)  # every leg from the same post-reset distribution (the cost of a step depends on the state it finds)
         for k in range(warm):
             env.step(cycle[k % 25])
         torch.cuda.synchronize()
