@@ -310,3 +310,46 @@ def test_attached_fused_at_benchmark_size_against_the_reference(vmas, scenario, 
             out_att = att.step([a.to(DEV) for a in acts])
             _compare_step(out_ref, out_att, scenario, f"{scenario} {B} t={t}")
     h.detach()
+
+
+# configurations beyond the fixtures': every scenario kwarg the reference accepts that changes what the ingest or the epilogue
+# computes, a few at a time (teacher-forced like the fixture test, 10 steps each)
+WIDER = [
+    ("balance", dict(n_agents=2, package_mass=1.5), {}),
+    ("balance", dict(n_agents=6, random_package_pos_on_line=False), dict(max_steps=5)),
+    ("balance", dict(n_agents=3), dict(continuous_actions=False)),
+    ("transport", dict(n_agents=2, n_packages=3, package_width=0.2, package_length=0.1, package_mass=10), {}),
+    ("transport", dict(n_agents=6), dict(clamp_actions=True, max_steps=7)),
+    ("navigation", dict(n_agents=2, lidar_range=0.5, n_lidar_rays=7), {}),
+    ("navigation", dict(n_agents=6, shared_rew=False, agent_collision_penalty=-0.3, final_reward=0.5, pos_shaping_factor=2.0), dict(max_steps=6)),
+    ("navigation", dict(n_agents=4, collisions=False, agents_with_same_goal=4), {}),
+    ("navigation", dict(n_agents=4, collisions=False, agents_with_same_goal=2, split_goals=True, observe_all_goals=True), {}),
+    ("navigation", dict(n_agents=3, enforce_bounds=True, world_spawning_x=0.6, world_spawning_y=0.6, agent_radius=0.05), dict(continuous_actions=False)),
+    ("football", dict(n_blue_agents=2, n_red_agents=2, ai_red_agents=False, agent_size=0.03, ball_size=0.025, goal_size=0.5, pitch_length=2.4,
+                      pitch_width=1.2, dense_reward=True), {}),  # (1 v 1 is refused by the reference itself: torch.cat of no teammates)
+    ("football", dict(n_blue_agents=4, n_red_agents=4, ai_red_agents=False, observe_teammates=False), dict(max_steps=8)),
+    ("football", dict(n_blue_agents=2, n_red_agents=3, ai_red_agents=False, observe_teammates=False, observe_adversaries=False), {}),
+    ("football", dict(n_blue_agents=3, n_red_agents=3, ai_red_agents=False, spawn_in_formation=True, u_multiplier=0.2, max_speed=0.3,
+                      ball_mass=0.5, scoring_reward=10.0, pos_shaping_factor_ball_goal=5.0, distance_to_ball_trigger=0.2), dict(continuous_actions=False)),
+]
+
+
+@pytest.mark.parametrize("scenario,kw,env_kw", WIDER)
+def test_attached_fused_wider_configurations_teacher_forced(vmas, scenario, kw, env_kw):
+    from vectorizedmultiagentsimulator_amd.adapter import attach
+
+    B = 40
+    ref = vmas.make_env(scenario, num_envs=B, device="cpu", seed=1, **env_kw, **kw)
+    att = vmas.make_env(scenario, num_envs=B, device=DEV, seed=1, **env_kw, **kw)
+    h = attach(att)
+    assert h.fused is not None, f"{scenario} {kw}: expected the one-launch step, got the fallback ({h.fused_reason})"
+    g = torch.Generator().manual_seed(17)
+    with torch.no_grad():
+        for t in range(10):
+            _force_state(ref, att, scenario)
+            acts = _actions(ref, g)
+            out_ref = ref.step([a.clone() for a in acts])
+            out_att = att.step([a.to(DEV) for a in acts])
+            _compare_step(out_ref, out_att, scenario, f"{scenario} {kw} {env_kw} t={t}")
+            assert torch.equal(att.steps.cpu(), ref.steps)
+    h.detach()
