@@ -261,20 +261,29 @@ class AttachedWorld:
         for e in w.entities:
             ts += [v for v in (e.__dict__.get("_gravity"), e.__dict__.get("_v_range"), e.__dict__.get("_mass")) if isinstance(v, torch.Tensor)]
         self._watched_tensors = [t for t in ts if isinstance(t, torch.Tensor)]
-        self._mini = self._mini_fingerprint()
+        # (what a step compares - integers and identities, no container is built per step)
+        self._seen_versions = [t._version for t in self._watched_tensors]
+        self._seen_counts = (len(getattr(w, "_joints", ())), len(getattr(w, "_landmarks", ())) + len(getattr(w, "_agents", ())))
+        self._seen_gravity = getattr(w, "_gravity", None)
         self._dirty = False
 
-    def _mini_fingerprint(self):
+    def _unchanged(self) -> bool:
         """What a ``__setattr__`` hook cannot see: in-place writes to tensor-valued statics, joints added to the dict,
         entities added to the world."""
         w = self.world
-        return (tuple((id(t), t._version) for t in self._watched_tensors), len(getattr(w, "_joints", ())),
-                len(getattr(w, "_landmarks", ())) + len(getattr(w, "_agents", ())), id(getattr(w, "_gravity", None)))
+        nj, ne = self._seen_counts
+        if (len(getattr(w, "_joints", ())) != nj or len(getattr(w, "_landmarks", ())) + len(getattr(w, "_agents", ())) != ne
+                or getattr(w, "_gravity", None) is not self._seen_gravity):
+            return False
+        for t, v in zip(self._watched_tensors, self._seen_versions):
+            if t._version != v:
+                return False
+        return True
 
     def _sync_static(self):
         """Rebuild the native world iff the live world's static description is no longer the one it was built from."""
         check, self._check_spec = self._check_spec, False
-        if not self._dirty and not (check and self._volatile_filters) and self._mini_fingerprint() == self._mini:
+        if not self._dirty and not (check and self._volatile_filters) and self._unchanged():
             return
         spec = spec_from_world(self.world)
         if spec != self.spec:
