@@ -1579,7 +1579,10 @@ constexpr int kFootballOneLaunchTilesPerCu = 1;
 template <class G, int ENV, class EnvArgs>
 static int launch_spec(VmasWorld* w, Sched* S, float* state, float* aft, long ld, const DevStepArgs& a, const EnvArgs& env,
                        size_t extra_lds, hipStream_t s, int batch) {
-  const size_t lds_spec = ((size_t)G::ROWS * ROWF + 8) * sizeof(float) + extra_lds;
+  size_t lds_spec = ((size_t)G::ROWS * ROWF + 8) * sizeof(float) + extra_lds;
+#ifdef VMAS_PROFILE  // occupancy probe (profiling build only): bytes of LDS requested on top of what the kernel uses
+  if (const char* pad = getenv("VMAS_DEBUG_LDS_PAD")) lds_spec += (size_t)atol(pad);
+#endif
   const bool tail = batch % TILE != 0;
   const int n = a.n_steps > 1 ? a.n_steps : 1;
   const dim3 grid((batch + TILE - 1) / TILE), block(TILE * G::NW);
