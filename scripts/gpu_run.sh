@@ -81,7 +81,7 @@ while [ $# -gt 0 ]; do
     grep -h "sustained\|traffic / alg\|share of wave" $OUT/${TAG}_navigation8192_env_step_pmc_summary.txt $OUT/${TAG}_football16384_physics_compact_pmc_summary.txt $OUT/${TAG}_balance32768_env_step_pmc_summary.txt
     ;;
   evidence)
-    BENCH="python $R/bench.py --no-cpu-baseline --no-fused --no-other-configs --no-attached --queues 1 --steps 2000 --warmup 200"
+    BENCH="python $R/bench.py --no-cpu-baseline --no-fused --no-other-configs --no-attached --no-traffic --queues 1 --steps 2000 --warmup 200"
     RATED=step_kernel_spec:physics bash $S/gpu_counters.sh ${TAG}_bench_q1 384 1700 32768 -- $BENCH > /dev/null 2>&1
     grep -h "sustained\|traffic / alg\|share of wave\|median" $OUT/${TAG}_bench_q1_pmc_summary.txt | head
     { echo "# scripts/micro/launch_floor (this round's box)"; scripts/micro/launch_floor 32768 8; } > $OUT/${TAG}_launch_floor.txt 2>&1; tail -6 $OUT/${TAG}_launch_floor.txt
