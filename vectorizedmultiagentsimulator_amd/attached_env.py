@@ -140,9 +140,6 @@ class _Profile:
     def aliases(self, env) -> Dict[str, object]:
         return {}
 
-    def n_packages(self, env) -> int:
-        return 0
-
     def reserve(self, env):
         """(post_kind, n_packages) for ``vmas_world_reserve_epilogue``, or None."""
         return None
@@ -249,7 +246,7 @@ def find_profile(env):
         return None, "not an Environment"
     mod = type(sc).__module__
     for p in _PROFILES:
-        if mod.endswith("scenarios." + p.module_tail):
+        if mod == "vmas.scenarios." + p.module_tail:
             odd = _defined_in(type(sc), _SCENARIO_METHODS, mod)
             if odd is not None:
                 return None, f"scenario.{odd} is not the reference's"
