@@ -580,6 +580,23 @@ def attached_reference_leg(name, kw, B, device, n=300, brief=False):
             # ... and without them
             h = attach(env, specialize=None, validate_actions=False)
             out["env_step_no_validate_us"], out["env_step_no_validate_gpu_us"] = time_env_steps(m)
+            # K steps of the reference's environment per launch (handle.fused.rollout: vmas_world_rollout_env on its objects)
+            if h.fused.one_launch and getattr(h.fused.post, "rollout_ok", True):
+                try:
+                    K = 50
+                    env.reset(seed=0)
+                    racts = [torch.stack([cycle[k % 25][i] for k in range(K)]).contiguous() for i in range(len(env.agents))]
+                    h.fused.rollout(racts)
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(4):
+                        h.fused.rollout(racts)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    out["rollout_us_per_step"] = e0.elapsed_time(e1) / (4 * K) * 1e3
+                except Exception as e:  # noqa: BLE001
+                    out["rollout_error"] = repr(e)[:200]
             h.detach()
         if not brief:
             # (3) only the seam rebound: the reference's own Environment.step around the native World.step

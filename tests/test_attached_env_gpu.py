@@ -66,6 +66,23 @@ def _force_state(ref, att, scenario):
     att.steps.copy_(ref.steps.to(DEV))
 
 
+def _force_state_same_device(src, dst, scenario):
+    """``dst`` := ``src`` (two environments on the GPU): entity state, agent forces, shaping terms, step counter."""
+    for ea, eb in zip(src.world.entities, dst.world.entities):
+        eb.set_pos(ea.state.pos.clone(), batch_index=None)
+        eb.set_vel(ea.state.vel.clone(), batch_index=None)
+        eb.set_rot(ea.state.rot.clone(), batch_index=None)
+        eb.set_ang_vel(ea.state.ang_vel.clone(), batch_index=None)
+    for aa, ab in zip(src.world.agents, dst.world.agents):
+        if aa.state.force is not None:
+            ab.state.force = aa.state.force.clone()
+        if aa.state.torque is not None:
+            ab.state.torque = aa.state.torque.clone()
+    for (oa, n), (ob, _) in zip(_terms(src, scenario), _terms(dst, scenario)):
+        getattr(ob, n).copy_(getattr(oa, n))
+    dst.steps.copy_(src.steps)
+
+
 def _close(got, want, what, scale=1.0):
     got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
     assert got.shape == want.shape, f"{what}: shape {got.shape} vs {want.shape}"
@@ -353,3 +370,32 @@ def test_attached_fused_wider_configurations_teacher_forced(vmas, scenario, kw, 
             _compare_step(out_ref, out_att, scenario, f"{scenario} {kw} {env_kw} t={t}")
             assert torch.equal(att.steps.cpu(), ref.steps)
     h.detach()
+
+
+@pytest.mark.parametrize("scenario,kw", [("balance", dict(n_agents=4)), ("transport", dict(n_packages=2)),
+                                         ("football", dict(n_blue_agents=3, n_red_agents=3, ai_red_agents=False))])
+def test_attached_fused_rollout_is_bitwise_k_single_steps(vmas, scenario, kw):
+    """``handle.fused.rollout`` (K steps of the reference's environment in ONE launch) against K ``env.step`` calls of a twin."""
+    from vectorizedmultiagentsimulator_amd.adapter import attach
+
+    B, K = 200, 7
+    a = vmas.make_env(scenario, num_envs=B, device=DEV, seed=0, max_steps=5, **kw)
+    b = vmas.make_env(scenario, num_envs=B, device=DEV, seed=0, max_steps=5, **kw)
+    ha, hb = attach(a, fused=True, validate_actions=False), attach(b, fused=True, validate_actions=False)
+    _force_state_same_device(a, b, scenario)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    acts = [(torch.rand(K, B, ag.action_size, device=DEV, generator=g) * 2 - 1) * 0.9 for ag in a.agents]
+    want = [a.step([u[k] for u in acts]) for k in range(K)]
+    got = hb.fused.rollout(acts)
+    for k in range(K):
+        obs, rew, done, info = want[k]
+        for i in range(len(a.agents)):
+            assert torch.equal(got["obs"][k, i], obs[i]), f"{scenario}: obs of agent {i} differs at step {k}"
+            assert torch.equal(got["rew"][k, i], rew[i]), f"{scenario}: reward of agent {i} differs at step {k}"
+        assert torch.equal(got["done"][k], done)
+    assert got["done"][4].all() and torch.equal(a.steps, b.steps)  # the time limit fell inside the rollout
+    assert torch.equal(ha.state, hb.state)
+    ob, rb, db, _ = b.step([u[0] for u in acts])  # and single steps go on from where the rollout left the world
+    oa, ra, da, _ = a.step([u[0] for u in acts])
+    assert all(torch.equal(x, y) for x, y in zip(oa, ob)) and all(torch.equal(x, y) for x, y in zip(ra, rb))
+    ha.detach(); hb.detach()

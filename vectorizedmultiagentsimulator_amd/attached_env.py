@@ -384,6 +384,27 @@ class FusedEnvStep:
             return [obs, rews, dones, truncated, infos]
         return [obs, rews, dones, infos]
 
+    def rollout(self, actions, out=None):
+        """K consecutive ``env.step`` calls with given actions in ONE kernel launch (``vmas_world_rollout_env``)
+        on the reference's environment: ``actions[i]`` = agent i's ``[K, num_envs, action_size]``; returns ``{"obs": [K, n_agents,
+        num_envs, obs_dim], "rew": [K, n_agents, num_envs], "done": [K, num_envs], ...info terms}`` - entry k is what the k-th
+        ``env.step`` would have returned, bit for bit; no resets in between.  The scenario's attributes are the last step's.
+        Validation (``validate_actions`` not False): the reference's asserts on the whole action tensors up front."""
+        env, h = self.env, self.handle
+        assert self.one_launch and getattr(self.post, "rollout_ok", True), (
+            "rollout() needs a configuration whose env.step is one launch without a per-step reduction over more tiles than CUs")
+        assert len(actions) == len(self.names), f"Expecting actions for {len(self.names)}, got {len(actions)} actions"
+        h._sync_static()
+        if h.backend is not self._backend:
+            self.build()
+        if env.steps is not self.steps:
+            self._adopt_steps()
+        K = int(actions[0].shape[0])
+        self.ingest.prepare_rollout(list(actions), K, self.validate_actions or self.deferred)
+        desc, buffers, out = self.post.prepare_rollout(K, out)
+        self.launch.rollout(self.post.kind, desc, buffers, K)
+        return out
+
     def check_actions(self):
         """Deferred validation: wait for the steps enqueued so far and raise if one of them was given a bad action."""
         torch.cuda.current_stream(self.view.device).synchronize()
