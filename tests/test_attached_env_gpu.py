@@ -399,3 +399,87 @@ def test_attached_fused_rollout_is_bitwise_k_single_steps(vmas, scenario, kw):
     oa, ra, da, _ = a.step([u[0] for u in acts])
     assert all(torch.equal(x, y) for x, y in zip(oa, ob)) and all(torch.equal(x, y) for x, y in zip(ra, rb))
     ha.detach(); hb.detach()
+
+
+RESET_CASES = [("balance", dict(n_agents=4)), ("transport", dict(n_packages=2)), ("navigation", dict(n_agents=4)),
+               ("football", dict(n_blue_agents=3, n_red_agents=3, ai_red_agents=False))]
+
+
+@pytest.mark.parametrize("scenario,kw", RESET_CASES)
+def test_attached_fused_reset_where_resets_exactly_the_masked_environments(vmas, scenario, kw):
+    """``handle.fused.reset_where(mask)`` on the reference's environment: the masked environments get a fresh initial state by the
+    scenario's own placement rules (bounds, zero velocities, step counter, shaping terms consistent with the new positions -
+    checked with the REFERENCE's formulas on the views), the others keep their bits; and the environment steps on, teacher-forced
+    against the CPU reference from the state the reset left."""
+    from vectorizedmultiagentsimulator_amd.adapter import attach
+
+    B = 300
+    att = vmas.make_env(scenario, num_envs=B, device=DEV, seed=0, **kw)
+    ref = vmas.make_env(scenario, num_envs=B, device="cpu", seed=0, **kw)
+    h = attach(att, fused=True)
+    g = torch.Generator().manual_seed(23)
+    for _ in range(6):
+        att.step([a.to(DEV) for a in _actions(att, g)])
+    before, steps_before = h.state.clone(), att.steps.clone()
+    mask = torch.zeros(B, dtype=torch.bool)
+    mask[::3] = True
+    mask[B - 1] = True
+    obs = h.fused.reset_where(mask.to(DEV), return_observations=True)
+    assert len(obs) == len(att.agents) and obs[0].shape[0] == B
+    m = mask.to(DEV)
+    st = h.state[:, :, :B]
+    assert torch.equal(st[:, :, ~m], before[:, :, :B][:, :, ~m]), "an unmasked environment was touched"
+    assert not torch.equal(st[:, 0:2, m], before[:, :, :B][:, 0:2, m])
+    assert torch.equal(att.steps[m], torch.zeros_like(att.steps[m])) and torch.equal(att.steps[~m], steps_before[~m])
+    assert float(st[:, 2:4, m].abs().max()) == 0.0 and float(st[:, 5, m].abs().max()) == 0.0  # World.reset: velocities zeroed
+    sc, w = att.scenario, att.world
+    if scenario == "balance":
+        want = torch.linalg.vector_norm(sc.package.state.pos - sc.package.goal.state.pos, dim=1) * sc.shaping_factor
+        assert torch.allclose(sc.global_shaping[m], want[m], atol=1e-4, rtol=1e-5)
+        assert float(sc.package.goal.state.pos[m, 1].min()) >= 0.0 and float(sc.package.goal.state.pos[m, 0].abs().max()) <= 1.0
+        assert torch.allclose(sc.line.state.pos[m, 1], torch.full_like(sc.line.state.pos[m, 1], -w.y_semidim + sc.agent_radius * 2))
+    if scenario == "transport":
+        for p in sc.packages:
+            want = torch.linalg.vector_norm(p.state.pos - p.goal.state.pos, dim=1) * sc.shaping_factor
+            assert torch.allclose(p.global_shaping[m], want[m], atol=1e-4, rtol=1e-5)
+            assert float(p.state.pos[m].abs().max()) <= sc.world_semidim
+        pos = torch.stack([a.state.pos for a in w.agents], dim=1)[m]  # agents at least two radii apart
+        d = torch.cdist(pos, pos) + torch.eye(len(w.agents), device=DEV) * 10
+        assert float(d.min()) >= sc.agent_radius * 2 - 1e-6
+    if scenario == "navigation":
+        for a in w.agents:
+            want = torch.linalg.vector_norm(a.state.pos - a.goal.state.pos, dim=1) * sc.pos_shaping_factor
+            assert torch.allclose(a.pos_shaping[m], want[m], atol=1e-5, rtol=1e-5)
+        ents = torch.stack([e.state.pos for e in w.entities], dim=1)[m]
+        d = torch.cdist(ents, ents) + torch.eye(len(w.entities), device=DEV) * 10
+        assert float(d.min()) >= sc.min_distance_between_entities - 1e-6 and float(ents.abs().max()) <= max(sc.world_spawning_x, sc.world_spawning_y)
+    if scenario == "football":
+        assert float(sc.ball.state.pos[m].abs().max()) == 0.0 and not bool(sc._done[m].any())
+        for a in sc.blue_agents:
+            assert float(a.state.pos[m, 0].max()) <= sc.agent_size + 1e-6
+        for a in sc.red_agents:
+            assert float(a.state.pos[m, 0].min()) >= -sc.agent_size - 1e-6 and torch.allclose(a.state.rot[m], torch.full_like(a.state.rot[m], torch.pi))
+        want = torch.linalg.vector_norm(sc.ball.state.pos - sc.right_goal_pos, dim=-1) * sc.pos_shaping_factor_ball_goal
+        assert torch.allclose(sc.ball.pos_shaping_blue[m], want[m], atol=1e-5, rtol=1e-5)
+        for lm in w.landmarks:  # walls and goal lines where the reference's reset_walls / reset_goals put them
+            assert torch.equal(lm.state.pos[m], lm.state.pos[~m][:1].expand_as(lm.state.pos[m]))
+    # a second reset of the same environments draws another episode
+    again = h.state.clone()
+    h.fused.reset_where(mask.to(DEV))
+    assert not torch.equal(h.state[:, 0:2, :B][:, :, m], again[:, 0:2, :B][:, :, m]) and torch.equal(h.state[:, :, :B][:, :, ~m], again[:, :, :B][:, :, ~m])
+    # ... and the environment goes on: teacher-forced against the CPU reference from the state the reset left
+    for ea, eb in zip(att.world.entities, ref.world.entities):
+        eb.set_pos(ea.state.pos.cpu(), batch_index=None); eb.set_vel(ea.state.vel.cpu(), batch_index=None)
+        eb.set_rot(ea.state.rot.cpu(), batch_index=None); eb.set_ang_vel(ea.state.ang_vel.cpu(), batch_index=None)
+    for (oa, n), (ob, _) in zip(_terms(att, scenario), _terms(ref, scenario)):
+        getattr(ob, n).copy_(getattr(oa, n).cpu())
+    for aa, ab in zip(att.world.agents, ref.world.agents):
+        if aa.state.force is not None:
+            ab.state.force = aa.state.force.cpu()
+    ref.steps.copy_(att.steps.cpu())
+    with torch.no_grad():
+        for t in range(3):
+            _force_state(ref, att, scenario)
+            acts = _actions(ref, g)
+            _compare_step(ref.step([a.clone() for a in acts]), att.step([a.to(DEV) for a in acts]), scenario, f"{scenario} after reset_where t={t}")
+    h.detach()

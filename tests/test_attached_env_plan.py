@@ -115,3 +115,30 @@ def test_attach_with_a_custom_backend_keeps_the_reference_env_step(vmas):
     h.exact_broad_phase = False  # (read at the next step: ADVICE r4)
     env.step([env.get_random_action(a) for a in env.agents])
     h.detach()
+
+
+@pytest.mark.parametrize("scenario,kw,n_ops,n_terms,n_flags", [("balance", dict(n_agents=4), 8, 1, 1), ("transport", dict(n_packages=2), 7, 2, 2),
+                                                               ("navigation", dict(n_agents=4), 8, 4, 0),
+                                                               ("football", dict(n_blue_agents=3, n_red_agents=3, ai_red_agents=False), 18, 6, 1)])
+def test_reset_programs_evaluate_on_the_reference_objects(vmas, scenario, kw, n_ops, n_terms, n_flags):
+    """``handle.fused.reset_where``: the spawn program is stated once (this package's scenario of the same name) and evaluated on
+    the REFERENCE's scenario through the view - every entity it names is one of the reference world's, every term a tensor of the
+    reference's objects."""
+    from vectorizedmultiagentsimulator_amd import attached_env as AE
+
+    env = vmas.make_env(scenario, num_envs=3, device="cpu", seed=0, **kw)
+    for i, e in enumerate(env.world.entities):
+        e.__dict__["_index"] = i
+    profile, _ = AE.find_profile(env)
+    prog = profile.reset_program(AE._ScenarioView(env.scenario, profile.aliases(env)))
+    assert (len(prog["ops"]), len(prog["terms"]), len(prog["flags"])) == (n_ops, n_terms, n_flags)
+    ents = set(map(id, env.world.entities))
+    assert all(id(op[1]) in ents for op in prog["ops"])
+    assert sorted(id(op[1]) for op in prog["ops"]) == sorted(ents), "every entity of the world is placed by the program"
+    for t in prog["terms"]:
+        x = t[0]() if callable(t[0]) else t[0]
+        assert isinstance(x, torch.Tensor) and x.shape == (3,)
+    # configurations whose reset is not a spawn program say so
+    env = vmas.make_env("navigation", num_envs=3, device="cpu", seed=0, n_agents=4, collisions=False, agents_with_same_goal=4)
+    profile, _ = AE.find_profile(env)
+    assert profile.reset_program(AE._ScenarioView(env.scenario, profile.aliases(env))) is None

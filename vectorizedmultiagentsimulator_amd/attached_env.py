@@ -147,6 +147,16 @@ class _Profile:
     def make_post(self, view):
         raise NotImplementedError
 
+    def reset_program(self, scenario_view):
+        """The scenario's ``reset_world_at`` as a spawn program for ``vmas_env_reset_where`` (fused.MaskedReset) - stated ONCE,
+        by this package's scenario of the same name (``scenarios/<name>.py::fused_reset_program``, whose law is pinned to the
+        reference's in tests/test_reset_law_vs_reference.py), and evaluated here on the reference's objects through the view.
+        None: this configuration's reset is not a spawn program (shared goals, formation spawning)."""
+        import importlib
+
+        mod = importlib.import_module(f"{__package__}.scenarios.{self.module_tail}")
+        return mod.Scenario.fused_reset_program(scenario_view)
+
 
 class _Balance(_Profile):
     module_tail, post_kind = "balance", A.POST_BALANCE
@@ -228,7 +238,12 @@ class _Football(_Profile):
             return [dict(kind=A.SCRIPT_FOOTBALL_BALL, agent=sc.ball,
                          params=[sc.agent_size * 2, sc.pitch_width / 2, sc.pitch_length / 2, sc.goal_size / 2])]
 
-        return {"fused_action_factors": fused_action_factors, "fused_agent_scripts": fused_agent_scripts}
+        # the walls, goal lines and nets: where the scenario's reset_walls / reset_goals (football.py:686-1020) put them - read
+        # from environment 0 as it stands after the reset make_env made (the same pose in every environment, every episode)
+        static = list(env.world.landmarks)
+        poses = [(lm.name, None, None, tuple(float(x) for x in lm.state.pos[0].tolist()), float(lm.state.rot[0, 0])) for lm in static]
+        return {"fused_action_factors": fused_action_factors, "fused_agent_scripts": fused_agent_scripts,
+                "_static_landmarks": static, "_static": poses}
 
     def make_post(self, view):
         from .fused import FootballPost
@@ -300,6 +315,8 @@ class FusedEnvStep:
         for i, a in enumerate(env.world.agents):
             a.__dict__["_agent_index"] = i
         self.steps = torch.zeros(env.num_envs, device=env.device, dtype=torch.float32)
+        self.reset_seed = 0  # reset_where's counter-based generator: keyed by (this, environment, that environment's episode)
+        self._masked_reset = None
         self._orig_step = env.__dict__.get("step")
         self.build()
         self._adopt_steps()
@@ -323,6 +340,7 @@ class FusedEnvStep:
         self.ingest_in_step = exact_in_launch and env.world.dim_c == 0
         self.one_launch = self.ingest_in_step and self.post.kind is not None
         self.launch = F.StepLauncher(view, self.ingest) if self.ingest_in_step else None
+        self._masked_reset = None
         self._finish = getattr(self.post, "finish", None)
         self._backend = h.backend
 
@@ -404,6 +422,31 @@ class FusedEnvStep:
         desc, buffers, out = self.post.prepare_rollout(K, out)
         self.launch.rollout(self.post.kind, desc, buffers, K)
         return out
+
+    def reset_where(self, mask, return_observations: bool = False):
+        """``env.reset_at(i)`` for every environment where ``mask`` [num_envs] is set - ONE launch, no host sync
+        (``vmas_env_reset_where``).  The reference resets one environment per Python call (each a few dozen
+        small launches on a GPU): a rollout over 32 768 environments that resets hundreds per step cannot afford it.  The
+        placement law is the scenario's ``reset_world_at`` restated as a spawn program on a counter-based generator keyed by
+        (``reset_seed``, environment, that environment's episode count); unmasked environments keep their bits, the scenario's
+        cached terms and flags of the reset environments are re-initialised in place, ``env.steps`` zeroed there.
+        ``return_observations``: by the reference's own ``get_from_scenario`` on the new state."""
+        from . import fused as F
+
+        env = self.env
+        if env.steps is not self.steps:
+            self._adopt_steps()
+        if self._masked_reset is None:
+            prog = self.profile.reset_program(self.view.scenario)
+            if prog is None or len(prog["ops"]) > A.RESET_MAX_OPS or len(prog.get("terms", [])) > A.RESET_MAX_TERMS:
+                raise NotImplementedError("reset_where(): this configuration's reset is not a spawn program the kernel runs "
+                                          "(shared goals / formation spawning / too many entities): use env.reset_at(i)")
+            self._masked_reset = F.MaskedReset(self.view, prog, int(self.reset_seed))
+        mask = mask.to(self.view.device).reshape(self.view.num_envs).bool().contiguous()
+        self._masked_reset(mask)
+        if return_observations:
+            return env.get_from_scenario(get_observations=True, get_rewards=False, get_infos=False, get_dones=False)[0]
+        return None
 
     def check_actions(self):
         """Deferred validation: wait for the steps enqueued so far and raise if one of them was given a bad action."""
