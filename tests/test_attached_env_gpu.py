@@ -395,6 +395,14 @@ def test_attached_fused_rollout_is_bitwise_k_single_steps(vmas, scenario, kw):
         assert torch.equal(got["done"][k], done)
     assert got["done"][4].all() and torch.equal(a.steps, b.steps)  # the time limit fell inside the rollout
     assert torch.equal(ha.state, hb.state)
+    # the same rollout stored straight into a gather buffer (shard.NativeRollout): the kernel writes the caller's tensors
+    from vectorizedmultiagentsimulator_amd.shard import EnvShard, NativeRollout
+    _force_state_same_device(a, b, scenario)
+    nr = NativeRollout(EnvShard(B, 0, 1), hb.fused.rollout_fields(K), torch.device(DEV))
+    a_again = [a.step([u[k] for u in acts]) for k in range(K)]
+    got2 = hb.fused.rollout(acts, out=nr.fields)
+    assert got2["obs"].data_ptr() == nr.fields["obs"].data_ptr()
+    assert all(torch.equal(nr.gather()["obs"][0][k, i], a_again[k][0][i]) for k in range(K) for i in range(len(a.agents)))
     ob, rb, db, _ = b.step([u[0] for u in acts])  # and single steps go on from where the rollout left the world
     oa, ra, da, _ = a.step([u[0] for u in acts])
     assert all(torch.equal(x, y) for x, y in zip(oa, ob)) and all(torch.equal(x, y) for x, y in zip(ra, rb))

@@ -402,6 +402,12 @@ class FusedEnvStep:
             return [obs, rews, dones, truncated, infos]
         return [obs, rews, dones, infos]
 
+    def rollout_fields(self, n_steps: int):
+        """(name, shape, dtype) of every per-step output ``rollout()`` writes for ``n_steps`` steps - what a caller-provided
+        ``out`` must hold (``shard.NativeRollout(shard, handle.fused.rollout_fields(K), device)`` lays them out in the ONE
+        buffer that the end-of-rollout ``all_gather_into_tensor`` sends as it is: SURVEY.md 8e on the reference's objects)."""
+        return self.post.rollout_fields(n_steps)
+
     def rollout(self, actions, out=None):
         """K consecutive ``env.step`` calls with given actions in ONE kernel launch (``vmas_world_rollout_env``)
         on the reference's environment: ``actions[i]`` = agent i's ``[K, num_envs, action_size]``; returns ``{"obs": [K, n_agents,
