@@ -85,6 +85,17 @@ int vmas_host_word_create(int32_t device_id, uint32_t** host, uint32_t** dev);
 void vmas_host_word_destroy(uint32_t* host);
 int vmas_env_validate_actions(const VmasIngestArgs* args, int32_t batch, const float* state /* scripts only, else NULL */,
                               float* agent_ft, int64_t ld, uint32_t* err_host, uint32_t* err_dev, void* stream);
+/* The same in two halves, so that the step can be LAUNCHED while the validation is still in flight and the host's wait
+ * overlaps the step's own execution: `_begin` enqueues the ingest-only launch (flags into the block's GATE word - device
+ * memory, `vmas_host_word_gate`) and the marker launch (gate -> host flags, sequence number -> host) and returns the
+ * sequence number (> 0); the caller then enqueues `vmas_world_step_env_gated(..., gate, ...)` - a step launch that does
+ * NOTHING, not a load, if the gate word is nonzero when it starts - and calls `_end(host, seq, stream)`: polls the marker,
+ * returns the flags (and re-opens the gate behind the refused step).  Semantics of the reference's asserts exactly - a
+ * refused action never reaches the world - without an idle queue between validation and step. */
+int vmas_env_validate_begin(const VmasIngestArgs* args, int32_t batch, const float* state /* scripts only, else NULL */,
+                            float* agent_ft, int64_t ld, uint32_t* err_host, uint32_t* err_dev, void* stream);
+int vmas_env_validate_end(uint32_t* err_host, int32_t seq, void* stream);
+uint32_t* vmas_host_word_gate(uint32_t* host);
 
 /* ---------------------------------------------------------------- step counter / time limit */
 typedef struct VmasStepLimit {
@@ -272,6 +283,13 @@ int vmas_env_reset_where(const VmasResetArgs* args, int32_t batch, int32_t n_ent
 int vmas_world_step_env(VmasWorld* w, float* state, float* agent_ft, int64_t ld, const VmasStepArgs* args /* may be NULL */,
                         const VmasIngestArgs* ingest /* may be NULL */, uint32_t* err_flags /* may be NULL */,
                         int32_t post_kind, const void* post_desc, const void* post_buffers, void* stream);
+
+/* vmas_world_step_env as a GATED launch: if `*gate` (device memory: vmas_host_word_gate) is nonzero when the launch starts,
+ * it does nothing at all.  For steps that are exactly one launch without a grid barrier: post_kind NONE / BALANCE /
+ * TRANSPORT, no exact broad phase (anything else: < 0). */
+int vmas_world_step_env_gated(VmasWorld* w, float* state, float* agent_ft, int64_t ld, const VmasStepArgs* args,
+                              const VmasIngestArgs* ingest, uint32_t* gate, int32_t post_kind, const void* post_desc,
+                              const void* post_buffers, void* stream);
 
 /* K consecutive Environment.step() calls in ONE launch: the same results, bit for bit, as
  * `n_steps` vmas_world_step_env launches without resets in between, but the tile of 64 environments stays in LDS from

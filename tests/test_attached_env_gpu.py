@@ -491,3 +491,47 @@ def test_attached_fused_reset_where_resets_exactly_the_masked_environments(vmas,
             acts = _actions(ref, g)
             _compare_step(ref.step([a.clone() for a in acts]), att.step([a.to(DEV) for a in acts]), scenario, f"{scenario} after reset_where t={t}")
     h.detach()
+
+
+@pytest.mark.parametrize("scenario,kw", [("balance", dict(n_agents=4)), ("transport", dict(n_packages=2))])
+def test_attached_fused_gated_validation_at_benchmark_size(vmas, scenario, kw):
+    """Above 1 024 environments (no grid barrier in the step) the reference's asserts cost no idle queue: the check is enqueued, the
+    step launched GATED on its result, the host waits behind both (vmas_env_validate_begin / vmas_world_step_env_gated /
+    vmas_env_validate_end).  Same behaviour: a refused action leaves the world, the step counter AND the scenario's attributes
+    exactly as they were; good steps are bitwise those of the unvalidated path."""
+    from vectorizedmultiagentsimulator_amd.adapter import attach
+
+    B = 4096
+    a = vmas.make_env(scenario, num_envs=B, device=DEV, seed=0, **kw)
+    b = vmas.make_env(scenario, num_envs=B, device=DEV, seed=0, **kw)
+    ha, hb = attach(a, fused=True, validate_actions=True), attach(b, fused=True, validate_actions=False)
+    assert ha.fused.launch.can_gate(ha.fused.post.kind) and not ha.exact_broad_phase
+    _force_state_same_device(b, a, scenario)
+    g = torch.Generator().manual_seed(4)
+    for t in range(5):
+        acts = [x.to(DEV) for x in _actions(a, g)]
+        oa, ra, da, _ = a.step([x.clone() for x in acts])
+        ob, rb, db, _ = b.step(acts)
+        assert all(torch.equal(x, y) for x, y in zip(oa, ob)) and all(torch.equal(x, y) for x, y in zip(ra, rb)) and torch.equal(da, db)
+    assert torch.equal(ha.state, hb.state)
+    before, steps = ha.state.clone(), a.steps.clone()
+    sc = a.scenario
+    attrs = {"balance": ("pos_rew", "ground_rew", "on_the_ground"), "transport": ("rew",)}[scenario]
+    kept = [getattr(sc, n) for n in attrs]
+    kept_vals = [x.clone() for x in kept]
+    shaping = [getattr(o, n).clone() for o, n in _terms(a, scenario)]
+    good = [x.to(DEV) for x in _actions(a, g)]
+    for poison, what in ((float("nan"), "NaN"), (1.7, "out of its range")):
+        bad = [x.clone() for x in good]
+        bad[-1][B - 3, 0] = poison
+        with pytest.raises(AssertionError, match=what):
+            a.step(bad)
+        torch.cuda.synchronize()
+        assert torch.equal(ha.state, before) and torch.equal(a.steps, steps), "a refused action must not touch the world"
+        assert all(getattr(sc, n) is k for n, k in zip(attrs, kept)), "the scenario's attributes are the previous step's again"
+        assert all(torch.equal(x, y) for x, y in zip(kept, kept_vals))
+        assert all(torch.equal(getattr(o, n), s) for (o, n), s in zip(_terms(a, scenario), shaping))
+    oa, ra, da, _ = a.step([x.clone() for x in good])  # the gate is open again
+    ob, rb, db, _ = b.step(good)
+    assert all(torch.equal(x, y) for x, y in zip(oa, ob)) and torch.equal(ha.state, hb.state) and torch.equal(a.steps, b.steps)
+    ha.detach(); hb.detach()

@@ -321,6 +321,10 @@ EXPORTED_SYMBOLS = (
     "vmas_host_word_create",
     "vmas_host_word_destroy",
     "vmas_env_validate_actions",
+    "vmas_env_validate_begin",
+    "vmas_env_validate_end",
+    "vmas_host_word_gate",
+    "vmas_world_step_env_gated",
     "vmas_balance_post_step",
     "vmas_transport_post_step",
     "vmas_navigation_post_step",
@@ -398,6 +402,12 @@ def load_library() -> C.CDLL:
     lib.vmas_host_word_destroy.restype = None
     lib.vmas_env_validate_actions.argtypes = [C.POINTER(IngestArgs), i32, vp, vp, i64, vp, vp, vp]
     lib.vmas_env_validate_actions.restype = C.c_int
+    lib.vmas_env_validate_begin.argtypes = [C.POINTER(IngestArgs), i32, vp, vp, i64, vp, vp, vp]
+    lib.vmas_env_validate_begin.restype = C.c_int
+    lib.vmas_env_validate_end.argtypes = [vp, i32, vp]
+    lib.vmas_env_validate_end.restype = C.c_int
+    lib.vmas_host_word_gate.argtypes = [vp]
+    lib.vmas_host_word_gate.restype = vp
     for fn, d, b in ((lib.vmas_balance_post_step, BalanceDesc, BalanceBuffers),
                      (lib.vmas_transport_post_step, TransportDesc, TransportBuffers),
                      (lib.vmas_navigation_post_step, NavigationDesc, NavigationBuffers),
@@ -406,6 +416,8 @@ def load_library() -> C.CDLL:
         fn.restype = C.c_int
     lib.vmas_world_step_env.argtypes = [vp, vp, vp, i64, C.POINTER(StepArgs), C.POINTER(IngestArgs), vp, i32, vp, vp, vp]
     lib.vmas_world_step_env.restype = C.c_int
+    lib.vmas_world_step_env_gated.argtypes = lib.vmas_world_step_env.argtypes
+    lib.vmas_world_step_env_gated.restype = C.c_int
     lib.vmas_env_reset_where.argtypes = [C.POINTER(ResetArgs), i32, i32, i32, vp, vp, vp, i64, vp]
     lib.vmas_env_reset_where.restype = C.c_int
     lib.vmas_world_rollout_env.argtypes = [vp, vp, vp, i64, C.POINTER(StepArgs), C.POINTER(IngestArgs), vp, i32, vp, vp, i32, vp]

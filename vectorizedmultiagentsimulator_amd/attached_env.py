@@ -376,10 +376,23 @@ class FusedEnvStep:
             ingest.pending()  # what an earlier step's launch found
         if self.one_launch:
             ingest.prepare(actions)
-            if self.validate_actions:
-                ingest.validate()  # raises before the world is touched, like the reference's asserts
-            desc, buffers, result = post.prepare()
-            self.launch(post.kind, desc, buffers, deferred)
+            if self.validate_actions and self.launch.can_gate(post.kind):
+                # the reference's asserts without an idle queue: the check is enqueued, the step launched GATED on its result
+                # (it does nothing if an action was refused), and only then does the host wait for the check - while the step
+                # is already running behind it
+                seq = ingest.validate_begin()
+                saved = post.save_bound()
+                desc, buffers, result = post.prepare()
+                self.launch.gated(post.kind, desc, buffers)
+                flags = ingest.validate_end(seq)
+                if flags:
+                    post.restore_bound(saved)  # (the scenario keeps the previous step's pos_rew ...: it saw nothing of this one)
+                    ingest._raise(flags)
+            else:
+                if self.validate_actions:
+                    ingest.validate()  # raises before the world is touched, like the reference's asserts
+                desc, buffers, result = post.prepare()
+                self.launch(post.kind, desc, buffers, deferred)
             if self._finish is not None:
                 result = self._finish(result)
         else:

@@ -125,6 +125,9 @@ template <int ENV, class EnvArgs, int OWN, bool PLAIN>
 __global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld W, DevCompact P, float* __restrict__ state,
                                                                         float* __restrict__ agent_ft, long ld, int batch,
                                                                         int padded, DevStepArgs args_in, const EnvArgs E) {
+  if constexpr (ENV != ENV_NONE) {  // a gated launch behind a validation that raised flags: not a single load or store
+    if (env_gate_closed(E)) return;
+  }
   DevStepArgs args = args_in;
   if constexpr (PLAIN) {
     args.pair_mask = nullptr; args.sync = nullptr; args.entity_gravity = nullptr; args.first_substep = 0; args.n_substeps = 0;

@@ -64,10 +64,13 @@ __global__ __launch_bounds__(256) void ingest_kernel(const VmasIngestArgs args, 
   if (err != nullptr && bad != 0) raise_action_error(err, bad);
 }
 
-// One thread, enqueued behind a kernel whose completion the host wants to see without a stream synchronisation: `seq` into a
-// word of pinned host memory.  (Tried first: the kernel's own blocks counting themselves and the last one writing the word -
-// a system-scope release per block is an L2 write-back each: +13 us at 512 blocks, +90 us at 2048.)
-__global__ void mark_done_kernel(uint32_t* done, uint32_t seq) {
+// One thread, enqueued behind a kernel whose completion the host wants to see without a stream synchronisation: the flags the
+// kernels in front of it raised (the device-side gate word) and `seq`, into pinned host memory.  (Tried first: the kernel's own
+// blocks counting themselves and the last one writing the word - a system-scope release per block is an L2 write-back each:
+// +13 us at 512 blocks, +90 us at 2048.)
+__global__ void mark_done_kernel(const uint32_t* gate, uint32_t* host_flags, uint32_t* done, uint32_t seq) {
+  const uint32_t f = *(const volatile uint32_t*)gate;
+  if (f != 0u) __hip_atomic_fetch_or(host_flags, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __hip_atomic_store(done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
@@ -386,7 +389,15 @@ int vmas_env_ingest_actions(const VmasIngestArgs* args, int32_t batch, const flo
 }
 
 // The flag block (pinned, mapped, coherent host memory, 64 bytes): word 0 the VMAS_ACTION_ERR_* flags, word 1 the sequence
-// number of the last validation launch that has completed (written by mark_done_kernel), word 2 the host's launch counter.
+// number of the last validation that has completed (written by mark_done_kernel), word 2 the host's launch counter, bytes
+// 16..23 the address of the GATE word - one uint32 in DEVICE memory that the validation's ingest kernel ORs its flags into and
+// a gated step launch (vmas_world_step_env_gated) reads when it starts.
+static uint32_t* gate_of(const uint32_t* host) {
+  uint32_t* g = nullptr;
+  memcpy(&g, host + 4, sizeof(g));
+  return g;
+}
+
 int vmas_host_word_create(int32_t device_id, uint32_t** host, uint32_t** dev) {
   if (!host || !dev) return host_fail("vmas_host_word_create: null argument");
   if (hipSetDevice(device_id) != hipSuccess) return host_fail("vmas_host_word_create: hipSetDevice failed");
@@ -397,47 +408,75 @@ int vmas_host_word_create(int32_t device_id, uint32_t** host, uint32_t** dev) {
   }
   memset(h, 0, 64);
   uint32_t* d = nullptr;
-  if (hipHostGetDevicePointer((void**)&d, h, 0) != hipSuccess || d == nullptr) {
+  uint32_t* gate = nullptr;
+  if (hipHostGetDevicePointer((void**)&d, h, 0) != hipSuccess || d == nullptr || hipMalloc((void**)&gate, 64) != hipSuccess ||
+      hipMemset(gate, 0, 64) != hipSuccess) {
     (void)hipGetLastError();
+    if (gate) (void)hipFree(gate);
     (void)hipHostFree(h);
-    return host_fail("vmas_host_word_create: hipHostGetDevicePointer failed");
+    return host_fail("vmas_host_word_create: mapping the word / allocating the gate failed");
   }
+  memcpy(h + 4, &gate, sizeof(gate));
   *host = h;
   *dev = d;
   return 0;
 }
 
 void vmas_host_word_destroy(uint32_t* host) {
-  if (host) (void)hipHostFree(host);
+  if (!host) return;
+  uint32_t* gate = gate_of(host);
+  if (gate) (void)hipFree(gate);
+  (void)hipHostFree(host);
 }
 
-int vmas_env_validate_actions(const VmasIngestArgs* args, int32_t batch, const float* state, float* agent_ft, int64_t ld,
-                              uint32_t* err_host, uint32_t* err_dev, void* stream) {
-  if (!err_host || !err_dev) return host_fail("vmas_env_validate_actions: needs the flag word of vmas_host_word_create");
+uint32_t* vmas_host_word_gate(uint32_t* host) { return host ? gate_of(host) : nullptr; }
+
+int vmas_env_validate_begin(const VmasIngestArgs* args, int32_t batch, const float* state, float* agent_ft, int64_t ld,
+                            uint32_t* err_host, uint32_t* err_dev, void* stream) {
+  if (!err_host || !err_dev) return host_fail("vmas_env_validate_begin: needs the flag word of vmas_host_word_create");
   if (check_ingest_args(args, batch, agent_ft, ld)) return -1;
-  if (args->n_scripts > 0 && !state) return host_fail("vmas_env_validate_actions: agent scripts need the world state");
-  if (args->n_agents + args->n_scripts == 0) return 0;
-  const uint32_t seq = ++err_host[2];
-  hipLaunchKernelGGL(ingest_kernel, dim3((batch + 255) / 256, args->n_agents + args->n_scripts), dim3(256), 0,
-                     (hipStream_t)stream, *args, batch, state, agent_ft, (long)ld, err_dev);
-  hipLaunchKernelGGL(mark_done_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, err_dev + 1, seq);
-  if (check_launch("vmas_env_validate_actions")) return -1;
+  if (args->n_scripts > 0 && !state) return host_fail("vmas_env_validate_begin: agent scripts need the world state");
+  uint32_t* gate = gate_of(err_host);
+  const uint32_t seq = (++err_host[2]) & 0x3fffffffu;
+  if (args->n_agents + args->n_scripts > 0)
+    hipLaunchKernelGGL(ingest_kernel, dim3((batch + 255) / 256, args->n_agents + args->n_scripts), dim3(256), 0,
+                       (hipStream_t)stream, *args, batch, state, agent_ft, (long)ld, gate);
+  hipLaunchKernelGGL(mark_done_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, gate, err_dev, err_dev + 1, seq);
+  if (check_launch("vmas_env_validate_begin")) return -1;
+  return (int)seq;
+}
+
+int vmas_env_validate_end(uint32_t* err_host, int32_t seq, void* stream) {
+  if (!err_host) return host_fail("vmas_env_validate_end: null flag word");
   // The wait: a one-thread kernel behind the ingest writes `seq` into host memory - polled here, not waited for through the
   // stream (hipStreamSynchronize costs ~15 us on this runtime).  Bounded: after a few milliseconds of polling (a queue backed up
   // behind earlier work) the stream is synchronised the ordinary way.
   bool seen = false;
   for (int spin = 0; spin < 400000; ++spin) {
-    if (__atomic_load_n(err_host + 1, __ATOMIC_ACQUIRE) == seq) { seen = true; break; }
+    if (__atomic_load_n(err_host + 1, __ATOMIC_ACQUIRE) == (uint32_t)seq) { seen = true; break; }
     __builtin_ia32_pause();
   }
   if (!seen) {
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) {
       (void)hipGetLastError();
-      return host_fail("vmas_env_validate_actions: hipStreamSynchronize failed");
+      return host_fail("vmas_env_validate_end: hipStreamSynchronize failed");
     }
   }
   const uint32_t flags = __atomic_exchange_n(err_host, 0u, __ATOMIC_ACQ_REL);
+  if (flags != 0u) {  // re-open the gate behind whatever was launched against it (stream order: a gated step in front stays shut)
+    if (hipMemsetAsync(gate_of(err_host), 0, sizeof(uint32_t), (hipStream_t)stream) != hipSuccess) {
+      (void)hipGetLastError();
+      return host_fail("vmas_env_validate_end: clearing the gate failed");
+    }
+  }
   return (int)(flags & 0x7fffffffu);
+}
+
+int vmas_env_validate_actions(const VmasIngestArgs* args, int32_t batch, const float* state, float* agent_ft, int64_t ld,
+                              uint32_t* err_host, uint32_t* err_dev, void* stream) {
+  const int seq = vmas_env_validate_begin(args, batch, state, agent_ft, ld, err_host, err_dev, stream);
+  if (seq < 0) return -1;
+  return vmas_env_validate_end(err_host, seq, stream);
 }
 
 // ------------------------------------------------------------------------------------ masked reset

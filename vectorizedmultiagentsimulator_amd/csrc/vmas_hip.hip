@@ -70,6 +70,9 @@ template <int LEVEL, int ENV, class EnvArgs, int PLAIN>
 __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel(DevWorld W_in, float* __restrict__ state,
                                                                float* __restrict__ agent_ft, long ld, int batch,
                                                                DevStepArgs args_in, const EnvArgs E) {
+  if constexpr (ENV != ENV_NONE) {  // a gated launch behind a validation that raised flags: not a single load or store
+    if (env_gate_closed(E)) return;
+  }
   DevStepArgs args = args_in;
   DevWorld W = W_in;
   if constexpr (PLAIN != 0) {
@@ -2406,7 +2409,7 @@ int vmas_world_rollout(VmasWorld* w, float* state, float* agent_ft, int64_t ld, 
 
 static int step_env_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld, const VmasStepArgs* args,
                          const VmasIngestArgs* ingest, uint32_t* err_flags, int32_t post_kind, const void* post_desc,
-                         const void* post_buffers, int32_t n_steps, void* stream);
+                         const void* post_buffers, int32_t n_steps, void* stream, int gated = 0);
 
 // LDS (bytes) a fused epilogue needs behind the tile: `fixed` + `per_wave` floats for each of min(waves per tile, cap)
 // waves.  If the tile plus that does not fit the CU, the shared pair rows are given up once (the schedule is rebuilt).
@@ -2480,6 +2483,12 @@ int vmas_world_step_env(VmasWorld* w, float* state, float* agent_ft, int64_t ld,
   return step_env_impl(w, state, agent_ft, ld, args, ingest, err_flags, post_kind, post_desc, post_buffers, 1, stream);
 }
 
+int vmas_world_step_env_gated(VmasWorld* w, float* state, float* agent_ft, int64_t ld, const VmasStepArgs* args,
+                              const VmasIngestArgs* ingest, uint32_t* gate, int32_t post_kind, const void* post_desc,
+                              const void* post_buffers, void* stream) {
+  return step_env_impl(w, state, agent_ft, ld, args, ingest, gate, post_kind, post_desc, post_buffers, 1, stream, 1);
+}
+
 int vmas_world_rollout_env(VmasWorld* w, float* state, float* agent_ft, int64_t ld, const VmasStepArgs* args,
                            const VmasIngestArgs* ingest, uint32_t* err_flags, int32_t post_kind, const void* post_desc,
                            const void* post_buffers, int32_t n_steps, void* stream) {
@@ -2492,8 +2501,18 @@ int vmas_world_rollout_env(VmasWorld* w, float* state, float* agent_ft, int64_t 
 
 static int step_env_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld, const VmasStepArgs* args,
                          const VmasIngestArgs* ingest, uint32_t* err_flags, int32_t post_kind, const void* post_desc,
-                         const void* post_buffers, int32_t n_steps, void* stream) {
+                         const void* post_buffers, int32_t n_steps, void* stream, int gated) {
   if (!w) return fail("vmas_world_step_env: null world");
+  if (gated) {
+    // A gated launch must be the WHOLE step: kinds whose step can be more than one launch (football beyond one tile per CU,
+    // navigation's collision kernel) or carries a grid barrier (its sequence numbers advance on the host whether or not the
+    // tiles arrive: the exact broad phase, navigation's collision reduction) are refused.
+    if (!err_flags) return fail("vmas_world_step_env_gated: needs the gate word");
+    if (post_kind != VMAS_POST_NONE && post_kind != VMAS_POST_BALANCE && post_kind != VMAS_POST_TRANSPORT)
+      return fail("vmas_world_step_env_gated: post_kind %d cannot be gated (more than one launch per step, or a grid barrier)", post_kind);
+    if (args && args->exact_broad_phase)
+      return fail("vmas_world_step_env_gated: the exact broad phase carries a grid barrier and cannot be gated");
+  }
   if (args && (args->first_substep != 0 || args->n_substeps > 0))
     return fail("vmas_world_step_env: partial substep ranges cannot carry an epilogue");
   if (post_kind != VMAS_POST_NONE && (!post_desc || !post_buffers))
@@ -2503,6 +2522,7 @@ static int step_env_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld
   static const int env_ablate = knob("VMAS_ENV_ABLATE") ? atoi(knob("VMAS_ENV_ABLATE")) : 0;
   env.ablate = env_ablate;
   env.err_flags = err_flags;
+  env.gated = gated ? 1 : 0;
   for (int a = 0; a < VMAS_ENV_MAX_AGENTS; ++a) env.script_of_agent[a] = -1;
   if (ingest) {
     if (vmas::check_ingest_args(ingest, w->batch, agent_ft, ld)) return -1;

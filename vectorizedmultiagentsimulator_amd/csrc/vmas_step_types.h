@@ -84,6 +84,8 @@ struct DevEnv {
   int32_t has_ingest;
   int32_t ablate;       // profiling only (env VMAS_ENV_ABLATE)
   int32_t scratch_off;  // floats from the LDS base to the epilogue's scratch (after the step's own LDS)
+  int32_t gated;        // vmas_world_step_env_gated: the launch does NOTHING if *err_flags != 0 when it starts (the word of a
+                        // validation launched in front of it on the same stream: a refused action never reaches the world)
   // `ingest.agents` is re-ordered by the host: slot a belongs to AGENT a (action == action_index == NULL: no action
   // for it), so the prologue reads its slot with one kernarg fetch, no indirection.  Scripts: agent -> script or -1.
   int8_t script_of_agent[VMAS_ENV_MAX_AGENTS];
@@ -98,6 +100,12 @@ struct DevEnv {
   };
 };
 struct NoEnv {};
+// block-uniform: every thread of the launch reads the same word (a scalar load; the validation's launch in front of this one
+// on the same stream wrote it - kernel boundaries make it visible)
+__device__ __forceinline__ bool env_gate_closed(const DevEnv& E) {
+  return E.gated != 0 && __builtin_amdgcn_readfirstlane((int)*(const volatile uint32_t*)E.err_flags) != 0;
+}
+__device__ __forceinline__ bool env_gate_closed(const NoEnv&) { return false; }
 
 // What a code object compiled at run time (specialize.py) must agree with the library on besides the schedule: the layout of
 // the kernel arguments.  Both sides compute this from THEIR headers - the library when it was built, the specialisation when

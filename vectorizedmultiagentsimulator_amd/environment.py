@@ -414,10 +414,21 @@ class Environment:
         self._bound = None
         if self._one_launch:
             self._ingest.prepare(actions)
-            if self.validate_actions:
-                self._ingest.validate()  # raises before the world is touched, like the reference
-            desc, buffers, result = self._post.prepare()
-            self._launch(self._post.kind, desc, buffers, False)
+            if self.validate_actions and self._launch.can_gate(self._post.kind):
+                # the check enqueued, the step launched GATED on its result, the host's wait behind both (fused.StepLauncher.gated)
+                seq = self._ingest.validate_begin()
+                saved = self._post.save_bound()
+                desc, buffers, result = self._post.prepare()
+                self._launch.gated(self._post.kind, desc, buffers)
+                flags = self._ingest.validate_end(seq)
+                if flags:
+                    self._post.restore_bound(saved)
+                    self._ingest._raise(flags)
+            else:
+                if self.validate_actions:
+                    self._ingest.validate()  # raises before the world is touched, like the reference
+                desc, buffers, result = self._post.prepare()
+                self._launch(self._post.kind, desc, buffers, False)
             self._lidar_cache = None
             fin = getattr(self._post, "finish", None)  # (tensor ops on the step's outputs: football's red rewards, ball_pos)
             return result if fin is None else fin(result)

@@ -120,6 +120,7 @@ class ActionIngest:
         _check(self.lib.vmas_host_word_create(dev.index if dev.index is not None else torch.cuda.current_device(), C.byref(h), C.byref(d)))
         self._err_host_ptr, self.err_ptr = h.value, d.value
         self._err_word = C.c_uint32.from_address(h.value)
+        self.gate_ptr = self.lib.vmas_host_word_gate(h.value)  # device memory: what a gated step launch reads (StepLauncher.gated)
         self._ft = w._packed_agent_ft()
         self._keep = None
         self._fast = None
@@ -257,6 +258,24 @@ class ActionIngest:
         _check(self.lib.vmas_env_ingest_actions(C.byref(self.args), env.num_envs, env.world._packed_state().data_ptr(),
                                                 ft.data_ptr(), ft.shape[-1], None, _stream(env.device)))
 
+    def validate_begin(self) -> int:
+        """First half of ``validate()`` - enqueue the check, do not wait: the caller launches the step GATED on its result
+        (``StepLauncher.gated``) and then calls ``validate_end``; the wait overlaps the step's own execution."""
+        env = self.env
+        ft = env.world._packed_agent_ft()
+        seq = self.lib.vmas_env_validate_begin(C.byref(self.args), env.num_envs, env.world._packed_state().data_ptr(), ft.data_ptr(),
+                                               ft.shape[-1], self._err_host_ptr, self.err_ptr, _stream(env.device))
+        if seq < 0:
+            raise VmasHipError(A.last_error())
+        return seq
+
+    def validate_end(self, seq: int) -> int:
+        """The flags of the validation ``seq`` (0: the gated step behind it ran; nonzero: it did nothing - the caller raises)."""
+        flags = self.lib.vmas_env_validate_end(self._err_host_ptr, seq, _stream(self.env.device))
+        if flags < 0:
+            raise VmasHipError(A.last_error())
+        return flags
+
     def validate(self):
         """``validate_actions`` on a path whose ingest is the physics kernel's prologue: the reference asserts BEFORE it
         touches the world (environment.py:621,651-653), so the actions are checked by the small stand-alone kernel (it
@@ -369,6 +388,8 @@ class StepLauncher:
         self._exact = bool(w.exact_broad_phase)
         self._ing = C.byref(self.ingest.args)
         self._err = C.c_void_p(self.ingest.err_ptr)
+        self._gate = C.c_void_p(self.ingest.gate_ptr)
+        self._gated_fn = A.load_library().vmas_world_step_env_gated
         self._dev = self.env.device
 
     def __call__(self, kind: int, desc, buffers, validate: bool):
@@ -403,6 +424,31 @@ class StepLauncher:
         if rc != 0:
             raise VmasHipError(A.last_error())
 
+
+    def can_gate(self, kind) -> bool:
+        """A gated launch must be the whole step and carry no grid barrier (include/vmas_env_hip.h)."""
+        if self._be is None or self.env.world._backend is not self._be:
+            self._bind()
+        return kind in (0, A.POST_BALANCE, A.POST_TRANSPORT) and not self._exact
+
+    def gated(self, kind: int, desc, buffers):
+        """``vmas_world_step_env_gated``: the step launch that does nothing if the validation in front of it raised flags."""
+        w = self.env.world
+        if self._be is None or w._backend is not self._be:
+            self._bind()
+        w._query_cache = None
+        args = None
+        if self._per_env:
+            jfr, eg = w._per_env_inputs()
+            sa = A.StepArgs()
+            sa.joint_fixed_rot = jfr.data_ptr() if jfr is not None else None
+            sa.entity_gravity = eg.data_ptr() if eg is not None else None
+            args = C.byref(sa)
+        rc = self._gated_fn(self._h, self._st, self._ft, self._ld, args, self._ing, self._gate, kind,
+                            C.byref(desc) if desc is not None else None, C.byref(buffers) if buffers is not None else None,
+                            _stream(self._dev))
+        if rc != 0:
+            raise VmasHipError(A.last_error())
 
     def rollout(self, kind: int, desc, buffers, n_steps: int):
         """``vmas_world_rollout_env``: n_steps Environment.step() calls in one launch."""
@@ -494,6 +540,20 @@ class _Post:
     def persistent_tensors(self) -> List[Tensor]:
         """Scenario tensors the kernel reads AND writes (shaping terms ...)."""
         raise NotImplementedError
+
+    #: (object getter, attribute) pairs ``prepare()`` re-points at the step's output set: saved / restored around a gated
+    #: step that a validation refuses (the reference raises before its scenario sees anything of the step)
+    def bound_attributes(self):
+        return []
+
+    def save_bound(self):
+        return [(o, n, o.__dict__.get(n, None) if hasattr(o, "__dict__") else getattr(o, n, None)) for o, n in self.bound_attributes()]
+
+    @staticmethod
+    def restore_bound(saved):
+        for o, n, v in saved:
+            if v is not None:
+                setattr(o, n, v)
 
     def _limit(self) -> A.StepLimit:
         lim = A.StepLimit()
@@ -595,6 +655,11 @@ class BalancePost(_Post):
     def persistent_tensors(self):
         return [self.env.scenario.global_shaping]
 
+    def bound_attributes(self):
+        sc = self.env.scenario
+        sc = getattr(sc, "_sc", sc)  # (attached_env._ScenarioView: the reference's scenario behind it)
+        return [(sc, "pos_rew"), (sc, "ground_rew"), (sc, "on_the_ground")]
+
     def _new_set(self):
         n, B = self.n, self.B
         st = _OutSet()
@@ -681,6 +746,10 @@ class TransportPost(_Post):
 
     def persistent_tensors(self):
         return [self.global_shaping, self.on_goal]
+
+    def bound_attributes(self):
+        sc = self.env.scenario
+        return [(getattr(sc, "_sc", sc), "rew")]
 
     def _rebind(self):
         for i, p in enumerate(self.env.scenario.packages):  # reset() may have rebound them
