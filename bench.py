@@ -1170,7 +1170,7 @@ def main():
                 line = others[other]
                 okw = o["kwargs"]
                 try:
-                    line["attached_reference"] = attached_reference_leg(other, okw, o["envs_per_gpu"], device, n=100, brief=True)
+                    line["attached_reference"] = attached_reference_leg(other, okw, o["envs_per_gpu"], device, n=300, brief=True)
                 except Exception as e:  # noqa: BLE001
                     line["attached_reference"] = {"error": repr(e)[:300]}
                 if args.no_cpu_baseline:
