@@ -535,3 +535,42 @@ def test_attached_fused_gated_validation_at_benchmark_size(vmas, scenario, kw):
     ob, rb, db, _ = b.step(good)
     assert all(torch.equal(x, y) for x, y in zip(oa, ob)) and torch.equal(ha.state, hb.state) and torch.equal(a.steps, b.steps)
     ha.detach(); hb.detach()
+
+
+def test_attached_fused_follows_scenario_parameters_written_after_attach(vmas):
+    """The reference reads its scenario's parameters at every step; the kernels' descriptors are built once.  A write after
+    attach() - ``scenario.shaping_factor = 50`` - reaches the kernel at the next step; one that leaves the kernels' coverage -
+    football's ``dense_reward = False`` - hands ``env.step`` back to the reference (still on the native World.step)."""
+    from vectorizedmultiagentsimulator_amd.adapter import attach
+
+    B = 64
+    ref = vmas.make_env("balance", num_envs=B, device="cpu", seed=0, n_agents=3)
+    att = vmas.make_env("balance", num_envs=B, device=DEV, seed=0, n_agents=3)
+    h = attach(att, fused=True)
+    g = torch.Generator().manual_seed(8)
+    for t in range(6):
+        if t == 3:
+            for e in (ref, att):
+                e.scenario.shaping_factor = 50
+                e.scenario.fall_reward = -3
+        _force_state(ref, att, "balance")
+        if t == 3:  # (the cached shaping term is in units of the old factor on both sides: keep them equal, not meaningful)
+            pass
+        acts = _actions(ref, g)
+        _compare_step(ref.step([a.clone() for a in acts]), att.step([a.to(DEV) for a in acts]), "balance", f"balance params t={t}")
+    assert h.fused is not None and h.fused.post.desc.shaping_factor == 50 and h.fused.post.desc.fall_reward == -3
+    h.detach()
+    kw = dict(n_blue_agents=2, n_red_agents=2, ai_red_agents=False)
+    ref = vmas.make_env("football", num_envs=B, device="cpu", seed=0, **kw)
+    att = vmas.make_env("football", num_envs=B, device=DEV, seed=0, **kw)
+    h = attach(att)
+    assert h.fused is not None
+    for t in range(4):
+        if t == 2:
+            for e in (ref, att):
+                e.scenario.dense_reward = False
+        _force_state(ref, att, "football")
+        acts = _actions(ref, g)
+        _compare_step(ref.step([a.clone() for a in acts]), att.step([a.to(DEV) for a in acts]), "football", f"football params t={t}")
+    assert h.fused is None and "dense_reward" in h.fused_reason and "step" not in att.__dict__
+    h.detach()

@@ -126,6 +126,38 @@ def _defined_in(cls, names, module: str) -> Optional[str]:
 
 _SCENARIO_METHODS = ("reward", "observation", "done", "info", "process_action", "pre_step", "post_step")
 
+# Scenario / action parameters the kernels' descriptors are built from (fused.*Post, fused.ActionIngest): the reference reads
+# them at every step, so a write to one - ``scenario.shaping_factor = 50`` mid-run - must reach the kernel.  A ``__setattr__`` hook
+# on the scenario's class (and the agents' Action class) marks the attached step dirty; the next ``env.step`` re-checks the
+# configuration and rebuilds the descriptors, or hands ``env.step`` back to the reference if no kernel covers it any more.
+_DIRTY = "_vmas_amd_fused_dirty"
+_PARAMS = frozenset((
+    "shaping_factor", "fall_reward",                                                                   # balance, transport
+    "shared_rew", "collisions", "observe_all_goals", "pos_shaping_factor", "final_reward", "agent_collision_penalty",
+    "min_collision_distance",                                                                          # navigation
+    "observe_teammates", "observe_adversaries", "dense_reward", "pitch_length", "pitch_width", "ball_size", "goal_size",
+    "agent_size", "pos_shaping_factor_ball_goal", "pos_shaping_factor_agent_ball", "distance_to_ball_trigger", "scoring_reward",
+    "ai_red_agents", "ai_blue_agents", "enable_shooting", "physically_different", "dict_obs",          # football
+    "_u_range", "_u_multiplier", "_u_noise",                                                           # Action
+))
+
+
+def _hook_params(cls) -> None:
+    cur = cls.__setattr__
+    if getattr(cur, "_vmas_amd_params", False):
+        return
+
+    def hook(self, name, value, _orig=cur):
+        _orig(self, name, value)
+        if name in _PARAMS:
+            owner = self.__dict__.get(_DIRTY)
+            if owner is not None:
+                owner[0] = True
+
+    hook._vmas_amd_params = True
+    hook._vmas_amd = getattr(cur, "_vmas_amd", False)  # (adapter._patch_setattr's own mark, if its hook is underneath)
+    cls.__setattr__ = hook
+
 
 class _Profile:
     """One benchmark scenario of the reference: how to recognise it, which of its configurations the kernel covers, and
@@ -318,6 +350,11 @@ class FusedEnvStep:
         self.reset_seed = 0  # reset_where's counter-based generator: keyed by (this, environment, that environment's episode)
         self._masked_reset = None
         self._orig_step = env.__dict__.get("step")
+        self._dirty = [False]  # (a one-element list: the hooked objects hold a reference to it)
+        self._hooked = [env.scenario] + [a.action for a in env.world.agents]
+        for o in self._hooked:
+            _hook_params(type(o))
+            o.__dict__[_DIRTY] = self._dirty
         self.build()
         self._adopt_steps()
         env.step = self.step
@@ -344,6 +381,23 @@ class FusedEnvStep:
         self._finish = getattr(self.post, "finish", None)
         self._backend = h.backend
 
+    def _params_changed(self) -> bool:
+        """Re-plan after a parameter write: True = the fused step goes on with rebuilt descriptors, False = it was taken out
+        (``handle.fused`` is None, ``handle.fused_reason`` says why, ``env.step`` is the reference's again)."""
+        self._dirty[0] = False
+        env = self.env
+        reason = self.profile.check(env)
+        if reason is None:
+            al = self.profile.aliases(env)
+            scripts = al["fused_agent_scripts"]() if "fused_agent_scripts" in al else []
+            reason = _ingest_reason(env, {id(s_["agent"]) for s_ in scripts})
+        if reason is None:
+            self.build()
+            return True
+        self.handle.fused, self.handle.fused_reason = None, f"a parameter changed after attach(): {reason}"
+        self.detach()
+        return False
+
     def _adopt_steps(self):
         """``Environment._reset`` rebinds ``env.steps`` (environment.py:222): the kernel's counter is ONE tensor - take the
         new values over and put that tensor back."""
@@ -366,7 +420,10 @@ class FusedEnvStep:
         assert len(actions) == len(self.names), f"Expecting actions for {len(self.names)}, got {len(actions)} actions"
         h = self.handle
         h._sync_static()  # (masses, filters ... written since the last step: the native world follows - adapter.py)
-        if h.backend is not self._backend:
+        if self._dirty[0]:  # a scenario / action parameter the descriptors were built from was written
+            if not self._params_changed():
+                return env.step(actions)  # (no kernel covers the configuration any more: the reference's own step, restored)
+        elif h.backend is not self._backend:
             self.build()
         if env.steps is not self.steps:
             self._adopt_steps()
@@ -479,6 +536,8 @@ class FusedEnvStep:
         else:
             env.__dict__.pop("step", None)
         env.steps = self.steps.clone()
+        for o in self._hooked:  # (the class hooks stay: they do nothing for objects without an owner)
+            o.__dict__.pop(_DIRTY, None)
 
 
 def plan_fuse(env):
