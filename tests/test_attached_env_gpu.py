@@ -574,3 +574,19 @@ def test_attached_fused_follows_scenario_parameters_written_after_attach(vmas):
         _compare_step(ref.step([a.clone() for a in acts]), att.step([a.to(DEV) for a in acts]), "football", f"football params t={t}")
     assert h.fused is None and "dense_reward" in h.fused_reason and "step" not in att.__dict__
     h.detach()
+
+
+def test_attached_fused_follows_max_steps_written_after_attach(vmas):
+    from vectorizedmultiagentsimulator_amd.adapter import attach
+
+    att = vmas.make_env("transport", num_envs=64, device=DEV, seed=0)
+    h = attach(att, fused=True)
+    acts = [att.get_random_action(a) for a in att.agents]
+    for _ in range(3):
+        _, _, d, _ = att.step(acts)
+    assert not bool(d.all())
+    att.max_steps = 5
+    _, _, d4, _ = att.step(acts)
+    _, _, d5, _ = att.step(acts)
+    assert not bool(d4.all()) and bool(d5.all())
+    h.detach()

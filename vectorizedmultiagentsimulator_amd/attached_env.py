@@ -379,6 +379,7 @@ class FusedEnvStep:
         self.launch = F.StepLauncher(view, self.ingest) if self.ingest_in_step else None
         self._masked_reset = None
         self._finish = getattr(self.post, "finish", None)
+        self._max_steps = env.max_steps
         self._backend = h.backend
 
     def _params_changed(self) -> bool:
@@ -423,7 +424,7 @@ class FusedEnvStep:
         if self._dirty[0]:  # a scenario / action parameter the descriptors were built from was written
             if not self._params_changed():
                 return env.step(actions)  # (no kernel covers the configuration any more: the reference's own step, restored)
-        elif h.backend is not self._backend:
+        elif h.backend is not self._backend or env.max_steps != self._max_steps:  # (the time limit is part of the output sets)
             self.build()
         if env.steps is not self.steps:
             self._adopt_steps()
