@@ -148,3 +148,12 @@ def test_env_entry_points_report_errors_not_throw(lib):
     assert lib.vmas_world_step_env(None, None, None, 64, None, None, None, 1, None, None, None) == -1
     assert lib.vmas_world_reserve_epilogue(None, 1, 0) == -1
     assert b"null world" in lib.vmas_last_error()
+    # round 5: the validation entries and the gated step
+    assert lib.vmas_world_step_env_gated(None, None, None, 64, None, None, None, 1, None, None, None) == -1
+    good = _abi.IngestArgs()
+    assert lib.vmas_env_validate_actions(C.byref(good), 8, None, C.c_void_p(64), 64, None, None, None) == -1
+    assert b"flag word" in lib.vmas_last_error()
+    assert lib.vmas_env_validate_begin(C.byref(good), 8, None, C.c_void_p(64), 64, None, None, None) == -1
+    assert lib.vmas_env_validate_end(None, 1, None) == -1
+    assert lib.vmas_host_word_gate(None) is None
+    lib.vmas_host_word_destroy(None)  # (a no-op, like free(NULL))
