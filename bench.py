@@ -1173,6 +1173,22 @@ def main():
                     line["attached_reference"] = attached_reference_leg(other, okw, o["envs_per_gpu"], device, n=300, brief=True)
                 except Exception as e:  # noqa: BLE001
                     line["attached_reference"] = {"error": repr(e)[:300]}
+                if not args.no_traffic:  # HBM bytes per launch by the PMC counters, like the headline's
+                    try:
+                        import copy
+                        a2 = copy.copy(args)
+                        a2.config = other
+                        traffic, detail = measure_traffic(a2, o["n_queues"])
+                        rf = line["roofline"]
+                        rf["traffic"] = traffic
+                        if traffic is not None:
+                            rf["bytes_per_launch"] = o["bytes_per_env"] * o["envs_per_gpu"] // o["n_queues"]
+                            rf["traffic_over_algorithmic"] = traffic / rf["bytes_per_launch"]
+                            rf["traffic_kernel"] = detail["kernel"]
+                        else:
+                            rf["traffic_note"] = str(detail)[:200]
+                    except Exception as e:  # noqa: BLE001
+                        line["roofline"]["traffic_note"] = repr(e)[:200]
                 if args.no_cpu_baseline:
                     continue
                 try:

@@ -15,6 +15,7 @@ def r(x, n=2):
 
 es = d.get("environment_step", {})
 print("line:", {"value": r(d["value"], 0), "ms_per_step": r(d["ms_per_step"], 5), "frac": r(d["roofline"]["frac"], 4),
+                "traffic_x": r(d["roofline"].get("traffic_over_algorithmic"), 3),
                 "env_step_us": r(es.get("us_per_step")), "env_gpu_us": r(es.get("gpu_us_per_step")),
                 "bound_us": r(es.get("bound", {}).get("gpu_us_per_step")), "rollout_us": r(es.get("rollout", {}).get("us_per_step"))})
 if brief:
@@ -31,7 +32,7 @@ for name, o in (d.get("other_configs") or {}).items():
         continue
     e = o.get("environment_step", {})
     at = o.get("attached_reference", {})
-    print(name, {"us": r(o["us_per_step"]), "frac": r(o["roofline"]["frac"], 3), "env_us": r(e.get("us_per_step")), "env_gpu_us": r(e.get("gpu_us_per_step")),
+    print(name, {"us": r(o["us_per_step"]), "frac": r(o["roofline"]["frac"], 3), "traffic_x": r(o["roofline"].get("traffic_over_algorithmic"), 3), "env_us": r(e.get("us_per_step")), "env_gpu_us": r(e.get("gpu_us_per_step")),
                  "env_frac": r(e.get("roofline_frac"), 3), "bound_us": r(e.get("bound_us_per_step")), "rollout_us": r(e.get("rollout_us_per_step")),
                  "gpu_over_cpu": r(o.get("gpu_over_cpu"), 0), "env_over_cpu": r(e.get("gpu_over_cpu"), 0)})
     print("   attached:", {k: r(v) for k, v in at.items() if k not in ("value_is", "unit")})
