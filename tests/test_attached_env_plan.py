@@ -143,3 +143,171 @@ def test_reset_programs_evaluate_on_the_reference_objects(vmas, scenario, kw, n_
     env = vmas.make_env("navigation", num_envs=3, device="cpu", seed=0, n_agents=4, collisions=False, agents_with_same_goal=4)
     profile, _ = AE.find_profile(env)
     assert profile.reset_program(AE._ScenarioView(env.scenario, profile.aliases(env))) is None
+
+
+class _StubKernels:
+    """Stands in for fused.ActionIngest / *Post / StepLauncher on the CPU: the 'kernel' is the reference's own tensor-op ingest,
+    the oracle-backed World.step and the scenario's own reward / observation / done / info.  What is under test is the
+    attached step's host logic (attached_env.FusedEnvStep.step), not arithmetic."""
+
+    kind = 1
+    rollout_ok = True
+
+    def __init__(self, env, handle):
+        self.env, self.handle, self.acts = env, handle, None
+        self.validated = 0
+
+    # ingest
+    def prepare(self, actions):
+        self.acts = actions
+
+    def validate(self):
+        self.validated += 1
+        for a in self.acts:
+            assert not torch.as_tensor(a).isnan().any(), "actions contain NaN"
+
+    def pending(self):
+        pass
+
+    # post
+    def prepare_post(self):
+        return None, None, None
+
+    # launch
+    def __call__(self, kind, desc, buffers, validate):
+        env = self.env
+        for a, agent in zip(self.acts, env.agents):
+            env._set_action(a.clone(), agent)
+        for agent in env.world.agents:
+            env.scenario.env_process_action(agent)
+        self.handle.step()
+        env.steps += 1
+
+    def can_gate(self, kind):
+        return False
+
+
+def _stubbed_fused(vmas, scenario="balance", **env_kw):
+    from ref_backend import OracleBackend
+    from vectorizedmultiagentsimulator_amd import attached_env as AE
+    from vectorizedmultiagentsimulator_amd.adapter import AttachedWorld
+
+    env = vmas.make_env(scenario, num_envs=4, device="cpu", seed=0, n_agents=3, **env_kw)
+    h = AttachedWorld(env.world, OracleBackend, True, False)
+    profile, _ = AE.find_profile(env)
+
+    def build(self):
+        k = _StubKernels(self.env, self.handle)
+        self.view = AE._EnvView(self.env, AE._WorldView(self.handle), AE._ScenarioView(self.env.scenario, self.profile.aliases(self.env)),
+                                self.steps, self.split)
+        self.ingest = self.launch = k
+        self.ingest_in_step = self.one_launch = True
+        self._finish = None
+        self._masked_reset = None
+        self._max_steps = self.env.max_steps
+        self._backend = self.handle.backend
+
+        class Post:
+            kind = 1
+            desc = None
+
+            def prepare(_self):  # (placeholders: this stub's outputs are computed behind the "launch", in step() below)
+                n = len(self.env.agents)
+                return None, None, ([None] * n, [None] * n, torch.zeros(self.env.num_envs, dtype=torch.bool), [None] * n)
+
+        self.post = Post()
+
+    orig_build, orig_step = AE.FusedEnvStep.build, AE.FusedEnvStep.step
+
+    def step(self, actions):
+        out = orig_step(self, actions)
+        e = self.env
+        if self.handle.fused is not self:  # (handed back to the reference: its own return value)
+            return out
+        obs = [e.scenario.observation(a).clone() for a in e.agents]
+        rews = [e.scenario.reward(a).clone() for a in e.agents]
+        infos = [e.scenario.info(a) for a in e.agents]
+        dones = e.scenario.done().clone()
+        if e.max_steps is not None and not self.split:
+            dones = dones | (self.steps >= e.max_steps)
+        if self.dict_spaces:
+            n = self.names
+            obs, rews, infos = dict(zip(n, obs)), dict(zip(n, rews)), dict(zip(n, infos))
+        if self.split:
+            trunc = (self.steps >= e.max_steps) if e.max_steps is not None else torch.zeros_like(dones)
+            return [obs, rews, dones, trunc, infos]
+        return [obs, rews, dones, infos]
+
+    def restore():
+        AE.FusedEnvStep.build, AE.FusedEnvStep.step = orig_build, orig_step
+
+    AE.FusedEnvStep.build, AE.FusedEnvStep.step = build, step
+    try:
+        f = AE.FusedEnvStep(env, h, profile, validate_actions=True)
+    except Exception:
+        restore()
+        raise
+    h.fused = f
+    return env, h, f, restore
+
+
+def test_attached_step_host_logic_without_a_gpu(vmas):
+    """attached_env.FusedEnvStep.step with the kernels stubbed out (the reference's own tensor ops + the oracle World.step behind
+    the same three objects): argument handling, the step counter that survives the reference's reset, parameter writes that
+    hand env.step back, detach."""
+    env, h, f, restore = _stubbed_fused(vmas)
+    try:
+        twin = vmas.make_env("balance", num_envs=4, device="cpu", seed=0, n_agents=3)
+        for ea, eb in zip(env.world.entities, twin.world.entities):
+            eb.set_pos(ea.state.pos.clone(), batch_index=None)
+        twin.scenario.global_shaping = env.scenario.global_shaping.clone()
+        acts = [env.get_random_action(a) for a in env.agents]
+        assert env.__dict__["step"].__self__ is f
+        o1, r1, d1, i1 = env.step({a.name: u.clone() for a, u in zip(env.agents, acts)})  # dict actions
+        o2, r2, d2, i2 = twin.step([u.clone() for u in acts])
+        assert all(torch.allclose(a, b, atol=1e-6) for a, b in zip(o1, o2)) and all(torch.allclose(a, b, atol=1e-4) for a, b in zip(r1, r2))
+        assert env.steps is f.steps and float(env.steps[0]) == 1.0
+        with pytest.raises(AssertionError, match="not contained in action dict"):
+            env.step({"nobody": acts[0]})
+        with pytest.raises(AssertionError, match="Expecting actions"):
+            env.step(acts[:2])
+        bad = [u.clone() for u in acts]
+        bad[1][0, 0] = float("nan")
+        with pytest.raises(AssertionError, match="NaN"):
+            env.step(bad)
+        assert float(env.steps[0]) == 1.0  # (refused before the world was touched)
+        env.reset()  # the reference rebinds env.steps: adopted back at the next step
+        assert env.steps is not f.steps
+        env.step(acts)
+        assert env.steps is f.steps and float(env.steps[0]) == 1.0
+        env.reset_at(2)
+        assert float(env.steps[2]) == 0.0 and float(env.steps[0]) == 1.0
+        # a parameter the descriptors were built from: re-planned (still covered) ...
+        env.scenario.shaping_factor = 10
+        assert f._dirty[0]
+        env.step(acts)
+        assert not f._dirty[0] and h.fused is f
+        # ... detach restores the reference's own step and the hooks let go
+        h.detach()
+        assert "step" not in env.__dict__ and h.fused is None
+        env.scenario.shaping_factor = 20
+        env.step(acts)
+    finally:
+        restore()
+
+
+def test_attached_step_hands_env_step_back_when_a_parameter_leaves_the_kernels_coverage(vmas):
+    from vectorizedmultiagentsimulator_amd import attached_env as AE
+
+    env, h, f, restore = _stubbed_fused(vmas)
+    try:
+        acts = [env.get_random_action(a) for a in env.agents]
+        env.step(acts)
+        env.agents[0].action._u_noise = 0.05  # action noise: the ingest kernel does not draw it
+        assert f._dirty[0]
+        out = env.step(acts)  # this very call is already the reference's own Environment.step
+        assert len(out) == 4 and h.fused is None and "action noise" in h.fused_reason and "step" not in env.__dict__
+        assert AE._DIRTY not in env.scenario.__dict__
+        h.detach()
+    finally:
+        restore()
