@@ -50,6 +50,10 @@ int vmas_debug_football_form(VmasWorld* w, int32_t form);
  * out[0] = contacts counted by plain compacted launches, out[1] = (tile, substep)s those launches had, out[2] = times the
  * world was sent to the interpreter, out[3] = plain launches it still stays there.  Synchronises the device. */
 int vmas_debug_compact_stats(VmasWorld* w, int64_t out[4]);
+/* The lazy exact broad phase's counters since the world was made (synchronises the device): out[0] launches made with it,
+ * out[1] tiles that had to ask for the batch's words, out[2] ... and found a pair off for the whole batch (their pass was
+ * made again / the pair's contacts left out), out[3] polls that had to be repeated (a needed tile had not arrived yet). */
+int vmas_debug_lazy_stats(VmasWorld* w, int64_t out[4]);
 
 /* VMAS_TRACE=1 in a -DVMAS_TRACE build: copy out the per-wave s_memtime stamps of the last launch */
 int vmas_debug_trace(VmasWorld* w, unsigned long long* host, int64_t n_words);

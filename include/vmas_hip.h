@@ -144,11 +144,14 @@ typedef struct VmasStepArgs {
   int32_t first_substep; /* index of the first substep to run (drag is applied on 0) */
   int32_t n_substeps;    /* how many to run; <=0 => desc.substeps - first_substep */
   /* != 0: the reference's broad phase exactly - at every substep a pair is evaluated (for all environments) iff the
-   * bounding circles of SOME environment of the batch overlap (World.collides, core.py:2797-2801).  Batches of at most
-   * 64 x CUs environments (16384 on MI355X) run it INSIDE the step launch: every tile ORs its hits into a mask with
-   * device-scope atomics and the tiles meet at a grid-wide barrier before the narrow phase (all tiles are resident, one
-   * per CU).  Larger batches run a mask launch + a one-substep launch per substep (no fused epilogue then).  Mutually
-   * exclusive with pair_mask.  0 = every static pair is evaluated per environment (see pair_mask above). */
+   * bounding circles of SOME environment of the batch overlap (World.collides, core.py:2797-2801).  The library picks the
+   * form (vmas_world_exact_form): none needed where every pair is sphere-sphere (their force is exactly 0 wherever the
+   * circles do not overlap); the LAZY form INSIDE the step launch at any batch size (round 6: tiles step with every pair
+   * on, publish the pairs they overlap with fire-and-forget device-scope atomics, and only a tile that has an environment
+   * in a pair's band - circles apart, force non-zero - without an overlapping environment of its own reads the batch's
+   * words, waiting for the other tiles only if the bit is still clear); under HIP-graph capture a mask launch + a
+   * one-substep launch per substep (no fused epilogue then).  Mutually exclusive with pair_mask.
+   * 0 = every static pair is evaluated per environment (see pair_mask above). */
   int32_t exact_broad_phase;
   int32_t reserved;
 } VmasStepArgs;
@@ -222,6 +225,11 @@ int vmas_world_get_compact(VmasWorld* w);
  * vmas_world_exact_status synchronises the device and reports the same condition without clearing it: 0 if every barrier
  * so far completed, 1 if one gave up, < 0 on error (tests / debugging). */
 int vmas_world_exact_status(VmasWorld* w);
+/* The form VmasStepArgs.exact_broad_phase takes for a whole-batch launch of this world outside graph capture: 0 none needed
+ * (sphere-sphere pairs only), 1 lazy, inside the launch (any batch size; gated launches and fused epilogues allowed),
+ * 2 grid barrier inside the launch (at most one tile per CU; only when pinned by VMAS_EXACT_FORM=barrier), 3 a mask launch +
+ * a launch per substep.  < 0 on error. */
+int vmas_world_exact_form(VmasWorld* w);
 
 /* Batch-global broad phase of World.collides (core.py:2797-2801): mask[p/32] bit
  * p%32 = any_env(|pos_a - pos_b| <= R_a + R_b).  `mask` is zeroed on the stream

@@ -10,7 +10,8 @@ steps = int(sys.argv[3]) if len(sys.argv) > 3 else 300
 lanes = int(os.environ.get("LANES", "0"))
 kw = {"balance": dict(n_agents=4), "transport": {}, "navigation": dict(n_agents=8),
       "football": dict(n_blue_agents=5, n_red_agents=5, ai_red_agents=False)}[name]
-env = make_env(name, num_envs=B, device="cuda:0", seed=0, validate_actions=False, **kw)
+exact = os.environ.get("EXACT", "1") != "0"  # the reference's batch-global broad phase (the default of every host path since round 6)
+env = make_env(name, num_envs=B, device="cuda:0", seed=0, validate_actions=False, exact_broad_phase=exact, **kw)
 for _ in range(30):  # a few real steps so that the state is a typical mid-episode one
     env.step([env.get_random_action(a) for a in env.agents])
 forces = None
@@ -37,7 +38,7 @@ if os.environ.get("QUEUES"):
     be.set_queues(int(os.environ["QUEUES"]))
 t_warm = time.perf_counter()  # (a quarter of a second of launches first: the clocks of a just-started process are ramping)
 while time.perf_counter() - t_warm < 0.25:
-    be.step_n(min(50, steps), None if forces is None else forces[: min(50, steps)])
+    be.step_n(min(50, steps), None if forces is None else forces[: min(50, steps)], exact=exact)
     torch.cuda.synchronize()
     if os.environ.get("FORCES", "fixed") != "random":
         break  # (a held action changes the state it is timed on: keep the protocol of the earlier rounds, one warm-up call)
@@ -45,11 +46,14 @@ if forces is not None:
     env.set_state(snap)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-be.step_n(steps, forces)
+be.step_n(steps, forces, exact=exact)
+t_enq = time.perf_counter() - t0
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
+if os.environ.get("LAZY_STATS"):
+    print("lazy stats", be.lazy_stats(), file=sys.stderr)
 if os.environ.get("COMPACT_STATS"):
     print("compact stats", be.compact_stats(), file=sys.stderr)
 print(json.dumps({"scenario": name, "num_envs": B, "lanes": be.lanes_per_env, "queues": be.queues(steps), "specialized": be.specialized, "compact": be.compact,
-                  "lib": os.environ.get("VMAS_HIP_LIB", "libvmas_hip.so"), "ablate": os.environ.get("VMAS_ABLATE", "0"), "forces": os.environ.get("FORCES", "fixed"),
-                  "world_step_us": round(dt * 1e6, 2), "env_steps_per_s": round(B / dt)}))
+                  "lib": os.environ.get("VMAS_HIP_LIB", "libvmas_hip.so"), "ablate": os.environ.get("VMAS_ABLATE", "0"), "forces": os.environ.get("FORCES", "fixed"), "exact": exact, "exact_form": be.exact_form() if hasattr(be.lib, "vmas_world_exact_form") else None,
+                  "world_step_us": round(dt * 1e6, 2), "host_enqueue_us": round(t_enq / steps * 1e6, 2), "env_steps_per_s": round(B / dt)}))

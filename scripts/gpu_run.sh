@@ -12,6 +12,7 @@
 #   counters-shards  counters of the latency-regime shards (navigation 8192 env step, football 16384 compact, balance env step)
 #   evidence         rocprofv3 of the bench command itself (one queue): kernel stats + PMC summary
 #   traces           per-phase traces (football compact, navigation env step, balance env step)
+#   lazy / lazy-cost round 6: the lazy exact broad phase's tests / its cost against the per-environment form and round 5's library
 TAG=${TAG:-r05}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
@@ -89,6 +90,32 @@ while [ $# -gt 0 ]; do
   traces)
     python $S/trace_compact.py football 16384 2>&1 | grep -v amdgpu > $OUT/${TAG}_football16384_compact_phase_trace.txt; tail -20 $OUT/${TAG}_football16384_compact_phase_trace.txt
     VMAS_TRACE=2 python $S/trace_nav.py 8192 2>&1 | grep -v amdgpu > $OUT/${TAG}_navigation8192_env_step_phase_trace.txt; tail -20 $OUT/${TAG}_navigation8192_env_step_phase_trace.txt
+    ;;
+  lazy)   # round 6: the lazy exact broad phase - its own tests, the exact-form tests it now serves, and what it costs
+    rm -f gpurun_out/broad_phase_lazy.jsonl
+    timeout 2400 python -m pytest tests/test_broad_phase_lazy_gpu.py tests/test_hip_parity.py tests/test_compact_gpu.py tests/test_specialize_gpu.py \
+      -m gpu -q --timeout=900 -p no:cacheprovider ${PYTEST_X:-} --tb=short -k "${PYTEST_K:-exact or band or lazy or bitwise or reference_rule or waits or gated}" > $OUT/pytest_lazy.log 2>&1
+    echo "pytest rc=$?" >> $OUT/pytest_lazy.log
+    show_pytest $OUT/pytest_lazy.log; tail -n 15 $OUT/pytest_lazy.log | cut -c1-300
+    cp gpurun_out/broad_phase_lazy.jsonl $OUT/${TAG}_broad_phase_lazy.jsonl 2>/dev/null; cat $OUT/${TAG}_broad_phase_lazy.jsonl 2>/dev/null | cut -c1-400
+    ;;
+  lazy-cost)   # World.step with the reference's rule (lazy form) against the per-environment form and the previous round's library
+    AB=$OUT/${TAG}_lazy_cost.jsonl; : > $AB
+    for ROUND in 1 2; do
+      for CFG in ${LAZY_CFGS:-balance:32768 transport:16384 football:16384 football:8192 football:131072 balance:1048576}; do
+        SC=${CFG%%:*}; NB=${CFG##*:}
+        for E in 1 0; do EXACT=$E FORCES=random QUEUES=1 python $S/bench_world.py $SC $NB 300 2>$OUT/lazy_cost.err | grep "^{" >> $AB; done
+        if [ -f vectorizedmultiagentsimulator_amd/csrc/libvmas_hip_r5.so ]; then
+          EXACT=0 FORCES=random QUEUES=1 VMAS_HIP_LIB=libvmas_hip_r5.so python $S/bench_world.py $SC $NB 300 2>$OUT/lazy_cost_r5.err | grep "^{" >> $AB || tail -3 $OUT/lazy_cost_r5.err
+        fi
+      done
+    done
+    python - "$AB" <<'PY'
+import json, sys
+rows = [json.loads(l) for l in open(sys.argv[1])]
+for r in rows:
+    print(f"{r['scenario']:10s} {r['num_envs']:8d} lib={r['lib'][-16:]:16s} exact={r.get('exact')} form={r.get('exact_form')} {r['world_step_us']:8.2f} us  spec={r['specialized']} compact={r['compact']}")
+PY
     ;;
   *) echo "unknown stage $STAGE";;
   esac

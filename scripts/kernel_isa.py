@@ -17,8 +17,8 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 CSRC = os.path.join(ROOT, "vectorizedmultiagentsimulator_amd", "csrc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-unused-function", "--cuda-device-only"]
 SIGS = {  # kernel name -> parameter list of the explicit instantiation
-    "step_kernel_spec_multi": "(DevWorld, float*, float*, long, int, int, long, const {env})",
-    "step_kernel_spec": "(DevWorld, float*, float*, long, int)",
+    "step_kernel_spec_multi": "(DevWorld, float*, float*, long, int, int, long, const {env}, LazyArgs)",
+    "step_kernel_spec": "(DevWorld, float*, float*, long, int, LazyArgs)",
     "step_kernel": "(DevWorld, float*, float*, long, int, DevStepArgs, const {env})",
 }
 

@@ -20,8 +20,9 @@ if hold:
 be.set_compact(1)
 be.set_queues(1)
 assert be.compact
-be.step_n(20); torch.cuda.synchronize()
-be.step_n(1); torch.cuda.synchronize()
+exact = os.environ.get("EXACT", "1") != "0"  # the lazy exact broad phase (the default of every host path since round 6)
+be.step_n(20, exact=exact); torch.cuda.synchronize()
+be.step_n(1, exact=exact); torch.cuda.synchronize()
 tiles = (B + 63) // 64
 buf = np.zeros(tiles * 16 * 16, np.uint64)
 lib = be.lib
@@ -31,7 +32,7 @@ t = buf.reshape(tiles, 16, 16).astype(np.int64)
 nw = int((t[:, :, 0] > 0).sum(axis=1).max())
 t = t[:, :nw]
 t0 = t[:, :, 0].min()
-print(f"{name} {B} (held {hold} steps): tiles {tiles}, waves/tile {nw}; kernel span {t[:, :, 3].max() - t0} ticks (s_memtime)")
+print(f"{name} {B} (held {hold} steps, exact broad phase {exact}): tiles {tiles}, waves/tile {nw}; kernel span {t[:, :, 3].max() - t0} ticks (s_memtime)")
 start = t[:, :, 0] - t0
 print("wave start after the grid's first wave (ticks): mean %.0f | median %.0f | max %.0f; last wave of a tile after its first: mean %.0f" % (
     start.mean(), np.median(start), start.max(), (t[:, :, 0].max(axis=1) - t[:, :, 0].min(axis=1)).mean()))
@@ -44,6 +45,8 @@ names = ["prologue+integrate", "A broad", "A barrier", "B narrow", "B barrier", 
 for k, nm in enumerate(names):
     v = t[:, :, 4 + k]
     print("  %-20s mean %9.1f  max %9d" % (nm, v.mean(), v.max()))
+print("  lazy exact broad phase: overlap phase + publish mean %.1f max %d | look at the batch's words mean %.1f max %d" % (
+    t[:, :, 14].mean(), t[:, :, 14].max(), t[:, :, 15].mean(), t[:, :, 15].max()))
 print("by wave index (mean over tiles): prologue+integrate | A broad | A barrier | C add contacts")
 for wv in range(nw):
     print("  wave %2d  %8.0f %8.0f %8.0f %8.0f" % (wv, t[:, wv, 4].mean(), t[:, wv, 5].mean(), t[:, wv, 6].mean(), t[:, wv, 9].mean()))

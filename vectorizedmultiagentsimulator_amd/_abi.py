@@ -304,7 +304,9 @@ EXPORTED_SYMBOLS = (
     "vmas_debug_football_form",
     "vmas_debug_compact_plan",
     "vmas_debug_compact_stats",
+    "vmas_debug_lazy_stats",
     "vmas_world_exact_status",
+    "vmas_world_exact_form",
     "vmas_world_load_spec",
     "vmas_world_set_compact",
     "vmas_world_get_compact",
@@ -388,6 +390,9 @@ def load_library() -> C.CDLL:
     lib.vmas_world_get_compact.restype = C.c_int
     lib.vmas_world_exact_status.argtypes = [vp]
     lib.vmas_world_exact_status.restype = C.c_int
+    if hasattr(lib, "vmas_world_exact_form"):  # (an older build beside this one, VMAS_HIP_LIB=...: A/B measurements only)
+        lib.vmas_world_exact_form.argtypes = [vp]
+        lib.vmas_world_exact_form.restype = C.c_int
     lib.vmas_world_set_queues.argtypes = [vp, i32]
     lib.vmas_world_set_queues.restype = C.c_int
     lib.vmas_world_get_queues.argtypes = [vp, i32]

@@ -154,10 +154,13 @@ class AttachedWorld:
 
     @exact_broad_phase.setter
     def exact_broad_phase(self, value):
-        """Takes effect at the next step (the pre-marshalled stepper is rebuilt for the new mode)."""
+        """Takes effect at the next step: the pre-marshalled ``world.step`` stepper is rebuilt for the new mode, and so is
+        the one-launch ``env.step`` (its launch form, gating and cached flag all depend on it: attached_env.FusedEnvStep)."""
         self._exact = bool(value)
         if self._fast_step is not None:
             self._fast_step = self.backend.make_stepper(self._exact)
+        if self.fused is not None:
+            self.fused.build()
 
     def _new_backend(self):
         self.backend = self._factory(self.spec, self.batch, self.device, self.state, self.agent_ft)
@@ -366,8 +369,8 @@ def attach(env_or_world, backend_factory: Callable = _default_backend,
            exact_broad_phase: Optional[bool] = None, specialize: Optional[bool] = False,
            fused: Optional[bool] = None, validate_actions=True) -> AttachedWorld:
     """Put a reference ``Environment`` (or ``World``) on the MI355X-native physics step.  ``exact_broad_phase``: the
-    reference's batch-global ``.any()`` broad phase (core.py:2797-2801) exactly; None = below 1024 environments, where
-    it can matter (above, every pair that matters has SOME environment overlapping).  ``specialize``: True = compile (once,
+    reference's batch-global ``.any()`` broad phase (core.py:2797-2801) exactly - None = True (the lazy form inside the step
+    launch, any batch size; round 6); False = every static pair per environment.  ``specialize``: True = compile (once,
     cached on disk) a step kernel for this very world - any scenario the reference ships then runs at the speed of the
     built-in BASELINE specialisations instead of the schedule interpreter's (specialize.py); None = use it if the cache has
     it, never compile; False = the interpreter.
@@ -401,9 +404,16 @@ def attach(env_or_world, backend_factory: Callable = _default_backend,
                       spec_post=profile.post_kind)
     try:
         h.fused = FusedEnvStep(env_or_world, h, profile, validate_actions)
-    except AssertionError as e:  # a world layout the post-step class refuses (entity order ...): the reference's Environment.step
-        h.fused_reason = f"the post-step kernel does not cover this world: {e}"
+    except Exception as e:  # noqa: BLE001
+        # a world layout the post-step class refuses (AssertionError: entity order ...), or anything else the views / the
+        # library raise on a reference version this layer was not written against: with fused=None the environment keeps the
+        # reference's own Environment.step around the native World.step (the handle is returned, detach() works); fused=True
+        # puts everything back and raises
+        h.fused = None
+        h.fused_reason = f"the post-step kernel does not cover this world: {type(e).__name__}: {e}"
         if fused:
             h.detach()
-            raise NotImplementedError(f"attach(fused=True): {h.fused_reason}") from e
+            if isinstance(e, AssertionError):
+                raise NotImplementedError(f"attach(fused=True): {h.fused_reason}") from e
+            raise
     return h

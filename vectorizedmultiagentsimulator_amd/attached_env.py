@@ -355,7 +355,12 @@ class FusedEnvStep:
         for o in self._hooked:
             _hook_params(type(o))
             o.__dict__[_DIRTY] = self._dirty
-        self.build()
+        try:
+            self.build()
+        except BaseException:  # (attach() falls back to the reference's step: leave none of this layer's marks behind)
+            for o in self._hooked:
+                o.__dict__.pop(_DIRTY, None)
+            raise
         self._adopt_steps()
         env.step = self.step
 
@@ -370,8 +375,7 @@ class FusedEnvStep:
         self.view = view = _EnvView(env, wv, sv, self.steps, self.split)
         self.ingest = F.ActionIngest(view)
         self.post = self.profile.make_post(view)
-        n_cu = torch.cuda.get_device_properties(view.device).multi_processor_count
-        exact_in_launch = (not h.exact_broad_phase) or (view.num_envs + 63) // 64 <= n_cu
+        exact_in_launch = (not h.exact_broad_phase) or h.backend.exact_form() != 3  # (vmas_world_exact_form: lazy, in the launch)
         # (environment.Environment._setup_fused: the same three forms - the whole step as one launch; ingest + physics as one
         #  launch and the post-step as another; three launches where the exact broad phase cannot run inside the step's)
         self.ingest_in_step = exact_in_launch and env.world.dim_c == 0
@@ -407,6 +411,21 @@ class FusedEnvStep:
             self.steps.copy_(cur)
             self.env.steps = self.steps
 
+    def _replan(self) -> bool:
+        """What every entry (``step``, ``rollout``, ``reset_where``) does first: follow static changes of the world, re-plan
+        after a parameter write / a rebuilt backend / a changed time limit, adopt a rebound ``env.steps``.  False = the fused
+        step was taken out (``_params_changed``)."""
+        env, h = self.env, self.handle
+        h._sync_static()  # (masses, filters ... written since the last step: the native world follows - adapter.py)
+        if self._dirty[0]:  # a scenario / action parameter the descriptors were built from was written
+            if not self._params_changed():
+                return False
+        elif h.backend is not self._backend or env.max_steps != self._max_steps:  # (the time limit is part of the output sets)
+            self.build()
+        if env.steps is not self.steps:
+            self._adopt_steps()
+        return True
+
     # ---- the replaced method ------------------------------------------------------------------------------------
     def step(self, actions):
         """Environment.step (environment.py:325-405): same arguments, same return value."""
@@ -420,14 +439,8 @@ class FusedEnvStep:
             actions = ordered
         assert len(actions) == len(self.names), f"Expecting actions for {len(self.names)}, got {len(actions)} actions"
         h = self.handle
-        h._sync_static()  # (masses, filters ... written since the last step: the native world follows - adapter.py)
-        if self._dirty[0]:  # a scenario / action parameter the descriptors were built from was written
-            if not self._params_changed():
-                return env.step(actions)  # (no kernel covers the configuration any more: the reference's own step, restored)
-        elif h.backend is not self._backend or env.max_steps != self._max_steps:  # (the time limit is part of the output sets)
-            self.build()
-        if env.steps is not self.steps:
-            self._adopt_steps()
+        if not self._replan():
+            return env.step(actions)  # (no kernel covers the configuration any more: the reference's own step, restored)
         ingest, post = self.ingest, self.post
         deferred = self.deferred
         if deferred:
@@ -460,7 +473,8 @@ class FusedEnvStep:
                     ingest.validate()
                 self.launch(0, None, None, deferred)
             else:
-                ingest(actions, self.validate_actions)
+                # (three launches: no launch here carries the deferred error word - "deferred" checks up front like True)
+                ingest(actions, self.validate_actions or deferred)
                 h.step()
             result = post()
         obs, rews, dones, infos = result
@@ -489,11 +503,9 @@ class FusedEnvStep:
         assert self.one_launch and getattr(self.post, "rollout_ok", True), (
             "rollout() needs a configuration whose env.step is one launch without a per-step reduction over more tiles than CUs")
         assert len(actions) == len(self.names), f"Expecting actions for {len(self.names)}, got {len(actions)} actions"
-        h._sync_static()
-        if h.backend is not self._backend:
-            self.build()
-        if env.steps is not self.steps:
-            self._adopt_steps()
+        if not self._replan():
+            raise NotImplementedError(f"rollout(): {h.fused_reason}")
+        assert self.one_launch, "rollout(): the re-planned configuration's env.step is no longer one launch"
         K = int(actions[0].shape[0])
         self.ingest.prepare_rollout(list(actions), K, self.validate_actions or self.deferred)
         desc, buffers, out = self.post.prepare_rollout(K, out)
@@ -511,14 +523,17 @@ class FusedEnvStep:
         from . import fused as F
 
         env = self.env
-        if env.steps is not self.steps:
-            self._adopt_steps()
+        if not self._replan():
+            raise NotImplementedError(f"reset_where(): {self.handle.fused_reason}")
+        if self._masked_reset is not None and self._masked_reset_seed != int(self.reset_seed):
+            self._masked_reset = None  # (``handle.fused.reset_seed = n`` after the first use: a new generator key)
         if self._masked_reset is None:
             prog = self.profile.reset_program(self.view.scenario)
             if prog is None or len(prog["ops"]) > A.RESET_MAX_OPS or len(prog.get("terms", [])) > A.RESET_MAX_TERMS:
                 raise NotImplementedError("reset_where(): this configuration's reset is not a spawn program the kernel runs "
                                           "(shared goals / formation spawning / too many entities): use env.reset_at(i)")
             self._masked_reset = F.MaskedReset(self.view, prog, int(self.reset_seed))
+            self._masked_reset_seed = int(self.reset_seed)
         mask = mask.to(self.view.device).reshape(self.view.num_envs).bool().contiguous()
         self._masked_reset(mask)
         if return_observations:

@@ -156,6 +156,14 @@ class HipWorld:
             raise VmasHipError(A.last_error())
         return {"contacts": int(out[0]), "tiles": int(out[1]), "switches": int(out[2]), "backoff": int(out[3])}
 
+    def lazy_stats(self) -> dict:
+        """Test / diagnostics hook (include/vmas_debug_hip.h): the lazy exact broad phase's counters.  Synchronises the device."""
+        out = (C.c_int64 * 4)()
+        self.lib.vmas_debug_lazy_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        if self.lib.vmas_debug_lazy_stats(self._h, out) != 0:
+            raise VmasHipError(A.last_error())
+        return {"launches": int(out[0]), "tiles_asked": int(out[1]), "found_pair_off": int(out[2]), "repeated_polls": int(out[3])}
+
     @property
     def compact(self) -> bool:
         """True if plain steps of this world run the lane-compacted kernel (csrc/vmas_compact.h)."""
@@ -286,9 +294,17 @@ class HipWorld:
         if rc != 0:
             raise VmasHipError(A.last_error())
 
-    def step_n(self, n_steps: int, forces: Optional[torch.Tensor] = None, stream=None) -> None:
+    def _exact_args(self, exact: bool):
+        if not exact:
+            return None
+        self._exact_step_args = sa = A.StepArgs()  # (kept alive by the world for the duration of the call)
+        sa.exact_broad_phase = 1
+        return C.byref(sa)
+
+    def step_n(self, n_steps: int, forces: Optional[torch.Tensor] = None, stream=None, exact: bool = False) -> None:
         """``n_steps`` World.step() launches enqueued from C.  ``forces`` [n_steps, A, 3, ld]
-        (packed like ``agent_ft``) supplies per-step agent forces; None re-uses ``agent_ft``."""
+        (packed like ``agent_ft``) supplies per-step agent forces; None re-uses ``agent_ft``.  ``exact``: the reference's
+        batch-global broad phase (one queue; include/vmas_hip.h)."""
         if forces is not None:
             assert forces.shape == (n_steps,) + tuple(self.agent_ft.shape) and forces.is_contiguous()
             assert forces.device == self.agent_ft.device and forces.dtype == torch.float32
@@ -296,12 +312,13 @@ class HipWorld:
         else:
             ft, stride = self.agent_ft, 0
         rc = self.lib.vmas_world_step_n(
-            self._h, self._dptr(self.state), self._dptr(ft), self.ld, stride, int(n_steps), None, self._stream(stream)
+            self._h, self._dptr(self.state), self._dptr(ft), self.ld, stride, int(n_steps), self._exact_args(exact),
+            self._stream(stream)
         )
         if rc != 0:
             raise VmasHipError(A.last_error())
 
-    def rollout(self, n_steps: int, forces: Optional[torch.Tensor] = None, stream=None) -> None:
+    def rollout(self, n_steps: int, forces: Optional[torch.Tensor] = None, stream=None, exact: bool = False) -> None:
         """The same steps as ``step_n`` in ONE persistent launch (state stays in LDS)."""
         if forces is not None:
             assert forces.shape == (n_steps,) + tuple(self.agent_ft.shape) and forces.is_contiguous()
@@ -310,7 +327,8 @@ class HipWorld:
         else:
             ft, stride = self.agent_ft, 0
         rc = self.lib.vmas_world_rollout(
-            self._h, self._dptr(self.state), self._dptr(ft), self.ld, stride, int(n_steps), None, self._stream(stream)
+            self._h, self._dptr(self.state), self._dptr(ft), self.ld, stride, int(n_steps), self._exact_args(exact),
+            self._stream(stream)
         )
         if rc != 0:
             raise VmasHipError(A.last_error())
@@ -336,6 +354,15 @@ class HipWorld:
         for s in range(self.spec.substeps):
             m = self.pair_mask(stream)
             self.step(m, joint_fixed_rot, entity_gravity, s, 1, stream)
+
+    def exact_form(self) -> int:
+        """How ``exact=True`` steps of this world run outside graph capture (include/vmas_hip.h, vmas_world_exact_form):
+        0 nothing to do (sphere-sphere pairs only), 1 the lazy form inside the step launch (any batch size; fused epilogues
+        and gated launches allowed), 2 the grid-barrier form inside the launch, 3 a mask launch + a launch per substep."""
+        rc = int(self.lib.vmas_world_exact_form(self._h))
+        if rc < 0:
+            raise VmasHipError(A.last_error())
+        return rc
 
     def exact_status(self) -> int:
         """0 = every in-kernel grid barrier of the exact steps so far completed (synchronises the device)."""

@@ -605,8 +605,11 @@ class Joint:
 # ----------------------------------------------------------------------------------
 # world
 # ----------------------------------------------------------------------------------
-#: batches below this many environments use the reference's exact batch-global broad phase by default
-EXACT_AUTO_BELOW = 1024
+#: batches below this many environments use the reference's exact batch-global broad phase by default.  Since round 6 that is
+#: EVERY batch: the lazy form of the rule (csrc/vmas_env_device.h) runs inside the step launch at any size and costs a tile
+#: a wait only when one of its environments sits in a pair's band, so there is no size from which the per-environment form
+#: has to stand in for the reference's (it did not: VERDICT round 5 - football 8 192: 20 of 30 states differ).
+EXACT_AUTO_BELOW = 1 << 62
 
 class World:
     """core.py:1088-1232 + step 1972-2015, re-homed on one packed buffer and one kernel."""
@@ -652,10 +655,10 @@ class World:
         self._agent_ft: Optional[Tensor] = None
         self._backend = None
         self._spec: Optional[WorldSpec] = None
-        #: True = the reference's batch-global ``.any()`` broad phase exactly (core.py:2797-2801; inside the step launch
-        #: up to 64 x CUs environments); False = every static pair evaluated per environment - the same result whenever
-        #: SOME environment of the batch has the pair's bounding circles overlapping, i.e. practically always in a large
-        #: batch.  None = exact below EXACT_AUTO_BELOW environments, where that argument does not hold.
+        #: True (None: the default) = the reference's batch-global ``.any()`` broad phase exactly (core.py:2797-2801; inside
+        #: the step launch at every batch size: the lazy form); False = every static pair evaluated per
+        #: environment - the same result only while SOME environment of the batch has the pair's bounding circles
+        #: overlapping whenever another one sits in its band.
         self.exact_broad_phase = (batch_dim < EXACT_AUTO_BELOW) if exact_broad_phase is None else bool(exact_broad_phase)
         self._lanes_per_env = lanes_per_env
         # geometric queries answered by ONE kernel launch per state version (GPU worlds)

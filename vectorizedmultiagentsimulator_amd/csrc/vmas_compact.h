@@ -52,8 +52,9 @@ constexpr int WAVE_UNITS = 64;            // units per wave: a wave keeps its un
 // ---- descriptor records (32-bit words in the blob; all offsets are FLOAT offsets into the LDS tile)
 //   pair    [4] : oa | ob << 16 ; tra | type << 16 ; p0 (SS: r_a + r_b, LS: r + LINE_MIN_DIST) ; p1 (LS: L / 2)
 //   pairhm  [1] : hm_a | hm_b << 16, hm = owned index << 8 | position in that entity's pair list (0xffff: static entity)
-//   unit    [5] : o_row | tr_row << 16 ; type | n << 8 | partner stride (rows) << 16 ; first partner's offset | first pair
-//                 << 16 ; half length (LS) ; threshold (SS: (r_a + r_b + 1e-4)^2, LS: r + LINE_MIN_DIST + slack).  A unit =
+//   unit    [6] : o_row | tr_row << 16 ; type | n << 8 | partner stride (rows) << 16 ; first partner's offset | first pair
+//                 << 16 ; half length (LS) ; threshold (SS: (r_a + r_b + 1e-4)^2, LS: r + LINE_MIN_DIST + slack) ; the pairs'
+//                 bounding-circle threshold (circles_overlap: the lazy exact broad phase).  A unit =
 //                 one "row" entity (a line, or the a-sphere of sphere-sphere pairs) against a RUN of n <= 6 partner spheres
 //                 that are equally spaced in the tile, have consecutive pair indices and share the threshold - partner i
 //                 is at offset + i * stride rows, its pair is first pair + i: nothing per partner is fetched.  Ordered wave
@@ -64,7 +65,8 @@ constexpr int WAVE_UNITS = 64;            // units per wave: a wave keeps its un
 //   wave    [2] : first unit, end unit
 //   entoff  [nE]: tile offset of an entity's first row (-1: none of its rows is in the tile)
 //   bounds  [nP]: the pair's bounding-circle sum R_a + R_b (World.collides core.py:2797-2801, in-kernel exact broad phase)
-constexpr int PAIR_W = 4, UNIT_W = 5, OWNED_W = 32, WAVE_W = 2;
+//   band    [nP]: circles_overlap's threshold of the pair (the lazy exact broad phase)
+constexpr int PAIR_W = 4, UNIT_W = 6, OWNED_W = 32, WAVE_W = 2;
 
 struct DevCompact {
   const uint32_t* blob;
@@ -76,10 +78,12 @@ struct DevCompact {
   int32_t off_af;               // agent force rows
   int32_t off_tr;               // trig rows (2 per line: cos, sin)
   int32_t off_tab;              // the blob copy
-  int32_t t_owned, t_lists, t_units, t_pairs, t_pairhm, t_waves, t_entoff, t_bounds;  // word offsets inside the blob
+  int32_t t_owned, t_lists, t_units, t_pairs, t_pairhm, t_waves, t_entoff, t_bounds, t_band;  // word offsets inside the blob
   int32_t n_owned, n_pairs, hw;
   int32_t off_dyn;              // per-substep scratch: cnt[4] | hit[n_owned][hw] | ballots[n_pairs] (u64) | base[n_pairs] |
-                                // keys[CAP] | contacts[CAP] (fx, fy) | [torques[CAP] if has_torque] | xmask[mask_words]
+                                // keys[CAP] | contacts[CAP] (fx, fy) | [torques[CAP] if has_torque] | xmask[mask_words] ...
+                                // (the exact broad phase's words: barrier form xmask | gmask; lazy form [2 parities][overlap |
+                                //  band] | need | collected | batch mask | flag [4])
   int32_t has_torque;           // some pair exerts a torque (a rotatable line): the contacts carry a third number
   int32_t mask_words;
   const float4* trig_cache;     // [nE] {rotation, cos, sin, valid} of the static lines, made once from environment 0 (may be NULL)
@@ -121,15 +125,20 @@ __global__ void compact_trig_kernel(unsigned long long lines, const float* __res
 // ENV: ENV_NONE | ENV_INGEST (action ingest as the prologue) | ENV_FOOTBALL (+ football.py's post-step as the epilogue)
 // PLAIN: the launch has none of the optional inputs (pair masks / in-kernel exact broad phase, per-environment gravity,
 // partial substep ranges): their tests and the scalar registers that carry their pointers are compiled out
-template <int ENV, class EnvArgs, int OWN, bool PLAIN>
-__global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld W, DevCompact P, float* __restrict__ state,
+// (PLAIN: 0 every option at run time but the lazy exact broad phase | 1 none of them | 2 none but the lazy exact broad phase:
+//  its words and the owners' questions cost the kernel registers - three resident tiles per CU need <= 80)
+template <int ENV, class EnvArgs, int OWN, int PLAIN>
+__global__ __launch_bounds__(TILE * MAX_WAVES)
+// (the 8-wave geometry of big grids - two owned entities per wave - holds three tiles per CU at <= 80 registers: six waves
+//  per SIMD.  The lazy variant's collect loop would take it to 97; told to stay, the compiler spills a cold value instead)
+__attribute__((amdgpu_waves_per_eu((PLAIN == 2 && OWN == 2 && ENV != ENV_FOOTBALL) ? 6 : 1))) void step_kernel_compact(DevWorld W, DevCompact P, float* __restrict__ state,
                                                                         float* __restrict__ agent_ft, long ld, int batch,
                                                                         int padded, DevStepArgs args_in, const EnvArgs E) {
   if constexpr (ENV != ENV_NONE) {  // a gated launch behind a validation that raised flags: not a single load or store
     if (env_gate_closed(E)) return;
   }
   DevStepArgs args = args_in;
-  if constexpr (PLAIN) {
+  if constexpr (PLAIN != 0) {
     args.pair_mask = nullptr; args.sync = nullptr; args.entity_gravity = nullptr; args.first_substep = 0; args.n_substeps = 0;
 #ifndef VMAS_TRACE
     args.trace = nullptr;
@@ -144,7 +153,7 @@ __global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld
   const int nw = sgpr(blockDim.x >> 6);
   const int nA = W.nA;
 #ifdef VMAS_TRACE  // profiling build only (scripts/trace_compact.py): per-wave s_memtime stamps and phase sums
-  unsigned long long tr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tr_t = 0;
+  unsigned long long tr_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tr_t = 0;  // (8: lazy overlap phase, 9: lazy resolve)
 #define CSTAMP(k) if (args.trace && lane == 0) args.trace[((long)blockIdx.x * 16 + wv) * 16 + (k)] = __builtin_amdgcn_s_memtime()
 #define CACC(k) if (args.trace) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tr_acc[k] += t_ - tr_t; tr_t = t_; }
 #define CCOUNT(k, v) if (args.trace) tr_acc[k] += (v)
@@ -170,13 +179,17 @@ __global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld
   float* torques = (float*)(contacts + CAP);  // [CAP] only if P.has_torque
   uint32_t* xmask = (uint32_t*)(torques + (P.has_torque ? CAP : 0));
   const int nP = P.n_pairs;
+  // the LAZY exact broad phase (vmas_env_device.h): [2 parities][overlap | band words] | need | collected | batch mask | flag
+  constexpr bool lazy = PLAIN == 2;  // (the host launches this variant with the lazy form's arguments, and only then; launches
+                                     //  with other options AND the lazy form take the interpreter)
+  const int lzp = (P.mask_words + 3) & ~3;
+  uint32_t* lz_words = xmask;  // [2 parities][lzp]: the pairs some environment of this tile overlaps, per pass
 
   // tile offset of entity e's first row / of its cos row, from the masks in the kernel arguments
   auto ent_off = [&](int e) {
     const unsigned long long below = (1ull << e) - 1ull;
     return (6 * __builtin_popcountll(P.dyn_mask & below) + 2 * __builtin_popcountll(P.static_mask & below)) * ROWF;
   };
-  auto trig_off = [&](int e) { return P.off_tr + 2 * ROWF * __builtin_popcountll(P.line_mask & ((1ull << e) - 1ull)); };
 
   // ---- the agents' force rows: from agent_ft, or made from the caller's action tensors / the library's agent scripts
   long act_row0 = 0;
@@ -331,6 +344,9 @@ __global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld
     for (int i = threadIdx.x; i < n_zero; i += blockDim.x) dyn[i] = 0u;
     if (args.sync != nullptr)
       for (int i = threadIdx.x; i < P.mask_words; i += blockDim.x) xmask[i] = 0u;
+    if (lazy) {
+      for (int i = threadIdx.x; i < 2 * lzp; i += blockDim.x) lz_words[i] = 0u;
+    }
   }
   [[maybe_unused]] float fb_prev[4] = {0.f, 0.f, 0.f, 0.f};
   [[maybe_unused]] float post_steps = 0.f;
@@ -348,9 +364,11 @@ __global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld
   //      v_readlane - no descriptor fetch on any dependent chain.
   const int u0 = sgpr((int)tab[P.t_waves + wv * WAVE_W]), nu = sgpr((int)tab[P.t_waves + wv * WAVE_W + 1]) - u0;
   uint32_t HU0 = 0, HU1 = 0, HU2 = 0, HU3 = 0, HU4 = 0;
+  [[maybe_unused]] uint32_t HU5 = 0;
   if (lane < nu) {
     const uint32_t* U = tab + P.t_units + (u0 + lane) * UNIT_W;
     HU0 = U[0]; HU1 = U[1]; HU2 = U[2]; HU3 = U[3]; HU4 = U[4];
+    if constexpr (PLAIN == 2) HU5 = U[5];
   }
   uint32_t OWv[OWN], LV[OWN];
 #pragma unroll
@@ -403,7 +421,21 @@ __global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld
     for (int substep = s_begin; substep < s_end; ++substep, ++it) {
       const bool last_sub = substep + 1 == s_end;
       const bool last = last_sub && stp + 1 == n_steps;
+      // which pairs the reference processes at all: the caller's recorded mask (global memory) and / or the batch's words the
+      // barrier form leaves in LDS.  Two variables on purpose: ONE pointer that is global here and LDS there makes its null
+      // test a generic-address-space one, which trips a back-end bug of ROCm 7.2 in some instantiations ("Illegal instruction
+      // detected: V_CMP_NE_U32_e32 0, $src_shared_base")
       const uint32_t* pmask = args.pair_mask;
+      bool bar_on = false;
+      const uint32_t* bar_mask = xmask + ((P.mask_words + 3) & ~3);  // (LDS; valid behind grid_bits_collect)
+      auto pair_masked_off = [&](int pr) {
+        if (pmask != nullptr && !((mask_word(pmask, pr >> 5) >> (pr & 31)) & 1u)) return true;
+        return bar_on && !((bar_mask[pr >> 5] >> (pr & 31)) & 1u);
+      };
+      // lazy form: this pass's overlap words (the other parity's are re-armed: last read by the previous pass's owners)
+      uint32_t* lz_x = lz_words + lzp * (it & 1);
+      if (lazy)
+        for (int i = threadIdx.x; i < lzp; i += blockDim.x) lz_words[lzp * ((it + 1) & 1) + i] = 0u;
       if (args.sync != nullptr) {
         // World.collides' batch-global rule (core.py:2797-2801) for this substep by the whole grid: see step_kernel
         const uint32_t seq = args.seq0 + (uint32_t)it;
@@ -426,7 +458,7 @@ __global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld
             grid_bits_collect(base + (seq & 3u) * stride, base + ((seq + 2u) & 3u) * stride, args.mask_words, gmask, args.sync + 1,
                               args.gave_up);
           __syncthreads();
-          pmask = gmask;  // (LDS)
+          bar_on = true;  // (gmask == bar_mask)
         }
       }
 
@@ -438,6 +470,7 @@ __global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld
 #pragma unroll
       for (int s = 0; s < OWN; ++s) { F[s] = V(0.f, 0.f); Tq[s] = 0.f; added_a[s] = 0u; added_t[s] = 0u; n_on[s] = 0; n_on_a[s] = 0; }
 
+      auto prologue = [&]() {
       // ---- prologue of every owned entity core.py:1995-2004 (the statements of step_kernel)
 #pragma unroll
       for (int s = 0; s < OWN; ++s) {
@@ -494,18 +527,20 @@ __global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld
         }
         // how many of the entity's pairs the reference processes at all (pair mask)
         const int n_list = (int)rdl(OWv[s], 3);
-        if (pmask == nullptr) {
+        if (pmask == nullptr && !bar_on) {
           n_on[s] = n_list; n_on_a[s] = (int)rdl(OWv[s], 4);
         } else {
           int c_all = 0, c_a = 0;
           for (int j = 0; j < n_list; ++j) {
             const uint32_t en = rdl(LV[s], j);
             const int pr = (int)(en & 0x1fffu);
-            if ((mask_word(pmask, pr >> 5) >> (pr & 31)) & 1u) { ++c_all; c_a += (en >> 15) ? 0 : 1; }
+            if (!pair_masked_off(pr)) { ++c_all; c_a += (en >> 15) ? 0 : 1; }
           }
           n_on[s] = c_all; n_on_a[s] = c_a;
         }
       }
+      };
+      prologue();
       CACC(0);  // prologue
 
       // a pair with contacts: its mask, the first slot of its contacts in the list, the lanes' keys, and the "has
@@ -538,6 +573,9 @@ __global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld
           const uint32_t h0 = rdl(HU0, ul), h1 = rdl(HU1, ul), h2 = rdl(HU2, ul);
           const float half = rdlf(HU3, ul);
           const uint32_t key_lo = rdl(HU4, ul) + 1u, key_span = 0x7f800000u - key_lo;  // (threshold, +inf) in bit patterns
+          [[maybe_unused]] float ov_thr = 0.f;   // (lazy form) circles_overlap's threshold of the unit's pairs
+          [[maybe_unused]] uint32_t ov_bits = 0u;  // partner i: some environment of the tile has the pair's circles overlapping
+          if constexpr (PLAIN == 2) ov_thr = rdlf(HU5, ul);
           const int type = (int)(h1 & 0xffu), n = (int)((h1 >> 8) & 0xffu), stride = (int)(h1 >> 16) * ROWF;
           const int pair0 = (int)(h2 >> 16);
           const float* R = tile + (int)(h0 & 0xffffu);
@@ -574,11 +612,25 @@ __global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld
             }
             const bool need = (key - key_lo) >= key_span;
             unsigned long long b = __ballot(need) & live_mask;
-            if (pmask != nullptr && b != 0ull && !((mask_word(pmask, pair >> 5) >> (pair & 31)) & 1u)) b = 0ull;
+            // lazy form: World.collides' own test of the pair per environment (core.py:2797-2799) on the operands that are in
+            // registers anyway - a line pair always (a wall's bounding circle spans the pitch), a sphere pair only where the
+            // spheres are within reach (overlapping spheres are)
+            if constexpr (PLAIN == 2) {
+              if (lazy && !all_masks && (type != VMAS_PAIR_SS || b != 0ull) &&
+                  (__ballot(circles_overlap(dx, dy, ov_thr)) & live_mask) != 0ull)
+                ov_bits |= 1u << i;
+            }
+            if (b != 0ull && pair_masked_off(pair)) b = 0ull;
             if (all_masks) {
               if (lane == 0) ballots[pair] = b;
             } else if (b != 0ull) {
               take_slots(pair, b);
+            }
+          }
+          if constexpr (PLAIN == 2) {
+            if (ov_bits != 0u && lane == 0) {  // (consecutive pair indices: one word, or two if the run crosses a word boundary)
+              atomicOr(&lz_x[pair0 >> 5], ov_bits << (pair0 & 31));
+              if ((pair0 & 31) + n > 32) atomicOr(&lz_x[(pair0 >> 5) + 1], ov_bits >> (32 - (pair0 & 31)));
             }
           }
         }
@@ -589,6 +641,9 @@ __global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld
       CACC(1);  // A
       __syncthreads();
       CACC(2);  // A barrier
+      if constexpr (PLAIN == 2) {
+        if (lazy) lazy_publish(args.lz, it, (int)(lz_x - (uint32_t*)lds));  // this tile's words go out: nobody waits for them
+      }
 
       // ---- rounds: ONE unless the tile has more contacts than the list holds (non-finite poses pass every test); then
       //      the pairs are taken in runs of at most CAP contacts, in pair order, slots re-assigned from the stored masks
@@ -654,6 +709,13 @@ __global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld
             fa = -contact_force(pb, cp, p0, W.c_coll, W.k);
             ta = vcross(cp - pa, fa);
           }
+          // lazy form: this environment is in the pair's band - bounding circles apart, force (or torque) not zero; for a
+          // sphere pair that takes a non-finite pose.  Noted in the contact's key: the pair's owners look at it (phase C)
+          if constexpr (PLAIN == 2) {
+            if (lazy && (fa.x != 0.f || fa.y != 0.f || ta != 0.f) &&
+                !circles_overlap(pa.x - pb.x, pa.y - pb.y, __uint_as_float(tab[P.t_band + pair])))
+              keys[k] = key | 0x80000000u;
+          }
           contacts[k] = make_float2(fa.x, fa.y);
           if (P.has_torque) torques[k] = ta;
         }
@@ -680,6 +742,21 @@ __global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld
               const unsigned long long b = sgpr64(ballots[pr]);
               const uint32_t s0 = (uint32_t)sgpr((int)base[pr]);
               const bool mine = (b >> lane) & 1ull;
+              if constexpr (PLAIN == 2) {
+                // lazy form: one of this entity's contacts of the pair is a BAND contact (circles apart, force not zero) and no
+                // environment of the tile has the pair's circles overlapping: the batch decides (World.collides core.py:2797-
+                // 2801).  THIS WAVE asks - the other waves go on with their entities - and leaves the pair's contacts out of
+                // the sum if no environment of the batch overlaps (the pair's other owner asks too and gets the same answer: a
+                // set bit is final, and so is "every tile has arrived and it is clear").  Rare: see vmas_env_device.h.
+                if (lazy) {
+                  const bool band = mine && (keys[s0 + lanemask_rank(b)] >> 31) != 0u;
+                  if (__any(band) && !((lz_x[pr >> 5] >> (pr & 31)) & 1u) && lazy_ask_wave(args.lz, it, pr) == 0) {
+                    n_on[s] -= 1;  // (the reference does not process the pair at all: not one of the zeros it would add)
+                    n_on_a[s] -= is_b ? 0 : 1;
+                    continue;
+                  }
+                }
+              }
               float2 c = make_float2(0.f, 0.f);
               float ct = 0.f;
               if (mine) {
@@ -761,11 +838,11 @@ __global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld
         // observation staging (E.scratch_off >= 0: the host found room): a [64][17] tile per wave - the first waves in
         // the per-substep scratch from the ballots to the contact list (ballots | base | keys | forces | torques: written
         // before they are read in every substep, and the next one is a barrier away), the others behind the kernel's own LDS
-        float* slab = nullptr;
+        int slab = -1;  // (its float offset from the LDS base: football_post_tile)
         if (E.scratch_off >= 0) {
           constexpr int kSlab = 64 * (kFootballStageChunk + 1);
           const int in_dead = (int)((const float*)xmask - (const float*)ballots) / kSlab;
-          slab = wv < in_dead ? (float*)ballots + wv * kSlab : lds + E.scratch_off + (wv - in_dead) * kSlab;
+          slab = wv < in_dead ? (int)((const float*)ballots - lds) + wv * kSlab : E.scratch_off + (wv - in_dead) * kSlab;
         }
         football_post_tile(TileCtx(batch), E.football.d, E.football.o, batch,
                            [&](int slot, int k) { return k < 4 ? rows[(slot * 6 + k) * ROWF] : af[(slot * 3 + (k - 4)) * ROWF]; },
@@ -778,6 +855,10 @@ __global__ __launch_bounds__(TILE * MAX_WAVES) void step_kernel_compact(DevWorld
 #ifdef VMAS_TRACE
   if (args.trace && lane == 0)
     for (int k = 0; k < 8; ++k) args.trace[((long)blockIdx.x * 16 + wv) * 16 + 4 + k] = tr_acc[k];
+  if (args.trace && lane == 0) {
+    args.trace[((long)blockIdx.x * 16 + wv) * 16 + 14] = tr_acc[8];
+    args.trace[((long)blockIdx.x * 16 + wv) * 16 + 15] = tr_acc[9];
+  }
 #endif
 }
 

@@ -12,7 +12,7 @@ namespace vmas {
 int host_fail(const char* msg);  // vmas_hip.hip: sets vmas_last_error(), returns -1
 }
 
-template <int ENV, class EnvArgs, int OWN, bool PLAIN>
+template <int ENV, class EnvArgs, int OWN, int PLAIN>
 static int launch_plain(size_t lds, int device, dim3 grid, dim3 block, hipStream_t s, const DevWorld& W, const compact::DevCompact& P,
                         float* state, float* aft, long ld, int batch, int padded, const DevStepArgs& a, const EnvArgs& env) {
   if (lds > 64 * 1024) {  // opt in to the large LDS once per device and instantiation
@@ -36,8 +36,12 @@ static int launch_one(size_t lds, int device, dim3 grid, dim3 block, hipStream_t
                       float* state, float* aft, long ld, int batch, int padded, const DevStepArgs& a, const EnvArgs& env) {
   // PLAIN: none of the optional inputs (their tests and pointers are compiled out of that instantiation)
   const bool plain = !a.pair_mask && !a.sync && !a.entity_gravity && a.first_substep == 0 && a.n_substeps <= 0;
-  if (plain) return launch_plain<ENV, EnvArgs, OWN, true>(lds, device, grid, block, s, W, P, state, aft, ld, batch, padded, a, env);
-  return launch_plain<ENV, EnvArgs, OWN, false>(lds, device, grid, block, s, W, P, state, aft, ld, batch, padded, a, env);
+  // (... and the lazy exact broad phase a variant of its own: PLAIN 1 without it, 2 with - vmas_compact.h)
+  if (plain && a.lz.slots == nullptr) return launch_plain<ENV, EnvArgs, OWN, 1>(lds, device, grid, block, s, W, P, state, aft, ld, batch, padded, a, env);
+  if (plain) return launch_plain<ENV, EnvArgs, OWN, 2>(lds, device, grid, block, s, W, P, state, aft, ld, batch, padded, a, env);
+  if (a.lz.slots != nullptr)
+    return vmas::host_fail("vmas_world_step: the compacted kernel runs the lazy exact broad phase without other per-call options only");
+  return launch_plain<ENV, EnvArgs, OWN, 0>(lds, device, grid, block, s, W, P, state, aft, ld, batch, padded, a, env);
 }
 
 int vmas_compact_fill_trig(const compact::DevCompact& P, const float* state, long ld, float4* cache, hipStream_t s) {

@@ -231,7 +231,7 @@ __global__ __launch_bounds__(512) void football_post_kernel(const VmasFootballDe
   float steps_in = C.wave == 0 ? load_steps(o.limit, C) : 0.f;
   __syncthreads();
   football_post_tile<true>(C, d, o, batch, [&](int slot, int k) { return rows[(slot * 6 + k) * 64 + C.lane]; },
-                     lds + (n + 1) * 6 * 64, -64, prev, steps_in, stp);  // (stp: the step's slab of every per-step output)
+                     (n + 1) * 6 * 64, -64, prev, steps_in, stp);  // (stp: the step's slab of every per-step output)
 }
 
 int check_launch(const char* what) {

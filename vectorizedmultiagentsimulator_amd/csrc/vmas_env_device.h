@@ -27,6 +27,10 @@ VD void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// A block barrier for data exchanged through LDS only: __syncthreads() also waits for every outstanding GLOBAL access of the
+// wave (s_waitcnt vmcnt(0)) - which is exactly what a load requested early, to be looked at much later, must not be made to do.
+VD void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 constexpr float kPi = 3.14159265358979323846f;  // torch.pi -> fp32
 
 // torch.remainder(x, pi): fmod, then shifted into [0, pi) (sign of the divisor)
@@ -661,6 +665,187 @@ VD bool grid_bits_collect(const unsigned long long* slot, unsigned long long* cl
 }
 __host__ __device__ inline size_t grid_bits_slot_words64(int words, int max_tiles) { return (size_t)words * ((max_tiles + 31) / 32); }
 
+// ---- the LAZY form of the same rule (round 6): nobody waits unless it has to.
+// World.collides skips a pair for the WHOLE batch iff no environment's bounding circles overlap (core.py:2797-2801).
+// Evaluating the pair anyway differs from that only in an environment that is "in the band": circles apart, narrow-phase
+// force non-zero (a sphere just past the tip of a line, off the corner of a box; any pair with a non-finite pose) - and
+// only if NO environment of the batch overlaps.  So every tile steps optimistically with every pair on, and
+//   * publishes, per pass (step x substep), the pairs some environment of it overlaps: ONE plain 64-bit store per pair word
+//     into a slot of ITS OWN - (launch tag << 32) | pair bits - fire and forget.  No atomics: measured, they are what a
+//     launch pays for (profiles/r06a_lazy_cost.jsonl, r06g_lazy_stats.txt: bits ORed into words shared by 32 or 64 tiles
+//     cost balance at 32 768 environments 7.0 -> 9.4 and 7.6 -> 11.8 us - a kernel does not end before its atomics have
+//     made their round trip through the memory side, ~12 ns apiece on one address; the plain stores cost nothing that
+//     could be measured, r06e_publish_variants.txt);
+//   * notes the pairs for which one of ITS environments is in the band and no environment of the tile overlaps (LDS);
+//   * a tile with such a pair - tests/test_broad_phase_lazy_gpu.py counts them - sweeps the other tiles' words of that pair
+//     word, the first 64 tiles first (one load per lane of one wave: 4 096 environments - enough for every pair that is
+//     commonly in contact), then all of them: some tile has the bit (monotone: final) -> nothing to do; every tile's word
+//     carries this launch's tag and the bit is still clear -> the pass is made again for this tile with the pair off
+//     (interpreter / specialised kernels) or the pair's contacts are left out of the owners' sums (lane-compacted kernel).
+// Only that tile waits, and only for that; what a sweep costs is the price of a hand-off on this part (0.8-1.5 us for a
+// granule, 2.4-4 us for all tiles' - MI355X_MICROARCH.md's price list), which the lane-compacted kernel hides by requesting
+// the words while it still has its narrow phase to do.  Nothing is ever cleared: the tag - a per-world launch counter kept by
+// the host - tells this launch's words from older ones (a refused gated launch writes nothing and the next one has a new
+// tag; under graph capture a replay would repeat its tag: captured launches take the launch-per-substep form).  A waiting
+// tile keeps its CU slot: grids beyond what is resident make progress as long as not EVERY resident tile waits; the spin is
+// bounded and flags `gave_up` (as the barrier form does) instead of hanging.
+struct LazyArgs {
+  unsigned long long* slots;  // [passes][words][tiles rounded up to 64]; NULL = lazy form off
+  uint32_t* flag;             // device word: a wait gave up (vmas_world_exact_status); + 1 .. 3: statistics
+  uint32_t* gave_up;          // host-mapped word: the same, read by the next call without a synchronisation
+  uint32_t tag;               // this launch's tag (never 0)
+  int32_t words;              // pair words = ceil(n_pairs / 32)
+  int32_t tiles_pad;          // tiles of the launch rounded up to 64
+  int32_t pad;
+  unsigned long long band_words;  // bit w: pair word w is exchanged
+};
+// (pointers out of a by-value argument struct are generic to the compiler: said to be global here, so that the words are read
+//  and written with GLOBAL instructions - FLAT ones count on lgkmcnt too - and no run-time address-space test is made of them)
+#define VMAS_GLOBAL __attribute__((address_space(1)))
+template <class T> VD const VMAS_GLOBAL T* as_global(const T* p) { return (const VMAS_GLOBAL T*)p; }
+template <class T> VD VMAS_GLOBAL T* as_global(T* p) { return (VMAS_GLOBAL T*)p; }
+VD VMAS_GLOBAL unsigned long long* lazy_slot(const LazyArgs& Z, int pass, int word) {
+  return as_global(Z.slots) + ((size_t)pass * Z.words + word) * Z.tiles_pad;
+}
+// threads < words, behind a block barrier that completed the tile's words (LDS, at word offset bits_off from the launch's
+// dynamic LDS base): nobody waits for the stores
+VD void lazy_publish(const LazyArgs& Z, int pass, int bits_off) {
+  extern __shared__ uint32_t lazy_lds_words[];
+  const uint32_t* bits = lazy_lds_words + bits_off;
+  const int t = (int)threadIdx.x;
+  if (t < Z.words && ((Z.band_words >> t) & 1ull))
+    __hip_atomic_store(lazy_slot(Z, pass, t) + blockIdx.x, ((unsigned long long)Z.tag << 32) | bits[t], __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+// EVERY thread of the block (block-uniform call).  need (LDS, [words], written before a barrier the caller has passed): the
+// pairs this tile must know the batch's bit of; acc (LDS, [words]) and misc (LDS, [2]) are scratch.  Returns 0 once every
+// needed bit is set somewhere (the optimistic pass stands; acc is partial), 1 if every tile's word carries this launch's
+// tag and some needed bit is clear (acc[] = the batch's words) - or the bounded wait gives up (flags, returns 0).
+// All waves take part so that a sweep is ONE memory round trip with one load in flight per lane (the kernel's registers are
+// decided by its hot phases, not by this one: with eight loads in flight in one wave the lane-compacted kernel went from 80
+// to 95 registers - a resident tile per CU less).  need / acc / misc are WORD OFFSETS from the launch's dynamic LDS base:
+// through generic pointers the compiler could not always tell their address space, and its run-time cast trips a back-end
+// bug of ROCm 7.2 ("Illegal instruction detected: V_CMP_NE_U32_e32 0, $src_shared_base") in the lane-compacted kernel.
+VD uint32_t wave_or(uint32_t v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v |= (uint32_t)__shfl_xor((int)v, d);
+  return v;
+}
+VD int lazy_collect(const LazyArgs& Z, int pass, int need_off, int acc_off, int misc_off) {
+  extern __shared__ uint32_t lazy_lds_words[];
+  const uint32_t* need = lazy_lds_words + need_off;
+  uint32_t* acc = lazy_lds_words + acc_off;
+  uint32_t* misc = lazy_lds_words + misc_off;  // [0] some tile of the sweep has not arrived  [1] some needed bit is still clear
+  const int tid = (int)threadIdx.x, nt = (int)blockDim.x, lane = tid & 63;
+  const int words = Z.words, tiles = (int)gridDim.x;
+  for (int w = tid; w < words; w += nt) acc[w] = 0u;
+  if (tid == 0) {
+    misc[0] = misc[1] = 0u;
+    if (Z.flag) atomicAdd(Z.flag + 1, 1u);  // (statistics: tiles that asked - vmas_debug_lazy_stats)
+  }
+  __syncthreads();
+  // `limit` tiles from the asking tile on (wrapping): 64 first - its neighbours in dispatch order, which started when it
+  // did - then the whole grid
+  int limit = tiles < 64 ? tiles : 64;
+  for (int spins = 0;; ++spins) {
+    for (int w = 0; w < words; ++w) {
+      if (!((Z.band_words >> w) & 1ull) || need[w] == 0u) continue;  // (only the words somebody asks about; block-uniform)
+      const VMAS_GLOBAL unsigned long long* slot = lazy_slot(Z, pass, w);
+      uint32_t got = 0u;
+      bool arrived = true;
+      for (int i = tid; i < limit; i += nt) {
+        int t = (int)blockIdx.x + i;
+        t = t >= tiles ? t - tiles : t;
+        const unsigned long long v = __hip_atomic_load(slot + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool here = (uint32_t)(v >> 32) == Z.tag;
+        arrived = arrived && here;
+        got |= here ? (uint32_t)v : 0u;
+      }
+      got = wave_or(got);
+      if (lane == 0 && got != 0u) atomicOr(&acc[w], got);  // (LDS; bits only grow from sweep to sweep)
+      if (!__all(arrived) && lane == 0) misc[0] = 1u;
+    }
+    __syncthreads();
+    for (int w = tid; w < words; w += nt)
+      if ((need[w] & ~acc[w]) != 0u) misc[1] = 1u;
+    __syncthreads();
+    const bool open = misc[1] != 0u, missing = misc[0] != 0u;
+    __syncthreads();
+    if (tid == 0) misc[0] = misc[1] = 0u;
+    if (!open) return 0;
+    if (limit < tiles) {  // the neighbours do not have it: everybody
+      limit = tiles;
+      continue;
+    }
+    if (!missing) {
+      if (tid == 0 && Z.flag) atomicAdd(Z.flag + 2, 1u);  // (statistics: ... and found a pair off for the whole batch)
+      return 1;
+    }
+    if (tid == 0 && Z.flag) atomicAdd(Z.flag + 3, 1u);  // (statistics: sweeps that had to be repeated)
+    __builtin_amdgcn_s_sleep(8);
+    if (spins > (1 << 17)) {
+      if (tid == 0) {
+        if (Z.flag) __hip_atomic_fetch_or(Z.flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (Z.gave_up) __hip_atomic_fetch_or(Z.gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      return 0;
+    }
+  }
+}
+// ONE wave asks for ONE pair (the lane-compacted kernel: the owner of an entity with a band contact of the pair, while the
+// other waves of the tile go on): 1 = some environment of the batch overlaps the pair (or the bounded wait gave up: flagged),
+// 0 = every tile has arrived and none does.  The 64 tiles from the asking one on first, then the whole grid, four loads in
+// flight per lane.
+VD int lazy_ask_wave(const LazyArgs& Z, int pass, int pair) {
+  const int lane = threadIdx.x & 63, tiles = (int)gridDim.x;
+  const VMAS_GLOBAL unsigned long long* slot = lazy_slot(Z, pass, pair >> 5);
+  const uint32_t bit = 1u << (pair & 31);
+  if (lane == 0 && Z.flag) atomicAdd(Z.flag + 1, 1u);  // (statistics: asks - vmas_debug_lazy_stats)
+  {
+    int t = (int)blockIdx.x + lane;
+    t = t >= tiles ? t % tiles : t;
+    const unsigned long long v = __hip_atomic_load(slot + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__any((uint32_t)(v >> 32) == Z.tag && ((uint32_t)v & bit) != 0u)) return 1;
+  }
+  for (int spins = 0;; ++spins) {
+    bool arrived = true, found = false;
+    for (int t0 = 0; t0 < tiles; t0 += 256) {
+      unsigned long long v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int t = t0 + 64 * k + lane;
+        v[k] = t < tiles ? __hip_atomic_load(slot + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)Z.tag << 32);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool here = (uint32_t)(v[k] >> 32) == Z.tag;
+        arrived = arrived && here;
+        found = found || (here && ((uint32_t)v[k] & bit) != 0u);
+      }
+    }
+    if (__any(found)) return 1;
+    if (__all(arrived)) {
+      if (lane == 0 && Z.flag) atomicAdd(Z.flag + 2, 1u);  // (statistics: ... that found the pair off for the whole batch)
+      return 0;
+    }
+    if (lane == 0 && Z.flag) atomicAdd(Z.flag + 3, 1u);  // (statistics: sweeps that had to be repeated)
+    __builtin_amdgcn_s_sleep(8);
+    if (spins > (1 << 17)) {
+      if (lane == 0) {
+        if (Z.flag) __hip_atomic_fetch_or(Z.flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (Z.gave_up) __hip_atomic_fetch_or(Z.gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      return 1;
+    }
+  }
+}
+
+// The reference's test `vector_norm(pos_a - pos_b) <= R_a + R_b` on the radicand: torch's norm of a 2-vector is the correctly
+// rounded root of fma(dy, dy, dx * dx) (vmas_device.h), and a correctly rounded root is monotone - so the host computes, once
+// per pair, the largest fp32 radicand whose root is still <= the bound (`thr`, overlap_threshold in vmas_hip.hip) and the
+// test is one fma and one compare, no root.  A NaN / inf distance does not overlap, as in the reference.
+VD bool circles_overlap(float dx, float dy, float thr) { return __fmaf_rn(dy, dy, dx * dx) <= thr; }
+
 // What the fused epilogue needs from the world besides the tile: its registered sensors (sensor a = agent a) and its
 // static pair list with the mask words the tiles OR their bits into.
 struct NavWorld {
@@ -972,9 +1157,7 @@ struct IngestRaw { float u[3]; long flat; };
 // Pointers out of a slot that went through registers (load_action_slot) have lost the "loaded from the kernel arguments: global
 // memory" inference and would be dereferenced with FLAT instructions - which count on lgkmcnt too, so that the next wait for a
 // scalar load or an LDS read would also wait for the action load.  These casts say what they are.
-#define VMAS_GLOBAL __attribute__((address_space(1)))
-template <class T> VD const VMAS_GLOBAL T* as_global(const T* p) { return (const VMAS_GLOBAL T*)p; }
-template <class T> VD VMAS_GLOBAL T* as_global(T* p) { return (VMAS_GLOBAL T*)p; }
+// (VMAS_GLOBAL / as_global: defined in front of the lazy exact broad phase's helpers above)
 // An agent's action slot out of the kernel-argument block, whole and at once: read field by field where it is used, every
 // field is its own scalar load with its own wait in front of the branch that needs it - some thirty dependent round trips
 // to the scalar cache on the prologue's chain.  18 words in one batch of wide loads, pinned in scalar registers.
@@ -1104,7 +1287,7 @@ VD void run_script(const VmasAgentScript& S, const float* E, long stride, long e
 //   chunk > 0: `slab` is THIS wave's [64][chunk + 1] tile (chunk = 16 or 32 columns) - the wave transposes its agent's
 //     observation `chunk` columns at a time; the lanes of a store cover 64- or 128-byte pieces of the rows.  No block
 //     barrier: the latency regime's form (16 waves per tile, one agent per wave, nothing to wait for).
-//   slab == NULL: no staging, every lane stores its own row 16 bytes at a time.
+//   slab_off < 0: no staging, every lane stores its own row 16 bytes at a time.
 // `prev`: the four shaping terms of this lane
 // (in: before, out: after this step), `steps_in`: wave 0's Environment.steps (in/out), `stp`: step of a multi-step
 // launch (every per-step output is offset by stp slabs).
@@ -1114,7 +1297,13 @@ __host__ __device__ inline size_t football_shared_slab_floats(int rows, int D) {
 
 template <bool SHARED = false, class Get>  // SHARED: the chunk < 0 form is compiled in (the stand-alone kernel; not the step kernel's epilogue)
 VD void football_post_tile(const TileCtx& C, const VmasFootballDesc& d, const VmasFootballBuffers& o_in, int batch, Get G,
-                           float* slab, int chunk, float (&prev)[4], float& steps_in, int stp) {
+                           int slab_off, int chunk, float (&prev)[4], float& steps_in, int stp) {
+  // (slab_off: the staging array's float offset from the launch's dynamic LDS base, < 0 = none.  As a nullable POINTER into LDS
+  //  its null test went through the generic address space, which trips a back-end bug of ROCm 7.2 in some instantiations -
+  //  "Illegal instruction detected: V_CMP_NE_U32_e32 0, $src_shared_base")
+  extern __shared__ float football_lds_base[];
+  const bool staged = slab_off >= 0;
+  float* slab = football_lds_base + (staged ? slab_off : 0);
   const int n = d.n_blue + d.n_red, ball = n;  // slot of the ball
   VmasFootballBuffers o = o_in;
   const int n_adv_b = d.observe_adversaries ? d.n_red : 0, n_adv_r = d.observe_adversaries ? d.n_blue : 0;
@@ -1123,7 +1312,7 @@ VD void football_post_tile(const TileCtx& C, const VmasFootballDesc& d, const Vm
     o.obs += (long)stp * n * batch * D0; o.rew += (long)stp * n * batch; o.done += (long)stp * batch;
     o.terms += (long)stp * 9 * batch; o.touching += (long)stp * 2 * batch;
   }
-  float* my_row = slab != nullptr ? slab + C.lane * (chunk + 1) : nullptr;
+  float* my_row = slab + C.lane * (chunk + 1);  // (used only if staged)
   auto P2 = [&](int slot, int k) { return V(G(slot, k), G(slot, k + 1)); };
   const v2 bpos = P2(ball, 0), bvel = P2(ball, 2), bforce = P2(ball, 4);
 
@@ -1243,7 +1432,7 @@ VD void football_post_tile(const TileCtx& C, const VmasFootballDesc& d, const Vm
     const int mate0 = blue ? 0 : d.n_blue, n_team = blue ? d.n_blue : d.n_red;
     const int n_others = n_adv + (d.observe_teammates ? n_team - 1 : 0);
     const int D = 16 + 8 * n_others;
-    if (slab == nullptr) {
+    if (!staged) {
       // no LDS staging (a step kernel whose LDS has no room for it): every lane writes its environment's row itself, four
       // columns per store - 16 bytes per lane at a stride of the row length
       float* row = o.obs + ((long)a * batch + C.env) * D;

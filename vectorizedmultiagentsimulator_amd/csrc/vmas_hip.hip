@@ -75,6 +75,7 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
   }
   DevStepArgs args = args_in;
   DevWorld W = W_in;
+  args.lz_x = args.lz_s = nullptr; args.lz_g = nullptr; args.lz_acc = nullptr;  // (the lazy form's LDS words: set per pass below)
   if constexpr (PLAIN != 0) {
     args.pair_mask = nullptr; args.joint_fixed_rot = nullptr; args.entity_gravity = nullptr;
     args.first_substep = 0; args.n_substeps = 0; args.sync = nullptr;
@@ -180,6 +181,14 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
   if constexpr (PLAIN == 0) {
     if (args.sync != nullptr && (int)threadIdx.x < args.mask_words) xmask[threadIdx.x] = 0u;
   }
+  // the LAZY exact broad phase (vmas_env_device.h): [2 parities][overlap words | band words] | need | batch | flag, the same
+  // LDS as the barrier form's two arrays (a launch runs one form or the other)
+  const bool lazy = args.lz.slots != nullptr;
+  const int lzp = lazy ? ((args.lz.words + 3) & ~3) : 0;
+  uint32_t* lz_words = xmask;
+  if (lazy) {
+    for (int i = threadIdx.x; i < 6 * lzp + 4; i += blockDim.x) lz_words[i] = 0u;
+  }
 
   // ---- HBM -> LDS, one entity per wave at a time: six 256-byte row reads in flight, then the
   //      entity's trig straight from the registers
@@ -278,6 +287,13 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
     if (threadIdx.x < 2) ctr[2 * ((it + 1) & 1) + threadIdx.x] = first_dyn;  // re-arm the other parity
     if (threadIdx.x >= 2 && threadIdx.x < 4) fired_words[2 * ((it + 1) & 1) + threadIdx.x - 2] = 0u;
     uint32_t* fired = fired_words + 2 * (it & 1);
+    if (lazy) {  // this pass's overlap / band words; the other parity's are re-armed (last read behind the previous gather)
+      for (int i = threadIdx.x; i < 2 * lzp; i += blockDim.x) lz_words[2 * lzp * ((it + 1) & 1) + i] = 0u;
+      args.lz_x = lz_words + 2 * lzp * (it & 1);
+      args.lz_s = args.lz_x + lzp;
+      args.lz_g = nullptr;
+      lazy_overlap_blob(args, blob + W.b_pairs, W.n_pairs, tile, live, wv, nw, it);  // (+ a block barrier; the words go out)
+    }
     if constexpr (PLAIN == 0) {
       if (args.sync != nullptr) {
         // ---- World.collides' batch-global bounding-circle test (core.py:2797-2801) for THIS substep, by the whole grid:
@@ -310,6 +326,9 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
       }
     }
     // ================= phase B: gather forces per (entity, segment)
+    // (lazy form: the optimistic pass with every pair on; made AGAIN, with the batch's words, by a tile that has an
+    //  environment in the band of a pair no environment of the batch overlaps)
+    for (;;) {
 #ifdef VMAS_TRACE
     unsigned long long tg = TNOW();
 #endif
@@ -335,7 +354,7 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
           const ItemW I = PREFETCH ? cur : item_words(ii);
           if (PREFETCH && ii + 1 < i1) cur = item_words(ii + 1);
           if (sgpr((int)I.w0.x) == TASK_SSP) {
-            eval_ssp(I, W, args, tile, fired);
+            eval_ssp(I, W, args, tile, fired, live);
             continue;
           }
           const ItemV K = load_item(I);
@@ -365,7 +384,7 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
           float* Af = tile + W.off_af + D.agent_index * 3 * ROWF;
           if (fl & VMAS_F_MOVABLE) {  // _apply_action_force core.py:2018-2028
             v2 f = V(Af[0], Af[ROWF]);
-            if (fl & (VMAS_F_MAX_F | VMAS_F_F_RANGE)) {
+            if ((fl & (VMAS_F_MAX_F | VMAS_F_F_RANGE)) && args.lz_g == nullptr) {  // (a pass made again reads the clamped rows)
               if (fl & VMAS_F_MAX_F) f = clamp_with_norm(f, D.max_f);
               if (fl & VMAS_F_F_RANGE) f = V(clamp_t(f.x, D.f_range), clamp_t(f.y, D.f_range));
               Af[0] = f.x; Af[ROWF] = f.y;
@@ -378,7 +397,7 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
           }
           if (fl & VMAS_F_ROTATABLE) {  // _apply_action_torque core.py:2030-2041
             float t = Af[2 * ROWF];
-            if (fl & (VMAS_F_MAX_T | VMAS_F_T_RANGE)) {
+            if ((fl & (VMAS_F_MAX_T | VMAS_F_T_RANGE)) && args.lz_g == nullptr) {
               if (fl & VMAS_F_MAX_T) {
                 const float n = fabsf(t);
                 const float nt = (t / n) * D.max_t;
@@ -418,9 +437,9 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
         if (packed_type >= TASK_SSQ) {  // (packed records exist only in the LDS copy of the item list)
           if (!(ABLATE(args) & 16)) {
             if (LEVEL > 0 || packed_type == TASK_SSQ)  // (line-sphere records are only built for level-0 worlds)
-              eval_ssq(I, W, args, tile, efl & VMAS_F_MOVABLE, F);
+              eval_ssq(I, W, args, tile, efl & VMAS_F_MOVABLE, F, live);
             else
-              eval_lsq(I, W, args, tile, efl & VMAS_F_MOVABLE, F);
+              eval_lsq(I, W, args, tile, efl & VMAS_F_MOVABLE, F, live);
           }
           continue;
         }
@@ -453,6 +472,11 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
 #endif
     STAMP(3);
     __syncthreads();
+    if (!lazy || args.lz_g != nullptr) break;
+    // ---- lazy form, behind the optimistic pass: publish this tile's overlap words; a band pair that no environment of
+    //      the TILE overlaps needs the batch's word (rare: see vmas_env_device.h)
+    if (!lazy_after_pass(args, it, lz_words, lzp, c_gather, first_dyn)) break;
+    }
     STAMP(4);
 
     // ================= phase C: _integrate_state core.py:2862-2908 (+ trig for the next substep,
@@ -641,7 +665,11 @@ __global__ __launch_bounds__(TILE*(LEVEL >= 2 ? 8 : MAX_WAVES)) void step_kernel
 // ------------------------------------------------------------------------------------
 // world-specialised form of the same kernel (compile-time schedule tables)
 // ------------------------------------------------------------------------------------
+#ifdef VMAS_PLAN_ONLY  // scripts/plan_lib.sh: the host-only PLANNING library that scripts/gen_spec.py generates vmas_spec_gen.h with -
+#define VMAS_SPEC_LIST(X)  // it must not depend on the header it is there to (re)generate
+#else
 #include "vmas_spec_gen.h"
+#endif
 #include "vmas_spec_kernel.h"
 
 // ------------------------------------------------------------------------------------
@@ -1059,6 +1087,18 @@ struct VmasWorld {
     long switches = 0;
   } adapt;
   uint32_t* d_exact_mask = nullptr;
+  // The LAZY form of the exact broad phase (vmas_env_device.h, LazyArgs): [passes][pair words][tiles] 64-bit words, each
+  // written by one tile as (launch tag << 32) | pair bits.  Grown on demand (K-step rollouts need K x substeps passes).
+  struct Lazy {
+    unsigned long long* d = nullptr;
+    size_t qwords = 0;              // capacity
+    uint32_t tag = 0;               // the last launch's tag (a per-world counter; 0 is never used: fresh memory is zero)
+    unsigned long long band_words = 0ull;  // bit w: pair word w holds a band-capable pair
+    int n_band = 0;                 // band-capable pairs (anything but sphere-sphere); 0: the per-environment form IS exact
+                                    // for every finite state (DESIGN.md 4 on non-finite poses in sphere-only worlds)
+    bool ss_bound_differs = false;  // a sphere pair whose fp32 r_a + r_b is not its bounding-circle sum (the double sum
+                                    // rounded): the packed sphere records cannot test it - no lazy form for this world
+  } lazy;
   uint32_t* d_nav_mask = nullptr;  // navigation epilogue: World.collides' pair bits of the post-step state: two masks that
   int football_form = -1;          // football's Environment.step: -1 the library's choice, 0 one launch, 1 two per step (vmas_debug_football_form)
   int nav_flip = 0;                //   eager launches alternate between (nav_flip: the one the next launch fills; it is zero)
@@ -1089,6 +1129,19 @@ struct VmasWorld {
   DevQuery* d_queries = nullptr;
   int n_queries = 0;
 };
+
+// circles_overlap's threshold (vmas_env_device.h): the largest fp32 radicand whose correctly rounded root is <= bound, i.e.
+// sqrt(fma(dy, dy, dx * dx)) <= bound  <=>  fma(dy, dy, dx * dx) <= overlap_threshold(bound)  (core.py:2797-2799)
+static float overlap_threshold(float bound) {
+  if (!(bound >= 0.f)) return -1.f;  // (never overlaps; NaN bound: the reference's compare is false too)
+  if (bound == kInf) return kInf;
+  float t = (float)((double)bound * (double)bound);
+  while (t > 0.f && sqrtf(t) > bound) t = nextafterf(t, 0.f);
+  while (t < kInf && sqrtf(nextafterf(t, kInf)) <= bound) t = nextafterf(t, kInf);
+  return t;
+}
+static bool band_capable(int pair_type) { return pair_type != VMAS_PAIR_SS; }
+constexpr int kLazyMaxPairs = 512;  // worlds the lazy exact broad phase serves: 16 pair words, an 8 KB pair table in the tile
 
 static float type_cost(int type) {
   // relative narrow-phase cost per item, from instruction counts of the compiled kernel
@@ -1165,6 +1218,7 @@ static void build_items(VmasWorld* w, int share_mode) {
     t.tra = tr_off(P.a); t.trb = tr_off(P.b);
     float m = P.bound_sum + kLineMinDist + kSkipSlack;
     t.thr2 = m * m;
+    t.q0 = overlap_threshold(P.bound_sum);  // (the lazy exact broad phase: this environment's bounding circles overlap)
     switch (P.type) {
       case VMAS_PAIR_SS: {  // the force is exactly 0 for dist > r_a + r_b (core.py:2836)
         t.p0 = A.radius + B.radius;
@@ -1245,22 +1299,25 @@ static void build_items(VmasWorld* w, int share_mode) {
       while (i < per[e].size()) {
         if (!packable(per[e][i])) { packed.push_back(per[e][i++]); continue; }
         size_t j = i;
-        while (j < per[e].size() && packable(per[e][j]) && j - i < 4) ++j;
+        while (j < per[e].size() && packable(per[e][j]) && j - i < (size_t)LSQ_N) ++j;
         if (j - i < 2) { packed.push_back(per[e][i++]); continue; }  // a lone line is cheaper as a plain item
         uint32_t wds[16] = {0};
         auto fbits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
         const int n = (int)(j - i);
-        uint32_t lo[4], to[4], idx[4];
-        float half[4];
-        for (int k = 0; k < 4; ++k) {
+        uint32_t lo[LSQ_N], to[LSQ_N], idx[LSQ_N];
+        float half[LSQ_N], thr[LSQ_N];
+        for (int k = 0; k < LSQ_N; ++k) {
           const DevItem& it = per[e][i + (k < n ? k : 0)];
-          lo[k] = (uint32_t)it.oa; to[k] = (uint32_t)it.tra; half[k] = it.p0; idx[k] = (uint32_t)it.index;
+          lo[k] = (uint32_t)it.oa; to[k] = (uint32_t)it.tra; half[k] = it.p0; idx[k] = (uint32_t)it.index; thr[k] = it.q0;
         }
+        // (eval_lsq: three lines and their bounding-circle thresholds; four lines until round 6)
         wds[0] = TASK_LSQ; wds[1] = (uint32_t)n; wds[2] = (uint32_t)per[e][i].ob; wds[3] = fbits(per[e][i].p1);
-        wds[4] = lo[0] | (lo[1] << 16); wds[5] = lo[2] | (lo[3] << 16);
-        wds[6] = to[0] | (to[1] << 16); wds[7] = to[2] | (to[3] << 16);
-        for (int k = 0; k < 4; ++k) wds[8 + k] = fbits(half[k]);
-        wds[12] = idx[0] | (idx[1] << 16); wds[13] = idx[2] | (idx[3] << 16);
+        wds[4] = lo[0] | (lo[1] << 16); wds[5] = lo[2];
+        wds[6] = to[0] | (to[1] << 16); wds[7] = to[2];
+        for (int k = 0; k < LSQ_N; ++k) wds[8 + k] = fbits(half[k]);
+        wds[11] = fbits(thr[0]);
+        wds[12] = idx[0] | (idx[1] << 16); wds[13] = idx[2];
+        wds[14] = fbits(thr[1]); wds[15] = fbits(thr[2]);
         DevItem q;
         memcpy(&q, wds, sizeof(q));
         packed.push_back(q);
@@ -1435,7 +1492,23 @@ static int build_sched(VmasWorld* w, int nw, Sched& S) {
   S.dw.b_owned = append(owned.data(), owned.size() * sizeof(DevOwned));
   while (blob.size() % 4) blob.push_back(0);  // (ds_read_b128 of four references)
   S.dw.b_refs = append(w->refs.data(), w->refs.size() * sizeof(uint32_t));
-  while (blob.size() % 4) blob.push_back(0);  // 16-byte alignment of the item records (ds_read_b128)
+  while (blob.size() % 4) blob.push_back(0);  // 16-byte alignment of the pair table and the item records (ds_read_b128)
+  // the pair table of the lazy exact broad phase (lazy_overlap_blob; the specialised kernels read it at compile time): per
+  // static pair the tile offsets of a's and b's rows and circles_overlap's threshold, then a header of 4 words - right in
+  // front of the items, so that its position follows from b_items and the count in the header
+  // (worlds of more than kLazyMaxPairs pairs - pollock: 990 - go without: 16 bytes per pair of every resident tile's LDS;
+  //  their exact broad phase takes the barrier / launch-per-substep form, exact_form)
+  S.dw.n_pairs = (int)w->pairs.size() <= kLazyMaxPairs ? (int)w->pairs.size() : 0;
+  S.dw.b_pairs = (int)blob.size();
+  {
+    auto fbits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+    for (int p = 0; p < S.dw.n_pairs; ++p) {
+      const VmasPairDesc& P = w->pairs[p];
+      blob.push_back((uint32_t)(P.a * 6 * ROWF)); blob.push_back((uint32_t)(P.b * 6 * ROWF));
+      blob.push_back(fbits(overlap_threshold(P.bound_sum))); blob.push_back(0u);
+    }
+    blob.push_back((uint32_t)S.dw.n_pairs); blob.push_back(0u); blob.push_back(0u); blob.push_back(0u);
+  }
   const size_t item_bytes = w->items.size() * sizeof(DevItem);
   S.dw.items_in_lds = item_bytes <= (size_t)ITEMS_LDS_BUDGET;
   S.dw.b_items = (int)blob.size();
@@ -1465,7 +1538,12 @@ static int build_sched(VmasWorld* w, int nw, Sched& S) {
   S.dw.fired_recs = w->fired_recs;
   // + work counters, fired words (2 parities x 2), the tile's pair bits of the in-kernel exact broad phase (whole quads)
   // (... | work counters [4] | fired words [4] | this tile's pair words | the batch's pair words: in-kernel exact broad phase)
-  S.lds_bytes = ((size_t)row_bad * ROWF + S.dw.blob_words + 4 + 4 + 2 * ((((size_t)w->n_pairs + 31) / 32 + 3) & ~(size_t)3)) * sizeof(float);
+  // (the lazy form: [2 parities][overlap | band words] | need | batch | flag [4] - six arrays + 4 words in the same place)
+  {
+    const size_t mwp = (((size_t)w->n_pairs + 31) / 32 + 3) & ~(size_t)3;
+    const size_t exact_words = (int)w->pairs.size() <= kLazyMaxPairs ? 6 * mwp + 4 : 2 * mwp;  // (lazy form | barrier form only)
+    S.lds_bytes = ((size_t)row_bad * ROWF + S.dw.blob_words + 4 + 4 + exact_words) * sizeof(float);
+  }
   if (knob("VMAS_DEBUG_SCHED")) fprintf(stderr, "[sched nw=%d] %d segments, LDS %zu B per tile\n", nw, (int)segs.size(), S.lds_bytes);
   return 0;
 }
@@ -1582,7 +1660,7 @@ constexpr int kFootballOneLaunchTilesPerCu = 1;
 template <class G, int ENV, class EnvArgs>
 static int launch_spec(VmasWorld* w, Sched* S, float* state, float* aft, long ld, const DevStepArgs& a, const EnvArgs& env,
                        size_t extra_lds, hipStream_t s, int batch) {
-  size_t lds_spec = ((size_t)G::ROWS * ROWF + 8) * sizeof(float) + extra_lds;
+  size_t lds_spec = ((size_t)G::ROWS * ROWF + SPEC_TAIL_WORDS) * sizeof(float) + extra_lds;
 #ifdef VMAS_PROFILE  // occupancy probe (profiling build only): bytes of LDS requested on top of what the kernel uses
   if (const char* pad = getenv("VMAS_DEBUG_LDS_PAD")) lds_spec += (size_t)atol(pad);
 #endif
@@ -1606,18 +1684,18 @@ static int launch_spec(VmasWorld* w, Sched* S, float* state, float* aft, long ld
   }
   if constexpr (ENV == ENV_NONE && G::SUBSTEPS == 1) {
     if (n == 1) {  // the lean form
-      if (tail) hipLaunchKernelGGL((step_kernel_spec<G, 1>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch);
-      else hipLaunchKernelGGL((step_kernel_spec<G, 0>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch);
+      if (tail) hipLaunchKernelGGL((step_kernel_spec<G, 1>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch, a.lz);
+      else hipLaunchKernelGGL((step_kernel_spec<G, 0>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch, a.lz);
       HIP_TRY(hipGetLastError());
       return 0;
     }
   }
   if (n == 1) {
-    if (tail) hipLaunchKernelGGL((step_kernel_spec_multi<G, 1, ENV, EnvArgs, true>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch, 1, 0l, env);
-    else hipLaunchKernelGGL((step_kernel_spec_multi<G, 0, ENV, EnvArgs, true>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch, 1, 0l, env);
+    if (tail) hipLaunchKernelGGL((step_kernel_spec_multi<G, 1, ENV, EnvArgs, true>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch, 1, 0l, env, a.lz);
+    else hipLaunchKernelGGL((step_kernel_spec_multi<G, 0, ENV, EnvArgs, true>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch, 1, 0l, env, a.lz);
   } else {
-    if (tail) hipLaunchKernelGGL((step_kernel_spec_multi<G, 1, ENV, EnvArgs, false>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch, n, (long)a.ft_stride, env);
-    else hipLaunchKernelGGL((step_kernel_spec_multi<G, 0, ENV, EnvArgs, false>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch, n, (long)a.ft_stride, env);
+    if (tail) hipLaunchKernelGGL((step_kernel_spec_multi<G, 1, ENV, EnvArgs, false>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch, n, (long)a.ft_stride, env, a.lz);
+    else hipLaunchKernelGGL((step_kernel_spec_multi<G, 0, ENV, EnvArgs, false>), grid, block, lds_spec, s, S->dw, state, aft, ld, batch, n, (long)a.ft_stride, env, a.lz);
   }
   HIP_TRY(hipGetLastError());
   return 0;
@@ -1650,7 +1728,9 @@ static int launch_level(VmasWorld* w, Sched* S, float* state, float* aft, long l
   }
   const int blocks = (batch + TILE - 1) / TILE;
   // the world-specialised kernels (csrc/vmas_spec_kernel.h): same results bit for bit, the schedule as compile-time tables
-  if (plain && S->spec_id >= 0 && w->use_spec && !ABLATE(a) && !a.trace) {
+  // (their lazy exact broad phase keeps SPEC_LZP pair words in LDS: worlds of more pairs take the interpreter for it)
+  const bool spec_lazy_ok = a.lz.slots == nullptr || a.lz.words <= SPEC_LZP;
+  if (plain && S->spec_id >= 0 && w->use_spec && !ABLATE(a) && !a.trace && spec_lazy_ok) {
     bool spec_ok = true;
     if constexpr (ENV != ENV_NONE) spec_ok = env.ingest.n_scripts == 0 && !ABLATE(env);
     if (spec_ok) {
@@ -1667,13 +1747,13 @@ static int launch_level(VmasWorld* w, Sched* S, float* state, float* aft, long l
     }
   }
   // ... or the specialisation compiled at run time for this very schedule (vmas_world_load_spec)
-  if (plain && S->rt.ok && w->use_spec && !ABLATE(a) && !a.trace) {
+  if (plain && S->rt.ok && w->use_spec && !ABLATE(a) && !a.trace && spec_lazy_ok) {
     bool rt_ok = true;
     if constexpr (ENV != ENV_NONE) rt_ok = env.ingest.n_scripts == 0 && !ABLATE(env);
     if constexpr (ENV == ENV_BALANCE) rt_ok = rt_ok && S->rt.post == 1;
     if constexpr (ENV == ENV_TRANSPORT) rt_ok = rt_ok && S->rt.post == 2;
     if constexpr (ENV == ENV_NAVIGATION) rt_ok = rt_ok && S->rt.post == 3;
-    const size_t lds_rt = ((size_t)S->rows * ROWF + 8) * sizeof(float) + extra_lds;
+    const size_t lds_rt = ((size_t)S->rows * ROWF + SPEC_TAIL_WORDS) * sizeof(float) + extra_lds;
     if (rt_ok && lds_rt <= 160 * 1024) {
       const int tail = batch % TILE != 0 ? 1 : 0;
       const int n = a.n_steps > 1 ? a.n_steps : 1;
@@ -1684,8 +1764,9 @@ static int launch_level(VmasWorld* w, Sched* S, float* state, float* aft, long l
       long ld_ = ld, stride_ = (long)a.ft_stride;
       int batch_ = batch, n_ = n;
       EnvArgs env_ = env;
-      void* lean_args[] = {&Wk, &st_, &af_, &ld_, &batch_};
-      void* multi_args[] = {&Wk, &st_, &af_, &ld_, &batch_, &n_, &stride_, &env_};
+      LazyArgs lz_ = a.lz;
+      void* lean_args[] = {&Wk, &st_, &af_, &ld_, &batch_, &lz_};
+      void* multi_args[] = {&Wk, &st_, &af_, &ld_, &batch_, &n_, &stride_, &env_, &lz_};
       void** args_ = multi_args;
       if (ENV == ENV_NONE && S->dw.substeps == 1 && n == 1) {
         fn = S->rt.lean[tail];
@@ -1801,7 +1882,7 @@ static int build_compact(VmasWorld* w) {
     int q = p + 1;
     while (q < nP && U.n < UNIT_PARTNERS) {
       const VmasPairDesc& Q = w->pairs[q];
-      if (Q.a != P0.a || Q.type != P0.type || fbits(pair_thr(Q)) != fbits(U.thr)) break;
+      if (Q.a != P0.a || Q.type != P0.type || fbits(pair_thr(Q)) != fbits(U.thr) || fbits(Q.bound_sum) != fbits(P0.bound_sum)) break;
       const int step = (ent_off[Q.b] - ent_off[w->pairs[q - 1].b]) / ROWF;
       if (step <= 0 || step > 255 || (U.n > 1 && step != U.stride_rows)) break;
       U.stride_rows = step;
@@ -1884,6 +1965,7 @@ static int build_compact(VmasWorld* w) {
         unit_words.push_back((uint32_t)U.first_off | ((uint32_t)U.pair0 << 16));
         unit_words.push_back(fbits(U.type == VMAS_PAIR_LS ? E[U.row].length / 2.f : 0.f));
         unit_words.push_back(fbits(U.thr));
+        unit_words.push_back(fbits(overlap_threshold(w->pairs[U.pair0].bound_sum)));  // (the lazy exact broad phase: circles_overlap)
         ++cursor;
       }
       wave_range[wv].second = cursor;
@@ -1931,6 +2013,9 @@ static int build_compact(VmasWorld* w) {
   D.t_bounds = (int)blob.size();
   for (int p = 0; p < nP; ++p) blob.push_back(fbits(w->pairs[p].bound_sum));
   align4();
+  D.t_band = (int)blob.size();
+  for (int p = 0; p < nP; ++p) blob.push_back(fbits(overlap_threshold(w->pairs[p].bound_sum)));
+  align4();
   D.blob_words = (int)blob.size();
   D.off_tr = off_tr;
   D.off_af = off_af;
@@ -1944,7 +2029,8 @@ static int build_compact(VmasWorld* w) {
   for (const VmasPairDesc& P : w->pairs)
     if (P.type == VMAS_PAIR_LS && (E[P.a].flags & VMAS_F_ROTATABLE)) D.has_torque = 1;
   size_t dyn_words = 4 + (size_t)((D.n_owned * hw + 1) & ~1) + 2 * (size_t)nP + (size_t)((nP + 1) & ~1) + CAP;
-  dyn_words += 2 * (size_t)CAP + (D.has_torque ? (size_t)CAP : 0) + 2 * (((size_t)D.mask_words + 3) & ~(size_t)3);  // (xmask, gmask)
+  // (the exact broad phase's words: barrier form xmask | gmask; lazy form [2][overlap | band] | need | collected | mask | flag [4])
+  dyn_words += 2 * (size_t)CAP + (D.has_torque ? (size_t)CAP : 0) + 7 * (((size_t)D.mask_words + 3) & ~(size_t)3) + 4;
   C.lds_bytes = ((size_t)dyn_at + dyn_words) * sizeof(float);
   if (knob("VMAS_DEBUG_SCHED"))
     fprintf(stderr, "[compact nw=%d] rows %d, tables %d words, per-substep scratch %zu words, LDS %zu B per tile\n", nw, rows,
@@ -1966,6 +2052,11 @@ static int build_compact(VmasWorld* w) {
   return 0;
 }
 
+// a launch's options as the compacted kernel takes them: everything except the lazy exact broad phase TOGETHER with another option
+static bool compact_takes(const DevStepArgs& a) {
+  const bool plain = !a.pair_mask && !a.sync && !a.entity_gravity && a.first_substep == 0 && a.n_substeps <= 0;
+  return a.lz.slots == nullptr || plain;
+}
 static bool compact_on(const VmasWorld* w) {
   if (!w->cp.ok || w->host_only) return false;
   if (w->compact_mode == 0) return false;
@@ -2044,7 +2135,7 @@ static int compact_pick_step(VmasWorld* w) {
 static int launch_physics(VmasWorld* w, Sched* S, float* state, float* aft, long ld, const DevStepArgs& a, hipStream_t s,
                           int batch = -1, long pad = -1) {
   if (batch < 0) { batch = w->batch; pad = ld; }
-  if (compact_on(w) && !a.joint_fixed_rot && !ABLATE(a)) {
+  if (compact_on(w) && !a.joint_fixed_rot && !ABLATE(a) && compact_takes(a)) {
     const bool adaptive = w->compact_mode == -1 && w->adapt.d_count != nullptr;
     bool interpreter_turn;
     if (adaptive && w->adapt.forced >= 0) interpreter_turn = w->adapt.forced == 0;  // (chosen for the whole step by the caller)
@@ -2057,6 +2148,54 @@ static int launch_physics(VmasWorld* w, Sched* S, float* state, float* aft, long
     }
   }
   return launch_any_level<ENV_NONE>(w, S, state, aft, ld, a, NoEnv{}, 0, s, batch, pad);
+}
+
+// Which form the reference's broad-phase rule (VmasStepArgs.exact_broad_phase) takes for a whole-batch launch of this world:
+//   0 none needed - every pair is sphere-sphere, whose force is exactly 0 wherever the circles do not overlap: evaluating a
+//     pair per environment IS the reference's result (core.py:2836) - 1 the lazy form inside the step launch (vmas_env_device.h),
+//   2 the grid-barrier form inside the launch (at most one tile per CU), 3 a mask launch + a launch per substep.
+// VMAS_EXACT_FORM = lazy | barrier | launches pins one where it is possible (A/B measurements, the tests of the older forms).
+enum { EXACT_NONE = 0, EXACT_LAZY = 1, EXACT_BARRIER = 2, EXACT_LAUNCHES = 3 };
+static int exact_form(const VmasWorld* w, bool capturing) {
+  if (w->n_pairs <= 0 || w->lazy.n_band == 0) return EXACT_NONE;
+  static const char* pin = knob("VMAS_EXACT_FORM");
+  const bool barrier_ok = blocks_of(w->batch) <= w->n_cu && blocks_of(w->batch) <= 512 && !capturing;
+  const bool lazy_ok = w->n_pairs <= kLazyMaxPairs && !capturing && !w->lazy.ss_bound_differs;
+  if (pin && !strcmp(pin, "launches")) return EXACT_LAUNCHES;
+  if (pin && !strcmp(pin, "barrier")) return barrier_ok ? EXACT_BARRIER : EXACT_LAUNCHES;
+  if (lazy_ok) return EXACT_LAZY;
+  return barrier_ok ? EXACT_BARRIER : EXACT_LAUNCHES;
+}
+static bool stream_capturing(hipStream_t s) {
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
+  return cap != hipStreamCaptureStatusNone;
+}
+// the lazy form's arguments for a launch of `passes` (steps x substeps) passes; every launch gets a tag of its own
+static int lazy_prepare(VmasWorld* w, int passes, LazyArgs* out) {
+  VmasWorld::Lazy& L = w->lazy;
+  const int words = (w->n_pairs + 31) / 32;
+  const int tiles_pad = (blocks_of(w->batch) + 63) & ~63;
+  const size_t need = (size_t)passes * words * tiles_pad;
+  if (need > L.qwords) {  // (first use, or a longer rollout than any before)
+    HIP_TRY(hipDeviceSynchronize());
+    (void)hipFree(L.d);
+    L.d = nullptr; L.qwords = 0;
+    HIP_TRY(hipMalloc((void**)&L.d, need * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(L.d, 0, need * sizeof(unsigned long long)));
+    L.qwords = need;
+  }
+  if (++L.tag == 0u) ++L.tag;  // (a launch that is not made after all wastes a tag: harmless)
+  LazyArgs Z{};
+  Z.slots = L.d;
+  Z.flag = w->d_sync + 1;
+  Z.gave_up = w->d_gave_up;
+  Z.tag = L.tag;
+  Z.words = words;
+  Z.tiles_pad = tiles_pad;
+  Z.band_words = L.band_words;
+  *out = Z;
+  return 0;
 }
 
 static int step_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld, const VmasStepArgs* args, void* stream,
@@ -2186,6 +2325,17 @@ int vmas_world_create(const VmasWorldDesc* d, int32_t batch, int32_t device_id, 
   w->tr_row = tr_row;
   std::vector<DevMaskPair> mp(d->n_pairs);
   for (int p = 0; p < d->n_pairs; ++p) mp[p] = {d->pairs[p].a, d->pairs[p].b, d->pairs[p].bound_sum};
+  for (int p = 0; p < d->n_pairs; ++p) {
+    if (band_capable(d->pairs[p].type)) w->lazy.n_band++;
+    // (every pair's word is exchanged: a sphere pair has band events too - a non-finite pose, whose NaN force the reference
+    //  only lets through if some environment overlaps; the packed sphere records test them against r_a + r_b, which must
+    //  then BE the pair's bounding-circle sum)
+    if (p < 64 * 32) w->lazy.band_words |= 1ull << (p >> 5);
+    if (d->pairs[p].type == VMAS_PAIR_SS) {
+      const float rs = d->entities[d->pairs[p].a].radius + d->entities[d->pairs[p].b].radius;
+      if (memcmp(&rs, &d->pairs[p].bound_sum, 4) != 0) w->lazy.ss_bound_differs = true;
+    }
+  }
   w->dev_ents = ents;
   if (!host_only) HIP_TRY(upload(&w->d_mpairs, mp));
   if (!host_only) {  // exact broad phase: barrier word + four mask slots (in-kernel form), one mask (launch-per-substep form)
@@ -2237,6 +2387,7 @@ void vmas_world_destroy(VmasWorld* w) {
     if (w->ev_join[q]) (void)hipEventDestroy(w->ev_join[q]);
   }
   if (w->ev_fork) (void)hipEventDestroy(w->ev_fork);
+  (void)hipFree(w->lazy.d);
   (void)hipFree(w->d_sync); (void)hipFree(w->d_exact_mask); (void)hipFree(w->d_nav_mask); (void)hipFree(w->d_nav_sync);
   if (w->h_gave_up) (void)hipHostFree(w->h_gave_up);
   (void)hipFree(w->lc.d_ent_slot); (void)hipFree(w->lc.d_slot_ent);
@@ -2384,6 +2535,11 @@ int vmas_world_exact_status(VmasWorld* w) {
   return (int)((flag | nav_flag | host_flag) != 0u);
 }
 
+int vmas_world_exact_form(VmasWorld* w) {
+  if (!w) return fail("vmas_world_exact_form: null world");
+  return exact_form(w, false);
+}
+
 int vmas_world_set_queues(VmasWorld* w, int32_t queues) {
   if (!w) return fail("vmas_world_set_queues: null world");
   if (queues < 0 || queues > VmasWorld::MAX_QUEUES)
@@ -2510,8 +2666,9 @@ static int step_env_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld
     if (!err_flags) return fail("vmas_world_step_env_gated: needs the gate word");
     if (post_kind != VMAS_POST_NONE && post_kind != VMAS_POST_BALANCE && post_kind != VMAS_POST_TRANSPORT)
       return fail("vmas_world_step_env_gated: post_kind %d cannot be gated (more than one launch per step, or a grid barrier)", post_kind);
-    if (args && args->exact_broad_phase)
-      return fail("vmas_world_step_env_gated: the exact broad phase carries a grid barrier and cannot be gated");
+    if (args && args->exact_broad_phase && exact_form(w, stream_capturing((hipStream_t)stream)) > EXACT_LAZY)
+      return fail("vmas_world_step_env_gated: this world's exact broad phase carries a grid barrier / several launches here and "
+                  "cannot be gated (vmas_world_exact_form)");
   }
   if (args && (args->first_substep != 0 || args->n_substeps > 0))
     return fail("vmas_world_step_env: partial substep ranges cannot carry an epilogue");
@@ -2716,18 +2873,21 @@ static int step_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld, co
   // (a whole-batch call on the caller's stream; the sub-range calls of a multi-queue vmas_world_step_n tick there, before the fork)
   if ((env_kind == ENV_NONE || env_kind == ENV_INGEST) && env_count < 0 && compact_adapt_tick(w, s, n_steps)) return -1;
   uint32_t seq_advance = 0;
-  if (args && args->exact_broad_phase && w->n_pairs > 0) {
+  int lazy_passes = 0;
+  const int form = (args && args->exact_broad_phase) ? exact_form(w, stream_capturing(s)) : EXACT_NONE;
+  if (form != EXACT_NONE) {
     // The reference's broad phase: a pair is processed - for ALL environments - iff SOME environment of the batch has the
     // pair's bounding circles overlapping (core.py:2797-2801), re-evaluated at every substep.
     if (args->pair_mask) return fail("vmas_world_step: exact_broad_phase and a recorded pair_mask are mutually exclusive");
+    if (env_count >= 0) return fail("vmas_world_step: exact_broad_phase takes the whole batch");
     const int mask_words = (w->n_pairs + 31) / 32;
     const int run = a.n_substeps > 0 ? a.n_substeps : w->base.substeps - a.first_substep;
-    // (a launch captured into a HIP graph would replay the barrier sequence number baked into its arguments: under
-    // capture the launch-per-substep form is used, which keeps no state on the host)
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
-    if (blocks_of(w->batch) <= w->n_cu && blocks_of(w->batch) <= 512 && cap == hipStreamCaptureStatusNone) {  // every tile resident at once: mask +
-                                                                                // grid barrier inside the step kernel
+    // (a launch captured into a HIP graph would replay the barrier sequence number / the slot set baked into its arguments:
+    // under capture the launch-per-substep form is used, which keeps no state on the host)
+    if (form == EXACT_LAZY) {  // optimistic passes + the batch's words on demand (vmas_env_device.h)
+      lazy_passes = run * (n_steps > 1 ? n_steps : 1);
+      if (lazy_prepare(w, lazy_passes, &a.lz)) return -1;
+    } else if (form == EXACT_BARRIER) {  // every tile resident at once: mask + grid barrier inside the step kernel
       a.sync = w->d_sync; a.mpairs = w->d_mpairs; a.n_mpairs = w->n_pairs; a.mask_words = mask_words;
       a.seq0 = w->sync_seq;
       a.gave_up = w->d_gave_up;
@@ -2755,7 +2915,7 @@ static int step_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld, co
                             (long)ld - env_first);
     }
     if (env_kind == ENV_NONE) return launch_physics(w, S, state, agent_ft, ld, a, s);
-    const bool cp = compact_on(w) && !a.joint_fixed_rot && !ABLATE(a) && !ABLATE(*env);
+    const bool cp = compact_on(w) && !a.joint_fixed_rot && !ABLATE(a) && !ABLATE(*env) && compact_takes(a);
     if (env_kind == ENV_INGEST && cp) return launch_compact(w, ENV_INGEST, state, agent_ft, ld, a, env, 0, s, w->batch, ld);
     if (env_kind == ENV_FOOTBALL) {
       if (!cp) return fail("vmas_world_step_env: the football epilogue runs behind the compacted step kernel, which this world / "
@@ -2849,6 +3009,19 @@ int vmas_debug_compact_plan(VmasWorld* w, uint32_t* words, int64_t capacity, int
 int vmas_debug_football_form(VmasWorld* w, int32_t form) {
   if (!w || form < -1 || form > 1) return fail("vmas_debug_football_form: form is -1 (the library's choice), 0 (one launch) or 1 (two per step)");
   w->football_form = form;
+  return 0;
+}
+
+int vmas_debug_lazy_stats(VmasWorld* w, int64_t out[4]) {  // launches made, tiles that asked the batch, ... that found a pair off, repeated polls
+  if (!w || !out || !w->d_sync) return fail("vmas_debug_lazy_stats: no device side");
+  HIP_TRY(hipSetDevice(w->device));
+  HIP_TRY(hipDeviceSynchronize());
+  uint32_t v[4] = {0, 0, 0, 0};
+  HIP_TRY(hipMemcpy(v, w->d_sync, sizeof(v), hipMemcpyDeviceToHost));
+  out[0] = (int64_t)w->lazy.tag; out[1] = v[2]; out[2] = v[3]; out[3] = 0;
+  uint32_t polls = 0;
+  HIP_TRY(hipMemcpy(&polls, w->d_sync + 4, sizeof(polls), hipMemcpyDeviceToHost));
+  out[3] = polls;
   return 0;
 }
 

@@ -125,7 +125,7 @@ static_assert(sizeof(DevItem) == 64, "descriptor layout");
 // trips; the forces are added to F one by one, in the reference's order.  Both sides of a
 // sphere pair see force(own, other): cf(a,b) == -cf(b,a) bit for bit, so no sign flip is needed.
 __device__ __forceinline__ void eval_ssq(const ItemW& I, const DevWorld& W, const DevStepArgs& args,
-                                         const float* tile, bool movable, v2& F) {
+                                         const float* tile, bool movable, v2& F, bool live) {
   const uint4 w0 = I.w0, w1 = I.w1, w2 = I.w2, w3 = I.w3;
   const int n = sgpr((int)w0.y);
   const float* E = tile + (int)w1.x;
@@ -146,7 +146,7 @@ __device__ __forceinline__ void eval_ssq(const ItemW& I, const DevWorld& W, cons
     const float m = rs[k] + 1e-4f;  // the force is exactly 0 for dist > r_a + r_b (core.py:2836)
     bool need = !far_apart(dx * dx + dy * dy, m * m);
     bool on = k < n;
-    if (args.pair_mask) on = on && ((mask_word(args.pair_mask, sgpr(idx[k]) >> 5) >> (sgpr(idx[k]) & 31)) & 1u);
+    on = on && pair_on(args, sgpr(idx[k]));
     needbits |= (on && __any(need)) ? (1u << k) : 0u;
   }
   if (!needbits || (ABLATE(args) & 32)) return;
@@ -154,31 +154,41 @@ __device__ __forceinline__ void eval_ssq(const ItemW& I, const DevWorld& W, cons
   for (int k = 0; k < 4; ++k) {
     if (needbits & (1u << k)) {
       const v2 f = contact_force(pe, po[k], rs[k], W.c_coll, W.k);
+      // (lazy form: a sphere pair's only band events are non-finite poses - NaN force, circles "apart": rs is the pair's
+      //  bounding-circle sum, host-checked)
+      if (lazy_noting(args)) {
+        const bool ov = live && vnorm(pe - po[k]) <= rs[k];
+        lazy_acc_overlap(args, sgpr(idx[k]), ov);  // (overlapping spheres are within reach: this is the only place to look)
+        lazy_note_band(args, sgpr(idx[k]), live && !ov && (f.x != 0.f || f.y != 0.f));
+      }
       if (movable) F = F + f;
     }
   }
 }
 
-// Line-sphere pairs seen from the SPHERE (the owner; lines are mostly static walls), four lines to a record:
-//   w0: type, n, own offset, r + LINE_MIN_DIST   w1: line offsets 0|1, 2|3, trig offsets 0|1, 2|3 (16 bit each)
-//   w2: half lengths 0..3   w3: pair index 0|1<<16, 2|3<<16
+// Line-sphere pairs seen from the SPHERE (the owner; lines are mostly static walls), up to THREE lines to a record (four
+// until round 6: the fourth line's words now carry the pairs' bounding-circle thresholds, circles_overlap):
+//   w0: type, n, own offset, r + LINE_MIN_DIST   w1: line offsets 0|1, 2|-, trig offsets 0|1, 2|- (16 bit each)
+//   w2: half lengths 0..2, threshold 0   w3: pair index 0|1<<16, 2, thresholds 1..2
 // Same arithmetic as the unpacked item (own(-cf(sphere, cp)) with the b-side sign flip == cf(sphere, cp) bit for
-// bit), one descriptor fetch and sixteen operand reads in flight instead of four dependent round trips.
+// bit), one descriptor fetch and twelve operand reads in flight instead of three dependent round trips.
+constexpr int LSQ_N = 3;
 __device__ __forceinline__ void eval_lsq(const ItemW& I, const DevWorld& W, const DevStepArgs& args,
-                                         const float* tile, bool movable, v2& F) {
+                                         const float* tile, bool movable, v2& F, bool live) {
   const uint4 w0 = I.w0, w1 = I.w1, w2 = I.w2, w3 = I.w3;
   const int n = sgpr((int)w0.y);
   const float* E = tile + (int)w0.z;
   const float dist_min = __uint_as_float(w0.w);
   const v2 ps = V(E[0], E[ROWF]);
-  const int lo[4] = {(int)(w1.x & 0xffffu), (int)(w1.x >> 16), (int)(w1.y & 0xffffu), (int)(w1.y >> 16)};
-  const int to[4] = {(int)(w1.z & 0xffffu), (int)(w1.z >> 16), (int)(w1.w & 0xffffu), (int)(w1.w >> 16)};
-  const float half[4] = {__uint_as_float(w2.x), __uint_as_float(w2.y), __uint_as_float(w2.z), __uint_as_float(w2.w)};
-  const int idx[4] = {(int)(w3.x & 0xffffu), (int)(w3.x >> 16), (int)(w3.y & 0xffffu), (int)(w3.y >> 16)};
-  v2 pl[4];
-  float cs[4], sn[4];
+  const int lo[LSQ_N] = {(int)(w1.x & 0xffffu), (int)(w1.x >> 16), (int)(w1.y & 0xffffu)};
+  const int to[LSQ_N] = {(int)(w1.z & 0xffffu), (int)(w1.z >> 16), (int)(w1.w & 0xffffu)};
+  const float half[LSQ_N] = {__uint_as_float(w2.x), __uint_as_float(w2.y), __uint_as_float(w2.z)};
+  const float thr[LSQ_N] = {__uint_as_float(w2.w), __uint_as_float(w3.z), __uint_as_float(w3.w)};
+  const int idx[LSQ_N] = {(int)(w3.x & 0xffffu), (int)(w3.x >> 16), (int)(w3.y & 0xffffu)};
+  v2 pl[LSQ_N];
+  float cs[LSQ_N], sn[LSQ_N];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {  // unused slots repeat line 0 on the host: always valid rows
+  for (int k = 0; k < LSQ_N; ++k) {  // unused slots repeat line 0 on the host: always valid rows
     const float* L = tile + lo[k];
     const float* T = tile + to[k];
     pl[k] = V(L[0], L[ROWF]);
@@ -187,7 +197,7 @@ __device__ __forceinline__ void eval_lsq(const ItemW& I, const DevWorld& W, cons
   }
   uint32_t needbits = 0;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < LSQ_N; ++k) {
     // In the line's frame: the sphere's centre is farther than `m` from the segment's supporting line, or farther than
     // `m` beyond one of its ends -> the closest point of the segment is farther than dist_min and the force is exactly 0
     // (core.py:2836).  Football's walls span the pitch, their bounding circles never reject anything.  Only FINITE
@@ -203,15 +213,18 @@ __device__ __forceinline__ void eval_lsq(const ItemW& I, const DevWorld& W, cons
     bool need = !far_apart(dx * dx + dy * dy, m * m) || cs[k] != cs[k];
 #endif
     bool on = k < n;
-    if (args.pair_mask) on = on && ((mask_word(args.pair_mask, sgpr(idx[k]) >> 5) >> (sgpr(idx[k]) & 31)) & 1u);
+    on = on && pair_on(args, sgpr(idx[k]));
+    if (lazy_noting(args) && k < n) lazy_acc_overlap(args, sgpr(idx[k]), live && circles_overlap(dx, dy, thr[k]));
     needbits |= (on && __any(need)) ? (1u << k) : 0u;
   }
   if (!needbits || (ABLATE(args) & 32)) return;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < LSQ_N; ++k) {
     if (needbits & (1u << k)) {  // core.py:2341-2392
       const v2 cp = closest_point_line<true>(pl[k], cs[k], sn[k], half[k], ps);
       const v2 f = contact_force(ps, cp, dist_min, W.c_coll, W.k);
+      if (lazy_noting(args))  // (the padding columns of a tail tile are no environments)
+        lazy_note_band(args, sgpr(idx[k]), live && !circles_overlap(pl[k].x - ps.x, pl[k].y - ps.y, thr[k]) && (f.x != 0.f || f.y != 0.f));
       if (movable) F = F + f;
     }
   }
@@ -222,7 +235,7 @@ __device__ __forceinline__ void eval_lsq(const ItemW& I, const DevWorld& W, cons
 //   w0: type, n, tile offset of the first pair's rows (pair k: + 2k rows), -
 //   w1: a offsets 0|1<<16, 2|3<<16, b offsets 0|1<<16, 2|3<<16   w2: r_sum 0..3   w3: pair index 0|1<<16, 2|3<<16
 __device__ __forceinline__ void eval_ssp(const ItemW& I, const DevWorld& W, const DevStepArgs& args, float* tile,
-                                         uint32_t* fired) {
+                                         uint32_t* fired, bool live) {
   const uint4 w0 = I.w0, w1 = I.w1, w2 = I.w2, w3 = I.w3;
   const int n = sgpr((int)w0.y);
   const int rec = sgpr((int)w0.w);  // ordinal among the shared sphere-sphere records
@@ -246,7 +259,7 @@ __device__ __forceinline__ void eval_ssp(const ItemW& I, const DevWorld& W, cons
     const float m = rs[k] + 1e-4f;  // the force is exactly 0 for dist > r_a + r_b (core.py:2836)
     bool need = !far_apart(dx * dx + dy * dy, m * m);
     bool on = k < n;
-    if (args.pair_mask) on = on && ((mask_word(args.pair_mask, sgpr(idx[k]) >> 5) >> (sgpr(idx[k]) & 31)) & 1u);
+    on = on && pair_on(args, sgpr(idx[k]));
     needbits |= (on && __any(need)) ? (1u << k) : 0u;
   }
   if (ABLATE(args) & 32) needbits = 0;
@@ -260,7 +273,14 @@ __device__ __forceinline__ void eval_ssp(const ItemW& I, const DevWorld& W, cons
   for (int k = 0; k < 4; ++k) {
     if (k < n && (!published || (needbits & (1u << k)))) {
       v2 f = V(0.f, 0.f);
-      if (needbits & (1u << k)) f = contact_force(pa[k], pb[k], rs[k], W.c_coll, W.k);
+      if (needbits & (1u << k)) {
+        f = contact_force(pa[k], pb[k], rs[k], W.c_coll, W.k);
+        if (lazy_noting(args)) {  // (non-finite poses: see eval_ssq)
+          const bool ov = live && vnorm(pa[k] - pb[k]) <= rs[k];
+          lazy_acc_overlap(args, sgpr(idx[k]), ov);
+          lazy_note_band(args, sgpr(idx[k]), live && !ov && (f.x != 0.f || f.y != 0.f));
+        }
+      }
       R[(2 * k) * ROWF] = f.x;
       R[(2 * k + 1) * ROWF] = f.y;
     }
@@ -313,11 +333,12 @@ __device__ __forceinline__ void eval_item(const ItemV& K, const DevWorld& W, con
     f_out = own(fa);
     return;
   }
-  if (args.pair_mask && !((mask_word(args.pair_mask, K.index >> 5) >> (K.index & 31)) & 1u)) return;
+  if (!pair_on(args, K.index)) return;
   const float* TA = tile + K.tra;
   const float* TB = tile + K.trb;
   {  // conservative per-environment broad phase: beyond it the force is exactly zero
     const float dx = pa.x - pb.x, dy = pa.y - pb.y;
+    if (lazy_noting(args)) lazy_acc_overlap(args, K.index, live && circles_overlap(dx, dy, K.q0));
     bool need = !far_apart(dx * dx + dy * dy, K.thr2);
     if (VMAS_X_TIGHT_LS && K.type == VMAS_PAIR_LS) {  // a is a line: the sphere's gaps to the segment in the line's frame (see eval_lsq)
       const float along = fabsf(dx * TA[0] + dy * TA[ROWF]) - K.p0;
@@ -403,5 +424,60 @@ __device__ __forceinline__ void eval_item(const ItemV& K, const DevWorld& W, con
       break;
     default: break;
   }
+  // the lazy form's optimistic pass (K.q0: circles_overlap's threshold of the pair; the padding columns of a tail tile are no
+  // environments)
+  if (lazy_noting(args))
+    lazy_note_band(args, K.index, live && !circles_overlap(pa.x - pb.x, pa.y - pb.y, K.q0) &&
+                                      (f_out.x != 0.f || f_out.y != 0.f || t_out != 0.f || tb_out != 0.f));
 }
 
+// ---- the lazy exact broad phase around an optimistic gather pass (vmas_env_device.h), for the interpreter and its
+// world-specialised forms.
+// LDS layout at lz_words (lzp = pair words rounded up to 4): [2 parities][overlap words | band words] | need | batch | flag [4].
+//   lazy_overlap_blob  IN FRONT of the gather (the tile's positions are in LDS): which pairs some environment of the tile has
+//                      overlapping bounding circles - the pair table of the blob, pair p by wave p mod nw, two in flight -
+//                      then a block barrier and the tile's words go out (lazy_publish): they travel while the tile gathers,
+//                      and the tiles that will ask find them there.  (Published behind the gather in the first version,
+//                      the write-through store's latency sat on the launch's tail: transport 16 384: 4.5 -> 6.7 us.)
+//   lazy_after_pass    behind the barrier that ends the gather: did an item note a band event (lz_s)?  Then one wave asks
+//                      the batch (lazy_collect).  Returns true - with args.lz_g = the batch's words and the gather counter
+//                      re-armed - if the pass has to be made again with a pair off.
+constexpr int SPEC_LZP = 4;                          // the specialised kernels: worlds of at most 128 pairs
+constexpr int SPEC_TAIL_WORDS = 8 + 6 * SPEC_LZP + 4;  // their LDS behind the tile: counters [4] | fired words [4] | the lazy words
+__device__ __forceinline__ void lazy_overlap_blob(const DevStepArgs& args, const uint32_t* table, int n_pairs, const float* tile,
+                                                  bool live, int wv, int nw, int pass) {
+  for (int p0 = 2 * wv; p0 < n_pairs; p0 += 2 * nw) {
+    const int p1 = p0 + 1 < n_pairs ? p0 + 1 : p0;
+    const uint4 d0 = *(const uint4*)(table + 4 * p0), d1 = *(const uint4*)(table + 4 * p1);
+    const float* A0 = tile + (int)d0.x; const float* B0 = tile + (int)d0.y;
+    const float* A1 = tile + (int)d1.x; const float* B1 = tile + (int)d1.y;
+    const float ax0 = A0[0], ay0 = A0[ROWF], bx0 = B0[0], by0 = B0[ROWF], ax1 = A1[0], ay1 = A1[ROWF], bx1 = B1[0], by1 = B1[ROWF];
+    const bool h0 = live && circles_overlap(ax0 - bx0, ay0 - by0, __uint_as_float(d0.z));
+    const bool h1 = live && circles_overlap(ax1 - bx1, ay1 - by1, __uint_as_float(d1.z));
+    if (__any(h0) && (threadIdx.x & (TILE - 1)) == 0) atomicOr(&args.lz_x[p0 >> 5], 1u << (p0 & 31));  // (LDS)
+    if (__any(h1) && (threadIdx.x & (TILE - 1)) == 0) atomicOr(&args.lz_x[p1 >> 5], 1u << (p1 & 31));
+  }
+  __syncthreads();
+  extern __shared__ uint32_t lazy_lds_base[];
+  lazy_publish(args.lz, pass, (int)(args.lz_x - lazy_lds_base));
+}
+__device__ __forceinline__ bool lazy_after_pass(DevStepArgs& args, int pass, uint32_t* lz_words, int lzp, int* c_gather, int c_init) {
+  const int mw = args.lz.words;
+  bool open = false;
+  for (int w = 0; w < mw; ++w) open = open || (args.lz_s[w] & ~args.lz_x[w]) != 0u;  // (uniform LDS reads)
+  if (!open) return false;
+  uint32_t* need = lz_words + 4 * lzp;
+  uint32_t* got = need + lzp;
+  uint32_t* flag = got + lzp;  // [4]: collect's two scratch words | - | -
+  for (int w = threadIdx.x; w < mw; w += blockDim.x) need[w] = args.lz_s[w] & ~args.lz_x[w];  // (lz_s is complete: the caller's barrier)
+  __syncthreads();
+  extern __shared__ uint32_t lazy_lds_base[];
+  const int again = lazy_collect(args.lz, pass, (int)(need - lazy_lds_base), (int)(got - lazy_lds_base), (int)(flag - lazy_lds_base));
+  if (again == 0) return false;
+  __syncthreads();
+  for (int w = threadIdx.x; w < mw; w += blockDim.x) got[w] = ~(need[w] & ~got[w]);  // every pair on but the needed ones that stayed clear
+  if (threadIdx.x == 0) c_gather[0] = c_init;
+  __syncthreads();
+  args.lz_g = got;
+  return true;
+}

@@ -48,6 +48,8 @@ struct DevWorld {
   int32_t blob_words;   // words staged (items only when they fit the LDS budget)
   int32_t off_blob;     // tile offset (floats) of the blob copy in LDS
   int32_t b_ent, b_segs, b_owned, b_refs, b_items;
+  int32_t b_pairs, n_pairs;  // the pair table in front of the items: [n_pairs][4] = tile offsets of a / b, circles_overlap's
+                             // threshold, - ; then 4 words {n_pairs, -, -, -} (b_pairs = b_items - 4 - 4 * n_pairs)
   int32_t n_segs, n_owned;
   int32_t items_in_lds;
   int32_t fired_recs;    // shared sphere-sphere records (eval_ssp) that publish which of their pairs fired (<= 16)
@@ -72,6 +74,19 @@ struct DevStepArgs {
   int32_t first_substep, n_substeps;
   int32_t n_steps;    // > 1: persistent rollout, the tile stays in LDS between steps
   long ft_stride;     // floats between the agent-force slabs of consecutive steps
+  // the LAZY exact broad phase (vmas_env_device.h, LazyArgs): filled by the host (lz.slots == NULL: off) ...
+  LazyArgs lz;
+  // ... and, set by the kernel itself, its words in LDS: the pairs some environment of this tile overlaps (lz_x, [words]:
+  // made in front of the gather and published at once), the pairs one of its environments is in the band of without an
+  // overlapping environment of the tile (lz_s: noted by the items of the optimistic pass; NULL: not noting) and, in the pass
+  // made again for a tile that had to, the batch's words (lz_g; NULL in the optimistic pass)
+  uint32_t* lz_x;
+  uint32_t* lz_s;
+  const uint32_t* lz_g;
+  // (the world-specialised kernels make the overlap words WHILE they gather, from the positions an item has loaded anyway:
+  //  the wave's own words, in registers - pair indices are immediates there; flushed to lz_x behind the wave's last segment.
+  //  NULL: lz_x was made in front of the gather - lazy_overlap_blob, the interpreter)
+  uint32_t* lz_acc;
   unsigned long long* contacts;  // compacted kernel: device counter, + the contacts of every (tile, substep) (NULL: not counted)
   unsigned long long* trace;  // profiling only (env VMAS_TRACE): per-wave s_memtime stamps
   int32_t ablate;  // profiling only (env VMAS_ABLATE): 1 skip items, 2 skip integration, 4 skip prologue
@@ -115,7 +130,7 @@ constexpr uint32_t kLayoutHash =
     (uint32_t)sizeof(DevWorld) * 0x9E3779B1u ^ (uint32_t)sizeof(DevEnv) * 0x85EBCA77u ^ (uint32_t)sizeof(DevStepArgs) * 0xC2B2AE3Du ^
     (uint32_t)__builtin_offsetof(DevWorld, blob) * 0x27D4EB2Fu ^ (uint32_t)__builtin_offsetof(DevEnv, ingest) * 0x165667B1u ^
     (uint32_t)__builtin_offsetof(DevEnv, balance) * 0xD3A2646Cu ^ (uint32_t)sizeof(VmasActionSlot) * 0xFD7046C5u ^
-    (uint32_t)VMAS_ABI_VERSION * 0xB55A4F09u;
+    (uint32_t)VMAS_ABI_VERSION * 0xB55A4F09u ^ (uint32_t)sizeof(LazyArgs) * 0x68E31DA4u;
 
 // Profiling knobs (env VMAS_ABLATE / VMAS_ENV_ABLATE) exist only in -DVMAS_PROFILE builds (scripts/gpu_ablate.sh): in the
 // product build they are the literal 0, so their tests - and the scalar register that carried them through every loop -
@@ -132,6 +147,29 @@ __device__ __forceinline__ int sgpr(int v) { return __builtin_amdgcn_readfirstla
 // either way (until round 4 the exact form was read straight from the grid's slots, an agent-scope atomic load - a round
 // trip to the memory side - in front of every item).
 __device__ __forceinline__ uint32_t mask_word(const uint32_t* mask, int w) { return mask[w]; }
+// Is pair `idx` processed at all in this pass?  The caller's recorded mask / the barrier form's LDS copy (pair_mask), and -
+// only in the pass a tile makes AGAIN under the lazy form - the batch's words behind lazy_collect (lz_g, LDS).
+__device__ __forceinline__ bool pair_on(const DevStepArgs& a, int idx) {
+  if (a.pair_mask && !((mask_word(a.pair_mask, idx >> 5) >> (idx & 31)) & 1u)) return false;
+  if (a.lz_g && !((a.lz_g[idx >> 5] >> (idx & 31)) & 1u)) return false;
+  return true;
+}
+// The lazy form's note of an item of the optimistic pass whose narrow phase ran (uniform `idx`; lane = environment): some
+// environment is in the pair's band - bounding circles apart, force or torque not zero (a NaN counts: the reference would
+// not have evaluated the pair for it either) - and no environment of the TILE has the circles overlapping (lz_x: the tile's
+// own overlap words, complete before the gather starts - lazy_overlap_*): the batch's bit of the pair decides.
+__device__ __forceinline__ void lazy_note_band(const DevStepArgs& a, int idx, bool lane_in_band) {
+  if (!__any(lane_in_band)) return;
+  if (a.lz_acc == nullptr && ((a.lz_x[idx >> 5] >> (idx & 31)) & 1u)) return;  // (lz_x complete: an environment of the tile overlaps)
+  if ((threadIdx.x & 63) == 0) atomicOr(&a.lz_s[idx >> 5], 1u << (idx & 31));  // (LDS, no return value)
+}
+// (specialised kernels) some environment of the tile has pair `idx`'s bounding circles overlapping: into the wave's own words
+__device__ __forceinline__ void lazy_acc_overlap(const DevStepArgs& a, int idx, bool lane_overlaps) {
+  if (a.lz_acc != nullptr && __any(lane_overlaps)) a.lz_acc[idx >> 5] |= 1u << (idx & 31);
+}
+// is the optimistic pass of the lazy form running (the items note band events)?
+__device__ __forceinline__ bool lazy_noting(const DevStepArgs& a) { return a.lz_s != nullptr && a.lz_g == nullptr; }
+
 // A pair may be skipped only on a FINITE squared distance beyond its bound: a NaN or an infinite operand must reach the
 // narrow phase, where the reference's own arithmetic decides (inf * 0, cos(inf) ... = NaN poisons the pair however far
 // apart the shapes are).  Together with the NaN checks on the cos rows of Lines and Boxes this is why no separate

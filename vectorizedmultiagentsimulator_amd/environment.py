@@ -96,9 +96,9 @@ class Environment:
         # the whole step as ONE launch (vmas_world_step_env): ingest = prologue, post-step = epilogue of
         # the physics kernel.  Needs the hooks between the stages to be the base class no-ops.
         w = self.world
-        # (the exact broad phase runs inside the step launch while every 64-environment tile has a CU of its own)
-        exact_in_launch = (not w.exact_broad_phase or
-                           (self.num_envs + 63) // 64 <= torch.cuda.get_device_properties(self.device).multi_processor_count)
+        # (the exact broad phase runs inside the step launch - the lazy form, at any size - unless the library says it takes a
+        #  launch per substep for this world: vmas_world_exact_form)
+        exact_in_launch = not w.exact_broad_phase or w._get_backend().exact_form() != 3
         # (graph=True captures the generic step - ingest prologue + physics - when the scenario has no fused post-step; under
         # capture the exact broad phase runs one launch per substep (a replay would repeat a grid-barrier number), which
         # cannot carry the prologue: the stand-alone ingest kernel + World.step are captured instead)

@@ -429,7 +429,8 @@ class StepLauncher:
         """A gated launch must be the whole step and carry no grid barrier (include/vmas_env_hip.h)."""
         if self._be is None or self.env.world._backend is not self._be:
             self._bind()
-        return kind in (0, A.POST_BALANCE, A.POST_TRANSPORT) and not self._exact
+        # (the lazy form of the exact broad phase carries no barrier whose count the host advances: it can be gated)
+        return kind in (0, A.POST_BALANCE, A.POST_TRANSPORT) and (not self._exact or self._be.exact_form() <= 1)
 
     def gated(self, kind: int, desc, buffers):
         """``vmas_world_step_env_gated``: the step launch that does nothing if the validation in front of it raised flags."""
@@ -438,11 +439,12 @@ class StepLauncher:
             self._bind()
         w._query_cache = None
         args = None
-        if self._per_env:
-            jfr, eg = w._per_env_inputs()
+        if self._per_env or self._exact:
+            jfr, eg = w._per_env_inputs() if self._per_env else (None, None)
             sa = A.StepArgs()
             sa.joint_fixed_rot = jfr.data_ptr() if jfr is not None else None
             sa.entity_gravity = eg.data_ptr() if eg is not None else None
+            sa.exact_broad_phase = 1 if self._exact else 0
             args = C.byref(sa)
         rc = self._gated_fn(self._h, self._st, self._ft, self._ld, args, self._ing, self._gate, kind,
                             C.byref(desc) if desc is not None else None, C.byref(buffers) if buffers is not None else None,
