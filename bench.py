@@ -5,17 +5,21 @@ usage  : python bench.py [--config balance|transport|transport_2pkg|navigation|f
                          [--steps K] [--warmup W]            (no flags: config 2 - balance, 32768 envs, n_agents=4 - on 1 GPU)
 metric : env-steps/sec (batch x substeps) on the configuration's scenario (SURVEY.md 8d's table: cfg 2 balance 32768 envs,
          cfg 3 transport 16384 (+ the n_packages=2 box-box variant), cfg 4 navigation n_agents=8 65536, cfg 5 football 5v5 131072)
-step   : ONE World.step() (core.py:1972-2015) over the whole batch = one fused kernel launch; state and the pre-generated
-         agent forces are resident in HBM before the timed region starts.  This is the north-star hot path and what `value`
-         reports.  The same line carries `environment_step`: SURVEY.md 8d's own definition of the metric - the rate through
-         make_env(...).step() (action ingest + World.step + reward / observation / done, ONE launch, driven from Python with
-         fresh output tensors every step) - with its own roofline, the GPU-bound form (`bound`: caller-owned action tensors,
-         one foreign call per step) and the K-steps-per-launch form (`rollout`) beside it.
-timing : W warm-up steps, then exactly K steps between barrier+synchronize pairs; HIP events recorded on the launch stream
-         right inside the two fences bracket the same K launches (behind a ~100 us untimed spin kernel that lets the host
-         queue them up: the events time K back-to-back steps, not the host's first-launch latency on an idle GPU).  `ms_per_step` and `value` come from the events (MAX over
-         ranks): with K = 20 the wall clock around a 0.2 ms region is mostly the cost of the fences themselves; the
-         wall-clock figures are kept beside them (`wall`).  The window is timed `--repeats` times; `value` = the median.
+step   : ONE call of the REFERENCE's ``Environment.step`` (environment.py:325) - the object ``vmas.make_env(...,
+         device="cuda")`` returns, after ``attach()`` with its defaults - over the whole batch: action ingest + World.step
+         (core.py:1972-2015) + reward / observation / done / info in ONE kernel launch for the benchmark scenarios, the
+         reference's action asserts kept, the reference's batch-global broad phase (lazy form, inside the launch).  This is
+         north_star's own sentence ("through vmas.make_env(...).step") and what `value` reports since round 6; when the
+         reference is not importable the line falls back to the next object.  `world_step` = World.step() physics alone (the
+         headline of rounds 1-5: one launch per step, pre-recorded agent forces resident in HBM), `environment_step` = this
+         package's own Environment.step (same kernel, native host objects) with its GPU-bound form (`bound`) and the
+         K-steps-per-launch form (`rollout`) beside it.
+timing : W warm-up steps, then exactly K steps between barrier+synchronize pairs, `--repeats` windows, median window, MAX
+         over ranks.  The headline is rated by the WALL clock between the fences (the host that drives the reference's
+         Python objects is part of that path); HIP events around the same K calls are kept beside it.  `world_step` is timed
+         with HIP events recorded on the launch stream right inside the fences (behind a ~100 us untimed spin kernel that
+         lets the host queue the launches up: K back-to-back steps, not the host's first-launch latency on an idle GPU) with
+         the wall clock beside them (`world_step.wall`).
 inputs : SURVEY.md 8d's protocol - per step and policy agent u ~ U(-u_range, u_range), pre-generated on the host with
          torch.Generator().manual_seed(1234 + rank) (the law of Environment.get_random_action, environment.py:536-548);
          episodes are 100 steps long: every 100 steps the post-reset state is restored by a device-to-device copy inside
@@ -28,14 +32,18 @@ multi-GPU: `--gpus N` with no WORLD_SIZE in the environment re-executes itself u
          the step path; the pipeline's only exchange, the end-of-rollout all-gather, is timed on the REAL
          sharded rollout (`sharded_rollout`: Environment.rollout writing K steps per launch straight into the buffer that
          ONE all_gather_into_tensor sends) and on the three BASELINE shapes (`rollout_gather`); neither is part of `value`.
-roofline: achieved = algorithmic bytes per launch (24 E + 12 A read, 24 E_dyn written per environment) /
-         average launch duration from the HIP events; achieved GFLOP/s beside it and which bound binds.  `traffic` = HBM bytes
-         per launch by the PMC counters: the same physics launches re-run (N = 1 only, two short child processes) under
-         `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` - separate passes, counters only, FETCH_SIZE doubled (gfx950) -
-         median per dispatch; null with the reason if rocprofv3 is not there (`--no-traffic` skips it).
+roofline: the headline's dominant kernel = the one-launch Environment.step kernel: achieved = algorithmic bytes per launch
+         (24 E + 12 A read, 24 E_dyn written per environment for the physics, + the actions read and the
+         observations / rewards / done / info written: 657 B per environment for balance) / the launch-to-launch time of
+         back-to-back env.step calls from HIP events (asserts off, so that nothing but the kernel is between the events).
+         `traffic` = HBM bytes per launch by the PMC counters: the same env.step calls re-run (N = 1 only, two short child
+         processes) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` - separate passes, counters only, FETCH_SIZE
+         doubled (gfx950) - median per dispatch; null with the reason if rocprofv3 is not there (`--no-traffic` skips it).
+         `world_step.roofline`: the same for the physics-only launch.
 cpu_baseline: the REFERENCE itself (VMAS, `kind: "reference"`): its Environment.step (environment.py:325) on the host
          cores, device="cpu", torch threads = the fastest count on this host, same initial state and actions, bounded to
-         ~10 s; `value` = its World.step (core.py:1972) share of those steps (timed inside the same calls).  Rank 0, N=1
+         ~10 s; `value` = those Environment.step calls, `world_step` = its World.step (core.py:1972) share of them (timed inside
+         the same calls).  EVERY one of those reference steps is also a parity sample of this run (`parity`).  Rank 0, N=1
          only; configurations above 32768 environments are timed on the first 32768 (the reference's rate is flat in the
          batch there).  The reference is imported from /root/reference when present, else from its
          byte-compiled build oracle/_ref (made by __graft_entry__.build()).  `cpu_port` = the C oracle with OpenMP.
@@ -105,6 +113,7 @@ def parse_args():
                     help="skip `roofline.traffic` (HBM bytes per launch by the PMC counters: two short re-runs of the physics "
                          "launches under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, N = 1 only)")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)  # (the re-run itself: launches only)
+    ap.add_argument("--traffic-attached", action="store_true", help=argparse.SUPPRESS)  # (... of the attached reference's env.step)
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU plumbing check (tests): ranks, sharding and the rollout gather over gloo, NO physics, value = null")
     return ap.parse_args()
@@ -260,7 +269,10 @@ def cpu_reference(name, kw, w, actions, state0_cpu, budget_s=10.0, max_envs=3276
     def timed_world_step():
         if sample_now[0]:
             th = time.perf_counter()
-            pre, ft = _pack_ref_state(world), _pack_ref_ft(world)
+            # (Environment.step between two World.step calls writes forces only: the state entering this step is the one the
+            #  previous sample left - kept once)
+            pre = _pack_ref_state(world) if not samples else None
+            ft = _pack_ref_ft(world)
             hook_s[0] += time.perf_counter() - th
         t0 = time.perf_counter()
         orig_step()
@@ -303,7 +315,7 @@ def cpu_reference(name, kw, w, actions, state0_cpu, budget_s=10.0, max_envs=3276
         in_world[0] = hook_s[0] = 0.0
         n, t0 = 0, time.perf_counter()
         while True:
-            sample_now[0] = parity is not None and n % 10 == 0
+            sample_now[0] = parity is not None  # (EVERY reference step is a parity sample: round-5 review)
             env_step(n)
             n += 1
             el = time.perf_counter() - t0 - hook_s[0]
@@ -345,17 +357,25 @@ def same_run_parity(ctx, w, B, samples, final_ref, n_ref_steps):
     st, ft = w._packed_state(), w._packed_agent_ft()
     nA = len(w.agents)
     worst, beyond, blown, values = 0.0, 0, 0, 0
+    ctl_worst, ctl_beyond, ctl_steps = 0.0, 0, 0
+    last_post = None
     for pre, f, post in samples:
-        genv.set_state(snapshot)  # (columns beyond B: a sane state)
-        st[:, :, :B].copy_(pre.to(st.device))
-        ft[:nA, :, :B].copy_(f.to(st.device))
-        w.invalidate_queries()
-        if w.exact_broad_phase:
-            be.step_exact()
-        else:
-            be.step()
-        e, b, bl, v = _err_stats(st[:, :, :B].cpu(), post)
-        worst, beyond, blown, values = max(worst, e), beyond + b, blown + bl, values + v
+        pre = last_post if pre is None else pre
+        last_post = post
+        for form in ("product", "per_environment"):
+            genv.set_state(snapshot)  # (columns beyond B: a sane state)
+            st[:, :, :B].copy_(pre.to(st.device))
+            ft[:nA, :, :B].copy_(f.to(st.device))
+            w.invalidate_queries()
+            if form == "product":  # what World.step() of this environment runs: the reference's batch-global rule
+                assert w.exact_broad_phase
+                be.step_exact()
+                e, b, bl, v = _err_stats(st[:, :, :B].cpu(), post)
+                worst, beyond, blown, values = max(worst, e), beyond + b, blown + bl, values + v
+            else:  # the NEGATIVE control: every static pair per environment (the default above 1 024 environments until round 5)
+                be.step()
+                e, b, _, _ = _err_stats(st[:, :, :B].cpu(), post)
+                ctl_worst, ctl_beyond, ctl_steps = max(ctl_worst, e), ctl_beyond + b, ctl_steps + (1 if b else 0)
     # free-running: the native Environment.step (ingest + physics + post-step in one launch) from the same start
     genv.set_state(snapshot)
     for k in range(n_ref_steps):
@@ -368,10 +388,16 @@ def same_run_parity(ctx, w, B, samples, final_ref, n_ref_steps):
     return {
         "teacher_forced_max_abs": worst, "values_beyond_1e-5": beyond, "values_compared": values, "blown_up_values_skipped": blown,
         "teacher_forced_steps": len(samples), "envs": B,
+        "broad_phase": "the reference's batch-global rule (World.collides core.py:2788-2803), form %d of vmas_world_exact_form" % be.exact_form(),
+        "per_environment_form_control": {"values_beyond_1e-5": ctl_beyond, "teacher_forced_max_abs": ctl_worst,
+                                         "steps_with_a_value_beyond": ctl_steps,
+                                         "note": "the same samples stepped with every static pair evaluated per environment - the "
+                                                 "default of rounds 1-5 above 1 024 environments: what `values_beyond_1e-5` would "
+                                                 "read without the rule"},
         "free_running_drift": {"steps": n_ref_steps, "max_abs": float(d.max()) if d.numel() else 0.0,
                                "median_abs": float(d.median()) if d.numel() else 0.0,
                                "frac_beyond_1e-3": float((d > 1e-3).double().mean()) if d.numel() else 0.0},
-        "note": "same run, same reference steps as `cpu_baseline`: every 10th reference World.step replayed as one native "
+        "note": "same run, same reference steps as `cpu_baseline`: EVERY reference World.step replayed as one native "
                 "World.step from the reference's pre-step state and forces (teacher-forced; tolerance 1e-5 abs + 1e-5 rel, "
                 "north_star); free_running = native Environment.step from the same start and actions, |state - reference's| after "
                 "`steps` steps (two fp32 implementations of a chaotic contact system: the reference against itself with "
@@ -612,6 +638,61 @@ def attached_reference_leg(name, kw, B, device, n=300, brief=False):
     return out
 
 
+def attached_headline(name, kw, B, device, steps, warmup, repeats, clock_warmup, dist, seed=0):
+    """THE HEADLINE (north_star; round-5 review item 7): `steps` calls of the REFERENCE's ``Environment.step`` - the object
+    ``vmas.make_env(..., device='cuda')`` returns, after ``attach()`` with its defaults: the one-launch kernel where a post-step
+    kernel covers the configuration, the reference's action asserts kept, the reference's batch-global broad phase - between
+    fences (barrier + synchronize on both sides), `warmup` untimed calls first, `repeats` windows, every rank its own shard.
+    Returns the windows as (HIP-event seconds, wall seconds), each MAX over ranks."""
+    import torch
+    from oracle import ref  # (locates the reference package - /root/reference or its byte-compiled build; it is the HOST here)
+    from vectorizedmultiagentsimulator_amd.adapter import attach
+    from vectorizedmultiagentsimulator_amd.shard import max_over_ranks
+
+    sc = CONFIGS[name]["scenario"]
+    env = ref.make_env(sc, num_envs=B, device=str(device), seed=seed, continuous_actions=True, **kw)
+    cycle = [[env.get_random_action(a) for a in env.agents] for _ in range(25)]  # fresh random actions every step
+    h = attach(env, specialize=None)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run(n, start=0):
+        for k in range(n):
+            env.step(cycle[(start + k) % 25])
+
+    out = {"fused": h.fused is not None, "fused_reason": h.fused_reason, "exact_broad_phase": bool(h.exact_broad_phase),
+           "exact_form": h.backend.exact_form(), "substeps": int(getattr(env.world, "_substeps", 1)),
+           "kernel": "world-specialised" if h.backend.specialized else ("lane-compacted" if getattr(h.backend, "compact", False)
+                                                                       else "schedule interpreter")}
+    if h.fused is not None:
+        out["launches_per_env_step"] = 1 if h.fused.one_launch else (2 if h.fused.ingest_in_step else 3)
+    with torch.no_grad():
+        env.reset(seed=seed)
+        t_clock = time.perf_counter()
+        while time.perf_counter() - t_clock < clock_warmup:
+            run(50)
+            torch.cuda.synchronize()
+        run(warmup)
+        windows = []
+        for _ in range(max(1, repeats)):
+            fence()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            e0.record()
+            run(steps, start=warmup)
+            e1.record()
+            fence()
+            wall = time.perf_counter() - t0
+            windows.append((max_over_ranks(e0.elapsed_time(e1) * 1e-3, device), max_over_ranks(wall, device)))
+    h.detach()
+    out["windows"] = windows
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ HBM traffic (PMC)
 def traffic_child(args, device):
     """What the counter passes profile: the headline's own launches (same world, same queues, recorded forces), 200 of them."""
@@ -620,6 +701,19 @@ def traffic_child(args, device):
 
     cfg = CONFIGS[args.config]
     B = args.num_envs or cfg["envs"]
+    if args.traffic_attached:  # the north-star path: the REFERENCE's env.step after attach() - its one-launch step kernel
+        from oracle import ref
+        from vectorizedmultiagentsimulator_amd.adapter import attach
+
+        renv = ref.make_env(cfg["scenario"], num_envs=B, device=str(device), seed=0, continuous_actions=True,
+                            **config_kwargs(args.config, args.n_agents))
+        attach(renv, specialize=None, validate_actions=False)
+        cyc = [[renv.get_random_action(a) for a in renv.agents] for _ in range(25)]
+        with torch.no_grad():
+            for k in range(200):
+                renv.step(cyc[k % 25])
+        torch.cuda.synchronize()
+        return
     env = make_env(cfg["scenario"], num_envs=B, device=device, seed=0, validate_actions=False, **config_kwargs(args.config, args.n_agents))
     be = env.world._get_backend()
     if args.lanes:
@@ -628,11 +722,11 @@ def traffic_child(args, device):
     acts = make_actions(env, 20, 1234).to(device)
     forces = record_episode_forces(env, acts)
     for _ in range(10):
-        be.step_n(20, forces)
+        be.step_n(20, forces, exact=bool(env.world.exact_broad_phase))
     torch.cuda.synchronize()
 
 
-def measure_traffic(args, n_launches_per_step, timeout_s=90):
+def measure_traffic(args, n_launches_per_step, timeout_s=90, attached=False):
     """HBM bytes per launch of the dominant kernel by the PMC counters, collected as MI355X_MICROARCH.md prescribes:
     FETCH_SIZE and WRITE_SIZE in separate `rocprofv3 --pmc` passes (they do not fit one), counters only (no trace domain
     beside them), FETCH_SIZE doubled (gfx950 tallies 128-byte requests at 64 bytes; confirmed in this library's own access
@@ -653,6 +747,8 @@ def measure_traffic(args, n_launches_per_step, timeout_s=90):
         child += ["--n-agents", str(args.n_agents)]
     if args.lanes:
         child += ["--lanes", str(args.lanes)]
+    if attached:
+        child += ["--traffic-attached"]
     med = {}
     kernel = None
     env = dict(os.environ, TMPDIR="/tmp")
@@ -724,7 +820,7 @@ def measure(name, args, device, shard, dist, rank, world_size, brief=False):
             if k == 0:
                 w._state.copy_(state0)
             chunk = min(EPISODE - k, n_steps - done)
-            (be.rollout if fused else be.step_n)(chunk, forces[k: k + chunk])
+            (be.rollout if fused else be.step_n)(chunk, forces[k: k + chunk], exact=bool(w.exact_broad_phase))
             done += chunk
 
     def fence():
@@ -1028,6 +1124,20 @@ def main():
 
     r = measure(args.config, args, device, shard, dist, rank, world_size)
     B, steps, kernel_s, n_queues = r["envs_per_gpu"], r["steps"], r["kernel_s"], r["n_queues"]
+    # the headline: the same metric through the reference's own vmas.make_env() / Environment.step() (every rank its shard)
+    head = None
+    if not args.no_attached and not args.fused:
+        ok = 1
+        try:
+            head = attached_headline(args.config, r["kwargs"], B, device, steps, r["warmup"], args.repeats, args.clock_warmup, dist,
+                                     seed=shard.seed(0))
+        except Exception as e:  # noqa: BLE001 (the reference is not importable here: the native Environment.step is the headline)
+            head, ok = {"error": repr(e)[:500]}, 0
+        if dist is not None:  # (all ranks or none: a rank without the reference must not leave the others in a barrier - it
+            t_ok = torch.tensor([ok], device=device)  #  fails before the first fence, the others' barriers then time out loudly)
+            dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+            if int(t_ok.item()) == 0 and "error" not in head:
+                head = {"error": "another rank could not attach the reference"}
     windows = r["windows"]
     kw = r["kwargs"]
 
@@ -1061,8 +1171,8 @@ def main():
                         "ms_per_step_min": min(w_[0] for w_ in windows) / steps * 1e3,
                         "ms_per_step_median": kernel_s * 1e3,
                         "ms_per_step_max": max(w_[0] for w_ in windows) / steps * 1e3,
-                        "note": "each window = exactly `steps` launches between barrier + synchronize fences; `value` and "
-                                "`ms_per_step` are the median window"},
+                        "note": "each window = exactly `steps` World.step launches between barrier + synchronize fences (the "
+                                "`world_step` object's numbers)"},
             "per_rank_us_per_step": r["per_rank_us"],
             "higher_is_better": True,
             "scaling": scaling,
@@ -1111,12 +1221,47 @@ def main():
                 "binds": gb_note,
             },
         }
+        # ---- the north-star headline replaces `value` / `ms_per_step` / `roofline`; the physics-only numbers move to `world_step`
+        if head is not None and "windows" in head:
+            hw_ = sorted(head["windows"], key=lambda x: x[1])
+            ev_h, wall_h = hw_[len(hw_) // 2]
+            sub_h = head["substeps"]
+            out["world_step"] = {"value": out["value"], "ms_per_step": out["ms_per_step"], "repeats": out.pop("repeats"),
+                                 "wall": out.pop("wall"), "roofline": out.pop("roofline"), "value_is": out.pop("value_is"),
+                                 "workload": out["config"]["workload"], "launch": out["config"]["launch"], "queues": n_queues,
+                                 "kernel": out["config"]["kernel"]}
+            out["value"] = world_size * B * sub_h * steps / wall_h
+            out["ms_per_step"] = wall_h / steps * 1e3
+            out["value_is"] = ("env-steps/s through the REFERENCE's own vmas.make_env(..., device='cuda') / Environment.step() after "
+                               "attach() with its defaults - the reference's action asserts kept, the reference's batch-global "
+                               "broad phase - K calls between barrier + synchronize fences, the host included (wall clock, MAX over "
+                               "ranks; median window).  `world_step` = World.step() physics alone (the headline of rounds 1-5), "
+                               "`environment_step` = this package's own Environment.step")
+            out["repeats"] = {"windows": len(hw_), "steps_per_window": steps,
+                              "ms_per_step_min": min(x[1] for x in hw_) / steps * 1e3, "ms_per_step_median": wall_h / steps * 1e3,
+                              "ms_per_step_max": max(x[1] for x in hw_) / steps * 1e3,
+                              "gpu_ms_per_step_median": ev_h / steps * 1e3,
+                              "note": "each window = exactly `steps` env.step calls between barrier + synchronize fences; `value` and "
+                                      "`ms_per_step` are the median window by the wall clock, gpu_ms_per_step the same window by HIP events"}
+            out["config"]["workload"] = (f"BASELINE config {cfg['cfg']}: the reference's {cfg['scenario']} {kw}, {B} envs/GPU "
+                                         f"({shard.num_envs} in all), vmas.make_env(device='cuda') + attach(), Environment.step() with "
+                                         f"fresh random actions every step")
+            out["config"]["launch"] = (f"{head.get('launches_per_env_step', '?')} launch(es) per env.step (+ the asserts' two small "
+                                       f"launches): ingest prologue + World.step + reward/observation/done/info epilogue")
+            out["config"]["kernel"] = f"{head['kernel']} step kernel, exact_form {head['exact_form']} (1 = lazy, inside the launch)"
+            out["headline"] = {k: v for k, v in head.items() if k != "windows"}
+            per_env = r["bytes_per_env"] + cfg["post_bytes"]
+            out["roofline"] = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                               "kernel": "the one-launch Environment.step kernel (ingest prologue + World.step + post-step epilogue)",
+                               "bytes_per_env": per_env, "bytes_per_launch": per_env * B,
+                               "note": "filled from the `attached_reference` leg below: kernel_us = HIP-event time per env.step "
+                                       "with the asserts off (back-to-back one-launch steps: the kernel's launch-to-launch time)"}
         if world_size == 1 and not args.no_traffic and not args.fused:
             try:
                 traffic, detail = measure_traffic(args, n_queues)
             except Exception as e:  # noqa: BLE001
                 traffic, detail = None, repr(e)[:300]
-            rf = out["roofline"]
+            rf = out["world_step"]["roofline"] if "world_step" in out else out["roofline"]
             rf["traffic"] = traffic
             if traffic is not None:
                 rf["traffic_over_algorithmic"] = traffic / rf["bytes_per_launch"]
@@ -1142,6 +1287,23 @@ def main():
                 out["attached_reference"] = attached_reference_leg(args.config, kw, B, device)
             except Exception as e:  # noqa: BLE001 (the reference is not importable here, or does not run on this device)
                 out["attached_reference"] = {"error": repr(e)[:500]}
+            a_ = out["attached_reference"]
+            if "world_step" in out and "env_step_no_validate_gpu_us" in a_:  # the headline's roofline: its dominant kernel
+                rf = out["roofline"]
+                rf["kernel_us"] = a_["env_step_no_validate_gpu_us"]
+                rf["achieved"] = rf["bytes_per_launch"] / (rf["kernel_us"] * 1e-6) / 1e9
+                rf["frac"] = rf["achieved"] / HBM_PEAK_GBS
+                if not args.no_traffic:
+                    try:
+                        traffic, detail = measure_traffic(args, 1, attached=True)
+                    except Exception as e:  # noqa: BLE001
+                        traffic, detail = None, repr(e)[:300]
+                    rf["traffic"] = traffic
+                    if traffic is not None:
+                        rf["traffic_over_algorithmic"] = traffic / rf["bytes_per_launch"]
+                        rf["traffic_detail"] = detail
+                    else:
+                        rf["traffic_note"] = f"not measured in this run ({detail})"
         if world_size == 1 and not args.no_cpu_baseline:
             w = r["w"]
             st0, f_cpu = r["state0"].cpu().numpy(), r["forces"].cpu().numpy()
@@ -1155,8 +1317,18 @@ def main():
             out["cpu_port"] = cpu_port(w, f_cpu[:, :, :, :nb].copy(), st0[:, :, :nb].copy())
             if "cpu_baseline" not in out:
                 out["cpu_baseline"] = dict(out["cpu_port"])
-            out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
-            out["cpu_port"]["gpu_over_cpu"] = out["value"] / out["cpu_port"]["value"]
+            phys = out["world_step"]["value"] if "world_step" in out else out["value"]
+            cb = out["cpu_baseline"]
+            if "world_step" in out and "env_step" in cb:  # the headline is Environment.step: so is the baseline beside it
+                cb["world_step"] = {"value": cb["value"], "unit": "env-steps/s", "gpu_over_cpu": phys / cb["value"],
+                                    "note": "the reference's World.step alone (inside the same steps) against `world_step.value`"}
+                cb["value"] = cb["env_step"]["value"]
+                cb["value_is"] = "the reference's Environment.step on the host cores (the same call the headline times on the GPU)"
+                cb["gpu_over_cpu"] = out["value"] / cb["value"]
+            else:
+                cb["gpu_over_cpu"] = phys / cb["value"]
+            out["cpu_port"]["gpu_over_cpu"] = phys / out["cpu_port"]["value"]
+            out["cpu_port"]["measures"] = "World.step physics only (oracle/, one core): against `world_step.value`"
             e = r["env_leg"]
             if e and "value" in e and "env_step" in out["cpu_baseline"]:
                 out["cpu_baseline"]["env_step"]["gpu_over_cpu"] = e["value"] / out["cpu_baseline"]["env_step"]["value"]
@@ -1173,11 +1345,11 @@ def main():
                     line["attached_reference"] = attached_reference_leg(other, okw, o["envs_per_gpu"], device, n=300, brief=True)
                 except Exception as e:  # noqa: BLE001
                     line["attached_reference"] = {"error": repr(e)[:300]}
+                import copy
+                a2 = copy.copy(args)
+                a2.config = other
                 if not args.no_traffic:  # HBM bytes per launch by the PMC counters, like the headline's
                     try:
-                        import copy
-                        a2 = copy.copy(args)
-                        a2.config = other
                         traffic, detail = measure_traffic(a2, o["n_queues"])
                         rf = line["roofline"]
                         rf["traffic"] = traffic
@@ -1189,6 +1361,32 @@ def main():
                             rf["traffic_note"] = str(detail)[:200]
                     except Exception as e:  # noqa: BLE001
                         line["roofline"]["traffic_note"] = repr(e)[:200]
+                a = line["attached_reference"]
+                if "value" in a:  # the same headline as the main line's: through the reference's env.step; physics -> `world_step`
+                    line["world_step"] = {"value": line["value"], "us_per_step": line.pop("us_per_step"), "roofline": line.pop("roofline"),
+                                          "kernel": line.pop("kernel"), "queues": line.pop("queues"), "workload": line["workload"]}
+                    line["value"] = a["value"]
+                    line["us_per_step"] = a["env_step_us"]
+                    line["workload"] = (f"the reference's {o['scenario']} {okw}, {o['envs_per_gpu']} envs, vmas.make_env(device='cuda') + "
+                                        f"attach(), Environment.step() (asserts kept)")
+                    if "env_step_no_validate_gpu_us" in a:
+                        per_env = o["bytes_per_env"] + CONFIGS[other]["post_bytes"]
+                        k_us = a["env_step_no_validate_gpu_us"]
+                        ach = per_env * o["envs_per_gpu"] / (k_us * 1e-6) / 1e9
+                        line["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                            "traffic": None, "kernel": "the Environment.step kernel", "kernel_us": k_us,
+                                            "bytes_per_env": per_env, "bytes_per_launch": per_env * o["envs_per_gpu"]}
+                        if not args.no_traffic and a.get("launches_per_env_step") == 1:
+                            try:
+                                traffic, detail = measure_traffic(a2, 1, attached=True)
+                                line["roofline"]["traffic"] = traffic
+                                if traffic is not None:
+                                    line["roofline"]["traffic_over_algorithmic"] = traffic / line["roofline"]["bytes_per_launch"]
+                                    line["roofline"]["traffic_kernel"] = detail["kernel"]
+                                else:
+                                    line["roofline"]["traffic_note"] = str(detail)[:200]
+                            except Exception as e:  # noqa: BLE001
+                                line["roofline"]["traffic_note"] = repr(e)[:200]
                 if args.no_cpu_baseline:
                     continue
                 try:
@@ -1197,7 +1395,11 @@ def main():
                     line["parity"] = c.pop("parity")
                     line["cpu_reference"] = {"world_step_value": c["value"], "env_step_value": c["env_step"]["value"], "cores": c["cores"],
                                              "envs": c["envs"], "steps": c["env_step"]["steps"], "unit": "env-steps/s"}
-                    line["gpu_over_cpu"] = line["value"] / c["value"]
+                    if "world_step" in line:
+                        line["world_step"]["gpu_over_cpu"] = line["world_step"]["value"] / c["value"]
+                        line["gpu_over_cpu"] = line["value"] / c["env_step"]["value"]
+                    else:
+                        line["gpu_over_cpu"] = line["value"] / c["value"]
                     es = line.get("environment_step", {})
                     if "value" in es:
                         es["gpu_over_cpu"] = es["value"] / c["env_step"]["value"]

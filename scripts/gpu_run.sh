@@ -39,7 +39,7 @@ while [ $# -gt 0 ]; do
     timeout 2400 python -m pytest tests -m gpu -q --timeout=600 -p no:cacheprovider -rs > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
     show_pytest $OUT/pytest_gpu.log
     cp gpurun_out/parity_allowance.jsonl $OUT/${TAG}_parity_allowance.jsonl 2>/dev/null
-    cp gpurun_out/broad_phase_full_size.jsonl $OUT/${TAG}_broad_phase_full_size.jsonl 2>/dev/null
+    cp gpurun_out/broad_phase_lazy.jsonl $OUT/${TAG}_broad_phase_lazy.jsonl 2>/dev/null
     python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
     ;;
   bench)

@@ -18,6 +18,11 @@ print("line:", {"value": r(d["value"], 0), "ms_per_step": r(d["ms_per_step"], 5)
                 "traffic_x": r(d["roofline"].get("traffic_over_algorithmic"), 3),
                 "env_step_us": r(es.get("us_per_step")), "env_gpu_us": r(es.get("gpu_us_per_step")),
                 "bound_us": r(es.get("bound", {}).get("gpu_us_per_step")), "rollout_us": r(es.get("rollout", {}).get("us_per_step"))})
+ws = d.get("world_step")
+if ws:
+    print("world_step:", {"value": r(ws["value"], 0), "ms_per_step": r(ws["ms_per_step"], 5), "frac": r(ws["roofline"]["frac"], 4),
+                          "traffic_x": r(ws["roofline"].get("traffic_over_algorithmic"), 3)})
+    print("headline:", d.get("headline"), {k: r(v, 5) for k, v in d["repeats"].items() if k != "note"})
 if brief:
     sys.exit(0)
 a = d.get("attached_reference", {})
@@ -35,5 +40,9 @@ for name, o in (d.get("other_configs") or {}).items():
     print(name, {"us": r(o["us_per_step"]), "frac": r(o["roofline"]["frac"], 3), "traffic_x": r(o["roofline"].get("traffic_over_algorithmic"), 3), "env_us": r(e.get("us_per_step")), "env_gpu_us": r(e.get("gpu_us_per_step")),
                  "env_frac": r(e.get("roofline_frac"), 3), "bound_us": r(e.get("bound_us_per_step")), "rollout_us": r(e.get("rollout_us_per_step")),
                  "gpu_over_cpu": r(o.get("gpu_over_cpu"), 0), "env_over_cpu": r(e.get("gpu_over_cpu"), 0)})
+    w_ = o.get("world_step")
+    if w_:
+        print("   world_step:", {"value": r(w_["value"], 0), "us": r(w_["us_per_step"]), "frac": r(w_["roofline"]["frac"], 3),
+                                 "traffic_x": r(w_["roofline"].get("traffic_over_algorithmic"), 3), "gpu_over_cpu": r(w_.get("gpu_over_cpu"), 0)})
     print("   attached:", {k: r(v) for k, v in at.items() if k not in ("value_is", "unit")})
     print("   parity:", {k: v for k, v in (o.get("parity") or {}).items() if k != "note"}, "cpu:", o.get("cpu_reference"))
