@@ -363,9 +363,16 @@ def same_run_parity(ctx, w, B, samples, final_ref, n_ref_steps):
         pre = last_post if pre is None else pre
         last_post = post
         for form in ("product", "per_environment"):
-            genv.set_state(snapshot)  # (columns beyond B: a sane state)
-            st[:, :, :B].copy_(pre.to(st.device))
-            ft[:nA, :, :B].copy_(f.to(st.device))
+            # The rule is batch-GLOBAL: the native batch must hold exactly the environments the reference's batch held.  Where
+            # the reference was run on the first B of a larger batch (configurations above 32 768 / the short lines' 8 192) the
+            # sample is TILED over the rest - the same set of environments, so the same pairs are on for the batch.  (Until
+            # round 6 the rest kept its post-reset state: its overlaps switched pairs on that the reference's batch had off.)
+            genv.set_state(snapshot)
+            pre_d, f_d = pre.to(st.device), f.to(st.device)
+            for lo in range(0, w.batch_dim, B):
+                n_ = min(B, w.batch_dim - lo)
+                st[:, :, lo:lo + n_].copy_(pre_d[:, :, :n_])
+                ft[:nA, :, lo:lo + n_].copy_(f_d[:, :, :n_])
             w.invalidate_queries()
             if form == "product":  # what World.step() of this environment runs: the reference's batch-global rule
                 assert w.exact_broad_phase

@@ -285,11 +285,16 @@ int vmas_world_step_env(VmasWorld* w, float* state, float* agent_ft, int64_t ld,
                         int32_t post_kind, const void* post_desc, const void* post_buffers, void* stream);
 
 /* vmas_world_step_env as a GATED launch: if `*gate` (device memory: vmas_host_word_gate) is nonzero when the launch starts,
- * it does nothing at all.  For steps that are exactly one launch without a grid barrier: post_kind NONE / BALANCE /
- * TRANSPORT, no exact broad phase (anything else: < 0). */
+ * it does nothing at all - every kernel of the step reads the gate first (the step kernel, navigation's collision kernel,
+ * football's post-step kernel).  Single steps; every post_kind; the exact broad phase in its lazy form only
+ * (vmas_world_exact_form <= 1: the barrier form's sequence numbers advance on the host - < 0).
+ * A caller that learns from vmas_env_validate_end that the gate WAS shut calls `vmas_world_gated_refused(w)` before the
+ * world's next launch: it takes back what the host advanced for the launch that arrived nowhere (navigation's barrier
+ * number / which of its two masks is next). */
 int vmas_world_step_env_gated(VmasWorld* w, float* state, float* agent_ft, int64_t ld, const VmasStepArgs* args,
                               const VmasIngestArgs* ingest, uint32_t* gate, int32_t post_kind, const void* post_desc,
                               const void* post_buffers, void* stream);
+int vmas_world_gated_refused(VmasWorld* w);
 
 /* K consecutive Environment.step() calls in ONE launch: the same results, bit for bit, as
  * `n_steps` vmas_world_step_env launches without resets in between, but the tile of 64 environments stays in LDS from

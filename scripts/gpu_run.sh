@@ -12,6 +12,7 @@
 #   counters-shards  counters of the latency-regime shards (navigation 8192 env step, football 16384 compact, balance env step)
 #   evidence         rocprofv3 of the bench command itself (one queue): kernel stats + PMC summary
 #   traces           per-phase traces (football compact, navigation env step, balance env step)
+#   lazy-parts       round 6: the lazy form's parts in the compacted kernel (profiling library)
 #   lazy / lazy-cost round 6: the lazy exact broad phase's tests / its cost against the per-environment form and round 5's library
 TAG=${TAG:-r05}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -82,9 +83,15 @@ while [ $# -gt 0 ]; do
     grep -h "sustained\|traffic / alg\|share of wave" $OUT/${TAG}_navigation8192_env_step_pmc_summary.txt $OUT/${TAG}_football16384_physics_compact_pmc_summary.txt $OUT/${TAG}_balance32768_env_step_pmc_summary.txt
     ;;
   evidence)
-    BENCH="python $R/bench.py --no-cpu-baseline --no-fused --no-other-configs --no-attached --no-traffic --queues 1 --steps 2000 --warmup 200"
-    RATED=step_kernel_spec:physics bash $S/gpu_counters.sh ${TAG}_bench_q1 384 1700 32768 -- $BENCH > /dev/null 2>&1
+    # the bench command itself under rocprofv3.  (1) the HEADLINE of round 6: env.step of the attached reference environment - its
+    # one-launch kernel rated at the physics' bytes + the actions / observations / rewards / done / info (657 B per environment)
+    BENCH="python $R/bench.py --no-cpu-baseline --no-fused --no-other-configs --no-traffic --steps 2000 --warmup 200 --repeats 3"
+    RATED=step_kernel_spec_multi:env bash $S/gpu_counters.sh ${TAG}_bench_q1 657 1700 32768 -- $BENCH > /dev/null 2>&1
     grep -h "sustained\|traffic / alg\|share of wave\|median" $OUT/${TAG}_bench_q1_pmc_summary.txt | head
+    # (2) the physics-only launches (`world_step`), as in rounds 1-5
+    BENCHW="$BENCH --no-attached --queues 1"
+    RATED=step_kernel_spec:physics bash $S/gpu_counters.sh ${TAG}_bench_world_step_q1 384 1700 32768 -- $BENCHW > /dev/null 2>&1
+    grep -h "sustained\|traffic / alg\|share of wave\|median" $OUT/${TAG}_bench_world_step_q1_pmc_summary.txt | head
     { echo "# scripts/micro/launch_floor (this round's box)"; scripts/micro/launch_floor 32768 8; } > $OUT/${TAG}_launch_floor.txt 2>&1; tail -6 $OUT/${TAG}_launch_floor.txt
     ;;
   traces)
@@ -116,6 +123,20 @@ rows = [json.loads(l) for l in open(sys.argv[1])]
 for r in rows:
     print(f"{r['scenario']:10s} {r['num_envs']:8d} lib={r['lib'][-16:]:16s} exact={r.get('exact')} form={r.get('exact_form')} {r['world_step_us']:8.2f} us  spec={r['specialized']} compact={r['compact']}")
 PY
+    ;;
+  lazy-parts)  # what each part of the lazy form costs the compacted kernel (profiling library: VMAS_ABLATE bits 8 / 10)
+    LP=$OUT/${TAG}_lazy_parts.txt; : > $LP
+    for CFG in ${LAZY_CFGS:-football:16384 football:131072}; do
+      SC=${CFG%%:*}; NB=${CFG##*:}
+      for ROUND in 1 2; do
+        for V in "1:0:lazy form (product)" "1:1024:no band flags -> no tile asks" "1:1280:... and no overlap tests in the broad phase" "0:0:per-environment form"; do
+          E=${V%%:*}; R=${V#*:}; AB=${R%%:*}; WHAT=${R#*:}
+          echo -n "$SC $NB | $WHAT | " >> $LP
+          COMPACT=1 EXACT=$E VMAS_ABLATE=$AB FORCES=random QUEUES=1 VMAS_HIP_LIB=libvmas_hip_prof.so python $S/bench_world.py $SC $NB 300 2>$OUT/lazy_parts.err | grep "^{" | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print(d['world_step_us'], 'us')" >> $LP || tail -3 $OUT/lazy_parts.err
+        done
+      done
+    done
+    cat $LP
     ;;
   *) echo "unknown stage $STAGE";;
   esac

@@ -510,19 +510,30 @@ def test_attached_fused_reset_where_resets_exactly_the_masked_environments(vmas,
     h.detach()
 
 
-@pytest.mark.parametrize("scenario,kw", [("balance", dict(n_agents=4)), ("transport", dict(n_packages=2))])
-def test_attached_fused_gated_validation_at_benchmark_size(vmas, scenario, kw):
-    """Above 1 024 environments (no grid barrier in the step) the reference's asserts cost no idle queue: the check is enqueued, the
-    step launched GATED on its result, the host waits behind both (vmas_env_validate_begin / vmas_world_step_env_gated /
-    vmas_env_validate_end).  Same behaviour: a refused action leaves the world, the step counter AND the scenario's attributes
-    exactly as they were; good steps are bitwise those of the unvalidated path."""
+FOOTBALL_KW = dict(n_blue_agents=3, n_red_agents=3, ai_red_agents=False)
+
+
+@pytest.mark.parametrize("scenario,kw,B", [
+    ("balance", dict(n_agents=4), 4096), ("transport", dict(n_packages=2), 4096),
+    # (round 6) the kinds whose step is more than one kernel or carries a grid barrier:
+    ("navigation", dict(n_agents=4), 4096),     # collision reduction at a grid barrier inside the launch (64 tiles)
+    ("navigation", dict(n_agents=4), 20000),    # ... by a second kernel behind the step (313 tiles > 256 CUs)
+    ("football", FOOTBALL_KW, 4096),            # the post-step as the compacted kernel's epilogue
+    ("football", FOOTBALL_KW, 20000),           # ... as a second kernel
+], ids=lambda v: v if isinstance(v, (str, int)) else "")
+def test_attached_fused_gated_validation_at_benchmark_size(vmas, scenario, kw, B):
+    """The reference's asserts cost no idle queue: the check is enqueued, the step launched GATED on its result - every kernel of
+    it - and the host waits behind both (vmas_env_validate_begin / vmas_world_step_env_gated / vmas_env_validate_end; a refused
+    launch's host-side advances are taken back by vmas_world_gated_refused).  Same behaviour: a refused action leaves the
+    world, the step counter AND the scenario's attributes exactly as they were; good steps are bitwise those of the
+    unvalidated path - before AND after a refusal (navigation's barrier number / mask alternation must not slip)."""
     from vectorizedmultiagentsimulator_amd.adapter import attach
 
-    B = 4096
     a = vmas.make_env(scenario, num_envs=B, device=DEV, seed=0, **kw)
     b = vmas.make_env(scenario, num_envs=B, device=DEV, seed=0, **kw)
     ha, hb = attach(a, fused=True, validate_actions=True), attach(b, fused=True, validate_actions=False)
-    assert ha.fused.launch.can_gate(ha.fused.post.kind) and not ha.exact_broad_phase
+    assert ha.fused.one_launch and ha.fused.launch.can_gate(ha.fused.post.kind)
+    assert ha.exact_broad_phase and ha.backend.exact_form() <= 1
     _force_state_same_device(b, a, scenario)
     g = torch.Generator().manual_seed(4)
     for t in range(5):
@@ -533,7 +544,8 @@ def test_attached_fused_gated_validation_at_benchmark_size(vmas, scenario, kw):
     assert torch.equal(ha.state, hb.state)
     before, steps = ha.state.clone(), a.steps.clone()
     sc = a.scenario
-    attrs = {"balance": ("pos_rew", "ground_rew", "on_the_ground"), "transport": ("rew",)}[scenario]
+    attrs = {"balance": ("pos_rew", "ground_rew", "on_the_ground"), "transport": ("rew",), "navigation": ("pos_rew", "final_rew"),
+             "football": ("_sparse_reward_blue", "_done")}[scenario]
     kept = [getattr(sc, n) for n in attrs]
     kept_vals = [x.clone() for x in kept]
     shaping = [getattr(o, n).clone() for o, n in _terms(a, scenario)]
@@ -548,9 +560,14 @@ def test_attached_fused_gated_validation_at_benchmark_size(vmas, scenario, kw):
         assert all(getattr(sc, n) is k for n, k in zip(attrs, kept)), "the scenario's attributes are the previous step's again"
         assert all(torch.equal(x, y) for x, y in zip(kept, kept_vals))
         assert all(torch.equal(getattr(o, n), s) for (o, n), s in zip(_terms(a, scenario), shaping))
-    oa, ra, da, _ = a.step([x.clone() for x in good])  # the gate is open again
-    ob, rb, db, _ = b.step(good)
-    assert all(torch.equal(x, y) for x, y in zip(oa, ob)) and torch.equal(ha.state, hb.state) and torch.equal(a.steps, b.steps)
+    for t in range(3):  # the gate is open again, and the steps behind a refusal are the unvalidated path's, bit for bit
+        oa, ra, da, _ = a.step([x.clone() for x in good])
+        ob, rb, db, _ = b.step(good)
+        assert all(torch.equal(x, y) for x, y in zip(oa, ob)) and all(torch.equal(x, y) for x, y in zip(ra, rb)), f"step {t} after the refusals"
+        assert torch.equal(ha.state, hb.state) and torch.equal(a.steps, b.steps) and torch.equal(da, db)
+        good = [x.to(DEV) for x in _actions(a, g)]
+    torch.cuda.synchronize()
+    assert ha.backend.exact_status() == 0
     ha.detach(); hb.detach()
 
 

@@ -327,6 +327,7 @@ EXPORTED_SYMBOLS = (
     "vmas_env_validate_end",
     "vmas_host_word_gate",
     "vmas_world_step_env_gated",
+    "vmas_world_gated_refused",
     "vmas_balance_post_step",
     "vmas_transport_post_step",
     "vmas_navigation_post_step",
@@ -423,6 +424,8 @@ def load_library() -> C.CDLL:
     lib.vmas_world_step_env.restype = C.c_int
     lib.vmas_world_step_env_gated.argtypes = lib.vmas_world_step_env.argtypes
     lib.vmas_world_step_env_gated.restype = C.c_int
+    lib.vmas_world_gated_refused.argtypes = [vp]
+    lib.vmas_world_gated_refused.restype = C.c_int
     lib.vmas_env_reset_where.argtypes = [C.POINTER(ResetArgs), i32, i32, i32, vp, vp, vp, i64, vp]
     lib.vmas_env_reset_where.restype = C.c_int
     lib.vmas_world_rollout_env.argtypes = [vp, vp, vp, i64, C.POINTER(StepArgs), C.POINTER(IngestArgs), vp, i32, vp, vp, i32, vp]

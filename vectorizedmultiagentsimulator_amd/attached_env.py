@@ -457,6 +457,7 @@ class FusedEnvStep:
                 self.launch.gated(post.kind, desc, buffers)
                 flags = ingest.validate_end(seq)
                 if flags:
+                    self.launch.refused()
                     post.restore_bound(saved)  # (the scenario keeps the previous step's pos_rew ...: it saw nothing of this one)
                     ingest._raise(flags)
             else:

@@ -180,6 +180,11 @@ __attribute__((amdgpu_waves_per_eu((PLAIN == 2 && OWN == 2 && ENV != ENV_FOOTBAL
   uint32_t* xmask = (uint32_t*)(torques + (P.has_torque ? CAP : 0));
   const int nP = P.n_pairs;
   // the LAZY exact broad phase (vmas_env_device.h): [2 parities][overlap | band words] | need | collected | batch mask | flag
+#ifdef VMAS_PROFILE  // (A/B of the lazy form's parts, profiling builds only: VMAS_ABLATE bits 8.. - scripts/gpu_run.sh lazy-parts)
+#define LZ_ABL(bit) (((args.ablate >> (bit)) & 1) != 0)
+#else
+#define LZ_ABL(bit) false
+#endif
   constexpr bool lazy = PLAIN == 2;  // (the host launches this variant with the lazy form's arguments, and only then; launches
                                      //  with other options AND the lazy form take the interpreter)
   const int lzp = (P.mask_words + 3) & ~3;
@@ -616,7 +621,7 @@ __attribute__((amdgpu_waves_per_eu((PLAIN == 2 && OWN == 2 && ENV != ENV_FOOTBAL
             // registers anyway - a line pair always (a wall's bounding circle spans the pitch), a sphere pair only where the
             // spheres are within reach (overlapping spheres are)
             if constexpr (PLAIN == 2) {
-              if (lazy && !all_masks && (type != VMAS_PAIR_SS || b != 0ull) &&
+              if (lazy && !LZ_ABL(8) && !all_masks && (type != VMAS_PAIR_SS || b != 0ull) &&
                   (__ballot(circles_overlap(dx, dy, ov_thr)) & live_mask) != 0ull)
                 ov_bits |= 1u << i;
             }
@@ -712,7 +717,7 @@ __attribute__((amdgpu_waves_per_eu((PLAIN == 2 && OWN == 2 && ENV != ENV_FOOTBAL
           // lazy form: this environment is in the pair's band - bounding circles apart, force (or torque) not zero; for a
           // sphere pair that takes a non-finite pose.  Noted in the contact's key: the pair's owners look at it (phase C)
           if constexpr (PLAIN == 2) {
-            if (lazy && (fa.x != 0.f || fa.y != 0.f || ta != 0.f) &&
+            if (lazy && !LZ_ABL(10) && (fa.x != 0.f || fa.y != 0.f || ta != 0.f) &&
                 !circles_overlap(pa.x - pb.x, pa.y - pb.y, __uint_as_float(tab[P.t_band + pair])))
               keys[k] = key | 0x80000000u;
           }

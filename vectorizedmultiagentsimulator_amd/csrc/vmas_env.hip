@@ -161,7 +161,10 @@ __global__ __launch_bounds__(256) void navigation_collision_kernel(const VmasNav
                                                                   float* __restrict__ collision_rew,
                                                                   const int32_t* __restrict__ pair_index, int batch,
                                                                   const float* __restrict__ state, long ld,
-                                                                  uint32_t* __restrict__ mask, int mask_words) {
+                                                                  uint32_t* __restrict__ mask, int mask_words,
+                                                                  const uint32_t* gate) {
+  // (behind a GATED step launch: the validation in front of it refused an action - nothing of this step happens)
+  if (gate != nullptr && __builtin_amdgcn_readfirstlane((int)*(const volatile uint32_t*)gate) != 0) return;
   __shared__ uint32_t collide_with[VMAS_ENV_MAX_AGENTS];
   const int A = d.n_agents;
   if ((int)threadIdx.x < VMAS_ENV_MAX_AGENTS) collide_with[threadIdx.x] = 0u;
@@ -216,7 +219,9 @@ __global__ __launch_bounds__(256) void navigation_collision_kernel(const VmasNav
 // stand-alone form of football_post_tile (vmas_env_device.h).  LDS: rows[(n + 1) * 6][64] (pos, vel, force of every agent
 // and of the ball) | the tile's observation array [64][D + 2] (one pass per agent: its 64 * D floats leave as one run)
 __global__ __launch_bounds__(512) void football_post_kernel(const VmasFootballDesc d, const VmasFootballBuffers o, int batch,
-                                                            const float* __restrict__ state, long ld, int stp) {
+                                                            const float* __restrict__ state, long ld, int stp,
+                                                            const uint32_t* gate) {
+  if (gate != nullptr && __builtin_amdgcn_readfirstlane((int)*(const volatile uint32_t*)gate) != 0) return;  // (see above)
   extern __shared__ float lds[];
   const TileCtx C(batch);
   const int n = d.n_blue + d.n_red;
@@ -298,7 +303,7 @@ int check_navigation_args(const VmasNavigationDesc* d, const VmasNavigationBuffe
 
 // football's post-step (vmas_football_post_step; vmas_hip.hip: step `stp` of a rollout whose steps are two launches each)
 int launch_football_post(const VmasFootballDesc* d, const VmasFootballBuffers* o, int32_t batch, const float* state, int64_t ld,
-                         int stp, void* stream) {
+                         int stp, void* stream, const uint32_t* gate) {
   if (!d || !o || !state) return host_fail("vmas_football_post_step: null argument");
   if (batch <= 0 || ld < batch) return host_fail("vmas_football_post_step: bad batch / ld");
   if (d->n_blue < 1 || d->n_red < 1 || d->n_blue + d->n_red + 1 > VMAS_ENV_MAX_AGENTS || d->agent0 < 0)
@@ -308,16 +313,17 @@ int launch_football_post(const VmasFootballDesc* d, const VmasFootballBuffers* o
   const int nw = 8;
   const int n_others = (d->observe_adversaries ? std::max(d->n_red, d->n_blue) : 0) + (d->observe_teammates ? std::max(d->n_blue, d->n_red) - 1 : 0);
   const size_t lds = ((size_t)(d->n_blue + d->n_red + 1) * 6 * 64 + football_shared_slab_floats(64, 16 + 8 * n_others)) * sizeof(float);
-  LAUNCH_POST(football_post_kernel, nw, lds, "vmas_football_post_step", *d, *o, batch, state, (long)ld, stp);
+  LAUNCH_POST(football_post_kernel, nw, lds, "vmas_football_post_step", *d, *o, batch, state, (long)ld, stp, gate);
 }
 
 // behind a step kernel with the navigation epilogue, same stream (navigation_collision_kernel)
 int launch_navigation_collisions(const VmasNavigationDesc* d, const VmasNavigationBuffers* o, int32_t batch,
-                                 const float* state, int64_t ld, uint32_t* mask, int mask_words, void* stream) {
+                                 const float* state, int64_t ld, uint32_t* mask, int mask_words, void* stream,
+                                 const uint32_t* gate) {
   const size_t lds = (size_t)3 * d->n_agents * 256 * sizeof(float);
   if (ensure_lds(navigation_collision_kernel, lds, "vmas_world_step_env: hipFuncSetAttribute failed")) return -1;
   hipLaunchKernelGGL(navigation_collision_kernel, dim3((batch + 255) / 256), dim3(256), lds, (hipStream_t)stream, *d, o->rew,
-                     o->collision_rew, o->pair_index, batch, state, (long)ld, mask, mask_words);
+                     o->collision_rew, o->pair_index, batch, state, (long)ld, mask, mask_words, gate);
   return check_launch("vmas_world_step_env: navigation collision penalties");
 }
 
@@ -626,7 +632,7 @@ int vmas_navigation_post_step(const VmasNavigationDesc* d, const VmasNavigationB
 
 int vmas_football_post_step(const VmasFootballDesc* d, const VmasFootballBuffers* o, int32_t batch, const float* state,
                             int64_t ld, void* stream) {
-  return vmas::launch_football_post(d, o, batch, state, ld, 0, stream);
+  return vmas::launch_football_post(d, o, batch, state, ld, 0, stream, nullptr);
 }
 
 }  // extern "C"

@@ -964,11 +964,12 @@ int check_balance_args(const VmasBalanceDesc* d, const VmasBalanceBuffers* o, in
 int check_navigation_args(const VmasNavigationDesc* d, const VmasNavigationBuffers* o, int32_t batch, const float* state,
                           int64_t ld, int fused);
 int launch_navigation_collisions(const VmasNavigationDesc* d, const VmasNavigationBuffers* o, int32_t batch,
-                                 const float* state, int64_t ld, uint32_t* mask, int mask_words, void* stream);
+                                 const float* state, int64_t ld, uint32_t* mask, int mask_words, void* stream,
+                                 const uint32_t* gate);
 int check_transport_args(const VmasTransportDesc* d, const VmasTransportBuffers* o, int32_t batch, const float* state,
                          int64_t ld, int n_entities);
 int launch_football_post(const VmasFootballDesc* d, const VmasFootballBuffers* o, int32_t batch, const float* state, int64_t ld,
-                         int stp, void* stream);
+                         int stp, void* stream, const uint32_t* gate);
 }
 #define HIP_TRY(x)                                                                      \
   do {                                                                                  \
@@ -1105,6 +1106,9 @@ struct VmasWorld {
                                    //   and a third for captured launches
   uint32_t* d_nav_sync = nullptr;  // its grid-barrier form: unused | timeout flag | ring of four slots of 64-bit arrival-and-pair-bit words
   uint32_t nav_seq = 0;
+  // what the last GATED launch advanced on the host (vmas_world_gated_refused takes it back: a refused launch arrived nowhere)
+  uint32_t gated_nav_seq = 0;
+  int gated_nav_flip = 0;
   std::vector<DevLidar> h_lidars;  // host copy of the registered sensors (argument checks of the navigation epilogue)
   std::vector<DevTarget> h_targets;
   // the lane-compacted kernel's plan (vmas_compact.h): built at creation when the world qualifies
@@ -2135,7 +2139,7 @@ static int compact_pick_step(VmasWorld* w) {
 static int launch_physics(VmasWorld* w, Sched* S, float* state, float* aft, long ld, const DevStepArgs& a, hipStream_t s,
                           int batch = -1, long pad = -1) {
   if (batch < 0) { batch = w->batch; pad = ld; }
-  if (compact_on(w) && !a.joint_fixed_rot && !ABLATE(a) && compact_takes(a)) {
+  if (compact_on(w) && !a.joint_fixed_rot && !(ABLATE(a) & 0xff) && compact_takes(a)) {
     const bool adaptive = w->compact_mode == -1 && w->adapt.d_count != nullptr;
     bool interpreter_turn;
     if (adaptive && w->adapt.forced >= 0) interpreter_turn = w->adapt.forced == 0;  // (chosen for the whole step by the caller)
@@ -2645,6 +2649,14 @@ int vmas_world_step_env_gated(VmasWorld* w, float* state, float* agent_ft, int64
   return step_env_impl(w, state, agent_ft, ld, args, ingest, gate, post_kind, post_desc, post_buffers, 1, stream, 1);
 }
 
+int vmas_world_gated_refused(VmasWorld* w) {
+  if (!w) return fail("vmas_world_gated_refused: null world");
+  w->nav_seq -= w->gated_nav_seq;
+  if (w->gated_nav_flip) w->nav_flip ^= 1;
+  w->gated_nav_seq = 0; w->gated_nav_flip = 0;
+  return 0;
+}
+
 int vmas_world_rollout_env(VmasWorld* w, float* state, float* agent_ft, int64_t ld, const VmasStepArgs* args,
                            const VmasIngestArgs* ingest, uint32_t* err_flags, int32_t post_kind, const void* post_desc,
                            const void* post_buffers, int32_t n_steps, void* stream) {
@@ -2664,8 +2676,11 @@ static int step_env_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld
     // navigation's collision kernel) or carries a grid barrier (its sequence numbers advance on the host whether or not the
     // tiles arrive: the exact broad phase, navigation's collision reduction) are refused.
     if (!err_flags) return fail("vmas_world_step_env_gated: needs the gate word");
-    if (post_kind != VMAS_POST_NONE && post_kind != VMAS_POST_BALANCE && post_kind != VMAS_POST_TRANSPORT)
-      return fail("vmas_world_step_env_gated: post_kind %d cannot be gated (more than one launch per step, or a grid barrier)", post_kind);
+    if (n_steps != 1) return fail("vmas_world_step_env_gated: single steps only");
+    // (round 6: every launch of a step reads the gate - the step kernel, navigation's collision kernel, football's post-step
+    //  kernel - and what the host advances for a launch that arrives at a grid barrier or fills a mask is taken back by
+    //  vmas_world_gated_refused when the caller learns that the gate was shut)
+    w->gated_nav_seq = 0; w->gated_nav_flip = 0;
     if (args && args->exact_broad_phase && exact_form(w, stream_capturing((hipStream_t)stream)) > EXACT_LAZY)
       return fail("vmas_world_step_env_gated: this world's exact broad phase carries a grid barrier / several launches here and "
                   "cannot be gated (vmas_world_exact_form)");
@@ -2754,11 +2769,14 @@ static int step_env_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld
     if (step_impl(w, state, agent_ft, ld, args, stream, n_steps, 0, &env, ENV_NAVIGATION, nav_fixed, nav_per_wave, 0, -1,
                   1 << 20))  // (the per-wave columns for EVERY wave: with >= 2 waves per agent they share its block's writing)
       return -1;
-    if (grid_sync) w->nav_seq += (uint32_t)n_steps;  // (only a launch that was made has arrived at its barriers)
+    if (grid_sync) {
+      w->nav_seq += (uint32_t)n_steps;  // (only a launch that was made has arrived at its barriers)
+      if (gated) w->gated_nav_seq = (uint32_t)n_steps;  // (... and a gated one that found the gate shut has not: see above)
+    }
     if (d->collisions && !grid_sync) {
-      if (vmas::launch_navigation_collisions(d, o, w->batch, state, ld, mask, mw, stream)) return -1;
+      if (vmas::launch_navigation_collisions(d, o, w->batch, state, ld, mask, mw, stream, gated ? err_flags : nullptr)) return -1;
       if (capturing) HIP_TRY(hipMemsetAsync(mask, 0, (size_t)mw * sizeof(uint32_t), (hipStream_t)stream));
-      else w->nav_flip ^= 1;
+      else { w->nav_flip ^= 1; if (gated) w->gated_nav_flip = 1; }
     }
     return 0;
   }
@@ -2813,7 +2831,7 @@ static int step_env_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld
         } else if (step_impl(w, state, agent_ft, ld, args, stream, 1, 0, nullptr, ENV_NONE, 0, 0)) {
           return -1;
         }
-        if (vmas::launch_football_post(d, o, w->batch, state, ld, stp, stream)) return -1;
+        if (vmas::launch_football_post(d, o, w->batch, state, ld, stp, stream, gated ? err_flags : nullptr)) return -1;
       }
       return 0;
     }
@@ -2915,7 +2933,7 @@ static int step_impl(VmasWorld* w, float* state, float* agent_ft, int64_t ld, co
                             (long)ld - env_first);
     }
     if (env_kind == ENV_NONE) return launch_physics(w, S, state, agent_ft, ld, a, s);
-    const bool cp = compact_on(w) && !a.joint_fixed_rot && !ABLATE(a) && !ABLATE(*env) && compact_takes(a);
+    const bool cp = compact_on(w) && !a.joint_fixed_rot && !(ABLATE(a) & 0xff) && !ABLATE(*env) && compact_takes(a);
     if (env_kind == ENV_INGEST && cp) return launch_compact(w, ENV_INGEST, state, agent_ft, ld, a, env, 0, s, w->batch, ld);
     if (env_kind == ENV_FOOTBALL) {
       if (!cp) return fail("vmas_world_step_env: the football epilogue runs behind the compacted step kernel, which this world / "
@@ -3053,7 +3071,11 @@ int vmas_world_step_n(VmasWorld* w, float* state, float* agent_ft, int64_t ld, i
   // 2.9 us per enqueue (measured, profiles/r02_queues_sweep.jsonl: interpreter balance 32768 envs -15 %, 131072 -12 %,
   // 1 M -4 %, football 131072 -8.5 %, navigation 65536 -15 %; transport 16384 = one tile per CU in total: +11 %, not
   // split; the specialised balance kernel at 32768 envs is faster on one queue) and the call has >= 8 steps.
-  const int nq = !args ? queues_for(w, n_steps) : 1;
+  // (a call whose only argument is the exact broad phase on a world that needs none of it - no band-capable pair: navigation -
+  //  is a call without arguments: the rule holds per environment there, the parts of the batch need nothing from each other)
+  const bool no_args = !args || (!args->pair_mask && !args->joint_fixed_rot && !args->entity_gravity && args->first_substep == 0 &&
+                                 args->n_substeps <= 0 && (!args->exact_broad_phase || exact_form(w, false) == EXACT_NONE));
+  const int nq = no_args ? queues_for(w, n_steps) : 1;
   if (nq > 1) {
     int cur = -1;
     if (hipGetDevice(&cur) != hipSuccess || cur != w->device) HIP_TRY(hipSetDevice(w->device));

@@ -422,6 +422,7 @@ class Environment:
                 self._launch.gated(self._post.kind, desc, buffers)
                 flags = self._ingest.validate_end(seq)
                 if flags:
+                    self._launch.refused()
                     self._post.restore_bound(saved)
                     self._ingest._raise(flags)
             else:

@@ -426,11 +426,18 @@ class StepLauncher:
 
 
     def can_gate(self, kind) -> bool:
-        """A gated launch must be the whole step and carry no grid barrier (include/vmas_env_hip.h)."""
+        """Every kind of step can be launched gated (round 6: each of its kernels reads the gate; ``refused()`` takes back what
+        the host advanced for a launch that found it shut) - except with the exact broad phase in its grid-barrier / launch
+        per substep forms, whose sequence numbers advance on the host (include/vmas_env_hip.h)."""
         if self._be is None or self.env.world._backend is not self._be:
             self._bind()
         # (the lazy form of the exact broad phase carries no barrier whose count the host advances: it can be gated)
-        return kind in (0, A.POST_BALANCE, A.POST_TRANSPORT) and (not self._exact or self._be.exact_form() <= 1)
+        return not self._exact or self._be.exact_form() <= 1
+
+    def refused(self):
+        """The gated launch just made found the gate shut (``validate_end`` returned flags): ``vmas_world_gated_refused``."""
+        if A.load_library().vmas_world_gated_refused(self._h) != 0:
+            raise VmasHipError(A.last_error())
 
     def gated(self, kind: int, desc, buffers):
         """``vmas_world_step_env_gated``: the step launch that does nothing if the validation in front of it raised flags."""
@@ -921,6 +928,14 @@ class NavigationPost(_Post):
         b.pos_rew, b.final_rew = p + 2 * n * row_bytes, p + (2 * n + 1) * row_bytes
         return st
 
+    def bound_attributes(self):
+        sc = self.env.scenario
+        sc = getattr(sc, "_sc", sc)
+        out = [(sc, "pos_rew"), (sc, "final_rew")]
+        for a in self.env.world.agents:
+            out += [(a, "pos_rew"), (a, "agent_collision_rew")]
+        return out
+
     def _bind_outputs(self, dedicated: bool = False):
         """The output set of this step, bound to the scenario's / agents' attributes (nothing launched)."""
         sc, n = self.env.scenario, self.n
@@ -1046,6 +1061,13 @@ class FootballPost(_Post):
         b.obs, b.rew, b.done = v["obs"].data_ptr(), v["rew"].data_ptr(), v["done"].data_ptr()
         b.terms, b.touching = v["terms"].data_ptr(), v["touching"].data_ptr()
         return st
+
+    def bound_attributes(self):
+        sc = self.env.scenario
+        sc = getattr(sc, "_sc", sc)
+        ball = sc.ball
+        return [(sc, "_sparse_reward_blue"), (sc, "_done"), (sc, "min_agent_dist_to_ball_blue"), (sc, "min_agent_dist_to_ball_red"),
+                (ball, "pos_rew_blue"), (ball, "pos_rew_red"), (ball, "pos_rew_agent_blue"), (ball, "pos_rew_agent_red")]
 
     def prepare(self, dedicated: bool = False):
         """(descriptor, buffers, what env.step returns) - outputs bound to the scenario's attributes, nothing launched.
