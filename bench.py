@@ -770,14 +770,20 @@ def measure_traffic(args, n_launches_per_step, timeout_s=90, attached=False):
             for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
                     name = row["Kernel_Name"]
-                    if row["Counter_Name"] == counter and ("step_kernel" in name or "vmas_rt_" in name):
+                    if row["Counter_Name"] == counter and ("step_kernel" in name or "vmas_rt_" in name or (
+                            attached and ("post_kernel" in name or "collision_kernel" in name))):
                         vals.setdefault(name, []).append(float(row["Counter_Value"]))
             if not vals:
                 return None, f"no step-kernel dispatch in the {counter} pass (rc {r.returncode}): {r.stderr[-200:]}"
             name = max(vals, key=lambda n: len(vals[n]))  # the kernel of the timed launches (the recording steps are other forms)
-            v = sorted(vals[name][len(vals[name]) // 2:])  # (the second half: past the first touches of the buffers)
-            med[counter] = v[len(v) // 2]
-            kernel = name.split("(")[0][-80:]
+            # (an env.step that is two kernels - football's step + post-step, navigation's step + collision kernel beyond one tile
+            #  per CU: the step's traffic is the sum of both, each at its median)
+            names = [n for n in vals if len(vals[n]) * 2 > len(vals[name])] if attached else [name]
+            med[counter] = 0.0
+            for n in names:
+                v = sorted(vals[n][len(vals[n]) // 2:])  # (the second half: past the first touches of the buffers)
+                med[counter] += v[len(v) // 2]
+            kernel = " + ".join(n.split("(")[0][-80:] for n in names)
     traffic = (2.0 * med["FETCH_SIZE"] + med["WRITE_SIZE"]) * 1024.0
     return traffic, {"FETCH_SIZE_KiB_median": med["FETCH_SIZE"], "WRITE_SIZE_KiB_median": med["WRITE_SIZE"], "kernel": kernel,
                      "formula": "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 per dispatch (gfx950: FETCH_SIZE counts 128-B requests as 64 B)"}

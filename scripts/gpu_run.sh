@@ -138,6 +138,27 @@ PY
     done
     cat $LP
     ;;
+  lazy-counters)  # instruction counts / instruction-cache behaviour of the compacted kernel with and without the lazy form
+    LC=$OUT/${TAG}_lazy_counters.txt; : > $LC
+    cd /tmp && export TMPDIR=/tmp
+    for E in 0 1; do
+      for SET in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY" \
+                 "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_ANY SQ_WAIT_ANY"; do
+        W=/tmp/lc_$E; rm -rf $W
+        COMPACT=1 EXACT=$E FORCES=random QUEUES=1 rocprofv3 --pmc $SET --output-format csv -d $W -o p -- python $S/bench_world.py football ${LC_ENVS:-16384} 200 > $W.log 2>&1
+        python - $W $E >> $LC <<'PY'
+import csv, glob, sys, collections
+acc = collections.defaultdict(list)
+for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "step_kernel_compact" in r["Kernel_Name"]:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+print(f"exact={sys.argv[2]}", {k: round(sorted(v)[len(v) // 2]) for k, v in sorted(acc.items())}, "dispatches", max((len(v) for v in acc.values()), default=0))
+PY
+      done
+    done
+    cd $R; cat $LC
+    ;;
   *) echo "unknown stage $STAGE";;
   esac
 done

@@ -180,6 +180,9 @@ __attribute__((amdgpu_waves_per_eu((PLAIN == 2 && OWN == 2 && ENV != ENV_FOOTBAL
   uint32_t* xmask = (uint32_t*)(torques + (P.has_torque ? CAP : 0));
   const int nP = P.n_pairs;
   // the LAZY exact broad phase (vmas_env_device.h): [2 parities][overlap | band words] | need | collected | batch mask | flag
+#ifndef VMAS_LZ_CUT  // (compile-time cuts of the lazy form's parts: scripts/variant_lib.sh, measurement only)
+#define VMAS_LZ_CUT 0
+#endif
 #ifdef VMAS_PROFILE  // (A/B of the lazy form's parts, profiling builds only: VMAS_ABLATE bits 8.. - scripts/gpu_run.sh lazy-parts)
 #define LZ_ABL(bit) (((args.ablate >> (bit)) & 1) != 0)
 #else
@@ -439,7 +442,7 @@ __attribute__((amdgpu_waves_per_eu((PLAIN == 2 && OWN == 2 && ENV != ENV_FOOTBAL
       };
       // lazy form: this pass's overlap words (the other parity's are re-armed: last read by the previous pass's owners)
       uint32_t* lz_x = lz_words + lzp * (it & 1);
-      if (lazy)
+      if (lazy && !(VMAS_LZ_CUT & 16))
         for (int i = threadIdx.x; i < lzp; i += blockDim.x) lz_words[lzp * ((it + 1) & 1) + i] = 0u;
       if (args.sync != nullptr) {
         // World.collides' batch-global rule (core.py:2797-2801) for this substep by the whole grid: see step_kernel
@@ -578,9 +581,7 @@ __attribute__((amdgpu_waves_per_eu((PLAIN == 2 && OWN == 2 && ENV != ENV_FOOTBAL
           const uint32_t h0 = rdl(HU0, ul), h1 = rdl(HU1, ul), h2 = rdl(HU2, ul);
           const float half = rdlf(HU3, ul);
           const uint32_t key_lo = rdl(HU4, ul) + 1u, key_span = 0x7f800000u - key_lo;  // (threshold, +inf) in bit patterns
-          [[maybe_unused]] float ov_thr = 0.f;   // (lazy form) circles_overlap's threshold of the unit's pairs
-          [[maybe_unused]] uint32_t ov_bits = 0u;  // partner i: some environment of the tile has the pair's circles overlapping
-          if constexpr (PLAIN == 2) ov_thr = rdlf(HU5, ul);
+          [[maybe_unused]] uint32_t reach_bits = 0u;  // (lazy form) partner i has a contact candidate in some environment
           const int type = (int)(h1 & 0xffu), n = (int)((h1 >> 8) & 0xffu), stride = (int)(h1 >> 16) * ROWF;
           const int pair0 = (int)(h2 >> 16);
           const float* R = tile + (int)(h0 & 0xffffu);
@@ -617,25 +618,33 @@ __attribute__((amdgpu_waves_per_eu((PLAIN == 2 && OWN == 2 && ENV != ENV_FOOTBAL
             }
             const bool need = (key - key_lo) >= key_span;
             unsigned long long b = __ballot(need) & live_mask;
-            // lazy form: World.collides' own test of the pair per environment (core.py:2797-2799) on the operands that are in
-            // registers anyway - a line pair always (a wall's bounding circle spans the pitch), a sphere pair only where the
-            // spheres are within reach (overlapping spheres are)
-            if constexpr (PLAIN == 2) {
-              if (lazy && !LZ_ABL(8) && !all_masks && (type != VMAS_PAIR_SS || b != 0ull) &&
-                  (__ballot(circles_overlap(dx, dy, ov_thr)) & live_mask) != 0ull)
-                ov_bits |= 1u << i;
-            }
             if (b != 0ull && pair_masked_off(pair)) b = 0ull;
             if (all_masks) {
               if (lane == 0) ballots[pair] = b;
             } else if (b != 0ull) {
               take_slots(pair, b);
+              if constexpr (PLAIN == 2) reach_bits |= 1u << i;  // (on the rare path: nothing of the lazy form in the loop's hot part)
             }
           }
+          // lazy form: World.collides' own test of the pair per environment (core.py:2797-2799) - a line pair always (a wall's
+          // bounding circle spans the pitch), a sphere unit only if some pair of it is within reach (overlapping spheres are).
+          // A loop of ITS OWN behind the pair loop, on the positions that are still in registers: inside that loop the test's
+          // threshold, its result bits and the ballot's scalar pair were live across the unit's twelve partners - and the
+          // compiler paid for them with scalar spills in the kernel's hottest code: football 16 384 +2.9 us per step for tests
+          // that take 0.8 us to execute (profiles/r06s_lazy_cuts.txt)
           if constexpr (PLAIN == 2) {
-            if (ov_bits != 0u && lane == 0) {  // (consecutive pair indices: one word, or two if the run crosses a word boundary)
-              atomicOr(&lz_x[pair0 >> 5], ov_bits << (pair0 & 31));
-              if ((pair0 & 31) + n > 32) atomicOr(&lz_x[(pair0 >> 5) + 1], ov_bits >> (32 - (pair0 & 31)));
+            if (lazy && !(VMAS_LZ_CUT & 1) && !LZ_ABL(8) && !all_masks && (type != VMAS_PAIR_SS || reach_bits != 0u)) {
+              const float ov_thr = live ? rdlf(HU5, ul) : -1.f;  // (tail lanes never overlap: a squared distance is >= 0 or NaN)
+              uint32_t ov_bits = 0u;  // partner i: some environment of the tile has the pair's circles overlapping
+#pragma unroll
+              for (int i = 0; i < UNIT_PARTNERS; ++i) {
+                if (i >= n) break;
+                if (__ballot(circles_overlap(pr.x - ps[i].x, pr.y - ps[i].y, ov_thr)) != 0ull) ov_bits |= 1u << i;
+              }
+              if (ov_bits != 0u && lane == 0) {  // (consecutive pair indices: one word, or two if the run crosses a word boundary)
+                atomicOr(&lz_x[pair0 >> 5], ov_bits << (pair0 & 31));
+                if ((pair0 & 31) + n > 32) atomicOr(&lz_x[(pair0 >> 5) + 1], ov_bits >> (32 - (pair0 & 31)));
+              }
             }
           }
         }
@@ -647,7 +656,7 @@ __attribute__((amdgpu_waves_per_eu((PLAIN == 2 && OWN == 2 && ENV != ENV_FOOTBAL
       __syncthreads();
       CACC(2);  // A barrier
       if constexpr (PLAIN == 2) {
-        if (lazy) lazy_publish(args.lz, it, (int)(lz_x - (uint32_t*)lds));  // this tile's words go out: nobody waits for them
+        if (lazy && !(VMAS_LZ_CUT & 8)) lazy_publish(args.lz, it, (int)(lz_x - (uint32_t*)lds));  // this tile's words go out: nobody waits for them
       }
 
       // ---- rounds: ONE unless the tile has more contacts than the list holds (non-finite poses pass every test); then
@@ -717,7 +726,7 @@ __attribute__((amdgpu_waves_per_eu((PLAIN == 2 && OWN == 2 && ENV != ENV_FOOTBAL
           // lazy form: this environment is in the pair's band - bounding circles apart, force (or torque) not zero; for a
           // sphere pair that takes a non-finite pose.  Noted in the contact's key: the pair's owners look at it (phase C)
           if constexpr (PLAIN == 2) {
-            if (lazy && !LZ_ABL(10) && (fa.x != 0.f || fa.y != 0.f || ta != 0.f) &&
+            if (lazy && !(VMAS_LZ_CUT & 2) && !LZ_ABL(10) && (fa.x != 0.f || fa.y != 0.f || ta != 0.f) &&
                 !circles_overlap(pa.x - pb.x, pa.y - pb.y, __uint_as_float(tab[P.t_band + pair])))
               keys[k] = key | 0x80000000u;
           }
@@ -753,7 +762,10 @@ __attribute__((amdgpu_waves_per_eu((PLAIN == 2 && OWN == 2 && ENV != ENV_FOOTBAL
                 // 2801).  THIS WAVE asks - the other waves go on with their entities - and leaves the pair's contacts out of
                 // the sum if no environment of the batch overlaps (the pair's other owner asks too and gets the same answer: a
                 // set bit is final, and so is "every tile has arrived and it is clear").  Rare: see vmas_env_device.h.
-                if (lazy) {
+                // (Measured instead, r06u / r06v_lazy_cuts.txt: the whole tile asking behind phase B with lazy_collect - 7 us
+                // per launch where this costs 1.9; wave 0 asking there for everybody - 3.4: code between the phases sits on top of
+                // every owner's running sums, and the compiler pays for its registers in the hot loops.)
+                if (lazy && !(VMAS_LZ_CUT & 4)) {
                   const bool band = mine && (keys[s0 + lanemask_rank(b)] >> 31) != 0u;
                   if (__any(band) && !((lz_x[pr >> 5] >> (pr & 31)) & 1u) && lazy_ask_wave(args.lz, it, pr) == 0) {
                     n_on[s] -= 1;  // (the reference does not process the pair at all: not one of the zeros it would add)
