@@ -424,8 +424,9 @@ def load_library() -> C.CDLL:
     lib.vmas_world_step_env.restype = C.c_int
     lib.vmas_world_step_env_gated.argtypes = lib.vmas_world_step_env.argtypes
     lib.vmas_world_step_env_gated.restype = C.c_int
-    lib.vmas_world_gated_refused.argtypes = [vp]
-    lib.vmas_world_gated_refused.restype = C.c_int
+    if hasattr(lib, "vmas_world_gated_refused"):  # (an A/B against a library of an earlier round: scripts/gpu_run.sh lazy-cost)
+        lib.vmas_world_gated_refused.argtypes = [vp]
+        lib.vmas_world_gated_refused.restype = C.c_int
     lib.vmas_env_reset_where.argtypes = [C.POINTER(ResetArgs), i32, i32, i32, vp, vp, vp, i64, vp]
     lib.vmas_env_reset_where.restype = C.c_int
     lib.vmas_world_rollout_env.argtypes = [vp, vp, vp, i64, C.POINTER(StepArgs), C.POINTER(IngestArgs), vp, i32, vp, vp, i32, vp]
