@@ -1268,7 +1268,10 @@ def main():
                                "kernel": "the one-launch Environment.step kernel (ingest prologue + World.step + post-step epilogue)",
                                "bytes_per_env": per_env, "bytes_per_launch": per_env * B,
                                "note": "filled from the `attached_reference` leg below: kernel_us = HIP-event time per env.step "
-                                       "with the asserts off (back-to-back one-launch steps: the kernel's launch-to-launch time)"}
+                                       "with the asserts off (back-to-back one-launch steps: the kernel's launch-to-launch time).  "
+                                       "rocprofv3 over this command sees the same kernel mostly in the asserts-kept legs, where it "
+                                       "starts behind two tiny launches on a drained queue: its per-dispatch median there is ~10 % "
+                                       "longer (profiles/r06y_bench_q1_pmc_summary.txt: 14.1 us against 12.6)"}
         if world_size == 1 and not args.no_traffic and not args.fused:
             try:
                 traffic, detail = measure_traffic(args, n_queues)

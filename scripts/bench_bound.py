@@ -11,6 +11,8 @@ if os.environ.get("NAV_TILES"):  # A/B: navigation's one-launch step up to this 
 name = sys.argv[1] if len(sys.argv) > 1 else "balance"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32768
 kw = {"balance": dict(n_agents=4), "transport": {}, "navigation": dict(n_agents=8)}[name]
+if os.environ.get("EXACT") is not None:  # A/B: the reference's broad-phase rule (default, the lazy form) against the per-environment form
+    kw = dict(kw, exact_broad_phase=bool(int(os.environ["EXACT"])))
 env = make_env(name, num_envs=B, device="cuda:0", seed=0, validate_actions=False, **kw)
 if os.environ.get("SPEC") == "0":
     env.world._get_backend().set_specialized(False)
@@ -47,6 +49,6 @@ if os.environ.get("DIAG"):
     o = env.step_bound()[0]
     print("DIAG obs lidar mean", float(torch.stack(o)[..., 6:].mean()), "nonzero frac", float((torch.stack(o)[..., 6:] > 0).float().mean()), file=sys.stderr)
 print(json.dumps({"scenario": name, "num_envs": B, "specialized": env.world._get_backend().specialized,
-                  "ablate": os.environ.get("VMAS_ENV_ABLATE"), "actions": os.environ.get("ACTIONS", "fixed"), "lanes": env.world._get_backend().lanes_per_env,
+                  "ablate": os.environ.get("VMAS_ENV_ABLATE"), "actions": os.environ.get("ACTIONS", "fixed"), "exact": os.environ.get("EXACT"), "lanes": env.world._get_backend().lanes_per_env,
                   "step_bound_us": round(med[0], 2), "enqueue_us": round(med[1], 2), "wall_us": round(med[2], 2),
                   "windows_us": [round(w[0], 2) for w in windows]}))
