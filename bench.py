@@ -114,6 +114,9 @@ def parse_args():
                          "launches under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, N = 1 only)")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)  # (the re-run itself: launches only)
     ap.add_argument("--traffic-attached", action="store_true", help=argparse.SUPPRESS)  # (... of the attached reference's env.step)
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="TESTING ONLY: every rank on cuda:0, process group over gloo - runs the N > 1 code path (sharding, fences, "
+                         "max-over-ranks, the attached headline on every rank) on a one-GPU box; the line says so and its value means nothing")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU plumbing check (tests): ranks, sharding and the rollout gather over gloo, NO physics, value = null")
     return ap.parse_args()
@@ -129,7 +132,7 @@ def maybe_spawn(args):
     """`python bench.py --gpus N` without a launcher: become `python -m torch.distributed.run ... bench.py --gpus N`."""
     if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
         return
-    if not args.dry_run:
+    if not args.dry_run and not args.share_gpu:
         import torch
 
         have = torch.cuda.device_count()
@@ -1078,6 +1081,8 @@ def main():
     if args.dry_run:
         device = torch.device("cpu")
     else:
+        if args.share_gpu:
+            local_rank = 0
         if torch.cuda.device_count() <= local_rank:
             sys.exit(f"bench.py: rank {rank} needs GPU {local_rank}, {torch.cuda.device_count()} visible")
         torch.cuda.set_device(local_rank)
@@ -1087,7 +1092,7 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.dry_run:
+        if args.dry_run or args.share_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world_size)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=device)
@@ -1272,6 +1277,16 @@ def main():
                                        "rocprofv3 over this command sees the same kernel mostly in the asserts-kept legs, where it "
                                        "starts behind two tiny launches on a drained queue: its per-dispatch median there is ~10 % "
                                        "longer (profiles/r06y_bench_q1_pmc_summary.txt: 14.1 us against 12.6)"}
+            if world_size > 1:  # (the asserts-off leg that isolates the kernel runs at N = 1 only)
+                rf = out["roofline"]
+                rf["kernel_us"] = ev_h / steps * 1e6
+                rf["achieved"] = rf["bytes_per_launch"] / (rf["kernel_us"] * 1e-6) / 1e9
+                rf["frac"] = rf["achieved"] / HBM_PEAK_GBS
+                rf["note"] = ("N > 1, per rank (every rank steps its own shard of the same size): kernel_us = HIP-event time per env.step "
+                              "of the slowest rank INCLUDING the asserts' two small launches - a lower bound of the kernel's rate; the "
+                              "N = 1 line isolates the kernel (asserts-off leg) and measures its HBM traffic")
+        if args.share_gpu:
+            out["share_gpu"] = "TESTING: every rank on cuda:0 over gloo - the N > 1 code path, not a measurement"
         if world_size == 1 and not args.no_traffic and not args.fused:
             try:
                 traffic, detail = measure_traffic(args, n_queues)

@@ -137,3 +137,21 @@ def test_bench_two_gpus_strong_scaling_config():
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["global_envs"] == 65536
     assert d["config"]["num_envs_per_gpu"] == 32768 and len(d["per_rank_us_per_step"]) == 2
+
+
+def test_bench_n_greater_1_code_path_on_one_gpu():
+    """`bench.py --gpus 2 --share-gpu` (testing mode: both ranks on cuda:0, process group over gloo): the N > 1 code path of the
+    line - environment sharding, barrier + synchronize fences, max over ranks, the attached headline on EVERY rank, the
+    per-rank roofline - runs on the one-GPU boxes too.  Its numbers mean nothing (two processes share a device); its shape
+    is what the driver's N = 2 / 4 / 8 runs will print."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--no-gather", "--steps", "30",
+                          "--warmup", "5", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["scaling"] == "weak" and "share_gpu" in d
+    assert d["config"]["global_envs"] == 2 * d["config"]["num_envs_per_gpu"] and len(d["per_rank_us_per_step"]) == 2
+    assert d["headline"]["fused"] and d["headline"]["launches_per_env_step"] == 1, "the attached reference's one-launch step on every rank"
+    assert d["value"] == pytest.approx(d["config"]["global_envs"] * d["headline"]["substeps"] / (d["ms_per_step"] * 1e-3), rel=1e-6)
+    assert d["world_step"]["value"] > 0 and d["roofline"]["frac"] is not None and 0 < d["roofline"]["frac"] < 1
+
