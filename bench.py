@@ -1285,6 +1285,9 @@ def main():
                 rf["note"] = ("N > 1, per rank (every rank steps its own shard of the same size): kernel_us = HIP-event time per env.step "
                               "of the slowest rank INCLUDING the asserts' two small launches - a lower bound of the kernel's rate; the "
                               "N = 1 line isolates the kernel (asserts-off leg) and measures its HBM traffic")
+        if head is not None and "error" in head:  # (the reference is not importable on this machine: physics-only headline)
+            out["headline_fallback"] = ("value = World.step() physics (the headline of rounds 1-5): the attached reference environment "
+                                        "could not be made - " + head["error"])
         if args.share_gpu:
             out["share_gpu"] = "TESTING: every rank on cuda:0 over gloo - the N > 1 code path, not a measurement"
         if world_size == 1 and not args.no_traffic and not args.fused:
