@@ -297,9 +297,12 @@ class HipWorld:
     def _exact_args(self, exact: bool):
         if not exact:
             return None
-        self._exact_step_args = sa = A.StepArgs()  # (kept alive by the world for the duration of the call)
-        sa.exact_broad_phase = 1
-        return C.byref(sa)
+        ref = getattr(self, "_exact_step_ref", None)
+        if ref is None:  # (ONE struct for the world's lifetime: it never changes, and making one per call is microseconds of host time)
+            self._exact_step_args = sa = A.StepArgs()
+            sa.exact_broad_phase = 1
+            ref = self._exact_step_ref = C.byref(sa)
+        return ref
 
     def step_n(self, n_steps: int, forces: Optional[torch.Tensor] = None, stream=None, exact: bool = False) -> None:
         """``n_steps`` World.step() launches enqueued from C.  ``forces`` [n_steps, A, 3, ld]
